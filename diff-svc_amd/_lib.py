@@ -1,0 +1,113 @@
+"""ctypes binding of libdsvc_hip.so (include/dsvc.h).  There is NO fallback: if the library is missing or
+does not load, every entry point raises."""
+import ctypes
+import os
+
+import torch  # noqa: F401  -- must be imported first so the HIP runtime torch ships is the one we bind to
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdsvc_hip.so")
+
+PREC_F16, PREC_F16_W2, PREC_F16_X3 = 0, 1, 2
+PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3}
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+class DenoiserCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("mel_bins", "hidden", "channels", "layers", "dilation_cycle", "max_steps", "precision")]
+
+
+class SampleArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("T", ctypes.c_int32), ("cond", ctypes.c_void_p), ("x_init", ctypes.c_void_p),
+                ("ref_mel", ctypes.c_void_p), ("mel2ph", ctypes.c_void_p), ("seed", ctypes.c_uint64),
+                ("first_clip", ctypes.c_int32), ("t_start", ctypes.c_int32), ("t_stop", ctypes.c_int32),
+                ("speedup", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("mel_out", ctypes.c_void_p),
+                ("x_out", ctypes.c_void_p)]
+
+
+class VocoderCfg(ctypes.Structure):
+    _fields_ = [("num_mels", ctypes.c_int32), ("upsample_initial_channel", ctypes.c_int32),
+                ("sampling_rate", ctypes.c_int32), ("n_ups", ctypes.c_int32),
+                ("upsample_rates", ctypes.c_int32 * 8), ("upsample_kernel_sizes", ctypes.c_int32 * 8),
+                ("n_kernels", ctypes.c_int32), ("resblock_kernel_sizes", ctypes.c_int32 * 4),
+                ("resblock_dilations", (ctypes.c_int32 * 3) * 4), ("harmonics", ctypes.c_int32),
+                ("precision", ctypes.c_int32)]
+
+
+class MelspecCfg(ctypes.Structure):
+    _fields_ = [("n_fft", ctypes.c_int32), ("win_size", ctypes.c_int32), ("hop", ctypes.c_int32),
+                ("n_mels", ctypes.c_int32), ("clip_val", ctypes.c_float)]
+
+
+# every symbol include/dsvc.h declares: (name, restype, argtypes)
+_VP = ctypes.c_void_p
+SYMBOLS = [
+    ("dsvc_abi_version", ctypes.c_int, []),
+    ("dsvc_last_error", ctypes.c_char_p, []),
+    ("dsvc_denoiser_create", ctypes.c_int, [ctypes.POINTER(DenoiserCfg), ctypes.POINTER(_VP)]),
+    ("dsvc_denoiser_load_tensor", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64]),
+    ("dsvc_denoiser_finalize", ctypes.c_int, [_VP]),
+    ("dsvc_denoiser_destroy", None, [_VP]),
+    ("dsvc_denoiser_forward", ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
+    ("dsvc_denoiser_debug_buffer", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64, c_i32p, c_i32p]),
+    ("dsvc_sampler_create", ctypes.c_int, [_VP, ctypes.POINTER(_VP)]),
+    ("dsvc_sampler_load_tensor", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64]),
+    ("dsvc_sampler_finalize", ctypes.c_int, [_VP]),
+    ("dsvc_sampler_destroy", None, [_VP]),
+    ("dsvc_sample", ctypes.c_int, [_VP, ctypes.POINTER(SampleArgs), _VP]),
+    ("dsvc_sampler_profile_gate_kernel", ctypes.c_int,
+     [_VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64), _VP]),
+    ("dsvc_vocoder_create", ctypes.c_int, [ctypes.POINTER(VocoderCfg), ctypes.POINTER(_VP)]),
+    ("dsvc_vocoder_load_tensor", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64]),
+    ("dsvc_vocoder_finalize", ctypes.c_int, [_VP]),
+    ("dsvc_vocoder_destroy", None, [_VP]),
+    ("dsvc_vocode", ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int32, _VP]),
+    ("dsvc_melspec_create", ctypes.c_int, [ctypes.POINTER(MelspecCfg), _VP, ctypes.POINTER(_VP)]),
+    ("dsvc_melspec_destroy", None, [_VP]),
+    ("dsvc_melspec_frames", ctypes.c_int, [_VP, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]),
+    ("dsvc_melspec_run", ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int64, _VP]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it is missing -- build it with diffsvc_amd.build.build()."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libdsvc_hip.so not found at %s: build it with `python -m diffsvc_amd.build` "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, res, args in SYMBOLS:
+            fn = getattr(handle, name)          # AttributeError if the ABI symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.dsvc_abi_version() != 1:
+            raise RuntimeError("libdsvc_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().dsvc_last_error()
+        raise RuntimeError("dsvc error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    """The caller's current HIP stream as void* (torch.cuda.current_stream)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def host_f32(t):
+    """Contiguous fp32 host copy of a checkpoint tensor + its pointer."""
+    h = t.detach().to("cpu", torch.float32).contiguous()
+    return h, ctypes.c_void_p(h.data_ptr())

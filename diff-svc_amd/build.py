@@ -1,0 +1,67 @@
+"""Build libdsvc_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+``python -m diffsvc_amd.build`` or ``diffsvc_amd.build.build()``.  hipcc cross-compiles gfx950 without a
+GPU; the resulting .so is git-ignored but travels with the tree to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libdsvc_hip.so")
+SOURCES = ["common.hip", "diffnet.hip", "vocoder.hip", "melspec.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (no CPU fallback exists)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "dsvc.h"))
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        if not force and not _stale(obj, [os.path.join(CSRC, src)] + headers):
+            return None
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-8000:]))
+        return src
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        built = [b for b in ex.map(compile_one, zip(srcs, objs)) if b]
+    if built or force or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-8000:])
+        if verbose:
+            print("built %s (%s)" % (OUT, ", ".join(built) if built else "relink"))
+    elif verbose:
+        print("up to date: %s" % OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,630 @@
+// DiffNet denoiser + Gaussian-diffusion sampler behind the C ABI (include/dsvc.h).
+// Reference: network/diff/net.py:58-135, network/diff/diffusion.py:100-123,131-198,255-283.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dsvc.h"
+#include "diffnet_kernels.h"
+
+using namespace dsvc;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        if (n <= bytes && p) return DSVC_OK;
+        release();
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; return fail(DSVC_ENOMEM, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
+        bytes = n;
+        return DSVC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+int upload(DevBuf& b, const void* host, size_t bytes) {
+    DSVC_TRY(b.alloc(bytes));
+    DSVC_HIP(hipMemcpy(b.p, host, bytes, hipMemcpyHostToDevice));
+    return DSVC_OK;
+}
+
+// pick a tiling for the problem shape.  "S*" = latency tilings (32-frame tile, reduction split over the
+// 4 SIMDs of a CU), "L64" = throughput tiling (128 frames x 256 columns per workgroup).
+template <class Epi, int NW, int NA>
+int dispatch_tiling(const ConvGemmArgs& a, const typename Epi::Args& e, hipStream_t st) {
+    if (a.n_rows >= 6144 && a.cin % 64 == 0) return conv_gemm_launch<4, 4, 1, 64, 2, NW, NA, Epi>(a, e, st);
+    if (a.cin % 384 == 0) return conv_gemm_launch<1, 1, 4, 384, 3, NW, NA, Epi>(a, e, st);
+    if (a.cin % 128 == 0) return conv_gemm_launch<1, 1, 4, 128, 2, NW, NA, Epi>(a, e, st);
+    return conv_gemm_launch<1, 2, 1, 16, 1, NW, NA, Epi>(a, e, st);
+}
+
+template <class Epi>
+int dispatch_prec(const ConvGemmArgs& a, const typename Epi::Args& e, int prec, hipStream_t st) {
+    switch (prec) {
+        case DSVC_PREC_F16: return dispatch_tiling<Epi, 1, 1>(a, e, st);
+        case DSVC_PREC_F16_W2: return dispatch_tiling<Epi, 2, 1>(a, e, st);
+        default: return dispatch_tiling<Epi, 2, 2>(a, e, st);
+    }
+}
+
+struct PackedConv {
+    DevBuf w;      // fragment-packed halfs (2 planes)
+    DevBuf bias;   // fp32 [n_ctiles*32]
+    int n_ctiles = 0, taps = 1, cin = 0;
+};
+
+// src(col, tap, ci) -> weight, bias(col) -> bias; cols >= cout must return 0
+template <class FW, class FB>
+int pack_conv(PackedConv& pc, int cout, int taps, int cin, FW&& src, FB&& bias) {
+    pc.n_ctiles = round_up(ceil_div(cout, 32), 2);
+    pc.taps = taps;
+    pc.cin = cin;
+    std::vector<_Float16> h(packed_halfs(pc.n_ctiles, taps, cin, 2));
+    pack_fragments(h.data(), pc.n_ctiles, taps, cin, 2, src);
+    DSVC_TRY(upload(pc.w, h.data(), h.size() * sizeof(_Float16)));
+    std::vector<float> b(pc.n_ctiles * 32, 0.f);
+    for (int c = 0; c < cout; ++c) b[c] = bias(c);
+    return upload(pc.bias, b.data(), b.size() * sizeof(float));
+}
+
+}  // namespace
+
+// =================================================================================================
+struct dsvc_denoiser {
+    dsvc_denoiser_cfg cfg;
+    std::map<std::string, std::vector<float>> host;
+    bool finalized = false;
+
+    PackedConv in_proj, skip_proj, fin_proj;
+    std::vector<PackedConv> dil, outp, condp;
+    DevBuf film;          // [max_steps][L][C]
+
+    // workspace for (B, T)
+    int wsB = 0, wsT = 0, Tp = 0, rows = 0;
+    DevBuf xin, xres, g, skip, s2, eps, condT, cproj, tsteps;
+    bool cond_ready = false;
+
+    ~dsvc_denoiser() {
+        for (DevBuf* b : {&film, &xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps}) b->release();
+        auto rel = [](PackedConv& p) { p.w.release(); p.bias.release(); };
+        rel(in_proj); rel(skip_proj); rel(fin_proj);
+        for (auto& p : dil) rel(p);
+        for (auto& p : outp) rel(p);
+        for (auto& p : condp) rel(p);
+    }
+
+    const std::vector<float>* get(const std::string& k, size_t numel) {
+        auto it = host.find(k);
+        if (it == host.end()) { fail(DSVC_ESTATE, "denoiser: tensor '%s' was never loaded", k.c_str()); return nullptr; }
+        if (it->second.size() != numel) {
+            fail(DSVC_EINVAL, "denoiser: tensor '%s' has %zu elements, expected %zu", k.c_str(), it->second.size(), numel);
+            return nullptr;
+        }
+        return &it->second;
+    }
+
+    int finalize();
+    int ensure_ws(int B, int T);
+    int prepare_cond(const float* cond_bht, int B, int T, hipStream_t st);
+
+    enum Tail { TAIL_EPS = 0, TAIL_DDPM = 1 };
+    // one denoiser evaluation on the frame-major state `x_fm` [rows][M]
+    int eval(const float* x_fm, const StepRef& step, Tail tail, const EpiDdpm::Args* ddpm, hipStream_t st);
+};
+
+int dsvc_denoiser::finalize() {
+    const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers, K = cfg.max_steps;
+    if (M % 16 || H % 16 || C % 64) return fail(DSVC_EINVAL, "denoiser: need mel_bins%%16==0, hidden%%16==0, channels%%64==0 (got %d,%d,%d)", M, H, C);
+    if (L < 1 || K < 1 || cfg.dilation_cycle < 1) return fail(DSVC_EINVAL, "denoiser: bad layers/steps/cycle");
+    if ((1 << ((L - 1) % cfg.dilation_cycle)) > 64 && cfg.dilation_cycle > 7) return fail(DSVC_EINVAL, "denoiser: dilation too large");
+#define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
+    {
+        GET(w, "input_projection.weight", C * M);
+        GET(b, "input_projection.bias", C);
+        DSVC_TRY(pack_conv(in_proj, C, 1, M,
+                           [&](int co, int, int ci) { return co < C ? (*w)[(size_t)co * M + ci] : 0.f; },
+                           [&](int co) { return (*b)[co]; }));
+    }
+    dil.resize(L); outp.resize(L); condp.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const std::string q = "residual_layers." + std::to_string(l) + ".";
+        GET(wd, q + "dilated_conv.weight", 2 * C * C * 3);
+        GET(bd, q + "dilated_conv.bias", 2 * C);
+        GET(wc, q + "conditioner_projection.weight", 2 * C * H);
+        GET(bc, q + "conditioner_projection.bias", 2 * C);
+        GET(wo, q + "output_projection.weight", 2 * C * C);
+        GET(bo, q + "output_projection.bias", 2 * C);
+        // packed column p of the gate GEMM: group = p/64, half = (p/32)&1, j = p%32  <->  conv channel half*C + group*32 + j
+        // (net.py:73-77: first C channels = gate -> sigmoid, last C = filter -> tanh)
+        auto chan = [C](int p) { return ((p >> 5) & 1) * C + (p >> 6) * 32 + (p & 31); };
+        DSVC_TRY(pack_conv(dil[l], 2 * C, 3, C,
+                           [&](int p, int tap, int ci) { return (*wd)[((size_t)chan(p) * C + ci) * 3 + tap]; },
+                           [&](int) { return 0.f; }));
+        // hoisted conditioner projection writes cproj in the same packed order, with BOTH biases folded in
+        DSVC_TRY(pack_conv(condp[l], 2 * C, 1, H,
+                           [&](int p, int, int ci) { return (*wc)[(size_t)chan(p) * H + ci]; },
+                           [&](int p) { return (*bc)[chan(p)] + (*bd)[chan(p)]; }));
+        DSVC_TRY(pack_conv(outp[l], 2 * C, 1, C,
+                           [&](int co, int, int ci) { return (*wo)[(size_t)co * C + ci]; },
+                           [&](int co) { return (*bo)[co]; }));
+    }
+    {
+        GET(w, "skip_projection.weight", C * C);
+        GET(b, "skip_projection.bias", C);
+        const float inv = 1.0f / sqrtf((float)L);      // sum(skip)/sqrt(L) (net.py:131) folded into the weights
+        DSVC_TRY(pack_conv(skip_proj, C, 1, C,
+                           [&](int co, int, int ci) { return (*w)[(size_t)co * C + ci] * inv; },
+                           [&](int co) { return (*b)[co]; }));
+    }
+    {
+        GET(w, "output_projection.weight", M * C);
+        GET(b, "output_projection.bias", M);
+        DSVC_TRY(pack_conv(fin_proj, M, 1, C,
+                           [&](int co, int, int ci) { return co < M ? (*w)[(size_t)co * C + ci] : 0.f; },
+                           [&](int co) { return (*b)[co]; }));
+    }
+    // ---- step tables: emb(t) -> mlp -> per-layer diffusion_projection, for every integer step ----
+    {
+        GET(w0, "mlp.0.weight", 4 * C * C);
+        GET(b0, "mlp.0.bias", 4 * C);
+        GET(w2, "mlp.2.weight", 4 * C * C);
+        GET(b2, "mlp.2.bias", C);
+        DevBuf dw0, db0, dw2, db2, emb, h1, e2, dwp, dbp;
+        DSVC_TRY(upload(dw0, w0->data(), w0->size() * 4)); DSVC_TRY(upload(db0, b0->data(), b0->size() * 4));
+        DSVC_TRY(upload(dw2, w2->data(), w2->size() * 4)); DSVC_TRY(upload(db2, b2->data(), b2->size() * 4));
+        DSVC_TRY(emb.alloc((size_t)K * C * 4)); DSVC_TRY(h1.alloc((size_t)K * 4 * C * 4)); DSVC_TRY(e2.alloc((size_t)K * C * 4));
+        DSVC_TRY(film.alloc((size_t)K * L * C * 4));
+        hipLaunchKernelGGL(k_sin_emb, dim3(ceil_div(K * C, 256)), dim3(256), 0, 0, emb.as<float>(), K, C);
+        hipLaunchKernelGGL(k_linear_rows, dim3(ceil_div(4 * C, 128), K), dim3(128), 0, 0, emb.as<float>(), dw0.as<float>(),
+                           db0.as<float>(), h1.as<float>(), K, C, 4 * C, 4 * C, 1);
+        hipLaunchKernelGGL(k_linear_rows, dim3(ceil_div(C, 128), K), dim3(128), 0, 0, h1.as<float>(), dw2.as<float>(),
+                           db2.as<float>(), e2.as<float>(), K, 4 * C, C, C, 0);
+        for (int l = 0; l < L; ++l) {
+            const std::string q = "residual_layers." + std::to_string(l) + ".diffusion_projection.";
+            GET(wp, q + "weight", C * C);
+            GET(bp, q + "bias", C);
+            DSVC_TRY(upload(dwp, wp->data(), wp->size() * 4)); DSVC_TRY(upload(dbp, bp->data(), bp->size() * 4));
+            hipLaunchKernelGGL(k_linear_rows, dim3(ceil_div(C, 128), K), dim3(128), 0, 0, e2.as<float>(), dwp.as<float>(),
+                               dbp.as<float>(), film.as<float>() + (size_t)l * C, K, C, C, L * C, 0);
+            DSVC_HIP(hipDeviceSynchronize());          // dwp/dbp are reused by the next layer
+        }
+        DSVC_HIP(hipGetLastError());
+        DSVC_HIP(hipDeviceSynchronize());
+        for (DevBuf* b : {&dw0, &db0, &dw2, &db2, &emb, &h1, &e2, &dwp, &dbp}) b->release();
+    }
+#undef GET
+    host.clear();
+    finalized = true;
+    return DSVC_OK;
+}
+
+int dsvc_denoiser::ensure_ws(int B, int T) {
+    if (B == wsB && T == wsT) return DSVC_OK;
+    if (B < 1 || T < 1) return fail(DSVC_EINVAL, "bad batch/frames %d/%d", B, T);
+    const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
+    const int max_dil = 1 << ((cfg.dilation_cycle - 1) < (L - 1) ? (cfg.dilation_cycle - 1) : (L - 1));
+    Tp = round_up(T + max_dil, 32);                  // gap rows >= the largest halo: clips never see each other
+    if ((long long)B * Tp > 0x3fffffff) return fail(DSVC_EINVAL, "batch too large");
+    rows = B * Tp;
+    const size_t r = (size_t)rows;
+    DSVC_TRY(xin.alloc(r * M * 4)); DSVC_TRY(xres.alloc(r * C * 4)); DSVC_TRY(g.alloc(r * C * 4));
+    DSVC_TRY(skip.alloc(r * C * 4)); DSVC_TRY(s2.alloc(r * C * 4)); DSVC_TRY(eps.alloc(r * M * 4));
+    DSVC_TRY(condT.alloc(r * H * 4)); DSVC_TRY(cproj.alloc(r * 2 * C * L * 4)); DSVC_TRY(tsteps.alloc((size_t)B * 4 + 16));
+    DSVC_HIP(hipMemset(xin.p, 0, r * M * 4));
+    DSVC_HIP(hipMemset(eps.p, 0, r * M * 4));
+    wsB = B; wsT = T;
+    cond_ready = false;
+    return DSVC_OK;
+}
+
+int dsvc_denoiser::prepare_cond(const float* cond_bht, int B, int T, hipStream_t st) {
+    const int H = cfg.hidden, C = cfg.channels, L = cfg.layers;
+    hipLaunchKernelGGL(k_to_frame_major, dim3(ceil_div(T, 32), ceil_div(H, 32), B), dim3(256), 0, st,
+                       cond_bht, condT.as<float>(), B, H, T, Tp, 1.0f);
+    for (int l = 0; l < L; ++l) {
+        ConvGemmArgs a{};
+        a.x = condT.as<float>(); a.ldx = H; a.n_rows = rows; a.clip_stride = Tp; a.clip_len = T;
+        a.cin = H; a.taps = 1; a.dil = 1; a.w = condp[l].w.as<_Float16>(); a.n_ctiles = condp[l].n_ctiles; a.w_planes = 2;
+        a.in_slope = 1.0f;
+        EpiBias::Args e{cproj.as<float>() + (size_t)l * rows * 2 * C, 2 * C, condp[l].bias.as<float>(), 2 * C};
+        DSVC_TRY(dispatch_prec<EpiBias>(a, e, DSVC_PREC_F16_X3, st));
+    }
+    cond_ready = true;
+    return DSVC_OK;
+}
+
+int dsvc_denoiser::eval(const float* x_fm, const StepRef& step, Tail tail, const EpiDdpm::Args* ddpm, hipStream_t st) {
+    const int M = cfg.mel_bins, C = cfg.channels, L = cfg.layers;
+    auto base = [&](const float* x, int ldx, int cin, const PackedConv& pc) {
+        ConvGemmArgs a{};
+        a.x = x; a.ldx = ldx; a.n_rows = rows; a.clip_stride = Tp; a.clip_len = wsT;
+        a.cin = cin; a.taps = pc.taps; a.dil = 1; a.w = pc.w.as<_Float16>(); a.n_ctiles = pc.n_ctiles; a.w_planes = 2;
+        a.in_slope = 1.0f;
+        return a;
+    };
+    {   // K1: input projection + ReLU (net.py:120-123)
+        ConvGemmArgs a = base(x_fm, M, M, in_proj);
+        EpiBiasRelu::Args e{xres.as<float>(), C, in_proj.bias.as<float>(), C};
+        DSVC_TRY(dispatch_prec<EpiBiasRelu>(a, e, DSVC_PREC_F16_X3, st));
+    }
+    for (int l = 0; l < L; ++l) {
+        {   // K3+K5+K6 (+ hoisted K4): FiLM add, dilated conv, gate (net.py:67-77)
+            ConvGemmArgs a = base(xres.as<float>(), C, C, dil[l]);
+            a.dil = 1 << (l % cfg.dilation_cycle);
+            a.film = film.as<float>() + (size_t)l * C;
+            a.film_step_stride = L * C;
+            a.step_ptr = step.ptr; a.step_off = step.off; a.step_per_clip = step.per_clip;
+            EpiGate::Args e{cproj.as<float>() + (size_t)l * rows * 2 * C, g.as<float>(), C};
+            DSVC_TRY(dispatch_prec<EpiGate>(a, e, cfg.precision, st));
+        }
+        {   // K7+K8: output projection, residual / skip (net.py:79-84,131)
+            ConvGemmArgs a = base(g.as<float>(), C, C, outp[l]);
+            EpiResSkip::Args e{xres.as<float>(), skip.as<float>(), outp[l].bias.as<float>(), C, l == 0 ? 1 : 0};
+            DSVC_TRY(dispatch_prec<EpiResSkip>(a, e, cfg.precision, st));
+        }
+    }
+    {   // K9a: skip projection + ReLU (net.py:132-133)
+        ConvGemmArgs a = base(skip.as<float>(), C, C, skip_proj);
+        EpiBiasRelu::Args e{s2.as<float>(), C, skip_proj.bias.as<float>(), C};
+        DSVC_TRY(dispatch_prec<EpiBiasRelu>(a, e, DSVC_PREC_F16_X3, st));
+    }
+    {   // K9b: output projection (net.py:134), optionally fused with the DDPM update (K10)
+        ConvGemmArgs a = base(s2.as<float>(), C, C, fin_proj);
+        if (tail == TAIL_DDPM) {
+            EpiDdpm::Args e = *ddpm;
+            e.bias = fin_proj.bias.as<float>();
+            DSVC_TRY(dispatch_prec<EpiDdpm>(a, e, DSVC_PREC_F16_X3, st));
+        } else {
+            EpiBias::Args e{eps.as<float>(), M, fin_proj.bias.as<float>(), M};
+            DSVC_TRY(dispatch_prec<EpiBias>(a, e, DSVC_PREC_F16_X3, st));
+        }
+    }
+    return DSVC_OK;
+}
+
+// =================================================================================================
+struct dsvc_sampler {
+    dsvc_denoiser* den = nullptr;
+    std::map<std::string, std::vector<float>> host;
+    bool finalized = false;
+    int K = 0, n_spec = 0;
+    std::vector<float> h_sqrt_ac, h_sqrt_1mac;
+    DevBuf alphas_cumprod, sqrt_recip, sqrt_recipm1, coef1, coef2, sigma, spec_min, spec_max;
+    DevBuf xstate, hist, xpred, step_dev;
+    int wsB = 0, wsT = 0;
+
+    // captured DDPM graph
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    int g_unroll = 0, gB = 0, gT = 0, g_prec = -1, g_clip0 = -1;
+    unsigned long long g_seed = 0;
+    const void* g_key = nullptr;
+
+    ~dsvc_sampler() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        for (DevBuf* b : {&alphas_cumprod, &sqrt_recip, &sqrt_recipm1, &coef1, &coef2, &sigma, &spec_min, &spec_max,
+                          &xstate, &hist, &xpred, &step_dev})
+            b->release();
+    }
+    int finalize();
+    int ensure_ws(int B, int T);
+    EpiDdpm::Args ddpm_args(unsigned long long seed, int clip0, int step_off);
+    int run_ddpm(const dsvc_sample_args* a, hipStream_t st);
+    int run_plms(const dsvc_sample_args* a, hipStream_t st);
+};
+
+int dsvc_sampler::finalize() {
+    auto need = [&](const char* k) -> const std::vector<float>* {
+        auto it = host.find(k);
+        if (it == host.end()) { fail(DSVC_ESTATE, "sampler: buffer '%s' was never loaded", k); return nullptr; }
+        return &it->second;
+    };
+    const char* tabs[] = {"alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                          "posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped",
+                          "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"};
+    const std::vector<float>* v[8];
+    for (int i = 0; i < 8; ++i) {
+        v[i] = need(tabs[i]);
+        if (!v[i]) return DSVC_ESTATE;
+        if (i == 0) K = (int)v[0]->size();
+        if ((int)v[i]->size() != K) return fail(DSVC_EINVAL, "sampler: '%s' has %zu entries, expected %d", tabs[i], v[i]->size(), K);
+    }
+    if (K < 1 || K > den->cfg.max_steps) return fail(DSVC_EINVAL, "sampler: %d timesteps but the denoiser tabulates %d", K, den->cfg.max_steps);
+    DSVC_TRY(upload(alphas_cumprod, v[0]->data(), K * 4)); DSVC_TRY(upload(sqrt_recip, v[1]->data(), K * 4));
+    DSVC_TRY(upload(sqrt_recipm1, v[2]->data(), K * 4)); DSVC_TRY(upload(coef1, v[3]->data(), K * 4));
+    DSVC_TRY(upload(coef2, v[4]->data(), K * 4));
+    std::vector<float> sg(K);
+    for (int i = 0; i < K; ++i) sg[i] = expf(0.5f * (*v[5])[i]);       // (0.5 * model_log_variance).exp()  (diffusion.py:163)
+    DSVC_TRY(upload(sigma, sg.data(), K * 4));
+    h_sqrt_ac = *v[6]; h_sqrt_1mac = *v[7];
+    const std::vector<float>* smin = need("spec_min");
+    const std::vector<float>* smax = need("spec_max");
+    if (!smin || !smax) return DSVC_ESTATE;
+    n_spec = (int)smin->size();
+    if ((int)smax->size() != n_spec || (n_spec != 1 && n_spec != den->cfg.mel_bins))
+        return fail(DSVC_EINVAL, "sampler: spec_min/spec_max must have 1 or mel_bins entries");
+    DSVC_TRY(upload(spec_min, smin->data(), n_spec * 4)); DSVC_TRY(upload(spec_max, smax->data(), n_spec * 4));
+    DSVC_TRY(step_dev.alloc(64));
+    host.clear();
+    finalized = true;
+    return DSVC_OK;
+}
+
+int dsvc_sampler::ensure_ws(int B, int T) {
+    DSVC_TRY(den->ensure_ws(B, T));
+    if (B == wsB && T == wsT) return DSVC_OK;
+    const size_t n = (size_t)den->rows * den->cfg.mel_bins * 4;
+    DSVC_TRY(xstate.alloc(n)); DSVC_TRY(hist.alloc(4 * n)); DSVC_TRY(xpred.alloc(n));
+    DSVC_HIP(hipMemset(xstate.p, 0, n)); DSVC_HIP(hipMemset(xpred.p, 0, n));
+    wsB = B; wsT = T;
+    if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+    return DSVC_OK;
+}
+
+EpiDdpm::Args dsvc_sampler::ddpm_args(unsigned long long seed, int clip0, int step_off) {
+    EpiDdpm::Args e{};
+    e.x = xstate.as<float>();
+    e.M = den->cfg.mel_bins;
+    e.tab = DdpmTables{sqrt_recip.as<float>(), sqrt_recipm1.as<float>(), coef1.as<float>(), coef2.as<float>(), sigma.as<float>()};
+    e.step = StepRef{step_dev.as<int>(), step_off, 0};
+    e.clip_stride = den->Tp; e.clip_len = den->wsT;
+    e.seed = seed; e.clip0 = clip0;
+    return e;
+}
+
+int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
+    int n = a->t_start - a->t_stop;
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), a->t_start - 1);
+    constexpr int UNROLL = 10;
+    if (a->use_graph && n >= 2 * UNROLL) {
+        const bool stale = !gexec || gB != a->B || gT != a->T || g_prec != den->cfg.precision || g_seed != a->seed ||
+                           g_clip0 != a->first_clip || g_key != den->cproj.p;
+        if (stale) {
+            if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+            // one eager step first: sets every function attribute outside the capture
+            {
+                EpiDdpm::Args e = ddpm_args(a->seed, a->first_clip, 0);
+                DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, st));
+                hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), -1);
+                n -= 1;
+            }
+            if (!cap_stream) DSVC_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+            DSVC_HIP(hipStreamSynchronize(st));
+            DSVC_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+            int rc = DSVC_OK;
+            for (int u = 0; u < UNROLL && rc == DSVC_OK; ++u) {
+                EpiDdpm::Args e = ddpm_args(a->seed, a->first_clip, u);
+                rc = den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), u, 0}, dsvc_denoiser::TAIL_DDPM, &e, cap_stream);
+            }
+            if (rc == DSVC_OK) hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, cap_stream, step_dev.as<int>(), -UNROLL);
+            hipGraph_t graph = nullptr;
+            hipError_t ce = hipStreamEndCapture(cap_stream, &graph);
+            if (rc != DSVC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (ce != hipSuccess) return fail(DSVC_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+            ce = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ce != hipSuccess) { gexec = nullptr; return fail(DSVC_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ce)); }
+            g_unroll = UNROLL; gB = a->B; gT = a->T; g_prec = den->cfg.precision; g_seed = a->seed; g_clip0 = a->first_clip;
+            g_key = den->cproj.p;
+        }
+        while (n >= g_unroll) {
+            DSVC_HIP(hipGraphLaunch(gexec, st));
+            n -= g_unroll;
+        }
+    }
+    for (; n > 0; --n) {
+        EpiDdpm::Args e = ddpm_args(a->seed, a->first_clip, 0);
+        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, st));
+        hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), -1);
+    }
+    return DSVC_OK;
+}
+
+int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
+    // diffusion.py:269-275: for i in reversed(range(0, t, interval)): x = p_sample_plms(x, i, interval, cond)
+    const int interval = a->speedup;
+    const size_t n = (size_t)den->rows * den->cfg.mel_bins;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    int n_hist = 0;
+    int first = ((a->t_start - 1) / interval) * interval;
+    for (int i = first; i >= a->t_stop; i -= interval) {
+        const int t_prev = i - interval > 0 ? i - interval : 0;
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), i);
+        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, st));
+        PlmsArgs p{};
+        p.x = xstate.as<float>(); p.eps = den->eps.as<float>(); p.hist = hist.as<float>(); p.x_pred = xpred.as<float>();
+        p.alphas_cumprod = alphas_cumprod.as<float>(); p.n = n; p.t = i; p.t_prev = t_prev; p.n_hist = n_hist;
+        if (n_hist == 0) {
+            p.phase = 0;
+            hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), t_prev);
+            DSVC_TRY(den->eval(xpred.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, st));
+            p.phase = 1;
+            hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
+            n_hist = 1;
+        } else {
+            p.phase = 2;
+            hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
+            n_hist += 1;
+        }
+    }
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+// =================================================================================================
+extern "C" {
+
+int dsvc_abi_version(void) { return DSVC_ABI_VERSION; }
+
+int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out) {
+    if (!cfg || !out) return fail(DSVC_EINVAL, "null argument");
+    if (cfg->precision < DSVC_PREC_F16 || cfg->precision > DSVC_PREC_F16_X3) return fail(DSVC_EINVAL, "unknown precision %d", cfg->precision);
+    int ndev = 0;
+    DSVC_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(DSVC_EHIP, "no HIP device visible");
+    dsvc_denoiser* d = new dsvc_denoiser();
+    d->cfg = *cfg;
+    *out = d;
+    return DSVC_OK;
+}
+
+int dsvc_denoiser_load_tensor(dsvc_denoiser* d, const char* name, const float* host, int64_t numel) {
+    if (!d || !name || !host || numel < 0) return fail(DSVC_EINVAL, "null argument");
+    if (d->finalized) return fail(DSVC_ESTATE, "denoiser already finalized");
+    d->host[name].assign(host, host + numel);
+    return DSVC_OK;
+}
+
+int dsvc_denoiser_finalize(dsvc_denoiser* d) {
+    if (!d) return fail(DSVC_EINVAL, "null handle");
+    if (d->finalized) return DSVC_OK;
+    return d->finalize();
+}
+
+void dsvc_denoiser_destroy(dsvc_denoiser* d) { delete d; }
+
+int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t, const float* cond, float* out,
+                          int32_t B, int32_t T, int32_t cond_changed, void* stream) {
+    if (!d || !spec || !t || !cond || !out) return fail(DSVC_EINVAL, "null argument");
+    if (!d->finalized) return fail(DSVC_ESTATE, "denoiser not finalized");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = d->cfg.mel_bins;
+    const bool fresh = !(B == d->wsB && T == d->wsT);
+    DSVC_TRY(d->ensure_ws(B, T));
+    if (fresh || cond_changed || !d->cond_ready) DSVC_TRY(d->prepare_cond(cond, B, T, st));
+    hipLaunchKernelGGL(k_to_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st, spec,
+                       d->xin.as<float>(), B, M, T, d->Tp, 1.0f);
+    DSVC_TRY(d->eval(d->xin.as<float>(), StepRef{t, 0, 1}, dsvc_denoiser::TAIL_EPS, nullptr, st));
+    hipLaunchKernelGGL(k_from_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st,
+                       d->eps.as<float>(), out, B, M, T, d->Tp);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, int64_t numel, int32_t* rows, int32_t* ld) {
+    if (!d || !name) return fail(DSVC_EINVAL, "null argument");
+    const std::string n(name);
+    const DevBuf* b = nullptr;
+    int width = 0;
+    const int M = d->cfg.mel_bins, C = d->cfg.channels, H = d->cfg.hidden;
+    if (n == "xin") { b = &d->xin; width = M; }
+    else if (n == "xres") { b = &d->xres; width = C; }
+    else if (n == "g") { b = &d->g; width = C; }
+    else if (n == "skip") { b = &d->skip; width = C; }
+    else if (n == "s2") { b = &d->s2; width = C; }
+    else if (n == "eps") { b = &d->eps; width = M; }
+    else if (n == "condT") { b = &d->condT; width = H; }
+    else if (n == "cproj") { b = &d->cproj; width = 2 * C; }
+    else if (n == "film") { b = &d->film; width = C; }
+    else return fail(DSVC_EINVAL, "unknown debug buffer '%s'", name);
+    if (rows) *rows = (n == "film") ? d->cfg.max_steps * d->cfg.layers : (n == "cproj" ? d->rows * d->cfg.layers : d->rows);
+    if (ld) *ld = width;
+    if (dst && numel > 0) {
+        const size_t bytes = (size_t)numel * 4 < b->bytes ? (size_t)numel * 4 : b->bytes;
+        DSVC_HIP(hipDeviceSynchronize());
+        DSVC_HIP(hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToDevice));
+    }
+    return DSVC_OK;
+}
+
+int dsvc_sampler_create(dsvc_denoiser* d, dsvc_sampler** out) {
+    if (!d || !out) return fail(DSVC_EINVAL, "null argument");
+    if (!d->finalized) return fail(DSVC_ESTATE, "finalize the denoiser before creating a sampler");
+    dsvc_sampler* s = new dsvc_sampler();
+    s->den = d;
+    *out = s;
+    return DSVC_OK;
+}
+
+int dsvc_sampler_load_tensor(dsvc_sampler* s, const char* name, const float* host, int64_t numel) {
+    if (!s || !name || !host || numel < 0) return fail(DSVC_EINVAL, "null argument");
+    if (s->finalized) return fail(DSVC_ESTATE, "sampler already finalized");
+    s->host[name].assign(host, host + numel);
+    return DSVC_OK;
+}
+
+int dsvc_sampler_finalize(dsvc_sampler* s) {
+    if (!s) return fail(DSVC_EINVAL, "null handle");
+    if (s->finalized) return DSVC_OK;
+    return s->finalize();
+}
+
+void dsvc_sampler_destroy(dsvc_sampler* s) { delete s; }
+
+int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
+    if (!s || !a || !a->cond || !a->mel_out) return fail(DSVC_EINVAL, "null argument");
+    if (!s->finalized) return fail(DSVC_ESTATE, "sampler not finalized");
+    if (a->t_start < 1 || a->t_start > s->K || a->t_stop < 0 || a->t_stop >= a->t_start)
+        return fail(DSVC_EINVAL, "t_start/t_stop %d/%d outside the %d-step schedule", a->t_start, a->t_stop, s->K);
+    hipStream_t st = (hipStream_t)stream;
+    dsvc_denoiser* d = s->den;
+    const int B = a->B, T = a->T, M = d->cfg.mel_bins;
+    if ((T * M) % 4) return fail(DSVC_EINVAL, "T*mel_bins must be a multiple of 4");
+    DSVC_TRY(s->ensure_ws(B, T));
+    DSVC_TRY(d->prepare_cond(a->cond, B, T, st));
+    float* xs = s->xstate.as<float>();
+    if (a->ref_mel) {
+        // use_gt_mel start (diffusion.py:255-261): x = q_sample(norm_spec(ref_mel), t_start-1)
+        return fail(DSVC_EINVAL, "ref_mel start is handled by the Python host (norm_spec + q_sample into x_init)");
+    } else if (a->x_init) {
+        hipLaunchKernelGGL(k_to_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st, a->x_init, xs, B, M, T, d->Tp, 1.0f);
+    } else {
+        hipLaunchKernelGGL(k_x_init, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, xs, B, T, M, d->Tp, a->seed, a->first_clip);
+    }
+    if (a->speedup > 1) DSVC_TRY(s->run_plms(a, st));
+    else DSVC_TRY(s->run_ddpm(a, st));
+    const size_t n = (size_t)B * T * M;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_finish_mel, dim3(blocks), dim3(256), 0, st, xs, a->mel_out, a->mel2ph, s->spec_min.as<float>(),
+                       s->spec_max.as<float>(), s->n_spec, B, T, M, d->Tp);
+    if (a->x_out)
+        hipLaunchKernelGGL(k_from_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st, xs, a->x_out, B, M, T, d->Tp);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters, float* avg_us, int64_t* rows, void* stream) {
+    if (!s || !avg_us || !rows || iters < 1) return fail(DSVC_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    dsvc_denoiser* d = s->den;
+    DSVC_TRY(s->ensure_ws(B, T));
+    if (!d->cond_ready) DSVC_HIP(hipMemsetAsync(d->cproj.p, 0, d->cproj.bytes, st));
+    const int C = d->cfg.channels, L = d->cfg.layers;
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, s->step_dev.as<int>(), 0);
+    hipEvent_t e0, e1;
+    DSVC_HIP(hipEventCreate(&e0)); DSVC_HIP(hipEventCreate(&e1));
+    double total = 0;
+    int count = 0;
+    for (int it = -2; it < iters; ++it) {                 // two untimed warm-up rounds
+        for (int l = 0; l < L; ++l) {
+            ConvGemmArgs a{};
+            a.x = d->xres.as<float>(); a.ldx = C; a.n_rows = d->rows; a.clip_stride = d->Tp; a.clip_len = d->wsT;
+            a.cin = C; a.taps = 3; a.dil = 1 << (l % d->cfg.dilation_cycle); a.w = d->dil[l].w.as<_Float16>();
+            a.n_ctiles = d->dil[l].n_ctiles; a.w_planes = 2; a.in_slope = 1.0f;
+            a.film = d->film.as<float>() + (size_t)l * C; a.film_step_stride = L * C; a.step_ptr = s->step_dev.as<int>();
+            EpiGate::Args e{d->cproj.as<float>() + (size_t)l * d->rows * 2 * C, d->g.as<float>(), C};
+            DSVC_HIP(hipEventRecord(e0, st));
+            DSVC_TRY(dispatch_prec<EpiGate>(a, e, d->cfg.precision, st));
+            DSVC_HIP(hipEventRecord(e1, st));
+            DSVC_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            DSVC_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (it >= 0) { total += ms; ++count; }
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = (float)(total * 1000.0 / count);
+    *rows = d->rows;
+    return DSVC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""Thin object wrappers over the C ABI handles (include/dsvc.h).  Device memory, streams and tensors come
+from PyTorch-ROCm; every FLOP on the hot path happens inside libdsvc_hip.so."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import PRECISIONS, check, host_f32, lib, ptr, stream_ptr
+
+SCHEDULE_KEYS = ("alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                 "posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped",
+                 "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "spec_min", "spec_max")
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("diffsvc_amd: tensors must live on the HIP device (got %s); there is no CPU path" % t.device)
+
+
+def _prec(p):
+    if isinstance(p, str):
+        if p not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
+        return PRECISIONS[p]
+    return int(p)
+
+
+class DenoiserHandle:
+    """dsvc_denoiser: DiffNet weights packed for the MFMA kernels + per-step FiLM tables."""
+
+    def __init__(self, state, mel_bins, hidden, channels, layers, dilation_cycle, max_steps,
+                 precision="f16_w2", prefix=""):
+        self._h = ctypes.c_void_p(0)
+        self.cfg = _lib.DenoiserCfg(mel_bins, hidden, channels, layers, dilation_cycle, max_steps, _prec(precision))
+        self.mel_bins, self.hidden = mel_bins, hidden
+        check(lib().dsvc_denoiser_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
+        n = 0
+        for k, v in state.items():
+            if not k.startswith(prefix):
+                continue
+            h, p = host_f32(v)
+            check(lib().dsvc_denoiser_load_tensor(self._h, k[len(prefix):].encode(), p, h.numel()))
+            n += 1
+        if n == 0:
+            raise RuntimeError("no tensors with prefix '%s' in the state dict" % prefix)
+        check(lib().dsvc_denoiser_finalize(self._h))
+
+    def forward(self, spec, t, cond, cond_changed=True):
+        """DiffNet.forward: spec [B,1,M,T], t [B] (any int dtype), cond [B,H,T] -> [B,1,M,T]."""
+        _need_cuda(spec, t, cond)
+        B, _, M, T = spec.shape
+        if M != self.mel_bins or cond.shape != (B, self.hidden, T):
+            raise ValueError("shape mismatch: spec %s cond %s" % (tuple(spec.shape), tuple(cond.shape)))
+        spec = spec.contiguous().float()
+        cond = cond.contiguous().float()
+        t32 = t.to(torch.int32).contiguous()
+        out = torch.empty_like(spec)
+        check(lib().dsvc_denoiser_forward(self._h, ptr(spec), ptr(t32), ptr(cond), ptr(out), B, T,
+                                          1 if cond_changed else 0, stream_ptr()))
+        return out
+
+    def debug_buffer(self, name):
+        """Copy of an internal frame-major buffer as a [rows, ld] tensor (parity-test aid)."""
+        rows, ld = ctypes.c_int32(0), ctypes.c_int32(0)
+        check(lib().dsvc_denoiser_debug_buffer(self._h, name.encode(), None, 0, ctypes.byref(rows), ctypes.byref(ld)))
+        out = torch.empty(rows.value, ld.value, device="cuda", dtype=torch.float32)
+        check(lib().dsvc_denoiser_debug_buffer(self._h, name.encode(), ptr(out), out.numel(), None, None))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().dsvc_denoiser_destroy(self._h)
+                self._h = ctypes.c_void_p(0)
+        except Exception:
+            pass
+
+
+class SamplerHandle:
+    """dsvc_sampler: schedule tables + DDPM / PLMS loops driving a DenoiserHandle."""
+
+    def __init__(self, denoiser, state):
+        self._h = ctypes.c_void_p(0)
+        self.den = denoiser
+        check(lib().dsvc_sampler_create(denoiser._h, ctypes.byref(self._h)))
+        for k in SCHEDULE_KEYS:
+            if k not in state:
+                raise KeyError("schedule buffer '%s' missing from the checkpoint state dict" % k)
+            h, p = host_f32(state[k].reshape(-1))
+            check(lib().dsvc_sampler_load_tensor(self._h, k.encode(), p, h.numel()))
+        check(lib().dsvc_sampler_finalize(self._h))
+
+    def sample(self, cond, t_start, speedup=1, x_init=None, mel2ph=None, seed=0, first_clip=0, t_stop=0,
+               use_graph=True, return_x=False):
+        """cond [B,H,T] -> mel_out [B,T,M] (denormalised, masked).  See dsvc_sample_args."""
+        _need_cuda(cond, x_init, mel2ph)
+        B, H, T = cond.shape
+        M = self.den.mel_bins
+        cond = cond.contiguous().float()
+        mel = torch.empty(B, T, M, device=cond.device, dtype=torch.float32)
+        xo = torch.empty(B, 1, M, T, device=cond.device, dtype=torch.float32) if return_x else None
+        xi = x_init.contiguous().float() if x_init is not None else None
+        m2p = mel2ph.to(torch.int32).contiguous() if mel2ph is not None else None
+        a = _lib.SampleArgs(B, T, cond.data_ptr(), xi.data_ptr() if xi is not None else None, None,
+                            m2p.data_ptr() if m2p is not None else None, seed, first_clip, t_start, t_stop,
+                            int(speedup), 1 if use_graph else 0, mel.data_ptr(), xo.data_ptr() if xo is not None else None)
+        check(lib().dsvc_sample(self._h, ctypes.byref(a), stream_ptr()))
+        return (mel, xo) if return_x else mel
+
+    def profile_gate_kernel(self, B, T, iters=5):
+        us = ctypes.c_float(0)
+        rows = ctypes.c_int64(0)
+        check(lib().dsvc_sampler_profile_gate_kernel(self._h, B, T, iters, ctypes.byref(us), ctypes.byref(rows), stream_ptr()))
+        return us.value, rows.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().dsvc_sampler_destroy(self._h)
+                self._h = ctypes.c_void_p(0)
+        except Exception:
+            pass

@@ -1,0 +1,164 @@
+/* dsvc.h -- C ABI of the MI355X-native diff-svc hot path (libdsvc_hip.so).
+ *
+ * The reference (prophesier/diff-svc) is pure Python; its "FFI" for this path is the set of Python
+ * plugin seams listed in SURVEY.md 8(b).  Each entry point below names the reference interface it
+ * replaces (file:line under /root/reference).  A binding needs nothing but ctypes: plain pointers,
+ * sizes and an opaque stream handle -- no torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a non-zero DSVC_E* code otherwise; nothing throws across
+ *     the ABI; dsvc_last_error() returns the calling thread's last message.
+ *   - "device" pointers are HIP device pointers owned by the caller (e.g. tensor.data_ptr()); they are
+ *     never retained past the call.  "host" pointers are read during the call only.
+ *   - work is enqueued on the caller's hipStream_t (void*; NULL = default stream).  Handles are
+ *     single-caller (the reference is not re-entrant either: diffusion.py:96,270).
+ *   - all floating-point tensors are fp32, C-contiguous, in the reference's own layouts.
+ */
+#ifndef DSVC_H
+#define DSVC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSVC_ABI_VERSION 1
+
+enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM = 4 };
+
+/* Operand precision of the MFMA contractions (fp32 accumulate everywhere):
+ *   F16    : w, x rounded to fp16                      1 MFMA per product   (~1e-2 mel error after 1000 steps)
+ *   F16_W2 : w = w_hi + w_lo, x fp16                   2 MFMAs              (passes the 1e-3 mel bar)
+ *   F16_X3 : w = w_hi + w_lo, x = x_hi + x_lo          3 MFMAs              (fp32-class, ~1e-5)           */
+enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2 };
+
+int dsvc_abi_version(void);
+const char* dsvc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Denoiser -- replaces network/diff/net.py:86-135 (class DiffNet), selected through the DIFF_DECODERS
+ * registry (infer_tools/infer_tool.py:107-111,124; training/task/SVC_task.py:19-23).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsvc_denoiser dsvc_denoiser;
+
+typedef struct {
+    int32_t mel_bins;        /* in_dims = hparams['audio_num_mel_bins']          (net.py:87)  */
+    int32_t hidden;          /* encoder_hidden = hparams['hidden_size']          (net.py:91)  */
+    int32_t channels;        /* residual_channels                                 (net.py:93)  */
+    int32_t layers;          /* residual_layers                                   (net.py:92)  */
+    int32_t dilation_cycle;  /* dilation_cycle_length                             (net.py:94)  */
+    int32_t max_steps;       /* number of integer diffusion steps to tabulate (timesteps)      */
+    int32_t precision;       /* DSVC_PREC_* for the two big per-layer contractions              */
+} dsvc_denoiser_cfg;
+
+int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out);
+/* name = state_dict key of DiffNet (e.g. "residual_layers.3.dilated_conv.weight"); host fp32 data in the
+ * checkpoint's own layout (Conv1d [out,in,k], Linear [out,in]).  Replaces load_state_dict for this module
+ * (utils/__init__.py:178-209). */
+int dsvc_denoiser_load_tensor(dsvc_denoiser* d, const char* name, const float* host, int64_t numel);
+/* packs weights into MFMA fragment order on the device and builds the step-embedding / FiLM tables */
+int dsvc_denoiser_finalize(dsvc_denoiser* d);
+void dsvc_denoiser_destroy(dsvc_denoiser* d);
+
+/* DiffNet.forward(spec, diffusion_step, cond)  (net.py:112-135)
+ *   spec [B,1,M,T] device, t [B] int32 device (one step per clip), cond [B,H,T] device -> out [B,1,M,T] device.
+ * cond_changed != 0 recomputes the hoisted conditioner projections (they depend on cond only). */
+int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t, const float* cond,
+                          float* out, int32_t B, int32_t T, int32_t cond_changed, void* stream);
+
+/* debugging aid for the parity tests: copy an internal frame-major buffer ("xres", "g", "skip", "s2", "eps",
+ * "condT", "cproj", "film", "xin") to a device pointer; rows/ld receive its logical shape. */
+int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, int64_t numel, int32_t* rows, int32_t* ld);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampler -- replaces GaussianDiffusion.forward(infer=True) from the initial x to mel_out
+ * (network/diff/diffusion.py:255-283) with p_sample (:156-163) and p_sample_plms (:165-198).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsvc_sampler dsvc_sampler;
+
+int dsvc_sampler_create(dsvc_denoiser* d, dsvc_sampler** out);
+/* the registered buffers of GaussianDiffusion (diffusion.py:100-123): "alphas_cumprod",
+ * "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+ * "posterior_mean_coef2", "posterior_log_variance_clipped", "sqrt_alphas_cumprod",
+ * "sqrt_one_minus_alphas_cumprod", "spec_min", "spec_max".  Taken from the checkpoint, never recomputed
+ * (SURVEY.md 0.8). */
+int dsvc_sampler_load_tensor(dsvc_sampler* s, const char* name, const float* host, int64_t numel);
+int dsvc_sampler_finalize(dsvc_sampler* s);
+void dsvc_sampler_destroy(dsvc_sampler* s);
+
+typedef struct {
+    int32_t B, T;              /* clips, mel frames per clip                                               */
+    const float* cond;         /* [B,H,T] device: ret['decoder_inp'].transpose(1,2)  (diffusion.py:232-234) */
+    const float* x_init;       /* [B,1,M,T] device, or NULL: x_T ~ N(0,1) from Philox(seed, clip)          */
+    const float* ref_mel;      /* [B,T,M] device or NULL: use_gt_mel start (diffusion.py:255-261)          */
+    const int32_t* mel2ph;     /* [B,T] device or NULL: output mask (mel2ph > 0)      (diffusion.py:280-281) */
+    uint64_t seed;             /* Philox key for x_T and the per-step noise z                                */
+    int32_t first_clip;        /* Philox clip id of batch element 0 (clip b uses first_clip + b)             */
+    int32_t t_start;           /* K_step, or add_noise_step with ref_mel: runs t = t_start-1 ... 0           */
+    int32_t t_stop;            /* normally 0; tests may stop the chain early (runs down to t_stop)           */
+    int32_t speedup;           /* hparams['pndm_speedup']: <= 1 -> DDPM, > 1 -> PLMS with that interval      */
+    int32_t use_graph;         /* replay the step through a captured hipGraph (1) or launch eagerly (0)      */
+    float* mel_out;            /* [B,T,M] device: denorm_spec(x) * (mel2ph > 0)                              */
+    float* x_out;              /* [B,1,M,T] device or NULL: final normalised state (for tests)              */
+} dsvc_sample_args;
+
+int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream);
+
+/* per-kernel timing of the last dsvc_sample call, for bench.py's roofline: average duration in
+ * microseconds of the dominant kernel (dilated conv + gate) measured with HIP events on the launch
+ * stream, and the number of frames (rows) one launch processed. */
+int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters,
+                                     float* avg_us, int64_t* rows, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vocoder -- replaces modules/nsf_hifigan/models.py:325-387 (Generator.forward) + :14-30 (load_model),
+ * called through network/vocoders/nsf_hifigan.py:47-73 (NsfHifiGAN.spec2wav).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsvc_vocoder dsvc_vocoder;
+
+typedef struct {
+    int32_t num_mels, upsample_initial_channel, sampling_rate;
+    int32_t n_ups;                 /* len(upsample_rates) <= 8   */
+    int32_t upsample_rates[8];
+    int32_t upsample_kernel_sizes[8];
+    int32_t n_kernels;             /* len(resblock_kernel_sizes) <= 4 */
+    int32_t resblock_kernel_sizes[4];
+    int32_t resblock_dilations[4][3];
+    int32_t harmonics;             /* harmonic_num = 8 (models.py:334) */
+    int32_t precision;             /* DSVC_PREC_* (F16_X3 keeps the waveform within 1e-4 RMS) */
+} dsvc_vocoder_cfg;
+
+int dsvc_vocoder_create(const dsvc_vocoder_cfg* cfg, dsvc_vocoder** out);
+/* name = key of the checkpoint's 'generator' dict, weight-norm pairs included
+ * ("ups.0.weight_g", "ups.0.weight_v", ...); folded here like remove_weight_norm (models.py:28,389-396). */
+int dsvc_vocoder_load_tensor(dsvc_vocoder* v, const char* name, const float* host, int64_t numel);
+int dsvc_vocoder_finalize(dsvc_vocoder* v);
+void dsvc_vocoder_destroy(dsvc_vocoder* v);
+
+/* Generator.forward(2.30259 * mel^T, f0)   mel [B,T,M] log10 device, f0 [B,T] Hz device -> wav [B, T*hop] device.
+ * The source module's random draws (models.py:192,271) come from Philox(seed, first_clip + b). */
+int dsvc_vocode(dsvc_vocoder* v, const float* mel, const float* f0, float* wav, int32_t B, int32_t T,
+                uint64_t seed, int32_t first_clip, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mel front-end -- replaces modules/nsf_hifigan/nvSTFT.py:72-104 (STFT.get_mel) + the log10 scale of
+ * network/vocoders/nsf_hifigan.py:86-91 (wav2spec).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsvc_melspec dsvc_melspec;
+
+typedef struct {
+    int32_t n_fft, win_size, hop, n_mels;
+    float clip_val;                /* 1e-5 */
+} dsvc_melspec_cfg;
+
+/* mel_basis: host [n_mels][n_fft/2+1] fp32 (librosa.filters.mel, built by the Python host) */
+int dsvc_melspec_create(const dsvc_melspec_cfg* cfg, const float* mel_basis, dsvc_melspec** out);
+void dsvc_melspec_destroy(dsvc_melspec* m);
+/* wav [B,N] device -> mel [B,T,n_mels] log10 device, T = (N - hop) / hop + 1 ... see dsvc_melspec_frames */
+int dsvc_melspec_frames(const dsvc_melspec* m, int64_t n_samples, int32_t* frames);
+int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, int64_t n_samples, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSVC_H */

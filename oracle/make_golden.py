@@ -1,0 +1,121 @@
+"""Mint tests/golden/*.npz by running the REAL reference (/root/reference, imported behind
+oracle/refshim.py) on synthetic checkpoints and seeded inputs.  Container-only: the GPU box has no
+/root/reference, it only sees the committed vectors.  TEST INFRASTRUCTURE.
+
+    python oracle/make_golden.py
+
+Random draws of the reference (torch.randn in diffusion.py:34-37,160,265-268 and models.py:192,271) are
+replaced by the Philox streams of oracle/dsvc_oracle.py so that a GPU kernel can reproduce them.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import diffsvc_amd  # noqa: E402
+from diffsvc_amd import synth  # noqa: E402
+import dsvc_oracle as O  # noqa: E402
+import refshim  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED = 20260922
+
+
+def build_reference_model(hp, sd):
+    refshim.set_hparams(hp)
+    from network.diff.diffusion import GaussianDiffusion
+    from network.diff.net import DiffNet
+    m = GaussianDiffusion(None, hp["audio_num_mel_bins"], DiffNet(hp["audio_num_mel_bins"]),
+                          timesteps=hp["timesteps"], K_step=hp["K_step"], loss_type=hp["diff_loss_type"],
+                          spec_min=hp["spec_min"], spec_max=hp["spec_max"])
+    m.load_state_dict(sd, strict=True)          # the strict load the real tool does (utils/__init__.py:202)
+    return m.eval()
+
+
+def clip_batch(hp, clips, T, n_units):
+    hub, m2p, f0 = [], [], []
+    for c in clips:
+        h, m, f, _ = synth.clip_inputs(c, T=T, n_units=n_units, H=hp["hidden_size"])
+        hub.append(h); m2p.append(m); f0.append(f)
+    return (torch.from_numpy(np.stack(hub)), torch.from_numpy(np.stack(m2p)), torch.from_numpy(np.stack(f0)))
+
+
+def run_reference_sampler(model, hp, hub, m2p, f0, clips, speedup, seed):
+    """GaussianDiffusion.forward(infer=True) with Philox noise injected."""
+    import network.diff.diffusion as D
+    B, T = m2p.shape
+    M = hp["audio_num_mel_bins"]
+    state = {"t": None}
+    orig_noise_like, orig_p_sample, orig_randn = D.noise_like, model.p_sample, torch.randn
+
+    def noise_like(shape, device, repeat=False):
+        return O.ddpm_noise_ref_layout(seed, clips, state["t"], T, M)
+
+    def p_sample(x, t, cond, **kw):
+        state["t"] = int(t[0])
+        return orig_p_sample(x, t, cond, **kw)
+
+    def randn(*shape, **kw):
+        shape = shape[0] if len(shape) == 1 and not isinstance(shape[0], int) else shape
+        assert tuple(shape) == (B, 1, M, T), shape
+        return O.ddpm_noise_ref_layout(seed, clips, 0, T, M, O.PURPOSE_X_INIT)
+
+    D.noise_like = noise_like
+    model.p_sample = p_sample
+    torch.randn = randn
+    refshim.set_hparams(dict(hp, pndm_speedup=speedup))
+    try:
+        with torch.no_grad():
+            ret = model(hub.clone(), mel2ph=m2p.clone(), f0=f0.clone(), uv=None, energy=None, ref_mels=None, infer=True)
+    finally:
+        D.noise_like, model.p_sample, torch.randn = orig_noise_like, orig_p_sample, orig_randn
+    return ret
+
+
+def golden_diffnet(name, hp, wseed, B, T):
+    sd = synth.acoustic_state(hp, wseed)
+    model = build_reference_model(hp, sd)
+    g = np.random.Generator(np.random.PCG64(SEED + T))
+    M, H = hp["audio_num_mel_bins"], hp["hidden_size"]
+    spec = torch.from_numpy(g.standard_normal((B, 1, M, T)).astype(np.float32))
+    cond = torch.from_numpy((g.standard_normal((B, H, T)) * 0.5).astype(np.float32))
+    t = torch.from_numpy(g.integers(0, hp["timesteps"], size=(B,)).astype(np.int64))
+    with torch.no_grad():
+        out = model.denoise_fn(spec, t, cond)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), spec=spec.numpy(), cond=cond.numpy(), t=t.numpy(),
+                        out=out.numpy(), wseed=wseed)
+    print(name, "out std %.3f" % out.std().item())
+
+
+def golden_sampler(name, hp, wseed, clips, T, n_units, speedup, seed):
+    sd = synth.acoustic_state(hp, wseed)
+    model = build_reference_model(hp, sd)
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    ret = run_reference_sampler(model, hp, hub, m2p, f0, clips, speedup, seed)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), mel_out=ret["mel_out"].numpy(),
+                        decoder_inp=ret["decoder_inp"].numpy(), f0_denorm=ret["f0_denorm"].numpy(),
+                        pitch=ret["pitch_pred"].numpy(), wseed=wseed, clips=np.array(clips), T=T, n_units=n_units,
+                        speedup=speedup, seed=seed, K_step=hp["K_step"])
+    print(name, "mel range %.3f..%.3f" % (ret["mel_out"].min().item(), ret["mel_out"].max().item()))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    tiny = synth.tiny_hparams()
+    full = dict(synth.HPARAMS_44K)
+    golden_diffnet("diffnet_tiny", tiny, 3, B=2, T=40)
+    golden_diffnet("diffnet_44k", full, 0, B=2, T=48)
+    golden_sampler("ddpm_tiny", tiny, 3, clips=[0, 5], T=40, n_units=23, speedup=1, seed=77)
+    golden_sampler("plms_tiny_s10", tiny, 3, clips=[2], T=40, n_units=23, speedup=10, seed=78)
+    golden_sampler("plms_tiny_s5", tiny, 3, clips=[1], T=52, n_units=30, speedup=5, seed=79)
+    golden_sampler("ddpm_44k_k20", dict(full, K_step=20), 0, clips=[0], T=32, n_units=19, speedup=1, seed=80)
+    golden_sampler("plms_44k_k100_s20", dict(full, K_step=100), 0, clips=[4], T=32, n_units=19, speedup=20, seed=81)
+
+
+if __name__ == "__main__":
+    main()

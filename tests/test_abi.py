@@ -1,0 +1,35 @@
+"""CPU: the C-ABI shared library builds, loads and exports every symbol include/dsvc.h declares.
+No compute call is made here (there is no GPU in the build container)."""
+import os
+import re
+
+import pytest
+
+import diffsvc_amd
+from diffsvc_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from diffsvc_amd import build
+    build.build(verbose=False)              # incremental: a no-op when the .so is newer than its sources
+    lib = _lib.lib()
+    assert lib.dsvc_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "dsvc.h")).read()
+    declared = set(re.findall(r"\b(dsvc_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_error_convention_without_gpu():
+    import ctypes
+    lib = _lib.lib()
+    h = ctypes.c_void_p(0)
+    rc = lib.dsvc_denoiser_create(None, ctypes.byref(h))
+    assert rc != 0 and b"null" in lib.dsvc_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(rc)

