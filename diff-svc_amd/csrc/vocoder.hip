@@ -1,10 +1,528 @@
-// placeholder until the vocoder lands (keeps the ABI symbol set complete)
-#include "common.h"
+// NSF-HiFiGAN generator behind the C ABI (include/dsvc.h).
+// Reference: modules/nsf_hifigan/models.py:14-30 (load_model), :33-64 (ResBlock1), :148-323 (SineGen,
+// SourceModuleHnNSF), :325-387 (Generator); called through network/vocoders/nsf_hifigan.py:47-73.
+//
+// Layout: every activation is frame-major fp32 [rows][channels]; row = clip*clip_stride_s + n at the stage's
+// sample rate.  All dense convs go through conv_gemm (MFMA, split-fp16 operands):
+//   * Conv1d(k, dilation d)          -> taps = k, dil = d
+//   * ConvTranspose1d(k, stride u)   -> polyphase: a 3-tap conv over the INPUT rows producing u*cout columns;
+//                                       column phi*cout+co of input row q is output sample q*u+phi, which is
+//                                       exactly the frame-major address of the upsampled signal.
+//   * leaky_relu in front of a conv  -> applied while the tile is staged into LDS (ConvGemmArgs::in_slope)
+//   * "+ x", MRF mean, "+ x_source"  -> epilogue (EpiAffine: out = alpha*(acc + b + res) + beta*out)
+#include <math.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "conv_gemm.h"
+
 using namespace dsvc;
-extern "C" {
-int dsvc_vocoder_create(const dsvc_vocoder_cfg*, dsvc_vocoder**) { return fail(DSVC_ESTATE, "vocoder not built yet"); }
-int dsvc_vocoder_load_tensor(dsvc_vocoder*, const char*, const float*, int64_t) { return fail(DSVC_ESTATE, "vocoder not built yet"); }
-int dsvc_vocoder_finalize(dsvc_vocoder*) { return fail(DSVC_ESTATE, "vocoder not built yet"); }
-void dsvc_vocoder_destroy(dsvc_vocoder*) {}
-int dsvc_vocode(dsvc_vocoder*, const float*, const float*, float*, int32_t, int32_t, uint64_t, int32_t, void*) { return fail(DSVC_ESTATE, "vocoder not built yet"); }
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        if (n <= bytes && p) return DSVC_OK;
+        release();
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; return fail(DSVC_ENOMEM, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
+        bytes = n;
+        return DSVC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+int upload(DevBuf& b, const void* host, size_t bytes) {
+    DSVC_TRY(b.alloc(bytes));
+    DSVC_HIP(hipMemcpy(b.p, host, bytes, hipMemcpyHostToDevice));
+    return DSVC_OK;
 }
+
+// ---- epilogues ----
+struct EpiAffine {
+    static constexpr bool PAIRED = false;
+    struct Args {
+        float* out; int ld;
+        const float* bias; int bias_mod;     // bias index = col % bias_mod
+        int cout;                            // valid columns
+        const float* res; int ldres;         // optional residual
+        float alpha;
+        int accumulate;                      // out = alpha*(..) + out
+    };
+    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
+        if (col >= e.cout) return;
+        v += e.bias[col % e.bias_mod];
+        if (e.res) v += e.res[(size_t)row * e.ldres + col];
+        v *= e.alpha;
+        float* p = e.out + (size_t)row * e.ld + col;
+        if (e.accumulate) v += *p;
+        *p = v;
+    }
+};
+
+// conv_post + tanh (models.py:383-385): column 0 only, written to the caller's [B][clip_len] waveform
+struct EpiTanhWav {
+    static constexpr bool PAIRED = false;
+    struct Args { float* wav; const float* bias; int clip_stride, clip_len; };
+    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
+        if (col != 0) return;
+        const int clip = row / e.clip_stride;
+        const int n = row - clip * e.clip_stride;
+        if (n < e.clip_len) e.wav[(size_t)clip * e.clip_len + n] = tanhf(v + e.bias[0]);
+    }
+};
+
+template <class Epi, int NW, int NA>
+int voc_tiling(const ConvGemmArgs& a, const typename Epi::Args& e, hipStream_t st) {
+    if (a.cin % 64 == 0) {
+        if (a.n_ctiles >= 8) return conv_gemm_launch<4, 4, 1, 64, 2, NW, NA, Epi>(a, e, st);
+        if (a.n_ctiles >= 4) return conv_gemm_launch<4, 2, 1, 64, 2, NW, NA, Epi>(a, e, st);
+        return conv_gemm_launch<4, 1, 1, 64, 2, NW, NA, Epi>(a, e, st);
+    }
+    if (a.cin % 32 == 0) return conv_gemm_launch<4, 1, 1, 32, 2, NW, NA, Epi>(a, e, st);
+    return conv_gemm_launch<4, 1, 1, 16, 1, NW, NA, Epi>(a, e, st);
+}
+
+template <class Epi>
+int voc_dispatch(const ConvGemmArgs& a, const typename Epi::Args& e, int prec, hipStream_t st) {
+    switch (prec) {
+        case DSVC_PREC_F16: return voc_tiling<Epi, 1, 1>(a, e, st);
+        case DSVC_PREC_F16_W2: return voc_tiling<Epi, 2, 1>(a, e, st);
+        default: return voc_tiling<Epi, 2, 2>(a, e, st);
+    }
+}
+
+struct PackedConv {
+    DevBuf w, bias;
+    int n_ctiles = 0, taps = 1, cin = 0, cout = 0, dil = 1;
+};
+
+template <class FW>
+int pack_conv(PackedConv& pc, int cout, int taps, int cin, int dil, FW&& src, const float* bias, int nbias) {
+    pc.n_ctiles = round_up(ceil_div(cout, 32), 2);
+    pc.taps = taps; pc.cin = cin; pc.cout = cout; pc.dil = dil;
+    std::vector<_Float16> h(packed_halfs(pc.n_ctiles, taps, cin, 2));
+    pack_fragments(h.data(), pc.n_ctiles, taps, cin, 2, [&](int col, int tap, int ci) { return col < cout ? src(col, tap, ci) : 0.f; });
+    DSVC_TRY(upload(pc.w, h.data(), h.size() * sizeof(_Float16)));
+    return upload(pc.bias, bias, (size_t)nbias * sizeof(float));
+}
+
+// ---- small kernels ----
+
+// mel [B][T][M] (log10) -> frame-major [B*stride][M] natural log (nsf_hifigan.py:63-65: c = 2.30259 * mel)
+__global__ void k_prep_mel(const float* __restrict__ mel, float* __restrict__ dst, int B, int T, int M, int stride) {
+    const size_t n = (size_t)B * T * M;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % M);
+        const size_t bt = i / M;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        dst[((size_t)b * stride + t) * M + m] = 2.30259f * mel[i];
+    }
+}
+
+// ---- harmonic source (SineGen._f02sine, models.py:183-213) in closed form ----
+// torch's CPU cumsum accumulates fp32 inputs in double, and f0 is piecewise constant (nearest upsampling), so
+// the running sum inside frame f is  base_f + (j+1)*r_f.  The "-1 at every wrap" shift (models.py:205-209)
+// fires exactly when floor(fp32(cumsum)) increases, so the number of shifts up to a sample is a difference
+// of floors, and the fp32 rounding of (rad - 1) adds delta_f per shift.  A tiny sequential pass per
+// (clip, harmonic) over the T frames produces the per-frame constants; the per-sample pass is then parallel.
+struct SrcFrame { double base; double flprev; double delta_acc; };
+
+__global__ void k_source_frames(const float* __restrict__ f0, SrcFrame* __restrict__ fr, float* __restrict__ fl00,
+                                int T, int hop, int dim, float sr, unsigned long long seed, int clip0) {
+    const int b = blockIdx.x, h = threadIdx.x;
+    if (h >= dim) return;
+    float ini = 0.f;
+    if (h > 0) {
+        const u32x4 r = philox4x32((unsigned)(h >> 2), 0u, (unsigned)(clip0 + b), PURPOSE_SINE_PHASE, seed);
+        const unsigned w = (h & 3) == 0 ? r.x : (h & 3) == 1 ? r.y : (h & 3) == 2 ? r.z : r.w;
+        ini = u01_open_high(w);
+    }
+    const float mult = (float)(h + 1);
+    double base = 0.0, delta_acc = 0.0, flprev = 0.0;
+    for (int f = 0; f < T; ++f) {
+        const float fh = f0[(size_t)b * T + f] * mult;
+        const float q = __fdiv_rn(fh, sr);
+        const float r = q - floorf(q);                          // (f / sr) % 1, f >= 0
+        if (f == 0) {
+            const float rad0 = r + ini;                         // rad_values[:, 0, :] += rand_ini  (fp32)
+            base = (double)rad0 - (double)r;
+            flprev = (double)floorf(rad0);                      // floor(fp32(cumsum[0])): no shift at sample 0
+            fl00[b * dim + h] = (float)flprev;
+        }
+        SrcFrame o; o.base = base; o.flprev = flprev; o.delta_acc = delta_acc;
+        fr[((size_t)b * T + f) * dim + h] = o;
+        const double d_end = base + (double)hop * (double)r;
+        const double flend = (double)floorf((float)d_end);
+        const float sr32 = r + (-1.0f);                         // fp32(rad + shift)
+        const double delta = (double)sr32 - ((double)r - 1.0);
+        delta_acc += delta * (flend - flprev);
+        flprev = flend;
+        base = d_end;
+    }
+}
+
+__global__ void k_source_samples(const float* __restrict__ f0, const SrcFrame* __restrict__ fr, const float* __restrict__ fl00,
+                                 const float* __restrict__ lin_w, const float* __restrict__ lin_b, float* __restrict__ har,
+                                 int T, int hop, int dim, float sr, int stride_samples, unsigned long long seed, int clip0,
+                                 float sine_amp, float noise_std) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * hop) return;
+    const int f = i / hop, j = i - f * hop;
+    const float f0v = f0[(size_t)b * T + f];
+    const float uv = f0v > 0.f ? 1.f : 0.f;
+    const float noise_amp = uv * noise_std + ((1.f - uv) * sine_amp) / 3.f;
+    float zs[12];
+    for (int q = 0; q < (dim + 3) / 4; ++q)
+        philox_normal4((unsigned)i, (unsigned)q, (unsigned)(clip0 + b), PURPOSE_SINE_NOISE, seed, zs + 4 * q);
+    float acc = 0.f;
+    for (int h = 0; h < dim; ++h) {
+        const float fh = f0v * (float)(h + 1);
+        const float q = __fdiv_rn(fh, sr);
+        const float r = q - floorf(q);
+        const SrcFrame s = fr[((size_t)b * T + f) * dim + h];
+        const double D = s.base + (double)(j + 1) * (double)r;
+        const double fl = (double)floorf((float)D);
+        const float sr32 = r + (-1.0f);
+        const double delta = (double)sr32 - ((double)r - 1.0);
+        const double P = D - (fl - (double)fl00[b * dim + h]) + s.delta_acc + delta * (fl - s.flprev);
+        const float ph = (float)P;
+        const float sine = sinf((ph * 2.0f) * 3.14159265358979323846f) * sine_amp;
+        const float v = sine * uv + noise_amp * zs[h];
+        acc += lin_w[h] * v;
+    }
+    har[(size_t)b * stride_samples + i] = tanhf(acc + lin_b[0]);
+}
+
+// noise_convs[i] (models.py:346-350): Conv1d(1, cout, kernel K, stride s, padding pad) on the excitation,
+// written (not accumulated) into the stage's frame-major buffer before the transposed conv adds onto it.
+__global__ void k_noise_conv(const float* __restrict__ har, const float* __restrict__ w, const float* __restrict__ bias,
+                             float* __restrict__ out, int cout, int K, int s, int pad, int len_out, int len_in,
+                             int stride_out, int stride_in) {
+    extern __shared__ float sm[];          // [64*s + K] excitation samples
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * 64;
+    const int span = 63 * s + K;
+    const int base = n0 * s - pad;
+    for (int i = threadIdx.x; i < span; i += blockDim.x) {
+        const int p = base + i;
+        sm[i] = (p >= 0 && p < len_in) ? har[(size_t)b * stride_in + p] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * cout; e += blockDim.x) {
+        const int nl = e / cout, co = e - nl * cout;
+        const int n = n0 + nl;
+        if (n >= len_out) continue;
+        const float* wr = w + (size_t)co * K;
+        float acc = 0.f;
+        for (int j = 0; j < K; ++j) acc = fmaf(wr[j], sm[nl * s + j], acc);
+        out[((size_t)b * stride_out + n) * cout + co] = acc + bias[co];
+    }
+}
+
+}  // namespace
+
+// =================================================================================================
+struct dsvc_vocoder {
+    dsvc_vocoder_cfg cfg;
+    std::map<std::string, std::vector<float>> host;
+    bool finalized = false;
+    int hop = 1, dim = 9;
+
+    PackedConv conv_pre, conv_post;
+    std::vector<PackedConv> ups;                 // polyphase transposed convs
+    std::vector<DevBuf> nc_w, nc_b;              // noise convs (plain fp32)
+    std::vector<int> nc_k, nc_s, nc_pad;
+    std::vector<PackedConv> rb1, rb2;            // [stage*nk*3 + j*3 + m]
+    DevBuf lin_w, lin_b;
+    int gap_frames = 8;
+
+    // workspace
+    int wsB = 0, wsT = 0, Tp = 0;
+    DevBuf mel_in, har, frames, fl00, buf[5];
+
+    ~dsvc_vocoder() {
+        auto rel = [](PackedConv& p) { p.w.release(); p.bias.release(); };
+        rel(conv_pre); rel(conv_post);
+        for (auto& p : ups) rel(p);
+        for (auto& p : rb1) rel(p);
+        for (auto& p : rb2) rel(p);
+        for (auto& b : nc_w) b.release();
+        for (auto& b : nc_b) b.release();
+        for (DevBuf* b : {&lin_w, &lin_b, &mel_in, &har, &frames, &fl00, &buf[0], &buf[1], &buf[2], &buf[3], &buf[4]}) b->release();
+    }
+
+    // folded weight of a weight-normed layer, or the plain weight (remove_weight_norm, models.py:28,389-396)
+    int folded(const std::string& base, size_t numel, int dim0, std::vector<float>& out) {
+        auto wi = host.find(base + ".weight");
+        if (wi != host.end()) {
+            if (wi->second.size() != numel) return fail(DSVC_EINVAL, "vocoder: '%s.weight' has %zu elements, expected %zu", base.c_str(), wi->second.size(), numel);
+            out = wi->second;
+            return DSVC_OK;
+        }
+        auto gi = host.find(base + ".weight_g"), vi = host.find(base + ".weight_v");
+        if (gi == host.end() || vi == host.end()) return fail(DSVC_ESTATE, "vocoder: neither '%s.weight' nor its weight_g/weight_v pair was loaded", base.c_str());
+        if (vi->second.size() != numel || (int)gi->second.size() != dim0)
+            return fail(DSVC_EINVAL, "vocoder: '%s' weight_v/weight_g have %zu/%zu elements, expected %zu/%d", base.c_str(), vi->second.size(), gi->second.size(), numel, dim0);
+        out.resize(numel);
+        const size_t inner = numel / dim0;
+        for (int o = 0; o < dim0; ++o) {
+            const float* v = vi->second.data() + (size_t)o * inner;
+            float ss = 0.f;
+            for (size_t i = 0; i < inner; ++i) ss += v[i] * v[i];
+            const float sc = gi->second[o] / sqrtf(ss);
+            for (size_t i = 0; i < inner; ++i) out[(size_t)o * inner + i] = v[i] * sc;
+        }
+        return DSVC_OK;
+    }
+    const std::vector<float>* plain(const std::string& k, size_t numel) {
+        auto it = host.find(k);
+        if (it == host.end()) { fail(DSVC_ESTATE, "vocoder: tensor '%s' was never loaded", k.c_str()); return nullptr; }
+        if (it->second.size() != numel) { fail(DSVC_EINVAL, "vocoder: tensor '%s' has %zu elements, expected %zu", k.c_str(), it->second.size(), numel); return nullptr; }
+        return &it->second;
+    }
+
+    int finalize();
+    int ensure_ws(int B, int T);
+    int run(const float* mel, const float* f0, float* wav, int B, int T, unsigned long long seed, int clip0, hipStream_t st);
+};
+
+int dsvc_vocoder::finalize() {
+    const int nu = cfg.n_ups, nk = cfg.n_kernels, ch0 = cfg.upsample_initial_channel, M = cfg.num_mels;
+    if (nu < 1 || nu > 8 || nk < 1 || nk > 4) return fail(DSVC_EINVAL, "vocoder: bad stage / kernel counts");
+    if (M % 16) return fail(DSVC_EINVAL, "vocoder: num_mels must be a multiple of 16");
+    dim = cfg.harmonics + 1;
+    if (dim > 12) return fail(DSVC_EINVAL, "vocoder: at most 11 harmonics");
+    hop = 1;
+    for (int i = 0; i < nu; ++i) hop *= cfg.upsample_rates[i];
+    if ((ch0 >> nu) < 16 || ((ch0 >> nu) % 16)) return fail(DSVC_EINVAL, "vocoder: channel count after the last stage must be a multiple of 16");
+    std::vector<float> w;
+    {   // conv_pre: Conv1d(num_mels, ch0, 7, padding 3)  (models.py:336)
+        DSVC_TRY(folded("conv_pre", (size_t)ch0 * M * 7, ch0, w));
+        const std::vector<float>* b = plain("conv_pre.bias", ch0);
+        if (!b) return DSVC_ESTATE;
+        DSVC_TRY(pack_conv(conv_pre, ch0, 7, M, 1, [&](int co, int tap, int ci) { return w[((size_t)co * M + ci) * 7 + tap]; }, b->data(), ch0));
+    }
+    ups.resize(nu); nc_w.resize(nu); nc_b.resize(nu); nc_k.resize(nu); nc_s.resize(nu); nc_pad.resize(nu);
+    rb1.resize((size_t)nu * nk * 3); rb2.resize((size_t)nu * nk * 3);
+    int need_gap = 3;
+    int rate = 1;
+    for (int i = 0; i < nu; ++i) {
+        const int u = cfg.upsample_rates[i], k = cfg.upsample_kernel_sizes[i];
+        const int cin = ch0 >> i, cout = ch0 >> (i + 1);
+        const int p = (k - u) / 2;
+        if ((k - u) % 2) return fail(DSVC_EINVAL, "vocoder: upsample kernel %d / rate %d: odd padding is not supported", k, u);
+        // ConvTranspose1d(cin, cout, k, u, padding p) (models.py:342-345), weight [cin][cout][k], as a polyphase conv:
+        //   out[q*u + phi] = sum_o sum_ci W[ci][co][phi + p - o*u] * x[q + o],   o in [omin, omax]
+        DSVC_TRY(folded("ups." + std::to_string(i), (size_t)cin * cout * k, cin, w));
+        const std::vector<float>* b = plain("ups." + std::to_string(i) + ".bias", cout);
+        if (!b) return DSVC_ESTATE;
+        const int omax = (u - 1 + p) / u;             // largest o with phi + p - o*u >= 0   (phi = u-1)
+        const int omin = -((k - 1 - p) / u);          // smallest o with phi + p - o*u <= k-1 (phi = 0)
+        const int reach = omax > -omin ? omax : -omin;
+        const int taps = 2 * reach + 1;
+        DSVC_TRY(pack_conv(ups[i], u * cout, taps, cin, 1,
+                           [&](int col, int tap, int ci) {
+                               const int phi = col / cout, co = col % cout, o = tap - reach;
+                               const int j = phi + p - o * u;
+                               return (j >= 0 && j < k) ? w[((size_t)ci * cout + co) * k + j] : 0.f;
+                           },
+                           b->data(), cout));
+        rate *= u;
+        // noise conv (models.py:346-350)
+        int s = 1;
+        for (int q = i + 1; q < nu; ++q) s *= cfg.upsample_rates[q];
+        const bool last = (i + 1 == nu);
+        nc_s[i] = last ? 1 : s; nc_k[i] = last ? 1 : 2 * s; nc_pad[i] = last ? 0 : s / 2;
+        const std::vector<float>* nw = plain("noise_convs." + std::to_string(i) + ".weight", (size_t)cout * nc_k[i]);
+        const std::vector<float>* nb = plain("noise_convs." + std::to_string(i) + ".bias", cout);
+        if (!nw || !nb) return DSVC_ESTATE;
+        DSVC_TRY(upload(nc_w[i], nw->data(), nw->size() * 4)); DSVC_TRY(upload(nc_b[i], nb->data(), nb->size() * 4));
+        // resblocks (ResBlock1, models.py:33-64)
+        for (int j = 0; j < nk; ++j) {
+            const int rk = cfg.resblock_kernel_sizes[j];
+            if (!(rk & 1)) return fail(DSVC_EINVAL, "vocoder: even resblock kernel size");
+            for (int m = 0; m < 3; ++m) {
+                const int d = cfg.resblock_dilations[j][m];
+                const std::string base = "resblocks." + std::to_string(i * nk + j) + ".";
+                const size_t idx = ((size_t)i * nk + j) * 3 + m;
+                DSVC_TRY(folded(base + "convs1." + std::to_string(m), (size_t)cout * cout * rk, cout, w));
+                const std::vector<float>* b1 = plain(base + "convs1." + std::to_string(m) + ".bias", cout);
+                if (!b1) return DSVC_ESTATE;
+                DSVC_TRY(pack_conv(rb1[idx], cout, rk, cout, d, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b1->data(), cout));
+                DSVC_TRY(folded(base + "convs2." + std::to_string(m), (size_t)cout * cout * rk, cout, w));
+                const std::vector<float>* b2 = plain(base + "convs2." + std::to_string(m) + ".bias", cout);
+                if (!b2) return DSVC_ESTATE;
+                DSVC_TRY(pack_conv(rb2[idx], cout, rk, cout, 1, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b2->data(), cout));
+                const int halo = (rk / 2) * d;
+                if (ceil_div(halo, rate) > need_gap) need_gap = ceil_div(halo, rate);
+            }
+        }
+        if (ceil_div(reach, rate / u) > need_gap) need_gap = ceil_div(reach, rate / u);
+    }
+    {   // conv_post: Conv1d(c_last, 1, 7, padding 3)  (models.py:357)
+        const int cl = ch0 >> nu;
+        DSVC_TRY(folded("conv_post", (size_t)cl * 7, 1, w));
+        const std::vector<float>* b = plain("conv_post.bias", 1);
+        if (!b) return DSVC_ESTATE;
+        DSVC_TRY(pack_conv(conv_post, 1, 7, cl, 1, [&](int, int tap, int ci) { return w[(size_t)ci * 7 + tap]; }, b->data(), 1));
+    }
+    {
+        const std::vector<float>* lw = plain("m_source.l_linear.weight", dim);
+        const std::vector<float>* lb = plain("m_source.l_linear.bias", 1);
+        if (!lw || !lb) return DSVC_ESTATE;
+        DSVC_TRY(upload(lin_w, lw->data(), dim * 4)); DSVC_TRY(upload(lin_b, lb->data(), 4));
+    }
+    gap_frames = need_gap < 8 ? 8 : need_gap;
+    host.clear();
+    finalized = true;
+    return DSVC_OK;
+}
+
+int dsvc_vocoder::ensure_ws(int B, int T) {
+    if (B == wsB && T == wsT) return DSVC_OK;
+    if (B < 1 || T < 1) return fail(DSVC_EINVAL, "bad batch/frames %d/%d", B, T);
+    Tp = round_up(T + gap_frames, 32);
+    const size_t frames_total = (size_t)B * Tp;
+    if (frames_total * hop > 0x7fffffffull) return fail(DSVC_EINVAL, "vocoder: batch too large for 32-bit row indices; split the batch");
+    DSVC_TRY(mel_in.alloc(frames_total * cfg.num_mels * 4));
+    DSVC_TRY(har.alloc(frames_total * hop * 4));
+    DSVC_TRY(frames.alloc((size_t)B * T * dim * sizeof(SrcFrame)));
+    DSVC_TRY(fl00.alloc((size_t)B * dim * 4));
+    // largest stage buffer: rows * channels is maximal where rate/2^(i+1) peaks
+    size_t mx = frames_total * cfg.upsample_initial_channel;
+    int rate = 1;
+    for (int i = 0; i < cfg.n_ups; ++i) {
+        rate *= cfg.upsample_rates[i];
+        const size_t e = frames_total * rate * (cfg.upsample_initial_channel >> (i + 1));
+        if (e > mx) mx = e;
+    }
+    for (int i = 0; i < 5; ++i) DSVC_TRY(buf[i].alloc(mx * 4));
+    wsB = B; wsT = T;
+    return DSVC_OK;
+}
+
+int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int T, unsigned long long seed, int clip0, hipStream_t st) {
+    DSVC_TRY(ensure_ws(B, T));
+    const int nu = cfg.n_ups, nk = cfg.n_kernels, ch0 = cfg.upsample_initial_channel, M = cfg.num_mels;
+    const int prec = cfg.precision;
+    {
+        const size_t n = (size_t)B * T * M;
+        hipLaunchKernelGGL(k_prep_mel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, mel, mel_in.as<float>(), B, T, M, Tp);
+    }
+    // excitation (models.py:363-366)
+    hipLaunchKernelGGL(k_source_frames, dim3(B), dim3(32), 0, st, f0, frames.as<SrcFrame>(), fl00.as<float>(), T, hop, dim,
+                       (float)cfg.sampling_rate, seed, clip0);
+    hipLaunchKernelGGL(k_source_samples, dim3(ceil_div(T * hop, 256), B), dim3(256), 0, st, f0, frames.as<SrcFrame>(), fl00.as<float>(),
+                       lin_w.as<float>(), lin_b.as<float>(), har.as<float>(), T, hop, dim, (float)cfg.sampling_rate, Tp * hop, seed, clip0,
+                       0.1f, 0.003f);
+    auto conv = [&](const PackedConv& pc, const float* x, int rows, int stride, int len, float slope) {
+        ConvGemmArgs a{};
+        a.x = x; a.ldx = pc.cin; a.n_rows = rows; a.clip_stride = stride; a.clip_len = len;
+        a.cin = pc.cin; a.taps = pc.taps; a.dil = pc.dil; a.w = pc.w.as<_Float16>(); a.n_ctiles = pc.n_ctiles; a.w_planes = 2;
+        a.in_slope = slope;
+        return a;
+    };
+    float* U = buf[0].as<float>();
+    float* A = buf[1].as<float>();
+    float* Tm = buf[2].as<float>();
+    float* prev = buf[4].as<float>();
+    int rate = 1;
+    {   // conv_pre (models.py:367)
+        ConvGemmArgs a = conv(conv_pre, mel_in.as<float>(), B * Tp, Tp, T, 1.0f);
+        EpiAffine::Args e{prev, ch0, conv_pre.bias.as<float>(), ch0, ch0, nullptr, 0, 1.0f, 0};
+        DSVC_TRY(voc_dispatch<EpiAffine>(a, e, prec, st));
+    }
+    for (int i = 0; i < nu; ++i) {
+        const int u = cfg.upsample_rates[i];
+        const int cin = ch0 >> i, cout = ch0 >> (i + 1);
+        const int rows_in = B * Tp * rate, stride_in = Tp * rate, len_in = T * rate;
+        rate *= u;
+        const int rows = B * Tp * rate, stride = Tp * rate, len = T * rate;
+        float* S = buf[(i & 1) ? 4 : 3].as<float>();
+        // x_source = noise_convs[i](har)  (models.py:373) written into U ...
+        {
+            const size_t sm = (size_t)(64 * nc_s[i] + nc_k[i]) * 4;
+            hipLaunchKernelGGL(k_noise_conv, dim3(ceil_div(len, 64), B), dim3(256), sm, st, har.as<float>(), nc_w[i].as<float>(),
+                               nc_b[i].as<float>(), U, cout, nc_k[i], nc_s[i], nc_pad[i], len, T * hop, stride, Tp * hop);
+        }
+        // ... then x = ups[i](leaky_relu(x, 0.1)) + x_source  (models.py:369-375)
+        {
+            ConvGemmArgs a = conv(ups[i], prev, rows_in, stride_in, len_in, 0.1f);
+            (void)cin;
+            EpiAffine::Args e{U, u * cout, ups[i].bias.as<float>(), cout, u * cout, nullptr, 0, 1.0f, 1};
+            DSVC_TRY(voc_dispatch<EpiAffine>(a, e, prec, st));
+        }
+        // MRF: mean over the nk ResBlock1 (models.py:376-382)
+        for (int j = 0; j < nk; ++j) {
+            for (int m = 0; m < 3; ++m) {
+                const size_t idx = ((size_t)i * nk + j) * 3 + m;
+                const float* xin = (m == 0) ? U : A;
+                {   // xt = c1(leaky_relu(x))
+                    ConvGemmArgs a = conv(rb1[idx], xin, rows, stride, len, 0.1f);
+                    EpiAffine::Args e{Tm, cout, rb1[idx].bias.as<float>(), cout, cout, nullptr, 0, 1.0f, 0};
+                    DSVC_TRY(voc_dispatch<EpiAffine>(a, e, prec, st));
+                }
+                {   // x = c2(leaky_relu(xt)) + x ; the last one lands in the running MRF mean
+                    ConvGemmArgs a = conv(rb2[idx], Tm, rows, stride, len, 0.1f);
+                    const bool lastm = (m == 2);
+                    EpiAffine::Args e{lastm ? S : A, cout, rb2[idx].bias.as<float>(), cout, cout, xin, cout,
+                                      lastm ? 1.0f / (float)nk : 1.0f, (lastm && j > 0) ? 1 : 0};
+                    DSVC_TRY(voc_dispatch<EpiAffine>(a, e, prec, st));
+                }
+            }
+        }
+        prev = S;
+    }
+    {   // x = tanh(conv_post(leaky_relu(x)))  -- F.leaky_relu default slope 0.01 (models.py:383-385)
+        ConvGemmArgs a = conv(conv_post, prev, B * Tp * rate, Tp * rate, T * rate, 0.01f);
+        EpiTanhWav::Args e{wav, conv_post.bias.as<float>(), Tp * rate, T * rate};
+        DSVC_TRY(voc_dispatch<EpiTanhWav>(a, e, prec, st));
+    }
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+extern "C" {
+
+int dsvc_vocoder_create(const dsvc_vocoder_cfg* cfg, dsvc_vocoder** out) {
+    if (!cfg || !out) return fail(DSVC_EINVAL, "null argument");
+    if (cfg->precision < DSVC_PREC_F16 || cfg->precision > DSVC_PREC_F16_X3) return fail(DSVC_EINVAL, "unknown precision %d", cfg->precision);
+    int ndev = 0;
+    DSVC_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(DSVC_EHIP, "no HIP device visible");
+    dsvc_vocoder* v = new dsvc_vocoder();
+    v->cfg = *cfg;
+    *out = v;
+    return DSVC_OK;
+}
+
+int dsvc_vocoder_load_tensor(dsvc_vocoder* v, const char* name, const float* host, int64_t numel) {
+    if (!v || !name || !host || numel < 0) return fail(DSVC_EINVAL, "null argument");
+    if (v->finalized) return fail(DSVC_ESTATE, "vocoder already finalized");
+    v->host[name].assign(host, host + numel);
+    return DSVC_OK;
+}
+
+int dsvc_vocoder_finalize(dsvc_vocoder* v) {
+    if (!v) return fail(DSVC_EINVAL, "null handle");
+    if (v->finalized) return DSVC_OK;
+    return v->finalize();
+}
+
+void dsvc_vocoder_destroy(dsvc_vocoder* v) { delete v; }
+
+int dsvc_vocode(dsvc_vocoder* v, const float* mel, const float* f0, float* wav, int32_t B, int32_t T, uint64_t seed,
+                int32_t first_clip, void* stream) {
+    if (!v || !mel || !f0 || !wav) return fail(DSVC_EINVAL, "null argument");
+    if (!v->finalized) return fail(DSVC_ESTATE, "vocoder not finalized");
+    return v->run(mel, f0, wav, B, T, seed, first_clip, (hipStream_t)stream);
+}
+
+}  // extern "C"

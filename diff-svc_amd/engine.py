@@ -121,3 +121,93 @@ class SamplerHandle:
                 self._h = ctypes.c_void_p(0)
         except Exception:
             pass
+
+
+class VocoderHandle:
+    """dsvc_vocoder: NSF-HiFiGAN generator.  ``state`` is the checkpoint's 'generator' dict (weight-norm pairs
+    included), ``h`` its config.json (modules/nsf_hifigan/models.py:14-30)."""
+
+    def __init__(self, state, h, precision="f16_x3"):
+        self._h = ctypes.c_void_p(0)
+        if str(h.get("resblock", "1")) != "1":
+            raise NotImplementedError("only ResBlock1 generators are supported (resblock='1')")
+        rates, ksz = list(h["upsample_rates"]), list(h["upsample_kernel_sizes"])
+        rks, rds = list(h["resblock_kernel_sizes"]), [list(d) for d in h["resblock_dilation_sizes"]]
+        if len(rates) > 8 or len(rks) > 4 or any(len(d) != 3 for d in rds):
+            raise ValueError("unsupported generator geometry")
+        cfg = _lib.VocoderCfg()
+        cfg.num_mels, cfg.upsample_initial_channel, cfg.sampling_rate = h["num_mels"], h["upsample_initial_channel"], h["sampling_rate"]
+        cfg.n_ups = len(rates)
+        for i, (u, k) in enumerate(zip(rates, ksz)):
+            cfg.upsample_rates[i], cfg.upsample_kernel_sizes[i] = u, k
+        cfg.n_kernels = len(rks)
+        for j, (k, ds) in enumerate(zip(rks, rds)):
+            cfg.resblock_kernel_sizes[j] = k
+            for m, d in enumerate(ds):
+                cfg.resblock_dilations[j][m] = d
+        cfg.harmonics = 8                                # harmonic_num=8, models.py:334
+        cfg.precision = _prec(precision)
+        self.cfg = cfg
+        self.num_mels = h["num_mels"]
+        self.hop = 1
+        for u in rates:
+            self.hop *= u
+        check(lib().dsvc_vocoder_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+        for k, v in state.items():
+            hbuf, p = host_f32(v)
+            check(lib().dsvc_vocoder_load_tensor(self._h, k.encode(), p, hbuf.numel()))
+        check(lib().dsvc_vocoder_finalize(self._h))
+
+    def vocode(self, mel, f0, seed=0, first_clip=0):
+        """mel [B,T,M] log10, f0 [B,T] Hz (0 = unvoiced) -> wav [B, T*hop]."""
+        _need_cuda(mel, f0)
+        B, T, M = mel.shape
+        if M != self.num_mels or f0.shape != (B, T):
+            raise ValueError("shape mismatch: mel %s f0 %s" % (tuple(mel.shape), tuple(f0.shape)))
+        mel = mel.contiguous().float()
+        f0 = f0.contiguous().float()
+        wav = torch.empty(B, T * self.hop, device=mel.device, dtype=torch.float32)
+        check(lib().dsvc_vocode(self._h, ptr(mel), ptr(f0), ptr(wav), B, T, seed, first_clip, stream_ptr()))
+        return wav
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().dsvc_vocoder_destroy(self._h)
+                self._h = ctypes.c_void_p(0)
+        except Exception:
+            pass
+
+
+class MelspecHandle:
+    """dsvc_melspec: STFT -> mel -> log10 (modules/nsf_hifigan/nvSTFT.py:72-104 + nsf_hifigan.py:86-91)."""
+
+    def __init__(self, sr, n_fft, win_size, hop, n_mels, fmin, fmax, clip_val=1e-5):
+        from .melfb import mel_filterbank
+        self._h = ctypes.c_void_p(0)
+        self.n_mels = n_mels
+        basis = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax)).contiguous()
+        cfg = _lib.MelspecCfg(n_fft, win_size, hop, n_mels, clip_val)
+        check(lib().dsvc_melspec_create(ctypes.byref(cfg), ctypes.c_void_p(basis.data_ptr()), ctypes.byref(self._h)))
+
+    def frames(self, n_samples):
+        t = ctypes.c_int32(0)
+        check(lib().dsvc_melspec_frames(self._h, n_samples, ctypes.byref(t)))
+        return t.value
+
+    def mel(self, wav):
+        """wav [B,N] in [-1,1] -> mel [B,T,n_mels] log10."""
+        _need_cuda(wav)
+        wav = wav.contiguous().float()
+        B, N = wav.shape
+        out = torch.empty(B, self.frames(N), self.n_mels, device=wav.device, dtype=torch.float32)
+        check(lib().dsvc_melspec_run(self._h, ptr(wav), ptr(out), B, N, stream_ptr()))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().dsvc_melspec_destroy(self._h)
+                self._h = ctypes.c_void_p(0)
+        except Exception:
+            pass

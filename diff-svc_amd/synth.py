@@ -52,7 +52,7 @@ def tiny_hparams(M=16, H=32, C=64, L=4, K=50, cycle=4):
                 residual_layers=L, dilation_cycle_length=cycle, timesteps=K, K_step=K)
 
 
-def tiny_vocoder(num_mels=16, ch=32, rates=(4, 2, 2), ksz=(8, 4, 4), rks=(3, 5), rds=((1, 3, 5), (1, 3, 5))):
+def tiny_vocoder(num_mels=16, ch=128, rates=(4, 2, 2), ksz=(8, 4, 4), rks=(3, 5), rds=((1, 3, 5), (1, 3, 5))):
     return dict(VOCODER_44K, num_mels=num_mels, upsample_initial_channel=ch, upsample_rates=list(rates),
                 upsample_kernel_sizes=list(ksz), resblock_kernel_sizes=list(rks),
                 resblock_dilation_sizes=[list(d) for d in rds], hop_size=int(np.prod(rates)))

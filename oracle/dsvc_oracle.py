@@ -511,7 +511,7 @@ def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
         upper = ramps[i + 2] / fdiff[i + 1]
         w[i] = np.maximum(0, np.minimum(lower, upper))
     enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
-    w *= enorm[:, np.newaxis].astype(np.float32)
+    w *= enorm[:, np.newaxis]            # float32 *= float64: numpy multiplies in double, rounds once (as librosa does)
     return w
 
 

@@ -104,8 +104,92 @@ def golden_sampler(name, hp, wseed, clips, T, n_units, speedup, seed):
     print(name, "mel range %.3f..%.3f" % (ret["mel_out"].min().item(), ret["mel_out"].max().item()))
 
 
+def vocoder_inputs(h, clips, T):
+    M = h["num_mels"]
+    mels, f0s = [], []
+    for c in clips:
+        g = np.random.Generator(np.random.PCG64(SEED + 1000 + c))
+        mels.append((g.standard_normal((T, M)) * 0.8 - 2.5).astype(np.float32))       # log10 mel, [T, M]
+        _, _, _, f0_hz = synth.clip_inputs(c, T=T, n_units=max(2, T // 2), H=8)
+        if c % 2 == 1:
+            f0_hz = f0_hz * 2.7                                                         # exercise more phase wraps
+        f0s.append(f0_hz)
+    return np.stack(mels), np.stack(f0s)
+
+
+def golden_vocoder(name, h, wseed, clips, T, seed):
+    """Generator.forward of the REAL reference (weight-normed checkpoint -> load_state_dict ->
+    remove_weight_norm, models.py:14-30) with the source module's torch.rand / randn_like replaced by the
+    Philox streams."""
+    refshim.install()
+    import modules.nsf_hifigan.models as NM
+    from modules.nsf_hifigan.env import AttrDict
+    sdw = synth.vocoder_state(h, wseed)
+    gen = NM.Generator(AttrDict(h))
+    gen.load_state_dict(sdw, strict=True)
+    gen.eval()
+    gen.remove_weight_norm()
+    mel, f0 = vocoder_inputs(h, clips, T)
+    hop = int(np.prod(h["upsample_rates"]))
+    ini, nz = O.vocoder_rng(seed, clips, T * hop)
+    orig_rand, orig_randn_like = torch.rand, torch.randn_like
+
+    def rand(*shape, **kw):
+        assert tuple(shape) == tuple(ini.shape), shape
+        return ini.clone()
+
+    def randn_like(x, **kw):
+        if x.shape[-1] == nz.shape[-1]:
+            return nz.clone()
+        return torch.zeros_like(x)              # SourceModuleHnNSF's noise branch is discarded by Generator (models.py:322,365)
+
+    torch.rand, torch.randn_like = rand, randn_like
+    try:
+        with torch.no_grad():
+            c = 2.30259 * torch.from_numpy(mel).transpose(2, 1)          # spec2wav (nsf_hifigan.py:63-65)
+            wav = gen(c, torch.from_numpy(f0))
+    finally:
+        torch.rand, torch.randn_like = orig_rand, orig_randn_like
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), mel=mel, f0=f0, wav=wav.numpy().reshape(len(clips), -1),
+                        wseed=wseed, clips=np.array(clips), seed=seed)
+    print(name, "wav rms %.4f max %.3f" % (wav.pow(2).mean().sqrt().item(), wav.abs().max().item()))
+
+
+def golden_melspec(name, sr, n_fft, win, hop, n_mels, fmin, fmax, n_samples):
+    """STFT.get_mel of the REAL reference (nvSTFT.py:72-104).  Two shims are unavoidable on this image:
+    librosa's mel filterbank is replaced by the oracle's restatement (librosa is not installed), and
+    torch.stft gets return_complex=True + view_as_real (the legacy real-view output was removed in torch 2)."""
+    refshim.install()
+    import modules.nsf_hifigan.nvSTFT as NV
+    NV.librosa_mel_fn = lambda sr, n_fft, n_mels, fmin, fmax: O.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    g = np.random.Generator(np.random.PCG64(SEED + n_samples))
+    t = np.arange(n_samples) / sr
+    wav = (0.3 * np.sin(2 * np.pi * 220 * t * (1 + 0.1 * np.sin(2 * np.pi * 3 * t))) + 0.05 * g.standard_normal(n_samples)
+           + 0.2 * np.sin(2 * np.pi * 3100 * t)).astype(np.float32)
+    wav[n_samples // 3: n_samples // 3 + 2 * n_fft] *= 1e-4                         # a near-silent stretch
+    orig_stft = torch.stft
+
+    def stft(*a, **kw):
+        kw["return_complex"] = True
+        return torch.view_as_real(orig_stft(*a, **kw))
+
+    torch.stft = stft
+    try:
+        st = NV.STFT(sr, n_mels, n_fft, win, hop, fmin, fmax)
+        with torch.no_grad():
+            mel = st.get_mel(torch.from_numpy(wav)[None])[0].T * 0.434294          # wav2spec's log10 scale (nsf_hifigan.py:89-91)
+    finally:
+        torch.stft = orig_stft
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), wav=wav, mel=mel.numpy(), cfg=np.array([sr, n_fft, win, hop, n_mels, fmin, fmax]))
+    print(name, "mel", tuple(mel.shape), "range %.2f..%.2f" % (mel.min().item(), mel.max().item()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    golden_vocoder("vocoder_tiny", synth.tiny_vocoder(), 5, clips=[0, 3], T=24, seed=90)
+    golden_vocoder("vocoder_44k", dict(synth.VOCODER_44K), 1, clips=[1], T=12, seed=91)
+    golden_melspec("melspec_44k", 44100, 2048, 2048, 512, 128, 40, 16000, 20000)
+    golden_melspec("melspec_24k", 24000, 512, 512, 128, 80, 30, 12000, 6000)
     tiny = synth.tiny_hparams()
     full = dict(synth.HPARAMS_44K)
     golden_diffnet("diffnet_tiny", tiny, 3, B=2, T=40)
