@@ -1,0 +1,200 @@
+"""bench.py -- audio-seconds per wall-second of the diff-svc hot path on MI355X.
+
+One "step" = one pass of the whole hot path (cond -> K-step DDPM through the 20-layer DiffNet -> NSF-HiFiGAN
+PCM) over one batch of synthetic fixed-length 10 s / 44.1 kHz clips that are already resident in HBM.
+Default workload = BASELINE.json configs[1]: a single clip per GPU, full 1000-step DDPM.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 3 --warmup 1
+
+Rank 0 prints ONE JSON line (see README of the task for the contract) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import diffsvc_amd  # noqa: F401
+from diffsvc_amd import synth
+from diffsvc_amd.pipeline import SvcPipeline, gather_pcm, shard_clips
+
+CLIP_SECONDS = 10.0
+T_FRAMES = 861            # floor((441000 - 512) / 512) + 1   (nvSTFT.py:92-96)
+N_UNITS = 500
+FLOP_PER_FRAME_DILATED = 2 * 384 * 768 * 3        # the k=3 dilated conv of one residual layer
+PEAK_TFLOPS_F16 = 2500.0                           # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def make_inputs(clips, device):
+    hub, m2p, f0 = [], [], []
+    for c in clips:
+        a, b, c_, _ = synth.clip_inputs(c, T=T_FRAMES, n_units=N_UNITS, H=256)
+        hub.append(a); m2p.append(b); f0.append(c_)
+    return tuple(torch.from_numpy(np.stack(v)).to(device) for v in (hub, m2p, f0))
+
+
+def cpu_baseline(hp, sd, vs, h, budget_s=20.0):
+    """The oracle (a port: the reference tree is not on the GPU box) on the host cores, same synthetic clip:
+    time DDPM steps until ~budget, extrapolate linearly to 1000 (every step is identical work), time the
+    vocoder once in full."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dsvc_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    hub, m2p, f0, _ = synth.clip_inputs(0, T=T_FRAMES, n_units=N_UNITS, H=256)
+    hub, m2p, f0 = torch.from_numpy(hub)[None], torch.from_numpy(m2p)[None], torch.from_numpy(f0)[None]
+    cond, f0_denorm, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    cond_t = cond.transpose(1, 2).contiguous()
+    x = O.ddpm_noise_ref_layout(1, [0], 0, T_FRAMES, 128, O.PURPOSE_X_INIT)
+    z = O.ddpm_noise_ref_layout(1, [0], 999, T_FRAMES, 128)
+    t = torch.full((1,), 999, dtype=torch.long)
+    n, t_steps = 0, 0.0
+    with torch.no_grad():
+        for i in range(3 + 200):
+            t0 = time.perf_counter()
+            eps = O.diffnet_forward(sd, x, t, cond_t, hp["dilation_cycle_length"])
+            x = O.ddpm_update(sd, x, eps, t, z)
+            dt = time.perf_counter() - t0
+            if i >= 3:
+                n += 1
+                t_steps += dt
+                if t_steps > budget_s * 0.7 and n >= 5:
+                    break
+        hop = int(np.prod(h["upsample_rates"]))
+        ini, nz = O.vocoder_rng(1, [0], T_FRAMES * hop)
+        gw = O.fold_weight_norm(vs)
+        mel = torch.clamp(O.finish_mel(sd, x, m2p), hp["mel_vmin"], hp["mel_vmax"])
+        t0 = time.perf_counter()
+        O.generator_forward(gw, h, 2.30259 * mel.transpose(2, 1), f0_denorm, ini, nz)
+        t_voc = time.perf_counter() - t0
+    per_step = t_steps / n
+    total = 1000 * per_step + t_voc
+    return {"value": CLIP_SECONDS / total, "unit": "audio-sec/wall-sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of 1000 DDPM steps (%.3f s/step, extrapolated) + the full NSF-HiFiGAN pass (%.2f s), one 10 s clip, T=861"
+                      % (n, per_step, t_voc)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips-per-gpu", type=int, default=1)
+    ap.add_argument("--ddpm-steps", type=int, default=1000)
+    ap.add_argument("--speedup", type=int, default=1, help="pndm_speedup (>1 = PLMS); the headline config is 1")
+    ap.add_argument("--precision", default="f16_w2", choices=["f16", "f16_w2", "f16_x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the extra batched (32 clips/GPU) measurement")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device: the product path has no CPU fallback"
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    hp = dict(synth.HPARAMS_44K, K_step=args.ddpm_steps)
+    h = dict(synth.VOCODER_44K)
+    sd = synth.acoustic_state(hp, 0)
+    vs = synth.vocoder_state(h, 1)
+    pipe = SvcPipeline(hp, sd, vs, h, precision=args.precision, vocoder_precision="f16_x3")
+
+    B = args.clips_per_gpu
+    n_clips = B * world
+    my_clips = shard_clips(n_clips, rank, world) if world > 1 else list(range(B))
+    hub, m2p, f0 = make_inputs(my_clips, dev)
+
+    def one_step(seed):
+        # clips of a rank are strided (i % world), so Philox clip ids go through first_clip = rank, stride world:
+        # with one clip per GPU the id is just the rank; for B > 1 ids are rank-local but unique per (rank, b).
+        wav = pipe.infer(hub, m2p, f0, speedup=args.speedup, seed=seed, first_clip=rank * B, use_graph=True)
+        if world > 1:
+            wav = gather_pcm(wav, my_clips, n_clips)
+        return wav
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(100 + i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        wav = one_step(200 + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ok = bool(torch.isfinite(wav).all().item())
+    value = n_clips * CLIP_SECONDS * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (dilated conv + gate), HIP events on the launch stream ----
+        us, rows = pipe.model._handle().profile_gate_kernel(B, T_FRAMES, 5)
+        flop = FLOP_PER_FRAME_DILATED * B * T_FRAMES                 # algorithmic: valid frames only, one product per MAC
+        achieved = flop / (us * 1e-6) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_gemm<EpiGate> (dilated k=3 conv + FiLM + gate, one residual layer)",
+                "achieved": achieved, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_F16,
+                "avg_launch_us": us, "frames_per_launch": B * T_FRAMES, "traffic": None}
+        result = {
+            "metric": "audio-sec/wall-sec (RTF) end-to-end 44.1kHz %d-step %s + NSF-HiFiGAN" % (
+                args.ddpm_steps, "DDPM" if args.speedup <= 1 else "PLMS/%d" % args.speedup),
+            "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 operands (%s) / f32 accumulate" % args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: single 10 s clip per GPU, 44.1 kHz, full %d-step DDPM + NSF-HiFiGAN" % args.ddpm_steps,
+                       "clips_per_gpu": B, "mel_frames": T_FRAMES, "content_frames": N_UNITS, "sampler_steps": args.ddpm_steps,
+                       "pndm_speedup": args.speedup, "precision": args.precision, "vocoder_precision": "f16_x3",
+                       "weights": "random-init (synthetic checkpoint, seeds 0/1)", "parallelism": "utterance-sharded x%d, gather of PCM" % world},
+            "finite_output": ok,
+            "roofline": roof,
+        }
+        if not args.no_batched and world == 1 and B == 1:
+            # the throughput configuration (BASELINE configs[3] per-GPU share): 32 clips in one batch
+            Bb = 32
+            hb, mb, fb = make_inputs(list(range(Bb)), dev)
+            pipe.model.hp = dict(hp, K_step=30); pipe.model.K_step = 30
+            pipe.infer(hb, mb, fb, seed=1)                            # warm-up on a short chain
+            pipe.model.K_step = args.ddpm_steps
+            torch.cuda.synchronize(); tb = time.perf_counter()
+            pipe.infer(hb, mb, fb, seed=2)
+            torch.cuda.synchronize(); tb = time.perf_counter() - tb
+            usb, _ = pipe.model._handle().profile_gate_kernel(Bb, T_FRAMES, 3)
+            ach = FLOP_PER_FRAME_DILATED * Bb * T_FRAMES / (usb * 1e-6) / 1e12
+            result["batched"] = {"clips_per_gpu": Bb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
+                                 "s_per_batch": tb, "gate_kernel_us": usb, "gate_kernel_tflops": ach,
+                                 "gate_kernel_frac_of_peak": ach / PEAK_TFLOPS_F16}
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(hp, sd, vs, h)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""Condition builder -- the ``no_fs2: true`` branch of ``FastSpeech2.forward`` (modules/fastspeech/fs2.py:94-154)
+with ``add_pitch`` (fs2.py:185-238): cond = (gather(pad(hubert), mel2ph) + pitch_embed[coarse(2**f0)]) * (mel2ph>0).
+
+Index work (f0 -> coarse pitch bin) is kept bit-exact by doing it with the same fp32 torch-CPU
+ops the reference CPU path uses; the gather / embedding / mask are exact data movement on the device.
+Registered under the attribute name ``fs2`` so a reference checkpoint's ``fs2.*`` keys load strictly; the
+parameters the disabled FastSpeech2 branches own (mel_out, pitch_predictor) are accepted and kept as buffers."""
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+def f0_to_coarse(f0, hp):
+    """utils/pitch_utils.py:17-31 (torch branch), fp32, on the CPU."""
+    f0_bin, f0_max, f0_min = hp["f0_bin"], hp["f0_max"], hp["f0_min"]
+    mel_min = 1127 * np.log(1 + f0_min / 700)
+    mel_max = 1127 * np.log(1 + f0_max / 700)
+    m = 1127 * (1 + f0 / 700).log()
+    m[m > 0] = (m[m > 0] - mel_min) * (f0_bin - 2) / (mel_max - mel_min) + 1
+    m[m <= 1] = 1
+    m[m > f0_bin - 1] = f0_bin - 1
+    coarse = (m + 0.5).long()
+    assert coarse.max() <= 255 and coarse.min() >= 1, (coarse.max(), coarse.min())
+    return coarse
+
+
+class CondBuilder(nn.Module):
+    def __init__(self, hparams, out_dims=None):
+        super().__init__()
+        self.hp = hparams
+        self.hidden_size = hparams["hidden_size"]
+        self.padding_idx = 0
+        self.pitch_embed = nn.Embedding(300, self.hidden_size, self.padding_idx)
+        nn.init.normal_(self.pitch_embed.weight, mean=0, std=self.hidden_size ** -0.5)
+        nn.init.constant_(self.pitch_embed.weight[self.padding_idx], 0)
+        self._extras = {}          # checkpointed-but-unused fs2.* tensors (mel_out, pitch_predictor, ...)
+
+    # accept (and round-trip) the fs2.* tensors of the branches that are disabled by no_fs2 / use_pe=False
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for k in list(state_dict.keys()):
+            if k.startswith(prefix) and not k.startswith(prefix + "pitch_embed."):
+                self._extras[k[len(prefix):]] = state_dict[k].detach().clone()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        for k in list(unexpected_keys):
+            if k.startswith(prefix) and k[len(prefix):] in self._extras:
+                unexpected_keys.remove(k)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        for k, v in self._extras.items():
+            destination[prefix + k] = v
+
+    def forward(self, hubert, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
+                skip_decoder=True, spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, **kwargs):
+        hp = self.hp
+        if hp.get("use_spk_embed") or hp.get("use_spk_id") or hp.get("use_energy_embed") or not hp.get("no_fs2", False):
+            raise NotImplementedError("only the no_fs2 / pitch-embed configuration of the reference is supported")
+        ret = {"mel2ph": mel2ph}
+        dev = hubert.device
+        padded = F.pad(hubert, [0, 0, 1, 0])
+        idx = mel2ph[..., None].repeat([1, 1, hubert.shape[-1]])
+        gathered = torch.gather(padded, 1, idx)                               # [B, T, H]
+        nonpad = (mel2ph > 0).float()[:, :, None]
+        # ---- index work on the host, bit-exact with the reference CPU path (fs2.py:229-233, pitch_utils.py) ----
+        f0_cpu = f0.detach().to("cpu", torch.float32)
+        pad_cpu = (mel2ph == 0).cpu()
+        if hp.get("pitch_norm", "log") != "log":
+            raise NotImplementedError("pitch_norm must be 'log'")
+        f0_denorm = 2 ** f0_cpu
+        if uv is not None and hp.get("use_uv"):
+            f0_denorm[uv.cpu() > 0] = 0
+        f0_denorm[pad_cpu] = 0
+        f0[(mel2ph == 0)] = 0                                                  # the reference mutates its argument (fs2.py:231)
+        coarse = f0_to_coarse(f0_denorm.clone(), hp)
+        ret["f0_denorm"] = f0_denorm.to(dev)
+        ret["pitch_pred"] = coarse.unsqueeze(-1).to(dev)
+        emb = self.pitch_embed(coarse.to(dev))
+        ret["decoder_inp"] = (gathered + emb) * nonpad
+        return ret

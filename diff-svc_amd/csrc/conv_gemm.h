@@ -57,8 +57,13 @@ constexpr int FRAG_HALFS = 512;
 
 __device__ __forceinline__ int clip_local(int r, int stride) { return r - (r / stride) * stride; }
 
-template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int PF, int NW, int NA, class Epi>
-__global__ void __launch_bounds__(64 * WAVES_N * WAVES_K)
+// latency tilings want two waves per SIMD resident (two 4-wave workgroups, or one 8-wave one)
+constexpr int min_waves_per_simd(int wm_tiles, int waves) { return wm_tiles <= 2 ? (waves > 8 ? (waves + 3) / 4 : 2) : 1; }
+
+// latency tilings (one 32-frame tile) cap their registers at 256 so two workgroups share a CU; the
+// 128-frame throughput tiling needs 128 accumulators + staging and runs one wave per SIMD.
+template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int PF, int SPT, int NW, int NA, class Epi>
+__global__ void __launch_bounds__(64 * WAVES_N * WAVES_K, min_waves_per_simd(WM_TILES, WAVES_N * WAVES_K))
 conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
     constexpr int NT = 64 * WAVES_N * WAVES_K;
     constexpr int TM = 32 * WM_TILES;
@@ -68,6 +73,7 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
     constexpr int XS = KCB + 8;          // LDS row stride in halfs
     static_assert(KCW % 16 == 0, "k-slice must be a multiple of 16 channels");
     static_assert(KS % PF == 0, "prefetch depth must divide the k16 steps per tap");
+    static_assert(SPT >= 1 && SPT <= 32, "staging batch");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* xs = reinterpret_cast<_Float16*>(smem);
@@ -130,36 +136,56 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
     const int arow = (lane & 31);
     const int acol = 8 * (lane >> 5);
 
-    for (int c0 = 0; c0 < a.cin; c0 += KCB) {
-        if (c0 > 0) __syncthreads();                 // previous chunk fully consumed
-        // ---- stage (TM + 2*halo) x KCB of PRE(x) into LDS as fp16 planes ----
-        {
-            constexpr int IPR = KCB / 8;             // 8-channel items per row
-            const int items = rows_lds * IPR;
-            for (int it = tid; it < items; it += NT) {
+    // ---- staging: global fp32 -> registers (all loads of a batch in flight together) -> fp16 planes in LDS ----
+    constexpr int IPR = KCB / 8;                 // 8-channel items per row
+    const int items = rows_lds * IPR;
+    float* film_lds = reinterpret_cast<float*>(smem + (((size_t)NA * plane_halfs * 2 + 15) & ~(size_t)15));
+    if (film) {                                  // shared diffusion step: park the FiLM vector in LDS once
+        for (int c = tid * 4; c < a.cin; c += NT * 4)
+            *reinterpret_cast<float4*>(film_lds + c) = *reinterpret_cast<const float4*>(film + c);
+    }
+    auto stage_load = [&](int c0, int b0, float4 (&sr)[SPT][2], unsigned& vmask) {
+        vmask = 0;
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            const int it = b0 + tid + u * NT;
+            sr[u][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sr[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < items) {
                 const int rr = it / IPR;
                 const int c8 = (it - rr * IPR) * 8;
                 const int r = row0 - halo + rr;
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = 0.f;
                 bool valid = (r >= 0) && (r < a.n_rows);
-                int clip = 0;
+                if (valid) valid = clip_local(r, a.clip_stride) < a.clip_len;
                 if (valid) {
-                    clip = r / a.clip_stride;
-                    valid = (r - clip * a.clip_stride) < a.clip_len;
-                }
-                if (valid) {
-                    const float* film_r = film;
-                    if (a.film && a.step_per_clip)
-                        film_r = a.film + (size_t)(a.step_ptr[clip] - a.step_off) * a.film_step_stride;
                     const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)r * a.ldx + c0 + c8);
-                    const float4 p0 = src[0], p1 = src[1];
-                    v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w;
-                    v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
-                    if (film_r) {
-                        const float4* fs = reinterpret_cast<const float4*>(film_r + c0 + c8);
-                        const float4 f0 = fs[0], f1 = fs[1];
+                    sr[u][0] = src[0];
+                    sr[u][1] = src[1];
+                    vmask |= 1u << u;
+                }
+            }
+        }
+    };
+    auto stage_store = [&](int c0, int b0, const float4 (&sr)[SPT][2], unsigned vmask) {
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            const int it = b0 + tid + u * NT;
+            if (it < items) {
+                const int rr = it / IPR;
+                const int c8 = (it - rr * IPR) * 8;
+                float v[8] = {sr[u][0].x, sr[u][0].y, sr[u][0].z, sr[u][0].w, sr[u][1].x, sr[u][1].y, sr[u][1].z, sr[u][1].w};
+                if ((vmask >> u) & 1u) {
+                    if (a.film) {
+                        float4 f0, f1;
+                        if (film) {
+                            f0 = *reinterpret_cast<const float4*>(film_lds + c0 + c8);
+                            f1 = *reinterpret_cast<const float4*>(film_lds + c0 + c8 + 4);
+                        } else {                 // one step per clip (DiffNet.forward's t[B]): rare path, from global
+                            const int clip = (row0 - halo + rr) / a.clip_stride;
+                            const float* fr = a.film + (size_t)(a.step_ptr[clip] - a.step_off) * a.film_step_stride + c0 + c8;
+                            f0 = *reinterpret_cast<const float4*>(fr);
+                            f1 = *reinterpret_cast<const float4*>(fr + 4);
+                        }
                         v[0] += f0.x; v[1] += f0.y; v[2] += f0.z; v[3] += f0.w;
                         v[4] += f1.x; v[5] += f1.y; v[6] += f1.z; v[7] += f1.w;
                     }
@@ -180,7 +206,22 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
                 }
             }
         }
+    };
+
+    float4 sreg[SPT][2];
+    unsigned vmask = 0;
+    stage_load(0, 0, sreg, vmask);                   // first batch of chunk 0 in flight beside the weight ring
+    if (film) __syncthreads();                       // film_lds visible before the first store phase
+
+    for (int c0 = 0; c0 < a.cin; c0 += KCB) {
+        if (c0 > 0) __syncthreads();                 // previous chunk fully consumed
+        stage_store(c0, 0, sreg, vmask);
+        for (int b0 = NT * SPT; b0 < items; b0 += NT * SPT) {     // tile larger than the register batch (big halo)
+            stage_load(c0, b0, sreg, vmask);
+            stage_store(c0, b0, sreg, vmask);
+        }
         __syncthreads();
+        if (c0 + KCB < a.cin) stage_load(c0 + KCB, 0, sreg, vmask);   // next chunk's loads fly under this chunk's MFMAs
 
         if (active) {
             for (int tap = 0; tap < a.taps; ++tap) {
@@ -295,22 +336,23 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
 
 // LDS bytes a launch needs (x tile planes, or the split-K partial tiles, whichever is larger)
 template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int NA>
-inline size_t conv_gemm_smem(int taps, int dil) {
+inline size_t conv_gemm_smem(int taps, int dil, int cin) {
     const int halo = (taps / 2) * dil;
     size_t x = (size_t)NA * (32 * WM_TILES + 2 * halo) * (KCB + 8) * sizeof(_Float16);
+    x = ((x + 15) & ~(size_t)15) + (size_t)cin * sizeof(float);          // + the FiLM vector
     size_t p = WAVES_K > 1 ? (size_t)WAVES_K * 32 * WM_TILES * 64 * WAVES_N * sizeof(float) : 0;
     return x > p ? x : p;
 }
 
-template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int PF, int NW, int NA, class Epi>
+template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int PF, int SPT, int NW, int NA, class Epi>
 inline int conv_gemm_launch(const ConvGemmArgs& a, const typename Epi::Args& ea, hipStream_t stream) {
     if (a.cin % KCB != 0) return fail(DSVC_EINVAL, "conv_gemm: cin %d not a multiple of the staged chunk %d", a.cin, KCB);
     if (a.w_planes < NW) return fail(DSVC_EINVAL, "conv_gemm: weights packed with %d plane(s), kernel needs %d", a.w_planes, NW);
     if (a.ldx % 4 != 0) return fail(DSVC_EINVAL, "conv_gemm: ldx %d not a multiple of 4", a.ldx);
     if (a.n_ctiles & 1) return fail(DSVC_EINVAL, "conv_gemm: odd column-tile count %d", a.n_ctiles);
     if (a.clip_stride < 32) return fail(DSVC_EINVAL, "conv_gemm: clip_stride %d < 32", a.clip_stride);
-    auto kern = conv_gemm_kernel<WM_TILES, WAVES_N, WAVES_K, KCB, PF, NW, NA, Epi>;
-    const size_t smem = conv_gemm_smem<WM_TILES, WAVES_N, WAVES_K, KCB, NA>(a.taps, a.dil);
+    auto kern = conv_gemm_kernel<WM_TILES, WAVES_N, WAVES_K, KCB, PF, SPT, NW, NA, Epi>;
+    const size_t smem = conv_gemm_smem<WM_TILES, WAVES_N, WAVES_K, KCB, NA>(a.taps, a.dil, a.cin);
     if (smem > 160 * 1024) return fail(DSVC_EINVAL, "conv_gemm: %zu B of LDS requested", smem);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {

@@ -1,6 +1,7 @@
 // DiffNet denoiser + Gaussian-diffusion sampler behind the C ABI (include/dsvc.h).
 // Reference: network/diff/net.py:58-135, network/diff/diffusion.py:100-123,131-198,255-283.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -39,10 +40,19 @@ int upload(DevBuf& b, const void* host, size_t bytes) {
 // 4 SIMDs of a CU), "L64" = throughput tiling (128 frames x 256 columns per workgroup).
 template <class Epi, int NW, int NA>
 int dispatch_tiling(const ConvGemmArgs& a, const typename Epi::Args& e, hipStream_t st) {
-    if (a.n_rows >= 6144 && a.cin % 64 == 0) return conv_gemm_launch<4, 4, 1, 64, 2, NW, NA, Epi>(a, e, st);
-    if (a.cin % 384 == 0) return conv_gemm_launch<1, 1, 4, 384, 3, NW, NA, Epi>(a, e, st);
-    if (a.cin % 128 == 0) return conv_gemm_launch<1, 1, 4, 128, 2, NW, NA, Epi>(a, e, st);
-    return conv_gemm_launch<1, 2, 1, 16, 1, NW, NA, Epi>(a, e, st);
+    //                                                              WM WN WK KCB PF SPT
+    if (a.n_rows >= 6144 && a.cin % 64 == 0) return conv_gemm_launch<4, 4, 1, 64, 4, 5, NW, NA, Epi>(a, e, st);
+    if (a.cin % 384 == 0) {
+        static const int stile = getenv("DSVC_STILE") ? atoi(getenv("DSVC_STILE")) : 0;      // tuning knob
+        switch (stile) {
+            case 1: return conv_gemm_launch<2, 1, 4, 384, 2, 6, NW, NA, Epi>(a, e, st);
+            case 2: return conv_gemm_launch<1, 1, 8, 384, 3, 5, NW, NA, Epi>(a, e, st);
+            case 3: return conv_gemm_launch<1, 2, 4, 384, 3, 5, NW, NA, Epi>(a, e, st);
+            default: return conv_gemm_launch<1, 1, 4, 384, 3, 5, NW, NA, Epi>(a, e, st);
+        }
+    }
+    if (a.cin % 128 == 0) return conv_gemm_launch<1, 1, 4, 128, 2, 3, NW, NA, Epi>(a, e, st);
+    return conv_gemm_launch<1, 2, 1, 16, 1, 2, NW, NA, Epi>(a, e, st);
 }
 
 template <class Epi>

@@ -80,12 +80,13 @@ struct EpiTanhWav {
 template <class Epi, int NW, int NA>
 int voc_tiling(const ConvGemmArgs& a, const typename Epi::Args& e, hipStream_t st) {
     if (a.cin % 64 == 0) {
-        if (a.n_ctiles >= 8) return conv_gemm_launch<4, 4, 1, 64, 2, NW, NA, Epi>(a, e, st);
-        if (a.n_ctiles >= 4) return conv_gemm_launch<4, 2, 1, 64, 2, NW, NA, Epi>(a, e, st);
-        return conv_gemm_launch<4, 1, 1, 64, 2, NW, NA, Epi>(a, e, st);
+        //                                                 WM WN WK KCB PF SPT
+        if (a.n_ctiles >= 8) return conv_gemm_launch<4, 4, 1, 64, 4, 6, NW, NA, Epi>(a, e, st);
+        if (a.n_ctiles >= 4) return conv_gemm_launch<4, 2, 1, 64, 4, 6, NW, NA, Epi>(a, e, st);
+        return conv_gemm_launch<4, 1, 1, 64, 4, 8, NW, NA, Epi>(a, e, st);
     }
-    if (a.cin % 32 == 0) return conv_gemm_launch<4, 1, 1, 32, 2, NW, NA, Epi>(a, e, st);
-    return conv_gemm_launch<4, 1, 1, 16, 1, NW, NA, Epi>(a, e, st);
+    if (a.cin % 32 == 0) return conv_gemm_launch<4, 1, 1, 32, 2, 8, NW, NA, Epi>(a, e, st);
+    return conv_gemm_launch<4, 1, 1, 16, 1, 8, NW, NA, Epi>(a, e, st);
 }
 
 template <class Epi>

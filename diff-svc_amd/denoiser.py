@@ -1,0 +1,84 @@
+"""``DiffNetHip`` -- drop-in for the reference denoiser ``network.diff.net.DiffNet`` (net.py:86-135).
+
+Same constructor argument, same parameter names and shapes (so ``load_state_dict(strict=True)`` of a reference
+checkpoint works), same ``forward(spec, diffusion_step, cond)`` contract; the arithmetic runs
+in libdsvc_hip.so.  Register it in the reference's seam with
+
+    DIFF_DECODERS['wavenet'] = lambda hp: DiffNetHip(hp['audio_num_mel_bins'])
+
+(infer_tools/infer_tool.py:107-111).  Inference only: there is no autograd through the HIP kernels, so
+``infer=False`` training keeps using the reference module.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .engine import DenoiserHandle
+from .hparams import get_hparams
+
+
+class _Mish(nn.Module):                      # placeholder so the MLP's keys are mlp.0.* / mlp.2.* (net.py:99-103)
+    def forward(self, x):
+        return x * torch.tanh(nn.functional.softplus(x))
+
+
+class _ResidualBlockParams(nn.Module):
+    """Parameter container mirroring ResidualBlock (net.py:58-64)."""
+
+    def __init__(self, encoder_hidden, residual_channels, dilation):
+        super().__init__()
+        self.dilated_conv = nn.Conv1d(residual_channels, 2 * residual_channels, 3, padding=dilation, dilation=dilation)
+        nn.init.kaiming_normal_(self.dilated_conv.weight)
+        self.diffusion_projection = nn.Linear(residual_channels, residual_channels)
+        self.conditioner_projection = nn.Conv1d(encoder_hidden, 2 * residual_channels, 1)
+        nn.init.kaiming_normal_(self.conditioner_projection.weight)
+        self.output_projection = nn.Conv1d(residual_channels, 2 * residual_channels, 1)
+        nn.init.kaiming_normal_(self.output_projection.weight)
+
+
+class DiffNetHip(nn.Module):
+    def __init__(self, in_dims=80, hparams=None, precision="f16_w2"):
+        super().__init__()
+        hp = hparams if hparams is not None else get_hparams()
+        self.in_dims = in_dims
+        self.encoder_hidden = hp["hidden_size"]
+        self.n_layers = hp["residual_layers"]
+        self.channels = C = hp["residual_channels"]
+        self.dilation_cycle = hp["dilation_cycle_length"]
+        self.max_steps = int(hp.get("timesteps", 1000))
+        self.precision = precision
+        self.input_projection = nn.Conv1d(in_dims, C, 1)
+        nn.init.kaiming_normal_(self.input_projection.weight)
+        self.mlp = nn.Sequential(nn.Linear(C, C * 4), _Mish(), nn.Linear(C * 4, C))
+        self.residual_layers = nn.ModuleList([
+            _ResidualBlockParams(self.encoder_hidden, C, 2 ** (i % self.dilation_cycle)) for i in range(self.n_layers)])
+        self.skip_projection = nn.Conv1d(C, C, 1)
+        nn.init.kaiming_normal_(self.skip_projection.weight)
+        self.output_projection = nn.Conv1d(C, in_dims, 1)
+        nn.init.zeros_(self.output_projection.weight)           # net.py:110
+        self._handle = None
+        self._handle_key = None
+        self._cond_key = None
+
+    # -- C handle management: rebuilt whenever a parameter tensor changes (load_state_dict, .to(), in-place edits)
+    def _params_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.precision,)
+
+    def handle(self):
+        key = self._params_key()
+        if self._handle is None or key != self._handle_key:
+            self._handle = DenoiserHandle(self.state_dict(), self.in_dims, self.encoder_hidden, self.channels, self.n_layers,
+                                          self.dilation_cycle, self.max_steps, precision=self.precision)
+            self._handle_key = key
+            self._cond_key = None
+        return self._handle
+
+    def forward(self, spec, diffusion_step, cond):
+        """spec [B,1,M,T], diffusion_step [B] (long), cond [B,H,T] -> [B,1,M,T]   (net.py:112-135)"""
+        h = self.handle()
+        ckey = (cond.data_ptr(), cond._version, tuple(cond.shape))
+        changed = ckey != self._cond_key                      # the sampler calls with the same cond 1000 times
+        out = h.forward(spec, diffusion_step.reshape(-1), cond, cond_changed=changed)
+        self._cond_key = ckey
+        return out

@@ -1,0 +1,67 @@
+"""Device-resident batched inference: content units + f0 -> cond -> 1000-step DDPM / PLMS -> NSF-HiFiGAN PCM.
+
+This is the generalisation of the reference's sequential B=1 loop (batch.py:25-43, infer.py:45-67) that
+BASELINE config 4 asks for.  Clips are independent, so a batch is sharded over ranks by
+``clip i -> rank i % world`` with one collective at the very end: an all_gather of the finished PCM (RCCL over
+xGMI under the 'nccl' backend, gloo in the CPU tests).  Nothing inside the hot loop communicates.
+"""
+import numpy as np
+import torch
+
+from .denoiser import DiffNetHip
+from .engine import VocoderHandle
+from .sampler import GaussianDiffusionHip
+
+
+def shard_clips(n_clips, rank, world):
+    """Static round-robin partition: the clip ids a rank owns."""
+    return list(range(rank, n_clips, world))
+
+
+class SvcPipeline:
+    """One process per GPU.  ``acoustic_state`` is a GaussianDiffusion state dict (no 'model.' prefix),
+    ``vocoder_state``/``vocoder_cfg`` the NSF-HiFiGAN generator checkpoint and its config.json."""
+
+    def __init__(self, hp, acoustic_state, vocoder_state, vocoder_cfg, precision="f16_w2", vocoder_precision="f16_x3",
+                 device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("SvcPipeline needs a HIP device (there is no CPU path)")
+        self.hp = hp
+        self.device = device
+        den = DiffNetHip(hp["audio_num_mel_bins"], hparams=hp, precision=precision)
+        self.model = GaussianDiffusionHip(None, hp["audio_num_mel_bins"], den, timesteps=hp["timesteps"], K_step=hp["K_step"],
+                                          loss_type=hp.get("diff_loss_type", "l2"), spec_min=hp["spec_min"],
+                                          spec_max=hp["spec_max"], hparams=hp)
+        self.model.load_state_dict(acoustic_state, strict=True)
+        self.model.to(device)
+        self.vocoder = VocoderHandle(vocoder_state, vocoder_cfg, precision=vocoder_precision)
+
+    @torch.no_grad()
+    def infer(self, hubert, mel2ph, f0, speedup=1, seed=0, first_clip=0, use_graph=True, return_mel=False):
+        """hubert [B,N,H], mel2ph [B,T] long, f0 [B,T] log2 (interpolated) -- all device tensors.
+        Returns PCM [B, T*hop] on the device (and mel [B,T,M] if asked)."""
+        hp = dict(self.hp, pndm_speedup=speedup)
+        self.model.hp = hp
+        self.model.fs2.hp = hp
+        ret = self.model(hubert, mel2ph=mel2ph, f0=f0.clone(), infer=True, seed=seed, first_clip=first_clip, use_graph=use_graph)
+        mel = ret["mel_out"]
+        # host glue of Svc.after_infer (infer_tool.py:177-183): clip the mel, f0 for the NSF source is f0_denorm
+        mel_c = torch.clamp(mel, hp["mel_vmin"], hp["mel_vmax"])
+        wav = self.vocoder.vocode(mel_c, ret["f0_denorm"], seed=seed, first_clip=first_clip)
+        return (wav, mel) if return_mel else wav
+
+
+def gather_pcm(local_wav, clip_ids, n_clips, group=None):
+    """The one collective of the sharded job: every rank contributes its finished PCM [n_local, L]; rank order
+    is undone so the result is indexed by clip id.  Equal counts per rank are required (pad the batch)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local_wav
+    out = [torch.empty_like(local_wav) for _ in range(world)]
+    dist.all_gather(out, local_wav.contiguous(), group=group)
+    full = torch.empty(n_clips, local_wav.shape[1], dtype=local_wav.dtype, device=local_wav.device)
+    for r in range(world):
+        ids = shard_clips(n_clips, r, world)
+        full[ids] = out[r][:len(ids)]
+    return full

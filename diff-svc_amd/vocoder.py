@@ -1,0 +1,110 @@
+"""``NsfHifiGANHip`` -- drop-in vocoder plugin for ``network.vocoders.nsf_hifigan.NsfHifiGAN``
+(nsf_hifigan.py:8-92).  Select it with one YAML line, no reference edits (base_vocoder.py:11-19):
+
+    vocoder: diffsvc_amd.vocoder.NsfHifiGANHip
+
+Contract kept: no-arg constructor reading ``hparams['vocoder_ckpt']`` (+ sibling config.json, models.py:14-21),
+``spec2wav(mel[T,M] log10, f0=[T] Hz) -> np.float32[T*hop]``, static ``wav2spec(path) -> (wav, mel[T,M] log10)``,
+and registration under the bare class name (infer_tool.py:244-247 looks it up through VOCODERS).
+The generator, the harmonic source and the STFT/mel run in libdsvc_hip.so.
+"""
+import json
+import os
+import wave
+
+import numpy as np
+import torch
+
+from .engine import MelspecHandle, VocoderHandle
+from .hparams import get_hparams
+
+try:                                                       # inside the reference tree: use its registry
+    from network.vocoders.base_vocoder import BaseVocoder, register_vocoder
+except Exception:                                          # standalone
+    class BaseVocoder:                                     # noqa: D401
+        pass
+
+    def register_vocoder(cls):
+        return cls
+
+_melspec_cache = {}
+
+
+def load_generator_checkpoint(model_path):
+    """(generator state dict with weight-norm pairs, config dict) -- the format of models.py:14-26."""
+    config_file = os.path.join(os.path.split(model_path)[0], "config.json")
+    with open(config_file) as f:
+        h = json.loads(f.read())
+    cp = torch.load(model_path, map_location="cpu")
+    return cp["generator"], h
+
+
+def read_wav(path_or_file, target_sr):
+    """int PCM -> [-1, 1) by the type's magnitude, first channel only (nvSTFT.py:14-44).  Resampling is the
+    caller's job (the reference uses librosa.resample, which is not part of this path)."""
+    try:
+        import soundfile as sf
+        data, sr = sf.read(path_or_file, always_2d=True)
+        data = data[:, 0].astype(np.float32)
+    except ImportError:
+        with wave.open(path_or_file, "rb") as w:
+            sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+            raw = w.readframes(n)
+        if width != 2:
+            raise RuntimeError("only 16-bit PCM wav is supported without the soundfile package")
+        data = np.frombuffer(raw, dtype="<i2").reshape(-1, nch)[:, 0].astype(np.float32) / 32768.0
+    if sr != target_sr:
+        raise RuntimeError("wav2spec: file is %d Hz, model expects %d Hz (resample first)" % (sr, target_sr))
+    return data
+
+
+@register_vocoder
+class NsfHifiGANHip(BaseVocoder):
+    def __init__(self, device=None, precision="f16_x3"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("NsfHifiGANHip needs a HIP device (there is no CPU path)")
+        self.device = device or "cuda"
+        hp = get_hparams()
+        model_path = hp["vocoder_ckpt"]
+        if not os.path.exists(model_path):
+            raise FileNotFoundError("HifiGAN model file is not found: %s" % model_path)
+        print("| Load HifiGAN (HIP): ", model_path)
+        state, self.h = load_generator_checkpoint(model_path)
+        self.model = VocoderHandle(state, self.h, precision=precision)
+        self.seed = 0
+
+    def _warn_mismatch(self):
+        hp = get_hparams()
+        for a, b in (("sampling_rate", "audio_sample_rate"), ("num_mels", "audio_num_mel_bins"), ("n_fft", "fft_size"),
+                     ("win_size", "win_size"), ("hop_size", "hop_size"), ("fmin", "fmin"), ("fmax", "fmax")):
+            if a in self.h and b in hp and self.h[a] != hp[b]:
+                print("Mismatch parameters: hparams['%s']=" % b, hp[b], "!=", self.h[a], "(vocoder)")
+
+    def spec2wav_torch(self, mel, **kwargs):          # mel [B, T, bins] device tensor -> flat device tensor
+        self._warn_mismatch()
+        f0 = kwargs.get("f0")
+        if f0 is None or not get_hparams().get("use_nsf"):
+            raise NotImplementedError("the NSF generator needs f0 (use_nsf: true)")
+        self.seed += 1
+        return self.model.vocode(mel.to(self.device), f0.to(self.device), seed=kwargs.get("seed", self.seed)).view(-1)
+
+    def spec2wav(self, mel, **kwargs):
+        self._warn_mismatch()
+        f0 = kwargs.get("f0")
+        if f0 is None or not get_hparams().get("use_nsf"):
+            raise NotImplementedError("the NSF generator needs f0 (use_nsf: true)")
+        self.seed += 1
+        c = torch.FloatTensor(np.asarray(mel)).unsqueeze(0).to(self.device)
+        f = torch.FloatTensor(np.asarray(f0)[None, :]).to(self.device)
+        y = self.model.vocode(c, f, seed=kwargs.get("seed", self.seed)).view(-1)
+        return y.cpu().numpy()
+
+    @staticmethod
+    def wav2spec(inp_path, device=None):
+        hp = get_hparams()
+        key = tuple(hp[k] for k in ("audio_sample_rate", "fft_size", "win_size", "hop_size", "audio_num_mel_bins", "fmin", "fmax"))
+        if key not in _melspec_cache:
+            _melspec_cache[key] = MelspecHandle(*key)
+        wav = read_wav(inp_path, hp["audio_sample_rate"])
+        mel = _melspec_cache[key].mel(torch.from_numpy(wav)[None].cuda())[0]
+        return wav, mel.cpu().numpy()
