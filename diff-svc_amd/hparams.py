@@ -6,7 +6,7 @@ _own = {}
 
 def get_hparams():
     try:
-        import utils.hparams as ref            # the reference's module, when /root/reference is on sys.path
+        import utils.hparams as ref            # the reference's module, when the reference tree is on sys.path
         if isinstance(getattr(ref, "hparams", None), dict) and hasattr(ref, "set_hparams"):
             return ref.hparams
     except Exception:

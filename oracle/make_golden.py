@@ -184,8 +184,30 @@ def golden_melspec(name, sr, n_fft, win, hop, n_mels, fmin, fmax, n_samples):
     print(name, "mel", tuple(mel.shape), "range %.2f..%.2f" % (mel.min().item(), mel.max().item()))
 
 
+def golden_state_keys():
+    """Names and shapes of the state dicts the REAL reference modules own (the strict-load contract of
+    utils/__init__.py:178-209 and models.py:14-30), for the two acoustic configs and the vocoder."""
+    import json
+    out = {}
+    for tag, hp in (("tiny", synth.tiny_hparams()), ("44k", dict(synth.HPARAMS_44K))):
+        model = build_reference_model(hp, synth.acoustic_state(hp, 0))
+        out["acoustic_" + tag] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    refshim.install()
+    import modules.nsf_hifigan.models as NM
+    from modules.nsf_hifigan.env import AttrDict
+    for tag, h in (("tiny", synth.tiny_vocoder()), ("44k", dict(synth.VOCODER_44K))):
+        gen = NM.Generator(AttrDict(h))
+        out["vocoder_" + tag] = {k: list(v.shape) for k, v in gen.state_dict().items()}
+    with open(os.path.join(OUT, "state_keys.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("state_keys", {k: len(v) for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--keys-only" in sys.argv:
+        return golden_state_keys()
+    golden_state_keys()
     golden_vocoder("vocoder_tiny", synth.tiny_vocoder(), 5, clips=[0, 3], T=24, seed=90)
     golden_vocoder("vocoder_44k", dict(synth.VOCODER_44K), 1, clips=[1], T=12, seed=91)
     golden_melspec("melspec_44k", 44100, 2048, 2048, 512, 128, 40, 16000, 20000)

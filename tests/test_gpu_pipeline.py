@@ -1,0 +1,175 @@
+"""GPU: the drop-in modules behind the reference's plugin seams, end to end (units + f0 -> cond -> sampler ->
+NSF-HiFiGAN PCM), against the oracle; plus size-independent properties at the BASELINE clip size (T=861)."""
+import os
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from diffsvc_amd import synth
+import dsvc_oracle as O
+from util import clip_batch, oracle_sample
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_pipeline(K=30, precision="f16_x3"):
+    from diffsvc_amd.pipeline import SvcPipeline
+    hp = synth.tiny_hparams(K=K)
+    h = synth.tiny_vocoder(num_mels=hp["audio_num_mel_bins"])
+    sd, vs = synth.acoustic_state(hp, 3), synth.vocoder_state(h, 5)
+    return SvcPipeline(hp, sd, vs, h, precision=precision, vocoder_precision="f16_x3"), hp, h, sd, vs
+
+
+@pytest.mark.parametrize("speedup", [1, 10])
+def test_pipeline_end_to_end_vs_oracle(speedup):
+    pipe, hp, h, sd, vs = tiny_pipeline()
+    T, n_units, clips, seed = 40, 23, [0, 1], 11
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    wav, mel = pipe.infer(hub.cuda(), m2p.cuda(), f0.cuda(), speedup=speedup, seed=seed, first_clip=0, return_mel=True)
+    r = oracle_sample(hp, sd, clips, T, n_units, speedup, seed, hp["K_step"])
+    assert (mel.cpu() - r["mel_out"]).abs().max().item() < (1e-3 if speedup == 1 else 2e-3)
+    hop = int(np.prod(h["upsample_rates"]))
+    ini, nz = O.vocoder_rng(seed, clips, T * hop)
+    gw = O.fold_weight_norm(vs)
+    with torch.no_grad():                                   # same mel in: isolates the vocoder from sampler rounding
+        c = 2.30259 * torch.clamp(mel.cpu(), hp["mel_vmin"], hp["mel_vmax"]).transpose(2, 1)
+        wav_ref = O.generator_forward(gw, h, c, r["f0_denorm"], ini, nz).reshape(len(clips), -1)
+    assert wav.shape == (2, T * hop)
+    assert (wav.cpu() - wav_ref).pow(2).mean().sqrt().item() < 1e-4
+
+
+def test_denoiser_module_seam():
+    """DiffNetHip as the reference uses DiffNet: construct from hparams, strict load, .cuda(), call
+    denoise_fn(x, t, cond=cond) with an int64 step tensor (diffusion.py:147)."""
+    from diffsvc_amd.denoiser import DiffNetHip
+    hp = synth.tiny_hparams()
+    sd = synth.acoustic_state(hp, 3)
+    den = DiffNetHip(hp["audio_num_mel_bins"], hparams=hp, precision="f16_x3")
+    den.load_state_dict({k[len("denoise_fn."):]: v for k, v in sd.items() if k.startswith("denoise_fn.")}, strict=True)
+    den.cuda()
+    g = np.random.Generator(np.random.PCG64(2))
+    spec = torch.from_numpy(g.standard_normal((2, 1, 16, 33)).astype(np.float32))
+    cond = torch.from_numpy((g.standard_normal((2, 32, 33)) * 0.5).astype(np.float32))
+    t = torch.tensor([7, 41], dtype=torch.long)
+    out = den(spec.cuda(), t.cuda(), cond=cond.cuda())
+    with torch.no_grad():
+        ref = O.diffnet_forward(sd, spec, t, cond, hp["dilation_cycle_length"])
+    assert (out.cpu() - ref).abs().max().item() < 3e-4
+    # an in-place weight edit is picked up (the packed device copy is derived state, never stale)
+    with torch.no_grad():
+        den.output_projection.weight.mul_(2.0)
+        den.output_projection.bias.mul_(2.0)
+    out2 = den(spec.cuda(), t.cuda(), cond=cond.cuda())
+    assert (out2.cpu() - 2 * ref).abs().max().item() < 6e-4
+
+
+def test_sampler_module_use_gt_mel_start():
+    """use_gt_mel / add_noise_step (diffusion.py:255-261): the chain starts from q_sample(norm_spec(ref_mel), t-1)."""
+    from diffsvc_amd.denoiser import DiffNetHip
+    from diffsvc_amd.sampler import GaussianDiffusionHip
+    hp = synth.tiny_hparams(K=50)
+    sd = synth.acoustic_state(hp, 3)
+    M = hp["audio_num_mel_bins"]
+    model = GaussianDiffusionHip(None, M, DiffNetHip(M, hparams=hp, precision="f16_x3"), timesteps=50, K_step=50,
+                                 loss_type="l2", spec_min=hp["spec_min"], spec_max=hp["spec_max"], hparams=hp)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    model.hp = dict(hp, pndm_speedup=1)
+    T, n_units, seed, steps = 40, 23, 5, 20
+    hub, m2p, f0 = clip_batch(hp, [0], T, n_units)
+    g = np.random.Generator(np.random.PCG64(4))
+    ref_mel = torch.from_numpy((g.standard_normal((1, T, M)) * 0.7 - 2.5).astype(np.float32))
+    x0_dev = model.norm_spec(ref_mel.cuda()).transpose(1, 2)[:, None, :, :]
+    torch.manual_seed(99)
+    noise = torch.randn_like(x0_dev)                          # the very draw forward() makes (same shape and strides)
+    torch.manual_seed(99)
+    ret = model(hub.cuda(), mel2ph=m2p.cuda(), f0=f0.clone().cuda(), ref_mels=ref_mel.cuda(), infer=True,
+                use_gt_mel=True, add_noise_step=steps, seed=seed)
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    x0 = O.norm_spec(sd, ref_mel).transpose(1, 2)[:, None]
+    x = O.q_sample(sd, x0, torch.tensor([steps - 1]), noise.cpu())
+    x = O.sample_ddpm(sd, cond.transpose(1, 2).contiguous(), x, lambda i: O.ddpm_noise_ref_layout(seed, [0], i, T, M),
+                      hp["dilation_cycle_length"], t_start=steps)
+    assert (ret["mel_out"].cpu() - O.finish_mel(sd, x, m2p)).abs().max().item() < 1e-3
+
+
+def test_vocoder_plugin_contract(tmp_path):
+    """NsfHifiGANHip through the reference's vocoder contract (nsf_hifigan.py:8-92): no-arg constructor reading
+    hparams['vocoder_ckpt'] + sibling config.json, spec2wav(numpy mel, f0=numpy) -> numpy, static wav2spec(path)."""
+    from diffsvc_amd.hparams import set_hparams
+    from diffsvc_amd.vocoder import NsfHifiGANHip
+    h = synth.tiny_vocoder(num_mels=16)
+    vs = synth.save_vocoder_ckpt(str(tmp_path / "voc"), h, seed=5)
+    hp = dict(synth.tiny_hparams(), vocoder_ckpt=str(tmp_path / "voc" / "model"), audio_sample_rate=44100,
+              fft_size=512, win_size=512, hop_size=128, fmin=40, fmax=16000)
+    set_hparams(hp)
+    voc = NsfHifiGANHip()
+    T = 24
+    hop = int(np.prod(h["upsample_rates"]))
+    g = np.random.Generator(np.random.PCG64(6))
+    mel = (g.standard_normal((T, 16)) * 0.8 - 2.5).astype(np.float32)
+    f0 = synth.clip_inputs(2, T=T, n_units=12)[3]
+    wav = voc.spec2wav(mel, f0=f0, seed=42)
+    assert isinstance(wav, np.ndarray) and wav.dtype == np.float32 and wav.shape == (T * hop,)
+    ini, nz = O.vocoder_rng(42, [0], T * hop)
+    ref = O.spec2wav(O.fold_weight_norm(vs), h, mel, f0, ini, nz).numpy()
+    assert np.sqrt(np.mean((wav - ref) ** 2)) < 1e-4
+    # wav2spec: 16-bit PCM file -> (wav, mel[T, M] log10)
+    sr, n = 44100, 6000
+    t = np.arange(n) / sr
+    pcm = (0.4 * np.sin(2 * np.pi * 330 * t) * 32767).astype("<i2")
+    path = str(tmp_path / "a.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes(pcm.tobytes())
+    wav_in, mel_out = NsfHifiGANHip.wav2spec(path)
+    assert np.array_equal(wav_in, pcm.astype(np.float32) / 32768.0)
+    ref_mel = O.mel_spectrogram(torch.from_numpy(wav_in)[None], sr, 512, 512, 128, 16, 40, 16000)[0].numpy()
+    assert mel_out.shape == ref_mel.shape and np.abs(mel_out - ref_mel).max() < 1e-3
+    with pytest.raises(FileNotFoundError):
+        set_hparams(dict(hp, vocoder_ckpt=str(tmp_path / "missing" / "model")))
+        NsfHifiGANHip()
+
+
+def test_full_size_clip_properties():
+    """BASELINE clip size (T=861, 44.1 kHz architecture), 24 DDPM steps -- properties that need no oracle run:
+    (1) a chain split at an arbitrary step composes exactly (noise is keyed by (seed, clip, step));
+    (2) a batch of clips equals the per-clip runs bit for bit; (3) graph replay == eager; (4) output is finite
+    and inside the denormalised range [spec_min, spec_max] (x0 is clamped to [-1, 1] at t=0)."""
+    from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
+    hp = dict(synth.HPARAMS_44K)
+    sd = synth.acoustic_state(hp, 0)
+    den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision="f16_w2", prefix="denoise_fn.")
+    smp = SamplerHandle(den, sd)
+    T, K = 861, 24
+    hub, m2p, f0 = clip_batch(hp, [0, 1], T, 500)
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    cond = cond.transpose(1, 2).contiguous().cuda()
+    full, xf = smp.sample(cond, K, seed=5, first_clip=0, use_graph=False, return_x=True)
+    part, xp = smp.sample(cond, K, seed=5, first_clip=0, t_stop=9, use_graph=False, return_x=True)
+    rest, xr = smp.sample(cond, 9, x_init=xp, seed=5, first_clip=0, use_graph=False, return_x=True)
+    assert torch.equal(xr, xf) and torch.equal(rest, full)
+    one = smp.sample(cond[1:2], K, seed=5, first_clip=1, use_graph=False)
+    assert torch.equal(one[0], full[1])
+    graph = smp.sample(cond, K, seed=5, first_clip=0, use_graph=True)
+    assert torch.equal(graph, full)
+    assert torch.isfinite(full).all()
+    assert full.min().item() >= hp["spec_min"][0] - 1e-5 and full.max().item() <= hp["spec_max"][0] + 1e-5
+
+
+def test_full_size_vocoder_properties():
+    """10 s clip through the 44.1 kHz generator: output length T*512, finite, |y| <= 1 (tanh), and the first
+    frames equal a short-clip run wherever the receptive field allows (the net is fully convolutional)."""
+    from diffsvc_amd.engine import VocoderHandle
+    h = dict(synth.VOCODER_44K)
+    voc = VocoderHandle(synth.vocoder_state(h, 1), h, precision="f16_x3")
+    T = 861
+    g = np.random.Generator(np.random.PCG64(12))
+    mel = torch.from_numpy((g.standard_normal((1, T, 128)) * 0.8 - 2.5).astype(np.float32)).cuda()
+    f0 = torch.from_numpy(synth.clip_inputs(0, T=T)[3])[None].cuda()
+    wav = voc.vocode(mel, f0, seed=1, first_clip=0)
+    assert wav.shape == (1, T * 512) and torch.isfinite(wav).all() and wav.abs().max().item() <= 1.0
+    short = voc.vocode(mel[:, :64].contiguous(), f0[:, :64].contiguous(), seed=1, first_clip=0)
+    n = (64 - 24) * 512                                     # receptive field of the generator < 24 frames
+    assert (short[0, :n] - wav[0, :n]).abs().max().item() < 1e-5

@@ -1,0 +1,122 @@
+"""GPU parity: NSF-HiFiGAN generator and the STFT/mel front-end (HIP, through the C ABI) against the golden
+vectors minted from the real reference and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from diffsvc_amd import synth
+import dsvc_oracle as O
+from util import load_golden
+
+pytestmark = pytest.mark.gpu
+
+WAV_RMS_TOL = 1e-4          # north_star: waveform within 1e-4 RMS
+MEL_TOL = 1e-3              # north_star: mel within 1e-3 max-abs
+
+
+def vocoder_for(h, wseed, precision="f16_x3"):
+    from diffsvc_amd.engine import VocoderHandle
+    return VocoderHandle(synth.vocoder_state(h, wseed), h, precision=precision)
+
+
+@pytest.mark.parametrize("name", ["vocoder_tiny", "vocoder_44k"])
+def test_vocoder_vs_reference_golden(name):
+    g = load_golden(name)
+    h = synth.tiny_vocoder() if "tiny" in name else dict(synth.VOCODER_44K)
+    voc = vocoder_for(h, int(g["wseed"]))
+    clips = [int(c) for c in g["clips"]]
+    wavs = []
+    for i, c in enumerate(clips):
+        w = voc.vocode(torch.from_numpy(g["mel"][i:i + 1]).cuda(), torch.from_numpy(g["f0"][i:i + 1]).cuda(),
+                       seed=int(g["seed"]), first_clip=c)
+        wavs.append(w.cpu())
+    wav = torch.cat(wavs)
+    ref = torch.from_numpy(g["wav"])
+    rms = (wav - ref).pow(2).mean().sqrt().item()
+    assert rms < WAV_RMS_TOL, rms
+    assert (wav - ref).abs().max().item() < 2e-3
+
+
+def test_vocoder_batch_equals_per_clip_and_oracle_long_clip():
+    """A longer clip than the golden (several voiced/unvoiced transitions, phase wraps of every harmonic) and
+    a batch of two: batched == per clip bit for bit, and both within the RMS bar of the oracle."""
+    h = dict(synth.VOCODER_44K)
+    voc = vocoder_for(h, 1)
+    T, hop = 40, 512
+    g = np.random.Generator(np.random.PCG64(3))
+    mel = torch.from_numpy((g.standard_normal((2, T, 128)) * 0.8 - 2.5).astype(np.float32))
+    f0 = np.stack([synth.clip_inputs(c, T=T, n_units=23)[3] for c in (4, 9)])
+    f0[0, 5:9] = 0.0
+    f0[1, 30:] = 0.0
+    f0 = torch.from_numpy(f0)
+    full = voc.vocode(mel.cuda(), f0.cuda(), seed=77, first_clip=4)
+    one = voc.vocode(mel[1:2].cuda(), f0[1:2].cuda(), seed=77, first_clip=5)
+    assert torch.equal(full[1], one[0])
+    ini, nz = O.vocoder_rng(77, [4, 5], T * hop)
+    gw = O.fold_weight_norm(synth.vocoder_state(h, 1))
+    with torch.no_grad():
+        ref = O.generator_forward(gw, h, 2.30259 * mel.transpose(2, 1), f0, ini, nz).reshape(2, -1)
+    rms = (full.cpu() - ref).pow(2).mean().sqrt().item()
+    assert rms < WAV_RMS_TOL, rms
+
+
+def test_vocoder_all_unvoiced_and_constant_pitch():
+    """Edge cases of the harmonic source: f0 == 0 everywhere (noise excitation only) and a constant pitch whose
+    phase accumulates over every frame (the closed-form cumsum must track torch's sequential one)."""
+    h = synth.tiny_vocoder()
+    voc = vocoder_for(h, 5)
+    T = 64
+    hop = int(np.prod(h["upsample_rates"]))
+    g = np.random.Generator(np.random.PCG64(8))
+    mel = torch.from_numpy((g.standard_normal((2, T, h["num_mels"])) * 0.8 - 2.5).astype(np.float32))
+    f0 = torch.zeros(2, T)
+    f0[1] = 437.3
+    wav = voc.vocode(mel.cuda(), f0.cuda(), seed=3, first_clip=0).cpu()
+    ini, nz = O.vocoder_rng(3, [0, 1], T * hop)
+    gw = O.fold_weight_norm(synth.vocoder_state(h, 5))
+    with torch.no_grad():
+        ref = O.generator_forward(gw, h, 2.30259 * mel.transpose(2, 1), f0, ini, nz).reshape(2, -1)
+    assert (wav - ref).pow(2).mean().sqrt().item() < WAV_RMS_TOL
+
+
+def test_vocoder_rejects_bad_shapes():
+    h = synth.tiny_vocoder()
+    voc = vocoder_for(h, 5)
+    with pytest.raises(ValueError):
+        voc.vocode(torch.zeros(1, 8, h["num_mels"] + 1).cuda(), torch.zeros(1, 8).cuda())
+    with pytest.raises(RuntimeError):
+        voc.vocode(torch.zeros(1, 8, h["num_mels"]), torch.zeros(1, 8))          # CPU tensors: no CPU path
+
+
+@pytest.mark.parametrize("name", ["melspec_44k", "melspec_24k"])
+def test_melspec_vs_reference_golden(name):
+    from diffsvc_amd.engine import MelspecHandle
+    g = load_golden(name)
+    sr, n_fft, win, hop, n_mels, fmin, fmax = [int(v) for v in g["cfg"]]
+    ms = MelspecHandle(sr, n_fft, win, hop, n_mels, fmin, fmax)
+    wav = torch.from_numpy(g["wav"])[None]
+    assert ms.frames(wav.shape[1]) == g["mel"].shape[0]
+    mel = ms.mel(wav.cuda())[0].cpu().numpy()
+    err = np.abs(mel - g["mel"]).max()
+    assert err < MEL_TOL, err
+    assert err < 2e-4, err          # fp32 FFT: far inside the bar
+
+
+def test_melspec_full_clip_batch_and_silence():
+    """BASELINE-size input (10 s @ 44.1 kHz -> 861 frames), a batch of 2, one clip digital silence: the frame
+    count matches nvSTFT.py:92-96, silence lands exactly on log10(clip_val), rows are independent."""
+    from diffsvc_amd.engine import MelspecHandle
+    ms = MelspecHandle(44100, 2048, 2048, 512, 128, 40, 16000)
+    N = 441000
+    g = np.random.Generator(np.random.PCG64(1))
+    wav = torch.zeros(2, N)
+    wav[0] = torch.from_numpy((g.standard_normal(N) * 0.1).astype(np.float32))
+    assert ms.frames(N) == 861
+    mel = ms.mel(wav.cuda()).cpu()
+    assert mel.shape == (2, 861, 128)
+    sil = 0.434294 * np.log(1e-5)       # |X| = sqrt(1e-9) everywhere -> every filter sums below clip_val
+    assert torch.allclose(mel[1], torch.full_like(mel[1], float(sil)), atol=1e-6)
+    part = ms.mel(wav[:1, :20000].cuda()).cpu()            # a prefix shares its interior frames with the full clip
+    assert torch.equal(part[0, :30], mel[0, :30])
+    ref = O.mel_spectrogram(wav[:1, :20000], 44100, 2048, 2048, 512, 128, 40, 16000)[0]
+    assert (part[0] - ref).abs().max().item() < 2e-4

@@ -1,0 +1,153 @@
+"""CPU: host-side mirror of the reference seams (no GPU, no compute through the C ABI).
+
+  * state-dict contract: the drop-in modules own exactly the keys/shapes the REAL reference modules own
+    (tests/golden/state_keys.json, minted from /root/reference by oracle/make_golden.py), so the reference's
+    strict checkpoint load (utils/__init__.py:178-209) works on them;
+  * condition builder: index work bit-exact against the reference goldens;
+  * utterance sharding + the one collective (all_gather of PCM) under gloo, world_size 2;
+  * the product path refuses to run without a HIP device instead of falling back.
+"""
+import json
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from diffsvc_amd import synth
+from diffsvc_amd.cond import CondBuilder
+from diffsvc_amd.denoiser import DiffNetHip
+from diffsvc_amd.pipeline import gather_pcm, shard_clips
+from diffsvc_amd.sampler import GaussianDiffusionHip
+from util import GOLD, clip_batch, load_golden
+
+
+def _keys():
+    with open(os.path.join(GOLD, "state_keys.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("tag,hp", [("tiny", synth.tiny_hparams()), ("44k", dict(synth.HPARAMS_44K))])
+def test_acoustic_state_dict_contract(tag, hp):
+    ref = _keys()["acoustic_" + tag]
+    den = DiffNetHip(hp["audio_num_mel_bins"], hparams=hp)
+    model = GaussianDiffusionHip(None, hp["audio_num_mel_bins"], den, timesteps=hp["timesteps"], K_step=hp["K_step"],
+                                 loss_type=hp["diff_loss_type"], spec_min=hp["spec_min"], spec_max=hp["spec_max"], hparams=hp)
+    sd = synth.acoustic_state(hp, 0)
+    assert {k: list(v.shape) for k, v in sd.items()} == ref                 # the synthetic checkpoint has the reference's keys
+    model.load_state_dict(sd, strict=True)                                  # ... and loads strictly into the drop-in
+    own = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert own == ref, (set(own) ^ set(ref))
+    # loaded buffers win over recomputed ones: corrupt one and see it survive the load
+    sd2 = dict(sd, betas=sd["betas"] * 0.5)
+    model.load_state_dict(sd2, strict=True)
+    assert torch.equal(model.betas, sd2["betas"])
+
+
+@pytest.mark.parametrize("tag,h", [("tiny", synth.tiny_vocoder()), ("44k", dict(synth.VOCODER_44K))])
+def test_vocoder_checkpoint_keys_match_reference(tag, h):
+    ref = _keys()["vocoder_" + tag]
+    sd = synth.vocoder_state(h, 1)
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+
+
+@pytest.mark.parametrize("name", ["ddpm_tiny", "plms_tiny_s5", "ddpm_44k_k20"])
+def test_cond_builder_bit_exact_vs_reference(name):
+    g = load_golden(name)
+    hp = synth.tiny_hparams() if "tiny" in name else dict(synth.HPARAMS_44K)
+    sd = synth.acoustic_state(hp, int(g["wseed"]))
+    cb = CondBuilder(hp)
+    cb.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("fs2.")}, strict=True)
+    hub, m2p, f0 = clip_batch(hp, [int(c) for c in g["clips"]], int(g["T"]), int(g["n_units"]))
+    f0_arg = f0.clone()
+    ret = cb(hub, m2p, None, None, f0_arg, None, None, infer=True)
+    assert np.array_equal(ret["pitch_pred"].numpy(), g["pitch"])            # index work: bit-exact
+    assert np.array_equal(ret["f0_denorm"].numpy(), g["f0_denorm"])
+    assert np.array_equal(ret["decoder_inp"].detach().numpy(), g["decoder_inp"])
+
+
+def test_cond_builder_padding_and_unsupported_configs():
+    hp = synth.tiny_hparams()
+    cb = CondBuilder(hp)
+    hub, m2p, f0 = clip_batch(hp, [0], 40, 23)
+    m2p[0, 30:] = 0                                                         # padded frames
+    f0_arg = f0.clone()
+    ret = cb(hub, m2p, None, None, f0_arg, None, None, infer=True)
+    assert (ret["decoder_inp"][0, 30:] == 0).all() and (ret["f0_denorm"][0, 30:] == 0).all()
+    assert (f0_arg[0, 30:] == 0).all()                                      # the reference mutates its f0 argument (fs2.py:231)
+    with pytest.raises(NotImplementedError):
+        CondBuilder(dict(hp, no_fs2=False))(hub, m2p, None, None, f0.clone(), None, None)
+
+
+def test_shard_clips_partition():
+    for n, w in ((256, 8), (7, 2), (3, 4), (0, 2)):
+        parts = [shard_clips(n, r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, n_clips, L, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = shard_clips(n_clips, rank, world)
+    local = torch.stack([torch.full((L,), float(i)) + torch.arange(L) * 1e-3 for i in ids])
+    full = gather_pcm(local, ids, n_clips)
+    dist.barrier()
+    if rank == 0:
+        q.put(full.numpy())
+    dist.destroy_process_group()
+
+
+def test_gather_pcm_world2_gloo():
+    """The one collective of the sharded job (BASELINE configs[3]): clip i -> rank i % world, all_gather of the
+    finished PCM, rank order undone.  gloo on CPU stands in for RCCL."""
+    world, n_clips, L = 2, 6, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, n_clips, L, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([np.full(L, float(i), np.float32) + np.arange(L, dtype=np.float32) * 1e-3 for i in range(n_clips)])
+    assert np.array_equal(full, want)
+
+
+def test_product_path_has_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from diffsvc_amd.pipeline import SvcPipeline
+    hp = synth.tiny_hparams()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        SvcPipeline(hp, synth.acoustic_state(hp, 0), {}, synth.tiny_vocoder())
+    den = DiffNetHip(hp["audio_num_mel_bins"], hparams=hp)
+    den.load_state_dict({k[len("denoise_fn."):]: v for k, v in synth.acoustic_state(hp, 0).items() if k.startswith("denoise_fn.")})
+    with pytest.raises(RuntimeError):                                       # no device: the C ABI refuses, nothing falls back
+        den(torch.zeros(1, 1, 16, 8), torch.zeros(1, dtype=torch.long), torch.zeros(1, 32, 8))
+
+
+def test_product_sources_never_import_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "diff-svc_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert not re.search(r"^\s*(import|from)\s+(dsvc_oracle|refshim|oracle)\b", src, re.M), f
+                assert "/root/reference" not in src, f
