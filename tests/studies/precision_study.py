@@ -1,0 +1,128 @@
+"""CPU study (test infrastructure): which operand-precision scheme for the two big per-layer contractions keeps a
+full 1000-step DDPM chain within the 1e-3 mel bar?  Emulates the MFMA numerics (fp16 operands, fp32 accumulate) in
+PyTorch-CPU on top of the oracle.  Schemes:
+  f16        w -> fp16 (nearest), x -> fp16                       1 MFMA / product
+  w2         w exact (hi+lo), x -> fp16                           2 MFMAs
+  ditherK    w -> one of K fp16 roundings, variant = step % K; the K roundings average to w    1 MFMA
+Usage: python tests/studies/precision_study.py [T] [steps] [schemes...]
+"""
+import math, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.nn.functional as F
+import diffsvc_amd
+from diffsvc_amd import synth
+import dsvc_oracle as O
+from util import clip_batch
+
+def fp16_floor_ceil(w):
+    """(largest fp16 <= w, smallest fp16 >= w) as float32 arrays."""
+    h = w.astype(np.float16)
+    hf = h.astype(np.float32)
+    up = np.nextafter(h, np.float16(np.inf)).astype(np.float32)
+    dn = np.nextafter(h, np.float16(-np.inf)).astype(np.float32)
+    lo = np.where(hf <= w, hf, dn)
+    hi = np.where(hf >= w, hf, up)
+    return lo, hi
+
+def dither_variants(w, K, seed=0):
+    """K fp16 roundings of w whose mean is w +- ulp/(2K): variant k rounds up iff frac(w) > u_k, with the thresholds
+    u_k = ((k + 0.5)/K + phase(element)) mod 1 -- a per-element random phase decorrelates elements."""
+    w = w.numpy().astype(np.float32)
+    lo, hi = fp16_floor_ceil(w)
+    span = hi - lo
+    frac = np.where(span > 0, (w - lo) / np.where(span > 0, span, 1), 0.0)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    phase = rng.random(w.shape).astype(np.float32) if K > 1 else np.zeros_like(w)
+    out = []
+    for k in range(K):
+        u = ((k + 0.5) / K + phase) % 1.0
+        out.append(torch.from_numpy(np.where(frac > u, hi, lo).astype(np.float32)))
+    return out
+
+def r16(x):
+    return x.half().float()
+
+class Net:
+    def __init__(self, sd, hp, scheme):
+        self.sd, self.hp, self.scheme = sd, hp, scheme
+        self.L = hp["residual_layers"]; self.C = hp["residual_channels"]; self.cyc = hp["dilation_cycle_length"]
+        self.K = 1
+        p = "denoise_fn.residual_layers.%d.%s"
+        if scheme.startswith("dither"):
+            self.K = int(scheme[6:])
+        self.wd, self.wo = [], []
+        for l in range(self.L):
+            wd, wo = sd[p % (l, "dilated_conv.weight")], sd[p % (l, "output_projection.weight")]
+            if scheme == "f32" or scheme == "w2":
+                self.wd.append([wd]); self.wo.append([wo])
+            elif scheme == "f16":
+                self.wd.append([r16(wd)]); self.wo.append([r16(wo)])
+            else:
+                self.wd.append(dither_variants(wd, self.K, 2 * l)); self.wo.append(dither_variants(wo, self.K, 2 * l + 1))
+        self.order = list(range(self.K))
+        if self.K > 1:      # bit-reversed visiting order: consecutive steps use far-apart thresholds
+            bits = int(math.log2(self.K))
+            self.order = [int(format(i, "0%db" % bits)[::-1], 2) for i in range(self.K)] if 2 ** bits == self.K else self.order
+
+    def forward(self, spec, t, cond, cproj):
+        sd = self.sd; P = "denoise_fn."
+        p = lambda k: sd[P + k]
+        C = self.C
+        act = (lambda v: v) if self.scheme == "f32" else r16
+        x = F.relu(F.conv1d(spec[:, 0], p("input_projection.weight"), p("input_projection.bias")))
+        emb = O.step_embedding(sd, t)
+        skip = torch.zeros_like(x)
+        k = self.order[int(t[0]) % self.K]
+        for l in range(self.L):
+            q = lambda s: p("residual_layers.%d.%s" % (l, s))
+            d = 2 ** (l % self.cyc)
+            film = F.linear(emb, q("diffusion_projection.weight"), q("diffusion_projection.bias"))[:, :, None]
+            y = F.conv1d(act(x + film), self.wd[l][k % len(self.wd[l])], q("dilated_conv.bias"), padding=d, dilation=d) + cproj[l]
+            z = torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
+            o = F.conv1d(act(z), self.wo[l][k % len(self.wo[l])], q("output_projection.bias"))
+            x = (x + o[:, :C]) / math.sqrt(2.0)
+            skip = skip + o[:, C:]
+        s = skip / math.sqrt(self.L)
+        s = F.relu(F.conv1d(s, p("skip_projection.weight"), p("skip_projection.bias")))
+        return F.conv1d(s, p("output_projection.weight"), p("output_projection.bias"))[:, None]
+
+def chain(net, sd, hp, cond_t, x, seed, clips, T, steps, K_total):
+    M = hp["audio_num_mel_bins"]
+    cproj = [F.conv1d(cond_t, sd["denoise_fn.residual_layers.%d.conditioner_projection.weight" % l],
+                      sd["denoise_fn.residual_layers.%d.conditioner_projection.bias" % l]) for l in range(net.L)]
+    snaps = {}
+    with torch.no_grad():
+        for i in reversed(range(K_total - steps, K_total)):
+            t = torch.full((x.shape[0],), i, dtype=torch.long)
+            eps = net.forward(x, t, cond_t, cproj)
+            x = O.ddpm_update(sd, x, eps, t, O.ddpm_noise_ref_layout(seed, clips, i, T, M))
+    return x
+
+def main():
+    T = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    schemes = sys.argv[3:] or ["f32", "f16", "w2", "dither2", "dither4", "dither8", "dither16"]
+    torch.set_num_threads(8)
+    hp = dict(synth.HPARAMS_44K)
+    sd = synth.acoustic_state(hp, 0)
+    clips, seed = [0], 2024
+    hub, m2p, f0 = clip_batch(hp, clips, T, max(2, int(T * 500 / 861)))
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    cond_t = cond.transpose(1, 2).contiguous()
+    M = hp["audio_num_mel_bins"]
+    x0 = O.ddpm_noise_ref_layout(seed, clips, 0, T, M, O.PURPOSE_X_INIT)
+    ref = None
+    for s in schemes:
+        t0 = time.time()
+        x = chain(Net(sd, hp, s), sd, hp, cond_t, x0.clone(), seed, clips, T, steps, 1000)
+        mel = O.finish_mel(sd, x, m2p)
+        if ref is None:
+            ref = mel
+        err = (mel - ref).abs()
+        print("%-9s mel max-abs err %.3e  mean %.3e  p99.9 %.3e   (%.1fs)" % (s, err.max().item(), err.mean().item(),
+              err.flatten().kthvalue(int(err.numel() * 0.999)).values.item(), time.time() - t0), flush=True)
+
+if __name__ == "__main__":
+    main()

@@ -13,7 +13,7 @@ tail -5 $OUT/${TAG}_pytest_gpu.txt
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench rc=$?"; cat $OUT/${TAG}_bench.json; tail -3 $OUT/${TAG}_bench.err
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-batched --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-batched --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
 echo "rocprof rc=$?"
 find $OUT/${TAG}_prof -name "*stats*" | head
 F=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1)
