@@ -10,6 +10,20 @@ LIB_PATH = os.path.join(HERE, "libdsvc_hip.so")
 
 PREC_F16, PREC_F16_W2, PREC_F16_X3 = 0, 1, 2
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3}
+ABI_VERSION = 2
+
+
+def parse_precision(p):
+    """'f16' | 'f16_w2' | 'f16_x3' | 'f16_dN' (fp16 operands, N time-dithered weight roundings) -> (enum, variants)."""
+    if isinstance(p, (tuple, list)):
+        return int(p[0]), int(p[1])
+    if isinstance(p, int):
+        return p, 1
+    if p in PRECISIONS:
+        return PRECISIONS[p], 1
+    if p.startswith("f16_d") and p[5:].isdigit() and int(p[5:]) >= 1:
+        return PREC_F16, int(p[5:])
+    raise ValueError("precision must be one of %s or 'f16_dN'" % sorted(PRECISIONS))
 
 c_f32p = ctypes.POINTER(ctypes.c_float)
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -17,7 +31,7 @@ c_i32p = ctypes.POINTER(ctypes.c_int32)
 
 class DenoiserCfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("mel_bins", "hidden", "channels", "layers", "dilation_cycle", "max_steps", "precision")]
+                ("mel_bins", "hidden", "channels", "layers", "dilation_cycle", "max_steps", "precision", "weight_variants")]
 
 
 class SampleArgs(ctypes.Structure):
@@ -86,7 +100,7 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the ABI symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.dsvc_abi_version() != 1:
+        if handle.dsvc_abi_version() != ABI_VERSION:
             raise RuntimeError("libdsvc_hip.so ABI version mismatch")
         _lib = handle
     return _lib

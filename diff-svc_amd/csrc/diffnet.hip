@@ -9,7 +9,7 @@
 #include <vector>
 
 #include "../../include/dsvc.h"
-#include "diffnet_kernels.h"
+#include "diffnet_t.h"
 
 using namespace dsvc;
 
@@ -84,6 +84,59 @@ int pack_conv(PackedConv& pc, int cout, int taps, int cin, FW&& src, FB&& bias) 
     return upload(pc.bias, b.data(), b.size() * sizeof(float));
 }
 
+// ---- tgemm path: weights packed on the device in A-fragment order (tgemm.h) ----
+struct TPacked {
+    DevBuf w;       // [variant][m_tile][tap][k16][plane][lane][8] halfs
+    DevBuf bias;    // fp32, natural channel order
+    int m_tiles = 0, taps = 1, cin_pad = 0, planes = 1, n_variants = 1;
+    size_t variant_halfs = 0;
+};
+
+// src: host fp32 [O][I][taps]; rowmap(packed_row) -> source output channel or -1
+template <class FR>
+int tpack(TPacked& tp, const std::vector<float>& src, int O, int I, int taps, int m_tiles, int planes, int n_variants,
+          float scale, unsigned salt, FR&& rowmap, const float* bias, int nbias) {
+    tp.m_tiles = m_tiles; tp.taps = taps; tp.cin_pad = round_up(I, 128); tp.planes = planes; tp.n_variants = n_variants;
+    tp.variant_halfs = tpacked_halfs(m_tiles, taps, tp.cin_pad, planes, 1);
+    if ((size_t)O * I * taps != src.size()) return fail(DSVC_EINVAL, "tpack: weight tensor has %zu elements, expected %zu", src.size(), (size_t)O * I * taps);
+    std::vector<int> rm(m_tiles * 32);
+    for (int r = 0; r < m_tiles * 32; ++r) {
+        rm[r] = rowmap(r);
+        if (rm[r] >= O) return fail(DSVC_EINVAL, "tpack: row map out of range");
+    }
+    DevBuf dsrc, drm;
+    DSVC_TRY(upload(dsrc, src.data(), src.size() * 4));
+    DSVC_TRY(upload(drm, rm.data(), rm.size() * 4));
+    DSVC_TRY(tp.w.alloc(tp.variant_halfs * n_variants * sizeof(_Float16)));
+    const long long total = (long long)tp.variant_halfs / planes * n_variants;
+    const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    hipLaunchKernelGGL(k_tpack, dim3(blocks), dim3(256), 0, 0, dsrc.as<float>(), drm.as<int>(), tp.w.as<_Float16>(), I, taps,
+                       tp.cin_pad, m_tiles, planes, n_variants, scale, salt);
+    DSVC_HIP(hipGetLastError());
+    DSVC_HIP(hipDeviceSynchronize());
+    dsrc.release(); drm.release();
+    return upload(tp.bias, bias, (size_t)nbias * 4);
+}
+
+// tiling choice of the tgemm path: 128-frame tiles x 8 waves when the batch fills the chip, otherwise 32-frame tiles
+// x 4 waves with the output-channel passes spread over blockIdx.y
+template <class Epi, int NW>
+int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hipStream_t st) {
+    if (rows_alloc / 128 >= 48) {
+        const int tiles = rows_alloc / 128, passes = ceil_div(a.m_tiles, 8);
+        int ms = 256 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
+        return tgemm_launch<4, 8, 2, (NW == 2 ? 4 : 8), NW, Epi>(a, e, rows_alloc, ms, st);   // two planes: half the ring depth, same bytes in flight
+    }
+    const int tiles = rows_alloc / 32, passes = ceil_div(a.m_tiles, 4);
+    int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
+    return tgemm_launch<1, 4, 2, (NW == 2 ? 4 : 8), NW, Epi>(a, e, rows_alloc, ms, st);
+}
+
+template <class Epi>
+int tlaunch_prec(const TGemmArgs& a, const typename Epi::Args& e, int planes, int rows_alloc, hipStream_t st) {
+    return planes == 2 ? tlaunch<Epi, 2>(a, e, rows_alloc, st) : tlaunch<Epi, 1>(a, e, rows_alloc, st);
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -96,19 +149,33 @@ struct dsvc_denoiser {
     std::vector<PackedConv> dil, outp, condp;
     DevBuf film;          // [max_steps][L][C]
 
+    // tgemm path (precision F16 [+ dither variants] and F16_W2): fp16 activation buffers, device-packed A fragments
+    bool tpath = false;
+    int Cp = 0, Mp = 0, guard = 8;
+    TPacked in_t, skip_t, fin_t;
+    std::vector<TPacked> dil_t, out_t;
+    DevBuf xh, gh, skiph, s2h, xsh;   // fp16: layer operand (with guard rows), gate output, skip sum, relu(skip proj), sampler state
+
     // workspace for (B, T)
-    int wsB = 0, wsT = 0, Tp = 0, rows = 0;
+    int wsB = 0, wsT = 0, Tp = 0, rows = 0, rows_alloc = 0;
     DevBuf xin, xres, g, skip, s2, eps, condT, cproj, tsteps;
     bool cond_ready = false;
 
     ~dsvc_denoiser() {
-        for (DevBuf* b : {&film, &xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps}) b->release();
+        for (DevBuf* b : {&film, &xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps, &xh, &gh, &skiph, &s2h, &xsh}) b->release();
         auto rel = [](PackedConv& p) { p.w.release(); p.bias.release(); };
         rel(in_proj); rel(skip_proj); rel(fin_proj);
         for (auto& p : dil) rel(p);
         for (auto& p : outp) rel(p);
         for (auto& p : condp) rel(p);
+        auto relt = [](TPacked& p) { p.w.release(); p.bias.release(); };
+        relt(in_t); relt(skip_t); relt(fin_t);
+        for (auto& p : dil_t) relt(p);
+        for (auto& p : out_t) relt(p);
     }
+
+    RowMap rowmap() const { return RowMap{Tp, wsT, rows}; }
+    _Float16* xh_row0() const { return xh.as<_Float16>() + (size_t)guard * Cp; }
 
     const std::vector<float>* get(const std::string& k, size_t numel) {
         auto it = host.find(k);
@@ -125,8 +192,14 @@ struct dsvc_denoiser {
     int prepare_cond(const float* cond_bht, int B, int T, hipStream_t st);
 
     enum Tail { TAIL_EPS = 0, TAIL_DDPM = 1 };
-    // one denoiser evaluation on the frame-major state `x_fm` [rows][M]
-    int eval(const float* x_fm, const StepRef& step, Tail tail, const EpiDdpm::Args* ddpm, hipStream_t st);
+    // what the fused DDPM tail needs from the sampler (the epilogue-specific Args are built inside eval)
+    struct DdpmCtx { float* x; DdpmTables tab; unsigned long long seed; int clip0; };
+    // one denoiser evaluation on the frame-major state `x_fm` [rows][M]; `state_half_fresh`: the fp16 copy of the
+    // state (tgemm path) is already up to date (the previous DDPM tail wrote it)
+    int eval(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st);
+    int eval_conv(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, hipStream_t st);
+    int eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st);
+    int finalize_t();
 };
 
 int dsvc_denoiser::finalize() {
@@ -134,51 +207,61 @@ int dsvc_denoiser::finalize() {
     if (M % 16 || H % 16 || C % 64) return fail(DSVC_EINVAL, "denoiser: need mel_bins%%16==0, hidden%%16==0, channels%%64==0 (got %d,%d,%d)", M, H, C);
     if (L < 1 || K < 1 || cfg.dilation_cycle < 1) return fail(DSVC_EINVAL, "denoiser: bad layers/steps/cycle");
     if ((1 << ((L - 1) % cfg.dilation_cycle)) > 64 && cfg.dilation_cycle > 7) return fail(DSVC_EINVAL, "denoiser: dilation too large");
+    // F16 (optionally time-dithered) and F16_W2 run on the tgemm engine; F16_X3 (split activations) on conv_gemm
+    tpath = cfg.precision != DSVC_PREC_F16_X3 && !getenv("DSVC_FORCE_CONV_GEMM");
 #define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
-    {
-        GET(w, "input_projection.weight", C * M);
-        GET(b, "input_projection.bias", C);
-        DSVC_TRY(pack_conv(in_proj, C, 1, M,
-                           [&](int co, int, int ci) { return co < C ? (*w)[(size_t)co * M + ci] : 0.f; },
-                           [&](int co) { return (*b)[co]; }));
+    if (!tpath) {
+        {
+            GET(w, "input_projection.weight", C * M);
+            GET(b, "input_projection.bias", C);
+            DSVC_TRY(pack_conv(in_proj, C, 1, M,
+                               [&](int co, int, int ci) { return co < C ? (*w)[(size_t)co * M + ci] : 0.f; },
+                               [&](int co) { return (*b)[co]; }));
+        }
+        {
+            GET(w, "skip_projection.weight", C * C);
+            GET(b, "skip_projection.bias", C);
+            const float inv = 1.0f / sqrtf((float)L);      // sum(skip)/sqrt(L) (net.py:131) folded into the weights
+            DSVC_TRY(pack_conv(skip_proj, C, 1, C,
+                               [&](int co, int, int ci) { return (*w)[(size_t)co * C + ci] * inv; },
+                               [&](int co) { return (*b)[co]; }));
+        }
+        {
+            GET(w, "output_projection.weight", M * C);
+            GET(b, "output_projection.bias", M);
+            DSVC_TRY(pack_conv(fin_proj, M, 1, C,
+                               [&](int co, int, int ci) { return co < M ? (*w)[(size_t)co * C + ci] : 0.f; },
+                               [&](int co) { return (*b)[co]; }));
+        }
     }
-    dil.resize(L); outp.resize(L); condp.resize(L);
+    condp.resize(L);
+    if (!tpath) { dil.resize(L); outp.resize(L); }
     for (int l = 0; l < L; ++l) {
         const std::string q = "residual_layers." + std::to_string(l) + ".";
-        GET(wd, q + "dilated_conv.weight", 2 * C * C * 3);
         GET(bd, q + "dilated_conv.bias", 2 * C);
         GET(wc, q + "conditioner_projection.weight", 2 * C * H);
         GET(bc, q + "conditioner_projection.bias", 2 * C);
-        GET(wo, q + "output_projection.weight", 2 * C * C);
-        GET(bo, q + "output_projection.bias", 2 * C);
-        // packed column p of the gate GEMM: group = p/64, half = (p/32)&1, j = p%32  <->  conv channel half*C + group*32 + j
-        // (net.py:73-77: first C channels = gate -> sigmoid, last C = filter -> tanh)
-        auto chan = [C](int p) { return ((p >> 5) & 1) * C + (p >> 6) * 32 + (p & 31); };
-        DSVC_TRY(pack_conv(dil[l], 2 * C, 3, C,
-                           [&](int p, int tap, int ci) { return (*wd)[((size_t)chan(p) * C + ci) * 3 + tap]; },
-                           [&](int) { return 0.f; }));
-        // hoisted conditioner projection writes cproj in the same packed order, with BOTH biases folded in
+        // column p of the hoisted conditioner projection (cproj) <-> conv channel (net.py:73-77: first C channels = gate
+        // -> sigmoid, last C = filter -> tanh):
+        //   conv_gemm path: group = p/64, half = (p/32)&1, j = p%32  <->  half*C + group*32 + j   (EpiGate pairs tiles)
+        //   tgemm path:     block = p/32, half = (p/16)&1, j = p%16  <->  half*C + block*16 + j   (TEpiGate acc init)
+        const bool tp = tpath;
+        auto chan = [C, tp](int p) { return tp ? ((p >> 4) & 1) * C + (p >> 5) * 16 + (p & 15) : ((p >> 5) & 1) * C + (p >> 6) * 32 + (p & 31); };
+        // cproj carries BOTH biases (conditioner + dilated conv)
         DSVC_TRY(pack_conv(condp[l], 2 * C, 1, H,
                            [&](int p, int, int ci) { return (*wc)[(size_t)chan(p) * H + ci]; },
                            [&](int p) { return (*bc)[chan(p)] + (*bd)[chan(p)]; }));
-        DSVC_TRY(pack_conv(outp[l], 2 * C, 1, C,
-                           [&](int co, int, int ci) { return (*wo)[(size_t)co * C + ci]; },
-                           [&](int co) { return (*bo)[co]; }));
-    }
-    {
-        GET(w, "skip_projection.weight", C * C);
-        GET(b, "skip_projection.bias", C);
-        const float inv = 1.0f / sqrtf((float)L);      // sum(skip)/sqrt(L) (net.py:131) folded into the weights
-        DSVC_TRY(pack_conv(skip_proj, C, 1, C,
-                           [&](int co, int, int ci) { return (*w)[(size_t)co * C + ci] * inv; },
-                           [&](int co) { return (*b)[co]; }));
-    }
-    {
-        GET(w, "output_projection.weight", M * C);
-        GET(b, "output_projection.bias", M);
-        DSVC_TRY(pack_conv(fin_proj, M, 1, C,
-                           [&](int co, int, int ci) { return co < M ? (*w)[(size_t)co * C + ci] : 0.f; },
-                           [&](int co) { return (*b)[co]; }));
+        if (!tpath) {
+            GET(wd, q + "dilated_conv.weight", 2 * C * C * 3);
+            GET(wo, q + "output_projection.weight", 2 * C * C);
+            GET(bo, q + "output_projection.bias", 2 * C);
+            DSVC_TRY(pack_conv(dil[l], 2 * C, 3, C,
+                               [&](int p, int tap, int ci) { return (*wd)[((size_t)chan(p) * C + ci) * 3 + tap]; },
+                               [&](int) { return 0.f; }));
+            DSVC_TRY(pack_conv(outp[l], 2 * C, 1, C,
+                               [&](int co, int, int ci) { return (*wo)[(size_t)co * C + ci]; },
+                               [&](int co) { return (*bo)[co]; }));
+        }
     }
     // ---- step tables: emb(t) -> mlp -> per-layer diffusion_projection, for every integer step ----
     {
@@ -210,8 +293,60 @@ int dsvc_denoiser::finalize() {
         for (DevBuf* b : {&dw0, &db0, &dw2, &db2, &emb, &h1, &e2, &dwp, &dbp}) b->release();
     }
 #undef GET
+    if (tpath) DSVC_TRY(finalize_t());
     host.clear();
     finalized = true;
+    return DSVC_OK;
+}
+
+// tgemm path: A-fragment packing on the device.  The two big per-layer contractions take the configured precision
+// (1 plane with `weight_variants` dithered roundings, or hi+lo planes); the three small projections always carry
+// hi+lo planes (their cost is < 2 % of a step).
+int dsvc_denoiser::finalize_t() {
+    const int M = cfg.mel_bins, C = cfg.channels, L = cfg.layers;
+    Cp = round_up(C, 128); Mp = round_up(M, 128);
+    int max_dil = 1;
+    for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
+    guard = round_up(max_dil, 8);
+    const int planes = cfg.precision == DSVC_PREC_F16_W2 ? 2 : 1;
+    const int nvar = (planes == 1 && cfg.weight_variants > 1) ? cfg.weight_variants : 1;
+#define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
+    {
+        GET(w, "input_projection.weight", C * M);
+        GET(b, "input_projection.bias", C);
+        DSVC_TRY(tpack(in_t, *w, C, M, 1, C / 32, 2, 1, 1.0f, 11u,
+                       [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, b->data(), C));
+    }
+    dil_t.resize(L); out_t.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const std::string q = "residual_layers." + std::to_string(l) + ".";
+        GET(wd, q + "dilated_conv.weight", 2 * C * C * 3);
+        GET(wo, q + "output_projection.weight", 2 * C * C);
+        GET(bo, q + "output_projection.bias", 2 * C);
+        // gate kernel: tile mt holds g-channels 16*mt .. +15: rows 0..15 gate (conv channel c), 16..31 filter (C + c)
+        DSVC_TRY(tpack(dil_t[l], *wd, 2 * C, C, 3, C / 16, planes, nvar, 1.0f, 1000u + 2 * l,
+                       [&](int r) { const int mt = r >> 5, i = r & 31; return (i >> 4) * C + mt * 16 + trow_to_ch8(i & 15); },
+                       bo->data(), 1));
+        // output 1x1: tiles 0..C/32-1 residual half (conv channels 0..C-1), then the skip half (C..2C-1)
+        DSVC_TRY(tpack(out_t[l], *wo, 2 * C, C, 1, 2 * C / 32, planes, nvar, 1.0f, 1001u + 2 * l,
+                       [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, bo->data(), 2 * C));
+    }
+    {
+        GET(w, "skip_projection.weight", C * C);
+        GET(b, "skip_projection.bias", C);
+        DSVC_TRY(tpack(skip_t, *w, C, C, 1, C / 32, 2, 1, 1.0f / sqrtf((float)L), 12u,          // sum(skip)/sqrt(L) (net.py:131)
+                       [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, b->data(), C));
+    }
+    {
+        GET(w, "output_projection.weight", M * C);
+        GET(b, "output_projection.bias", M);
+        const int mt = ceil_div(M, 32);
+        std::vector<float> bias(mt * 32, 0.f);
+        for (int i = 0; i < M; ++i) bias[i] = (*b)[i];
+        DSVC_TRY(tpack(fin_t, *w, M, C, 1, mt, 2, 1, 1.0f, 13u,
+                       [&](int r) { const int c = (r >> 5) * 32 + trow_to_ch16(r & 31); return c < M ? c : -1; }, bias.data(), mt * 32));
+    }
+#undef GET
     return DSVC_OK;
 }
 
@@ -221,14 +356,25 @@ int dsvc_denoiser::ensure_ws(int B, int T) {
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
     const int max_dil = 1 << ((cfg.dilation_cycle - 1) < (L - 1) ? (cfg.dilation_cycle - 1) : (L - 1));
     Tp = round_up(T + max_dil, 32);                  // gap rows >= the largest halo: clips never see each other
-    if ((long long)B * Tp > 0x3fffffff) return fail(DSVC_EINVAL, "batch too large");
+    if ((long long)B * Tp > 0x3fffff00) return fail(DSVC_EINVAL, "batch too large");
     rows = B * Tp;
-    const size_t r = (size_t)rows;
-    DSVC_TRY(xin.alloc(r * M * 4)); DSVC_TRY(xres.alloc(r * C * 4)); DSVC_TRY(g.alloc(r * C * 4));
-    DSVC_TRY(skip.alloc(r * C * 4)); DSVC_TRY(s2.alloc(r * C * 4)); DSVC_TRY(eps.alloc(r * M * 4));
+    rows_alloc = tpath ? round_up(rows, 128) : rows;  // the tgemm tiles cover whole 128-frame blocks; the tail rows are gap rows
+    const size_t r = (size_t)rows_alloc;
+    DSVC_TRY(xin.alloc(r * M * 4)); DSVC_TRY(xres.alloc(r * C * 4)); DSVC_TRY(skip.alloc(r * C * 4)); DSVC_TRY(eps.alloc(r * M * 4));
     DSVC_TRY(condT.alloc(r * H * 4)); DSVC_TRY(cproj.alloc(r * 2 * C * L * 4)); DSVC_TRY(tsteps.alloc((size_t)B * 4 + 16));
     DSVC_HIP(hipMemset(xin.p, 0, r * M * 4));
     DSVC_HIP(hipMemset(eps.p, 0, r * M * 4));
+    if (tpath) {
+        // fp16 operands: zero once -- gap rows, guard rows and pad columns are never written afterwards
+        const size_t nxh = (r + 2 * (size_t)guard) * Cp * 2, nh = r * Cp * 2, ns = r * Mp * 2;
+        DSVC_TRY(xh.alloc(nxh)); DSVC_TRY(gh.alloc(nh)); DSVC_TRY(skiph.alloc(nh)); DSVC_TRY(s2h.alloc(nh)); DSVC_TRY(xsh.alloc(ns));
+        DSVC_HIP(hipMemset(xh.p, 0, nxh)); DSVC_HIP(hipMemset(gh.p, 0, nh)); DSVC_HIP(hipMemset(skiph.p, 0, nh));
+        DSVC_HIP(hipMemset(s2h.p, 0, nh)); DSVC_HIP(hipMemset(xsh.p, 0, ns));
+        DSVC_HIP(hipMemset(xres.p, 0, r * C * 4)); DSVC_HIP(hipMemset(skip.p, 0, r * C * 4));
+        DSVC_HIP(hipMemset(condT.p, 0, r * H * 4)); DSVC_HIP(hipMemset(cproj.p, 0, r * 2 * C * L * 4));
+    } else {
+        DSVC_TRY(g.alloc(r * C * 4)); DSVC_TRY(s2.alloc(r * C * 4));
+    }
     wsB = B; wsT = T;
     cond_ready = false;
     return DSVC_OK;
@@ -243,14 +389,18 @@ int dsvc_denoiser::prepare_cond(const float* cond_bht, int B, int T, hipStream_t
         a.x = condT.as<float>(); a.ldx = H; a.n_rows = rows; a.clip_stride = Tp; a.clip_len = T;
         a.cin = H; a.taps = 1; a.dil = 1; a.w = condp[l].w.as<_Float16>(); a.n_ctiles = condp[l].n_ctiles; a.w_planes = 2;
         a.in_slope = 1.0f;
-        EpiBias::Args e{cproj.as<float>() + (size_t)l * rows * 2 * C, 2 * C, condp[l].bias.as<float>(), 2 * C};
+        EpiBias::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, 2 * C, condp[l].bias.as<float>(), 2 * C};
         DSVC_TRY(dispatch_prec<EpiBias>(a, e, DSVC_PREC_F16_X3, st));
     }
     cond_ready = true;
     return DSVC_OK;
 }
 
-int dsvc_denoiser::eval(const float* x_fm, const StepRef& step, Tail tail, const EpiDdpm::Args* ddpm, hipStream_t st) {
+int dsvc_denoiser::eval(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st) {
+    return tpath ? eval_t(x_fm, step, tail, ddpm, state_half_fresh, st) : eval_conv(x_fm, step, tail, ddpm, st);
+}
+
+int dsvc_denoiser::eval_conv(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, hipStream_t st) {
     const int M = cfg.mel_bins, C = cfg.channels, L = cfg.layers;
     auto base = [&](const float* x, int ldx, int cin, const PackedConv& pc) {
         ConvGemmArgs a{};
@@ -271,7 +421,7 @@ int dsvc_denoiser::eval(const float* x_fm, const StepRef& step, Tail tail, const
             a.film = film.as<float>() + (size_t)l * C;
             a.film_step_stride = L * C;
             a.step_ptr = step.ptr; a.step_off = step.off; a.step_per_clip = step.per_clip;
-            EpiGate::Args e{cproj.as<float>() + (size_t)l * rows * 2 * C, g.as<float>(), C};
+            EpiGate::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, g.as<float>(), C};
             DSVC_TRY(dispatch_prec<EpiGate>(a, e, cfg.precision, st));
         }
         {   // K7+K8: output projection, residual / skip (net.py:79-84,131)
@@ -288,12 +438,68 @@ int dsvc_denoiser::eval(const float* x_fm, const StepRef& step, Tail tail, const
     {   // K9b: output projection (net.py:134), optionally fused with the DDPM update (K10)
         ConvGemmArgs a = base(s2.as<float>(), C, C, fin_proj);
         if (tail == TAIL_DDPM) {
-            EpiDdpm::Args e = *ddpm;
-            e.bias = fin_proj.bias.as<float>();
+            EpiDdpm::Args e{};
+            e.x = ddpm->x; e.bias = fin_proj.bias.as<float>(); e.M = M; e.tab = ddpm->tab; e.step = step;
+            e.clip_stride = Tp; e.clip_len = wsT; e.seed = ddpm->seed; e.clip0 = ddpm->clip0;
             DSVC_TRY(dispatch_prec<EpiDdpm>(a, e, DSVC_PREC_F16_X3, st));
         } else {
             EpiBias::Args e{eps.as<float>(), M, fin_proj.bias.as<float>(), M};
             DSVC_TRY(dispatch_prec<EpiBias>(a, e, DSVC_PREC_F16_X3, st));
+        }
+    }
+    return DSVC_OK;
+}
+
+// the tgemm path: every contraction reads fp16 activations that the previous kernel's epilogue left in HBM/L2
+int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st) {
+    const int M = cfg.mel_bins, C = cfg.channels, L = cfg.layers;
+    const RowMap rm = rowmap();
+    auto targs = [&](const _Float16* x, int cin_pad, const TPacked& tp, int taps, int dil) {
+        TGemmArgs a{};
+        a.x = x; a.cin = cin_pad; a.taps = taps; a.dil = dil; a.w = tp.w.as<_Float16>(); a.m_tiles = tp.m_tiles;
+        a.w_planes = tp.planes; a.variant_halfs = (long long)tp.variant_halfs; a.n_variants = tp.n_variants;
+        a.step_ptr = step.ptr; a.step_off = step.off;
+        return a;
+    };
+    if (!state_half_fresh)
+        hipLaunchKernelGGL(k_rows_to_half, dim3(ceil_div(rows * (M / 4), 256) < 2048 ? ceil_div(rows * (M / 4), 256) : 2048), dim3(256), 0, st,
+                           x_fm, xsh.as<_Float16>(), M, Mp, rm, rows);
+    {   // K1: input projection + ReLU (net.py:120-123); emits layer 0's operand xh = fp16(x + film_0)
+        TGemmArgs a = targs(xsh.as<_Float16>(), Mp, in_t, 1, 1);
+        TEpiInProj::Args e{xres.as<float>(), xh_row0(), in_t.bias.as<float>(), film.as<float>(), L * C, step, C, Cp, rm};
+        DSVC_TRY(tlaunch_prec<TEpiInProj>(a, e, 2, rows_alloc, st));
+    }
+    const char* stop_env = getenv("DSVC_DEBUG_STOP_AFTER_LAYERS");      // parity-debugging aid: run only the first n layers
+    const int stop_after = stop_env ? atoi(stop_env) : -1;
+    for (int l = 0; l < L; ++l) {
+        if (stop_after >= 0 && l >= stop_after) return DSVC_OK;
+        {   // K5+K6 (+ hoisted K4, K3 already folded into xh): dilated conv, gate (net.py:67-77)
+            TGemmArgs a = targs(xh_row0(), Cp, dil_t[l], 3, 1 << (l % cfg.dilation_cycle));
+            TEpiGate::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, gh.as<_Float16>(), C, Cp};
+            DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, dil_t[l].planes, rows_alloc, st));
+        }
+        {   // K7+K8: output projection, residual / skip (net.py:79-84,131) + next layer's FiLM (K3)
+            const bool last = l + 1 == L;
+            TGemmArgs a = targs(gh.as<_Float16>(), Cp, out_t[l], 1, 1);
+            TEpiResSkip::Args e{xres.as<float>(), last ? nullptr : xh_row0(), skip.as<float>(), last ? skiph.as<_Float16>() : nullptr,
+                                out_t[l].bias.as<float>(), last ? nullptr : film.as<float>() + (size_t)(l + 1) * C, L * C, step, C, Cp,
+                                l == 0 ? 1 : 0, rm};
+            DSVC_TRY(tlaunch_prec<TEpiResSkip>(a, e, out_t[l].planes, rows_alloc, st));
+        }
+    }
+    {   // K9a: skip projection + ReLU (net.py:132-133)
+        TGemmArgs a = targs(skiph.as<_Float16>(), Cp, skip_t, 1, 1);
+        TEpiReluHalf::Args e{s2h.as<_Float16>(), Cp, skip_t.bias.as<float>(), C};
+        DSVC_TRY(tlaunch_prec<TEpiReluHalf>(a, e, 2, rows_alloc, st));
+    }
+    {   // K9b: output projection (net.py:134), optionally fused with the DDPM update (K10)
+        TGemmArgs a = targs(s2h.as<_Float16>(), Cp, fin_t, 1, 1);
+        if (tail == TAIL_DDPM) {
+            TEpiDdpm::Args e{ddpm->x, xsh.as<_Float16>(), fin_t.bias.as<float>(), M, Mp, ddpm->tab, step, rm, ddpm->seed, ddpm->clip0};
+            DSVC_TRY(tlaunch_prec<TEpiDdpm>(a, e, 2, rows_alloc, st));
+        } else {
+            TEpiEps::Args e{eps.as<float>(), M, fin_t.bias.as<float>()};
+            DSVC_TRY(tlaunch_prec<TEpiEps>(a, e, 2, rows_alloc, st));
         }
     }
     return DSVC_OK;
@@ -326,7 +532,7 @@ struct dsvc_sampler {
     }
     int finalize();
     int ensure_ws(int B, int T);
-    EpiDdpm::Args ddpm_args(unsigned long long seed, int clip0, int step_off);
+    dsvc_denoiser::DdpmCtx ddpm_ctx(unsigned long long seed, int clip0);
     int run_ddpm(const dsvc_sample_args* a, hipStream_t st);
     int run_plms(const dsvc_sample_args* a, hipStream_t st);
 };
@@ -371,23 +577,20 @@ int dsvc_sampler::finalize() {
 int dsvc_sampler::ensure_ws(int B, int T) {
     DSVC_TRY(den->ensure_ws(B, T));
     if (B == wsB && T == wsT) return DSVC_OK;
-    const size_t n = (size_t)den->rows * den->cfg.mel_bins * 4;
+    const size_t n = (size_t)den->rows_alloc * den->cfg.mel_bins * 4;
     DSVC_TRY(xstate.alloc(n)); DSVC_TRY(hist.alloc(4 * n)); DSVC_TRY(xpred.alloc(n));
-    DSVC_HIP(hipMemset(xstate.p, 0, n)); DSVC_HIP(hipMemset(xpred.p, 0, n));
+    DSVC_HIP(hipMemset(xstate.p, 0, n)); DSVC_HIP(hipMemset(xpred.p, 0, n)); DSVC_HIP(hipMemset(hist.p, 0, 4 * n));
     wsB = B; wsT = T;
     if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
     return DSVC_OK;
 }
 
-EpiDdpm::Args dsvc_sampler::ddpm_args(unsigned long long seed, int clip0, int step_off) {
-    EpiDdpm::Args e{};
-    e.x = xstate.as<float>();
-    e.M = den->cfg.mel_bins;
-    e.tab = DdpmTables{sqrt_recip.as<float>(), sqrt_recipm1.as<float>(), coef1.as<float>(), coef2.as<float>(), sigma.as<float>()};
-    e.step = StepRef{step_dev.as<int>(), step_off, 0};
-    e.clip_stride = den->Tp; e.clip_len = den->wsT;
-    e.seed = seed; e.clip0 = clip0;
-    return e;
+dsvc_denoiser::DdpmCtx dsvc_sampler::ddpm_ctx(unsigned long long seed, int clip0) {
+    dsvc_denoiser::DdpmCtx c{};
+    c.x = xstate.as<float>();
+    c.tab = DdpmTables{sqrt_recip.as<float>(), sqrt_recipm1.as<float>(), coef1.as<float>(), coef2.as<float>(), sigma.as<float>()};
+    c.seed = seed; c.clip0 = clip0;
+    return c;
 }
 
 int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
@@ -401,8 +604,8 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
             if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
             // one eager step first: sets every function attribute outside the capture
             {
-                EpiDdpm::Args e = ddpm_args(a->seed, a->first_clip, 0);
-                DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, st));
+                dsvc_denoiser::DdpmCtx e = ddpm_ctx(a->seed, a->first_clip);
+                DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, st));
                 hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), -1);
                 n -= 1;
             }
@@ -411,8 +614,8 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
             DSVC_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
             int rc = DSVC_OK;
             for (int u = 0; u < UNROLL && rc == DSVC_OK; ++u) {
-                EpiDdpm::Args e = ddpm_args(a->seed, a->first_clip, u);
-                rc = den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), u, 0}, dsvc_denoiser::TAIL_DDPM, &e, cap_stream);
+                dsvc_denoiser::DdpmCtx e = ddpm_ctx(a->seed, a->first_clip);
+                rc = den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), u, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, cap_stream);
             }
             if (rc == DSVC_OK) hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, cap_stream, step_dev.as<int>(), -UNROLL);
             hipGraph_t graph = nullptr;
@@ -431,8 +634,8 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
         }
     }
     for (; n > 0; --n) {
-        EpiDdpm::Args e = ddpm_args(a->seed, a->first_clip, 0);
-        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, st));
+        dsvc_denoiser::DdpmCtx e = ddpm_ctx(a->seed, a->first_clip);
+        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, st));
         hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), -1);
     }
     return DSVC_OK;
@@ -448,7 +651,7 @@ int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
     for (int i = first; i >= a->t_stop; i -= interval) {
         const int t_prev = i - interval > 0 ? i - interval : 0;
         hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), i);
-        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, st));
+        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, st));
         PlmsArgs p{};
         p.x = xstate.as<float>(); p.eps = den->eps.as<float>(); p.hist = hist.as<float>(); p.x_pred = xpred.as<float>();
         p.alphas_cumprod = alphas_cumprod.as<float>(); p.n = n; p.t = i; p.t_prev = t_prev; p.n_hist = n_hist;
@@ -456,7 +659,7 @@ int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
             p.phase = 0;
             hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
             hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), t_prev);
-            DSVC_TRY(den->eval(xpred.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, st));
+            DSVC_TRY(den->eval(xpred.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, st));
             p.phase = 1;
             hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
             n_hist = 1;
@@ -481,6 +684,7 @@ int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out) {
     int ndev = 0;
     DSVC_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(DSVC_EHIP, "no HIP device visible");
+    if (cfg->weight_variants > 1024) return fail(DSVC_EINVAL, "weight_variants %d > 1024", cfg->weight_variants);
     dsvc_denoiser* d = new dsvc_denoiser();
     d->cfg = *cfg;
     *out = d;
@@ -513,7 +717,7 @@ int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t,
     if (fresh || cond_changed || !d->cond_ready) DSVC_TRY(d->prepare_cond(cond, B, T, st));
     hipLaunchKernelGGL(k_to_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st, spec,
                        d->xin.as<float>(), B, M, T, d->Tp, 1.0f);
-    DSVC_TRY(d->eval(d->xin.as<float>(), StepRef{t, 0, 1}, dsvc_denoiser::TAIL_EPS, nullptr, st));
+    DSVC_TRY(d->eval(d->xin.as<float>(), StepRef{t, 0, 1}, dsvc_denoiser::TAIL_EPS, nullptr, false, st));
     hipLaunchKernelGGL(k_from_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st,
                        d->eps.as<float>(), out, B, M, T, d->Tp);
     DSVC_HIP(hipGetLastError());
@@ -526,22 +730,34 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
     const DevBuf* b = nullptr;
     int width = 0;
     const int M = d->cfg.mel_bins, C = d->cfg.channels, H = d->cfg.hidden;
+    const DevBuf* hb = nullptr;       // fp16 buffers of the tgemm path are converted on the way out
+    int hld = 0;
+    size_t hoff = 0;
     if (n == "xin") { b = &d->xin; width = M; }
     else if (n == "xres") { b = &d->xres; width = C; }
-    else if (n == "g") { b = &d->g; width = C; }
+    else if (n == "g") { if (d->tpath) { hb = &d->gh; hld = d->Cp; } else b = &d->g; width = C; }
     else if (n == "skip") { b = &d->skip; width = C; }
-    else if (n == "s2") { b = &d->s2; width = C; }
+    else if (n == "s2") { if (d->tpath) { hb = &d->s2h; hld = d->Cp; } else b = &d->s2; width = C; }
+    else if (n == "xh") { if (!d->tpath) return fail(DSVC_EINVAL, "'xh' exists on the tgemm path only"); hb = &d->xh; hld = d->Cp; hoff = (size_t)d->guard * d->Cp; width = C; }
     else if (n == "eps") { b = &d->eps; width = M; }
     else if (n == "condT") { b = &d->condT; width = H; }
     else if (n == "cproj") { b = &d->cproj; width = 2 * C; }
     else if (n == "film") { b = &d->film; width = C; }
     else return fail(DSVC_EINVAL, "unknown debug buffer '%s'", name);
-    if (rows) *rows = (n == "film") ? d->cfg.max_steps * d->cfg.layers : (n == "cproj" ? d->rows * d->cfg.layers : d->rows);
+    const int r_ws = d->rows_alloc;
+    if (rows) *rows = (n == "film") ? d->cfg.max_steps * d->cfg.layers : (n == "cproj" ? r_ws * d->cfg.layers : r_ws);
     if (ld) *ld = width;
     if (dst && numel > 0) {
-        const size_t bytes = (size_t)numel * 4 < b->bytes ? (size_t)numel * 4 : b->bytes;
         DSVC_HIP(hipDeviceSynchronize());
-        DSVC_HIP(hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToDevice));
+        if (hb) {
+            if ((size_t)numel < (size_t)r_ws * width) return fail(DSVC_EINVAL, "debug buffer '%s' needs %zu elements", name, (size_t)r_ws * width);
+            hipLaunchKernelGGL(k_half_to_rows, dim3(1024), dim3(256), 0, 0, hb->as<_Float16>() + hoff, dst, width, hld, r_ws);
+            DSVC_HIP(hipGetLastError());
+            DSVC_HIP(hipDeviceSynchronize());
+        } else {
+            const size_t bytes = (size_t)numel * 4 < b->bytes ? (size_t)numel * 4 : b->bytes;
+            DSVC_HIP(hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToDevice));
+        }
     }
     return DSVC_OK;
 }
@@ -590,6 +806,9 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
     } else {
         hipLaunchKernelGGL(k_x_init, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, xs, B, T, M, d->Tp, a->seed, a->first_clip);
     }
+    if (d->tpath)      // fp16 copy of the state for the first input projection; every DDPM tail refreshes it afterwards
+        hipLaunchKernelGGL(k_rows_to_half, dim3(ceil_div(d->rows * (M / 4), 256) < 2048 ? ceil_div(d->rows * (M / 4), 256) : 2048), dim3(256), 0, st,
+                           xs, d->xsh.as<_Float16>(), M, d->Mp, d->rowmap(), d->rows);
     if (a->speedup > 1) DSVC_TRY(s->run_plms(a, st));
     else DSVC_TRY(s->run_ddpm(a, st));
     const size_t n = (size_t)B * T * M;
@@ -616,14 +835,24 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
     int count = 0;
     for (int it = -2; it < iters; ++it) {                 // two untimed warm-up rounds
         for (int l = 0; l < L; ++l) {
-            ConvGemmArgs a{};
-            a.x = d->xres.as<float>(); a.ldx = C; a.n_rows = d->rows; a.clip_stride = d->Tp; a.clip_len = d->wsT;
-            a.cin = C; a.taps = 3; a.dil = 1 << (l % d->cfg.dilation_cycle); a.w = d->dil[l].w.as<_Float16>();
-            a.n_ctiles = d->dil[l].n_ctiles; a.w_planes = 2; a.in_slope = 1.0f;
-            a.film = d->film.as<float>() + (size_t)l * C; a.film_step_stride = L * C; a.step_ptr = s->step_dev.as<int>();
-            EpiGate::Args e{d->cproj.as<float>() + (size_t)l * d->rows * 2 * C, d->g.as<float>(), C};
             DSVC_HIP(hipEventRecord(e0, st));
-            DSVC_TRY(dispatch_prec<EpiGate>(a, e, d->cfg.precision, st));
+            if (d->tpath) {
+                TGemmArgs a{};
+                a.x = d->xh_row0(); a.cin = d->Cp; a.taps = 3; a.dil = 1 << (l % d->cfg.dilation_cycle);
+                a.w = d->dil_t[l].w.as<_Float16>(); a.m_tiles = d->dil_t[l].m_tiles; a.w_planes = d->dil_t[l].planes;
+                a.variant_halfs = (long long)d->dil_t[l].variant_halfs; a.n_variants = d->dil_t[l].n_variants;
+                a.step_ptr = s->step_dev.as<int>(); a.step_off = 0;
+                TEpiGate::Args e{d->cproj.as<float>() + (size_t)l * d->rows_alloc * 2 * C, d->gh.as<_Float16>(), C, d->Cp};
+                DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, d->dil_t[l].planes, d->rows_alloc, st));
+            } else {
+                ConvGemmArgs a{};
+                a.x = d->xres.as<float>(); a.ldx = C; a.n_rows = d->rows; a.clip_stride = d->Tp; a.clip_len = d->wsT;
+                a.cin = C; a.taps = 3; a.dil = 1 << (l % d->cfg.dilation_cycle); a.w = d->dil[l].w.as<_Float16>();
+                a.n_ctiles = d->dil[l].n_ctiles; a.w_planes = 2; a.in_slope = 1.0f;
+                a.film = d->film.as<float>() + (size_t)l * C; a.film_step_stride = L * C; a.step_ptr = s->step_dev.as<int>();
+                EpiGate::Args e{d->cproj.as<float>() + (size_t)l * d->rows_alloc * 2 * C, d->g.as<float>(), C};
+                DSVC_TRY(dispatch_prec<EpiGate>(a, e, d->cfg.precision, st));
+            }
             DSVC_HIP(hipEventRecord(e1, st));
             DSVC_HIP(hipEventSynchronize(e1));
             float ms = 0;

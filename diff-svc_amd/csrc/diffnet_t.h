@@ -1,0 +1,355 @@
+// Epilogues of the DiffNet layer kernels on the tgemm engine (tgemm.h) and the small kernels around them.
+// Reference math: network/diff/net.py:58-135 (DiffNet / ResidualBlock), network/diff/diffusion.py:131-163 (p_sample).
+//
+// Conventions shared by every epilogue below (see tgemm.h): the accumulator of N-tile `nt` belongs to frame
+// row0 + 32*nt + (lane & 31); with h = lane >> 5 its 16 registers are 16 consecutive output channels
+// 32*m_tile + 16*h + r (plain tiles, packed with trow_to_ch16) or, for the gate kernel, registers 0..7 = gate and
+// 8..15 = filter pre-activations of g-channels 16*m_tile + 8*h + (r & 7) (packed with trow_to_ch8).
+#pragma once
+#include "diffnet_kernels.h"
+#include "tgemm.h"
+
+namespace dsvc {
+
+// which rows of the frame-major buffers are real frames: row = clip*clip_stride + t, t < clip_len, row < n_valid
+struct RowMap {
+    int clip_stride, clip_len, n_valid;
+    __device__ __forceinline__ bool valid(int row, int& clip, int& tl) const {
+        clip = row / clip_stride;
+        tl = row - clip * clip_stride;
+        return row < n_valid && tl < clip_len;
+    }
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// sigmoid(a) * tanh(b) = (1 - E2) / ((1 + E1) * (1 + E2)),  E1 = exp(-a), E2 = exp(-2b)   (net.py:73-77)
+__device__ __forceinline__ float gate_act(float a, float b) {
+    b = fminf(fmaxf(b, -15.0f), 15.0f);                    // tanh is +-1 to fp32 precision beyond |b| ~ 9; keeps E2 finite
+    const float e1 = __expf(-a);
+    const float e2 = __expf(-2.0f * b);
+    return (1.0f - e2) * __frcp_rn((1.0f + e1) * (1.0f + e2));
+}
+
+// ---- K4+K5+K6: dilated conv + hoisted conditioner projection + gate -> g (fp16) ----
+struct TEpiGate {
+    struct Args {
+        const float* cproj;     // [rows][2*C] per frame: [g-block of 16][gate 16 | filter 16], both biases folded in
+        _Float16* g;            // [rows][ldg] fp16
+        int C, ldg;
+    };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            const float* p = e.cproj + (size_t)frame * (2 * e.C) + mt * 32 + 8 * (lane >> 5);
+            const f32x4 v0 = ld4_nt(p), v1 = ld4_nt(p + 4), v2 = ld4_nt(p + 16), v3 = ld4_nt(p + 20);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[nt][i] = v0[i]; acc[nt][4 + i] = v1[i]; acc[nt][8 + i] = v2[i]; acc[nt][12 + i] = v3[i]; }
+        }
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            half8 o;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[r] = (_Float16)gate_act(acc[nt][r], acc[nt][8 + r]);
+            *reinterpret_cast<half8*>(e.g + (size_t)frame * e.ldg + mt * 16 + 8 * (lane >> 5)) = o;
+        }
+    }
+};
+
+// ---- K7+K8 (+K3 of the NEXT layer): output 1x1; residual half updates x and emits the next layer's fp16 operand
+//      xh = fp16(x + film_next), skip half accumulates ----
+struct TEpiResSkip {
+    struct Args {
+        float* x32;             // [rows][C] residual stream (in/out)
+        _Float16* xh;           // [rows][ldh] next layer's MFMA operand, row 0 (guard rows precede); null on the last layer
+        float* skip;            // [rows][C] running skip sum
+        _Float16* skiph;        // [rows][ldh] fp16(skip) for the skip projection; non-null on the last layer only
+        const float* bias;      // [2C]
+        const float* film;      // next layer's FiLM table slice: film[step*film_step_stride + c]; null on the last layer
+        int film_step_stride;
+        StepRef step;
+        int C, ldh;
+        int first;              // layer 0: skip = s (no read)
+        RowMap rm;
+    };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int rt = e.C >> 5;                            // residual tiles
+        const bool res = mt < rt;
+        const int cb = (res ? mt : mt - rt) * 32 + 16 * (lane >> 5);
+        const float* base = res ? e.x32 : e.skip;
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            if (!res && e.first) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+            } else {
+                const float* p = base + (size_t)frame * e.C + cb;
+                const f32x4 v0 = ld4(p), v1 = ld4(p + 4), v2 = ld4(p + 8), v3 = ld4(p + 12);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[nt][i] = v0[i]; acc[nt][4 + i] = v1[i]; acc[nt][8 + i] = v2[i]; acc[nt][12 + i] = v3[i]; }
+            }
+        }
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int rt = e.C >> 5;
+        const bool res = mt < rt;
+        const int cb = (res ? mt : mt - rt) * 32 + 16 * (lane >> 5);
+        float b[16];
+        {
+            const float* bp = e.bias + (res ? 0 : e.C) + cb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const f32x4 v = ld4(bp + 4 * q); b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3]; }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            float v[16];
+            if (res) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = (acc[nt][i] + b[i]) * 0.70710678118654752440f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = acc[nt][i] + b[i];
+            }
+            float* p = (res ? e.x32 : e.skip) + (size_t)frame * e.C + cb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st4(p + 4 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+            _Float16* hp = res ? e.xh : e.skiph;
+            if (hp) {
+                int clip, tl;
+                const bool ok = e.rm.valid(frame, clip, tl);
+                float hv[16];
+                if (ok && res) {
+                    const float* fp = e.film + (size_t)e.step.get(clip) * e.film_step_stride + cb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 f = ld4(fp + 4 * q);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hv[4 * q + i] = v[4 * q + i] + f[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) hv[i] = ok ? v[i] : 0.f;
+                }
+                half8 o0, o1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)hv[i]; o1[i] = (_Float16)hv[8 + i]; }
+                _Float16* q = hp + (size_t)frame * e.ldh + cb;
+                *reinterpret_cast<half8*>(q) = o0;
+                *reinterpret_cast<half8*>(q + 8) = o1;
+            }
+        }
+    }
+};
+
+// ---- K1: input projection + ReLU -> x (fp32) and layer 0's operand xh = fp16(x + film_0) ----
+struct TEpiInProj {
+    struct Args {
+        float* x32; _Float16* xh;
+        const float* bias; const float* film; int film_step_stride; StepRef step;
+        int C, ldh; RowMap rm;
+    };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int cb = mt * 32 + 16 * (lane >> 5);
+        if (cb >= e.C) return;
+        float b[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const f32x4 v = ld4(e.bias + cb + 4 * q); b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3]; }
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[nt][i] + b[i], 0.f);
+            float* p = e.x32 + (size_t)frame * e.C + cb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st4(p + 4 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+            int clip, tl;
+            const bool ok = e.rm.valid(frame, clip, tl);
+            half8 o0, o1;
+            if (ok) {
+                const float* fp = e.film + (size_t)e.step.get(clip) * e.film_step_stride + cb;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)(v[i] + fp[i]); o1[i] = (_Float16)(v[8 + i] + fp[8 + i]); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)0.f; o1[i] = (_Float16)0.f; }
+            }
+            _Float16* q = e.xh + (size_t)frame * e.ldh + cb;
+            *reinterpret_cast<half8*>(q) = o0;
+            *reinterpret_cast<half8*>(q + 8) = o1;
+        }
+    }
+};
+
+// ---- K9a: skip projection + ReLU -> fp16 operand of the final projection ----
+struct TEpiReluHalf {
+    struct Args { _Float16* out; int ld; const float* bias; int cout; };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int cb = mt * 32 + 16 * (lane >> 5);
+        if (cb >= e.cout) return;
+        float b[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = e.bias[cb + i];
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            half8 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)fmaxf(acc[nt][i] + b[i], 0.f); o1[i] = (_Float16)fmaxf(acc[nt][8 + i] + b[8 + i], 0.f); }
+            _Float16* q = e.out + (size_t)frame * e.ld + cb;
+            *reinterpret_cast<half8*>(q) = o0;
+            *reinterpret_cast<half8*>(q + 8) = o1;
+        }
+    }
+};
+
+// ---- K9b: final projection -> eps (fp32), for PLMS and DiffNet.forward ----
+struct TEpiEps {
+    struct Args { float* out; int M; const float* bias; };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int cb = mt * 32 + 16 * (lane >> 5);
+        if (cb >= e.M) return;
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            float* p = e.out + (size_t)frame * e.M + cb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = ld4(e.bias + cb + 4 * q);
+                st4(p + 4 * q, f32x4{acc[nt][4 * q] + bv[0], acc[nt][4 * q + 1] + bv[1], acc[nt][4 * q + 2] + bv[2], acc[nt][4 * q + 3] + bv[3]});
+            }
+        }
+    }
+};
+
+// ---- K9b+K10: final projection fused with the DDPM posterior step (diffusion.py:131-163); also refreshes the
+//      fp16 copy of the state that the next step's input projection reads ----
+struct TEpiDdpm {
+    struct Args {
+        float* x;                   // [rows][M] sampler state (in/out)
+        _Float16* xsh;              // [rows][ldh] fp16 copy (zero on gap rows)
+        const float* bias;          // [M]
+        int M, ldh;
+        DdpmTables tab;
+        StepRef step;
+        RowMap rm;
+        unsigned long long seed;
+        int clip0;
+    };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int cb = mt * 32 + 16 * (lane >> 5);
+        if (cb >= e.M) return;
+        float b[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = e.bias[cb + i];
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            int clip, tl;
+            if (!e.rm.valid(frame, clip, tl)) continue;
+            const int t = e.step.get(clip);
+            const float ra = e.tab.sqrt_recip_ac[t], rb = e.tab.sqrt_recipm1_ac[t], c1 = e.tab.coef1[t], c2 = e.tab.coef2[t];
+            const float sg = e.tab.sigma[t];
+            float* px = e.x + (size_t)frame * e.M + cb;
+            float hv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 xt = ld4(px + 4 * q);
+                float z[4] = {0.f, 0.f, 0.f, 0.f};
+                if (t > 0) {
+                    const unsigned el = (unsigned)tl * (unsigned)e.M + (unsigned)(cb + 4 * q);
+                    philox_normal4(el >> 2, (unsigned)t, (unsigned)(e.clip0 + clip), PURPOSE_DDPM_NOISE, e.seed, z);
+                }
+                f32x4 out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float eps = acc[nt][4 * q + i] + b[4 * q + i];
+                    float x0 = ra * xt[i] - rb * eps;
+                    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+                    float o = c1 * x0 + c2 * xt[i];
+                    if (t > 0) o += sg * z[i];
+                    out[i] = o;
+                    hv[4 * q + i] = o;
+                }
+                st4(px + 4 * q, out);
+            }
+            half8 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)hv[i]; o1[i] = (_Float16)hv[8 + i]; }
+            _Float16* hq = e.xsh + (size_t)frame * e.ldh + cb;
+            *reinterpret_cast<half8*>(hq) = o0;
+            *reinterpret_cast<half8*>(hq + 8) = o1;
+        }
+    }
+};
+
+// ---- small kernels of the tgemm path ----
+
+// fp32 frame-major [rows][C] -> fp16 [rows][ld] (valid rows only; gap rows and pad columns are left untouched = zero)
+__global__ void k_rows_to_half(const float* __restrict__ src, _Float16* __restrict__ dst, int C, int ld, RowMap rm, int rows) {
+    const int per_row = C >> 2;
+    const long long n = (long long)rows * per_row;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / per_row), c4 = (int)(i - (long long)row * per_row) * 4;
+        int clip, tl;
+        if (!rm.valid(row, clip, tl)) continue;
+        const f32x4 v = ld4(src + (size_t)row * C + c4);
+        _Float16* q = dst + (size_t)row * ld + c4;
+        q[0] = (_Float16)v[0]; q[1] = (_Float16)v[1]; q[2] = (_Float16)v[2]; q[3] = (_Float16)v[3];
+    }
+}
+
+// fp16 [rows][ld] -> fp32 [rows][C]  (debug taps)
+__global__ void k_half_to_rows(const _Float16* __restrict__ src, float* __restrict__ dst, int C, int ld, int rows) {
+    const long long n = (long long)rows * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / C), c = (int)(i - (long long)row * C);
+        dst[i] = (float)src[(size_t)row * ld + c];
+    }
+}
+
+}  // namespace dsvc

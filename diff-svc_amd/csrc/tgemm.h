@@ -1,0 +1,319 @@
+// tgemm.h -- the throughput MFMA engine of the DiffNet hot loop (gfx950 / CDNA4, wave64).
+//
+//   out[ch][frame] = EPI( INIT[ch][frame] + sum_{tap} sum_{ci}  W[ch][tap][ci] * xh[frame + (tap - taps/2)*dil][ci] )
+//
+// i.e. the same conv-as-GEMM contraction as conv_gemm.h, but TRANSPOSED and fed differently:
+//
+//   * activations live in HBM/L2 as fp16 frame-major rows ([frame][channel], already FiLM-shifted and rounded by the
+//     producing kernel's epilogue), so a workgroup's (TN + 2*halo) x K time tile is copied ONCE, straight into LDS,
+//     by the LDS-DMA path (global_load_lds_dwordx4: no VGPR round trip, no conversion VALU).  The DMA writes LDS
+//     lane-linearly, so the bank swizzle is applied on the SOURCE side: LDS slot (row r, 16-B chunk c') holds global
+//     chunk c' ^ (r & swz); readers XOR the same value, which makes every ds_read_b128 lane group hit 16 distinct
+//     16-B slots (conflict-free) although a row is a multiple of 256 B.
+//   * the tile stays resident for the whole workgroup: every tap and every output-channel pass re-reads it, and the
+//     main loop contains NO barrier -- the 8 waves (two per SIMD) drift apart, so one wave's epilogue VALU and
+//     memory latency hide under the other wave's MFMAs.
+//   * weights are the MFMA *A* operand (rows = output channels) and never touch LDS: they are packed on the host in
+//     fragment order [m_tile][step][plane][lane 64][8 halfs]; a wave streams its own 32 output channels as fully
+//     coalesced 1 KiB loads through a KG-deep register ring.  One weight fragment feeds NT_N (=4) MFMAs, so at full
+//     MFMA rate a CU pulls 32 B/clk of weights from L2 -- half of what the L1 can deliver.
+//   * D = W * X^T puts 16 CONSECUTIVE channels of one frame in a lane's accumulator (with the row permutation the
+//     packer applies), so every epilogue load/store is a 16-byte access in the frame-major layouts, and the
+//     epilogue's read-modify-write inputs (conditioner projection, residual stream, skip sum) are loaded straight
+//     into the accumulators before the main loop: "acc init" replaces an epilogue read.
+//   * math: v_mfma_f32_32x32x16_f16, fp32 accumulate.  NW = 2 adds the w_lo plane (w = w_hi + w_lo).  With one plane
+//     the systematic weight-rounding error would cost ~6e-3 of mel after 1000 DDPM steps, so the packer can emit
+//     n_variants differently-rounded copies (time-dithered rounding: step t uses copy t % n_variants; the copies
+//     average to w), which keeps 1 MFMA per product inside the 1e-3 bar.
+//   * `MSPLIT` output-channel passes can be spread over blockIdx.y for small batches (B = 1) to fill the chip.
+#pragma once
+#include "common.h"
+
+namespace dsvc {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TFRAG_HALFS = 512;          // one packed [lane 64][8 halfs] fragment
+
+struct TGemmArgs {
+    const _Float16* x;      // fp16 activations, row 0 of [guard | rows | guard][cin]; guard/gap rows are zero
+    int cin;                // channels per row (K per tap), multiple of 16
+    int swz;                // chunk swizzle mask (15, 7, 3, 1 or 0): largest 2^b-1 <= 15 with (cin/8) % 2^b == 0
+    int taps, dil;          // tap offset = (tap - taps/2) * dil rows
+    const _Float16* w;      // packed weights [variant][m_tile][taps*cin/16][planes][lane][8]
+    int m_tiles;            // 32-row output-channel tiles
+    int w_planes;           // planes stored per fragment (>= NW)
+    long long variant_halfs;// stride between dither variants
+    int n_variants;         // >= 1
+    const int* step_ptr;    // device int: current diffusion step (variant = (step - step_off) % n_variants); may be null
+    int step_off;
+};
+
+// the row <-> channel permutation inside a 32-row output tile that makes a lane's 16 accumulator registers hold 16
+// consecutive channels:  tile row i = 4h + 8j + e  (h = lane>>5, j = reg>>2, e = reg&3)  <->  channel 16h + 4j + e
+__host__ __device__ inline int trow_to_ch16(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
+// paired variant (gate | filter): rows 0..15 and 16..31 each hold 16 channels, 8 consecutive ones per lane half:
+// row i (< 16) = 4h + 8j + e  <->  channel 8h + 4j + e
+__host__ __device__ inline int trow_to_ch8(int i) { return 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3); }
+
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi>
+__global__ void __launch_bounds__(64 * WAVES, MINW) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
+    constexpr int TN = 32 * NT_N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * TN;
+    const int halo = (a.taps >> 1) * a.dil;
+    const int rows_lds = TN + 2 * halo;
+    const int chunks = a.cin >> 3;                       // 16-B chunks per row
+    const int row_bytes = a.cin * 2;
+
+    // ---- stage the time tile: HBM/L2 -> LDS by DMA, swizzled on the source side ----
+    {
+        const int total = rows_lds * chunks;             // 16-B slots
+        const int dq = (WAVES * 64) / chunks, dr = (WAVES * 64) - dq * chunks;
+        int slot = wave * 64 + lane;
+        int r = slot / chunks, c = slot - r * chunks;
+        const _Float16* xrow0 = a.x + (long long)(row0 - halo) * a.cin;
+        for (int it = wave; it * 64 < total; it += WAVES) {
+            const int rc = r < rows_lds ? r : rows_lds - 1;            // lanes past the tile re-read its last row
+            const _Float16* src = xrow0 + (long long)rc * a.cin + ((c ^ (rc & a.swz)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + it * 1024), 16, 0, 0);
+            c += dr; r += dq;
+            if (c >= chunks) { c -= chunks; r += 1; }
+        }
+    }
+
+    int variant = 0;
+    if (a.n_variants > 1 && a.step_ptr) {
+        const int st = *a.step_ptr - a.step_off;
+        variant = st % a.n_variants;
+        if (variant < 0) variant += a.n_variants;
+    }
+    constexpr int GROUP_HALFS = KG * NW * TFRAG_HALFS;   // one ring refill = KG k16-steps of one output tile
+    const _Float16* wbase = a.w + (long long)variant * a.variant_halfs + lane * 8;
+    const int gpt = (a.cin >> 4) / KG;                   // groups per tap
+    const int G = a.taps * gpt;                          // groups per output tile
+    const int passes = (a.m_tiles + WAVES - 1) / WAVES;
+    const long long tile_halfs = (long long)G * GROUP_HALFS;
+
+    // two waves share a SIMD (waves w and w + 4): give one of them priority so the pair drifts apart and one wave's
+    // epilogue / memory waits sit under the other's MFMAs instead of both stalling together
+    if (WAVES > 4 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+
+    auto load_group = [&](half8 (&ring)[KG][NW], const _Float16* p) {
+#pragma unroll
+        for (int u = 0; u < KG; ++u)
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+                ring[u][q] = *reinterpret_cast<const half8*>(p + (u * NW + q) * TFRAG_HALFS);
+    };
+    typedef const half8 __attribute__((address_space(3))) * lds_frag_ptr;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned nt_stride = 32u * (unsigned)row_bytes;
+    auto compute_group = [&](const half8 (&ring)[KG][NW], f32x16 (&acc)[NT_N], int g) {
+        const int tap = g / gpt, kb = (g - tap * gpt) * KG;
+        const int rr = halo + (tap - (a.taps >> 1)) * a.dil + (lane & 31);      // LDS row of this lane's frame, N-tile 0
+        // chunk of k16-step k, half h, row r lives at slot (2k + h) ^ (r & swz); kb is a multiple of 8, so only the low
+        // 4 chunk bits are touched:  byte offset = (kb << 5) + ((kk << 5) ^ xs),  xs = ((r & swz) ^ h) << 4
+        const unsigned xs = (unsigned)(((rr & a.swz) ^ (lane >> 5)) << 4);
+        unsigned base[NT_N];
+        base[0] = lds0 + (unsigned)rr * (unsigned)row_bytes + ((unsigned)kb << 5);
+#pragma unroll
+        for (int nt = 1; nt < NT_N; ++nt) base[nt] = base[nt - 1] + nt_stride;
+        // keep the per-group bases materialised: without this LLVM re-derives every address from scratch (4-5 VALU per ds_read)
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) asm volatile("" : "+v"(base[nt]));
+        half8 bq[2][NT_N];                               // B fragments: step kk in bq[kk & 1], step kk+1 being read
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) bq[0][nt] = *(lds_frag_ptr)(size_t)(base[nt] + xs);
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk) {
+            if (kk + 1 < KG) {
+                const unsigned off = ((unsigned)(kk + 1) << 5) ^ xs;
+#pragma unroll
+                for (int nt = 0; nt < NT_N; ++nt) bq[(kk + 1) & 1][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT_N; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][0], bq[kk & 1][nt], acc[nt], 0, 0, 0);
+                if constexpr (NW == 2)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][1], bq[kk & 1][nt], acc[nt], 0, 0, 0);
+            }
+        }
+        // pin the software pipeline: left alone, the scheduler sinks every ds_read to just above its MFMA (register
+        // pressure heuristic) and the wave then eats the full LDS latency once per MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, NT_N, 0);                     // B fragments of step 0
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk) {
+            if (kk + 1 < KG) __builtin_amdgcn_sched_group_barrier(0x100, NT_N, 0);  // ... of step kk+1, issued ahead of
+            __builtin_amdgcn_sched_group_barrier(0x008, NT_N * NW, 0);              // the MFMAs of step kk
+        }
+    };
+
+    Epi epi;
+    f32x16 acc[NT_N];
+    half8 ringA[KG][NW], ringB[KG][NW];
+    int pass = blockIdx.y;
+    int mt = pass * WAVES + wave;
+    bool active = mt < a.m_tiles;                        // wave-uniform
+    if (active) {
+        load_group(ringA, wbase + (long long)mt * tile_halfs);
+        epi.init(ea, mt, row0, lane, acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA'd tile (and the first operands) have landed
+    __syncthreads();
+
+    while (active) {
+        const _Float16* wp = wbase + (long long)mt * tile_halfs;
+        int g = 0;
+        for (; g + 1 < G; g += 2) {     // straight-line body (no branch): IR-level sinking cannot move a prefetch below its group
+            load_group(ringB, wp + (long long)(g + 1) * GROUP_HALFS);          // ringB <- group g+1, under group g's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group(ringA, acc, g);
+            const int gn = g + 2 < G ? g + 2 : G - 1;
+            load_group(ringA, wp + (long long)gn * GROUP_HALFS);               // ringA <- group g+2, under group g+1's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group(ringB, acc, g + 1);
+        }
+        if (g < G) compute_group(ringA, acc, g);                               // odd group count: the tail group
+        // next pass of this workgroup: start its weight stream and its accumulator-init loads before this pass's
+        // epilogue, so their latency sits under the epilogue's VALU and stores
+        const int pass_n = pass + gridDim.y;
+        const int mt_n = pass_n * WAVES + wave;
+        const bool active_n = pass_n < passes && mt_n < a.m_tiles;
+        f32x16 nxt[NT_N];
+        if (active_n) {
+            load_group(ringA, wbase + (long long)mt_n * tile_halfs);
+            epi.init(ea, mt_n, row0, lane, nxt);
+        }
+        epi.finish(ea, mt, row0, lane, acc);
+        if (!active_n) break;
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) acc[nt] = nxt[nt];
+        pass = pass_n; mt = mt_n;
+    }
+}
+
+template <int NT_N>
+inline size_t tgemm_smem(int taps, int dil, int cin) {
+    const size_t bytes = (size_t)(32 * NT_N + 2 * (taps / 2) * dil) * cin * 2;
+    return (bytes + 1023) & ~(size_t)1023;               // whole 1 KiB DMA pieces
+}
+
+inline int tgemm_swizzle_mask(int cin) {
+    const int chunks = cin / 8;
+    int m = 15;
+    while (m > 0 && (chunks % (m + 1)) != 0) m >>= 1;
+    return m;
+}
+
+// n_rows must be a multiple of 32*NT_N; m_split = number of blockIdx.y slices the output-channel passes are dealt over
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi>
+inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, int m_split, hipStream_t stream) {
+    if (a.cin % (16 * KG) != 0) return fail(DSVC_EINVAL, "tgemm: cin %d not a multiple of %d", a.cin, 16 * KG);
+    if (n_rows % (32 * NT_N) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N);
+    if (a.w_planes != NW) return fail(DSVC_EINVAL, "tgemm: weights packed with %d plane(s), kernel streams %d", a.w_planes, NW);
+    a.swz = tgemm_swizzle_mask(a.cin);
+    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi>;
+    const size_t smem = tgemm_smem<NT_N>(a.taps, a.dil, a.cin);
+    if (smem > 160 * 1024) return fail(DSVC_EINVAL, "tgemm: %zu B of LDS requested", smem);
+    static thread_local size_t smem_set = 0;
+    if (smem > 64 * 1024 && smem > smem_set) {
+        DSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        smem_set = smem;
+    }
+    const int passes = ceil_div(a.m_tiles, WAVES);
+    if (m_split < 1) m_split = 1;
+    if (m_split > passes) m_split = passes;
+    hipLaunchKernelGGL(kern, dim3(n_rows / (32 * NT_N), m_split), dim3(64 * WAVES), smem, stream, a, ea);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packing (on the device: a 64-variant dithered DiffNet is 3 GB of fragments).
+//   src [O][I][taps] fp32 in the checkpoint's Conv1d layout; rowmap[m_tiles*32] gives the source output channel of
+//   every packed row (or -1 = zero row) -- the caller folds the tile-row permutation (trow_to_ch16 / trow_to_ch8)
+//   into it.  Layout [variant][m_tile][tap][k16][plane][lane][8]; lane l of a fragment holds packed row (l & 31),
+//   k = k16*16 + 8*(l >> 5) + e.  plane 0 = fp16(w), plane 1 = fp16(w - plane0).
+//   Variant v of n rounds w to fp16 DOWN or UP so that the mean over the variants is w +- ulp/(2n): round up iff
+//   frac(w) > ((v' + 0.5)/n + phase(element)) mod 1, v' = bit-reversed v (consecutive diffusion steps use far-apart
+//   thresholds), phase = a per-element hash.  n == 1 is plain round-to-nearest.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t tg_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__device__ inline uint16_t tg_half_bits(_Float16 h) { return __builtin_bit_cast(uint16_t, h); }
+__device__ inline _Float16 tg_bits_half(uint16_t b) { return __builtin_bit_cast(_Float16, b); }
+
+// next representable fp16 towards +inf (up) or -inf of a finite value
+__device__ inline uint16_t tg_half_step(uint16_t b, bool up) {
+    const bool neg = (b & 0x8000) != 0;
+    const uint16_t mag = b & 0x7fff;
+    if (mag == 0) return up ? (uint16_t)0x0001 : (uint16_t)0x8001;
+    if (neg == up) return (uint16_t)((neg ? 0x8000 : 0) | (mag - 1));
+    return (uint16_t)((neg ? 0x8000 : 0) | (mag + 1));
+}
+
+__device__ inline _Float16 tg_round_dither(float w, float thresh) {
+    const _Float16 n = (_Float16)w;                       // nearest
+    const float nf = (float)n;
+    if (nf == w) return n;
+    _Float16 lo, hi;
+    if (nf < w) { lo = n; hi = tg_bits_half(tg_half_step(tg_half_bits(n), true)); }
+    else        { hi = n; lo = tg_bits_half(tg_half_step(tg_half_bits(n), false)); }
+    const float lf = (float)lo, hf = (float)hi;
+    const float frac = (w - lf) / (hf - lf);
+    return frac > thresh ? hi : lo;
+}
+
+__global__ void k_tpack(const float* __restrict__ src, const int* __restrict__ rowmap, _Float16* __restrict__ dst,
+                        int I, int taps, int cin_pad, int m_tiles, int planes, int n_variants, float scale, unsigned salt) {
+    const int nk16 = cin_pad >> 4;
+    const long long per_variant = (long long)m_tiles * taps * nk16 * 512;      // elements of ONE plane
+    const long long total = per_variant * n_variants;
+    int bits = 0;
+    while ((1 << bits) < n_variants) ++bits;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(idx / per_variant);
+        long long r = idx - (long long)v * per_variant;
+        const int e = (int)(r & 7), l = (int)((r >> 3) & 63);
+        r >>= 9;
+        const int k = (int)(r % nk16); r /= nk16;
+        const int tap = (int)(r % taps);
+        const int mt = (int)(r / taps);
+        const int row = mt * 32 + (l & 31), ci = k * 16 + 8 * (l >> 5) + e;
+        const int o = rowmap[row];
+        const float w = (o >= 0 && ci < I) ? src[((size_t)o * I + ci) * taps + tap] * scale : 0.f;
+        _Float16 hi;
+        if (n_variants > 1) {
+            int vr = 0;
+            for (int b = 0; b < bits; ++b) vr |= ((v >> b) & 1) << (bits - 1 - b);
+            if (vr >= n_variants) vr = v;
+            const uint32_t h = tg_hash32(((uint32_t)row * 0x9E3779B1u) ^ ((uint32_t)(tap * cin_pad + ci) * 0x85EBCA77u) ^ salt);
+            float th = ((float)vr + 0.5f) / (float)n_variants + (float)(h >> 8) * (1.0f / 16777216.0f);
+            if (th >= 1.0f) th -= 1.0f;
+            hi = tg_round_dither(w, th);
+        } else {
+            hi = (_Float16)w;
+        }
+        _Float16* f = dst + (size_t)v * per_variant * planes + ((((size_t)mt * taps + tap) * nk16 + k) * planes) * 512 + l * 8 + e;
+        f[0] = hi;
+        if (planes == 2) f[512] = (_Float16)(w - (float)hi);
+    }
+}
+
+inline size_t tpacked_halfs(int m_tiles, int taps, int cin_pad, int planes, int n_variants) {
+    return (size_t)n_variants * m_tiles * taps * (cin_pad / 16) * planes * TFRAG_HALFS;
+}
+
+}  // namespace dsvc

@@ -5,7 +5,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import PRECISIONS, check, host_f32, lib, ptr, stream_ptr
+from ._lib import PRECISIONS, check, host_f32, lib, parse_precision, ptr, stream_ptr
 
 SCHEDULE_KEYS = ("alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
                  "posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped",
@@ -32,7 +32,8 @@ class DenoiserHandle:
     def __init__(self, state, mel_bins, hidden, channels, layers, dilation_cycle, max_steps,
                  precision="f16_w2", prefix=""):
         self._h = ctypes.c_void_p(0)
-        self.cfg = _lib.DenoiserCfg(mel_bins, hidden, channels, layers, dilation_cycle, max_steps, _prec(precision))
+        prec, variants = parse_precision(precision)
+        self.cfg = _lib.DenoiserCfg(mel_bins, hidden, channels, layers, dilation_cycle, max_steps, prec, variants)
         self.mel_bins, self.hidden = mel_bins, hidden
         check(lib().dsvc_denoiser_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
         n = 0

@@ -72,14 +72,17 @@ def test_denoiser_batched_throughput_tiling_matches_oracle():
             assert (out[b:b + 1] - ref).abs().max() < 3e-4, b
 
 
+@pytest.mark.parametrize("precision", ["f16_x3", "f16_w2"])
 @pytest.mark.parametrize("name,tol", [("ddpm_tiny", 1e-3), ("plms_tiny_s10", 2e-3), ("plms_tiny_s5", 2e-3),
                                       ("ddpm_44k_k20", 1e-3), ("plms_44k_k100_s20", 2e-3)])
-def test_sampler_vs_reference_golden(name, tol):
+def test_sampler_vs_reference_golden(name, tol, precision):
     """mel within 1e-3 max-abs of the reference (north_star); PLMS' unclamped extrapolation amplifies
-    rounding, hence the looser bar there."""
+    rounding, hence the looser bar there.  f16_x3 runs on the conv_gemm engine, f16_w2 on the tgemm engine."""
     g = load_golden(name)
     hp = dict(hp_for(name), K_step=int(g["K_step"]))
-    sd, den, smp = make_handles(hp, int(g["wseed"]), "f16_x3")
+    if precision == "f16_w2" and "plms" in name:
+        tol = 4e-3          # fp16 activations, no clamp between the extrapolated steps
+    sd, den, smp = make_handles(hp, int(g["wseed"]), precision)
     clips = [int(c) for c in g["clips"]]
     cond = torch.from_numpy(g["decoder_inp"]).transpose(1, 2).contiguous().cuda()
     hub, m2p, f0 = clip_batch(hp, clips, int(g["T"]), int(g["n_units"]))
@@ -130,3 +133,27 @@ def test_full_chain_1000_steps_w2_within_mel_bar():
     mel = smp.sample(r["cond_t"].cuda(), 1000, mel2ph=r["mel2ph"].cuda(), seed=2024, first_clip=0, use_graph=True)
     err = (mel.cpu() - r["mel_out"]).abs().max().item()
     assert err < 1e-3, err
+
+
+def test_full_chain_1000_steps_dithered_f16_within_mel_bar():
+    """One MFMA per product: fp16 weights with 64 time-dithered roundings (step t uses copy t % 64).  Same chain
+    as above, same bar."""
+    hp = dict(synth.HPARAMS_44K)
+    sd, den, smp = make_handles(hp, 0, "f16_d64")
+    T, n_units = 64, 37
+    r = oracle_sample(hp, sd, [0], T, n_units, 1, 2024, 1000)
+    mel = smp.sample(r["cond_t"].cuda(), 1000, mel2ph=r["mel2ph"].cuda(), seed=2024, first_clip=0, use_graph=True)
+    err = (mel.cpu() - r["mel_out"]).abs().max().item()
+    assert err < 1e-3, err
+
+
+def test_plain_f16_fails_the_bar_dither_is_needed():
+    """Documents WHY the dither exists: round-to-nearest fp16 weights alone miss the 1e-3 bar on a 1000-step chain
+    (systematic rounding error), so 'f16' is not a shippable precision for the headline configuration."""
+    hp = dict(synth.HPARAMS_44K)
+    sd, den, smp = make_handles(hp, 0, "f16")
+    T, n_units = 64, 37
+    r = oracle_sample(hp, sd, [0], T, n_units, 1, 2024, 1000)
+    mel = smp.sample(r["cond_t"].cuda(), 1000, mel2ph=r["mel2ph"].cuda(), seed=2024, first_clip=0, use_graph=True)
+    err = (mel.cpu() - r["mel_out"]).abs().max().item()
+    assert 1e-3 < err < 5e-2, err
