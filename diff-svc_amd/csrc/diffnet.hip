@@ -93,10 +93,12 @@ struct TPacked {
 };
 
 // src: host fp32 [O][I][taps]; rowmap(packed_row) -> source output channel or -1
+// split_act: the activation operand is stored as [x_hi | x_lo] fp16 planes (K = 2 * padded I, same weights for both)
 template <class FR>
 int tpack(TPacked& tp, const std::vector<float>& src, int O, int I, int taps, int m_tiles, int planes, int n_variants,
-          float scale, unsigned salt, FR&& rowmap, const float* bias, int nbias) {
-    tp.m_tiles = m_tiles; tp.taps = taps; tp.cin_pad = round_up(I, 128); tp.planes = planes; tp.n_variants = n_variants;
+          float scale, unsigned salt, bool split_act, FR&& rowmap, const float* bias, int nbias) {
+    const int fold = split_act ? round_up(I, 128) : 0;
+    tp.m_tiles = m_tiles; tp.taps = taps; tp.cin_pad = split_act ? 2 * fold : round_up(I, 128); tp.planes = planes; tp.n_variants = n_variants;
     tp.variant_halfs = tpacked_halfs(m_tiles, taps, tp.cin_pad, planes, 1);
     if ((size_t)O * I * taps != src.size()) return fail(DSVC_EINVAL, "tpack: weight tensor has %zu elements, expected %zu", src.size(), (size_t)O * I * taps);
     std::vector<int> rm(m_tiles * 32);
@@ -111,7 +113,7 @@ int tpack(TPacked& tp, const std::vector<float>& src, int O, int I, int taps, in
     const long long total = (long long)tp.variant_halfs / planes * n_variants;
     const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
     hipLaunchKernelGGL(k_tpack, dim3(blocks), dim3(256), 0, 0, dsrc.as<float>(), drm.as<int>(), tp.w.as<_Float16>(), I, taps,
-                       tp.cin_pad, m_tiles, planes, n_variants, scale, salt);
+                       tp.cin_pad, fold, m_tiles, planes, n_variants, scale, salt);
     DSVC_HIP(hipGetLastError());
     DSVC_HIP(hipDeviceSynchronize());
     dsrc.release(); drm.release();
@@ -122,14 +124,16 @@ int tpack(TPacked& tp, const std::vector<float>& src, int O, int I, int taps, in
 // x 4 waves with the output-channel passes spread over blockIdx.y
 template <class Epi, int NW>
 int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hipStream_t st) {
+    constexpr int KG = NW == 2 ? 4 : 8;                  // two planes: half the ring depth, same bytes in flight
     if (rows_alloc / 128 >= 48) {
         const int tiles = rows_alloc / 128, passes = ceil_div(a.m_tiles, 8);
         int ms = 256 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
-        return tgemm_launch<4, 8, 2, (NW == 2 ? 4 : 8), NW, Epi>(a, e, rows_alloc, ms, st);   // two planes: half the ring depth, same bytes in flight
+        if (tgemm_smem<4>(a.taps, a.dil, a.cin) <= 160 * 1024) return tgemm_launch<4, 8, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
+        return tgemm_launch<2, 8, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);       // K too wide for a 128-frame tile in LDS
     }
     const int tiles = rows_alloc / 32, passes = ceil_div(a.m_tiles, 4);
     int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
-    return tgemm_launch<1, 4, 2, (NW == 2 ? 4 : 8), NW, Epi>(a, e, rows_alloc, ms, st);
+    return tgemm_launch<1, 4, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
 }
 
 template <class Epi>
@@ -301,7 +305,8 @@ int dsvc_denoiser::finalize() {
 
 // tgemm path: A-fragment packing on the device.  The two big per-layer contractions take the configured precision
 // (1 plane with `weight_variants` dithered roundings, or hi+lo planes); the three small projections always carry
-// hi+lo planes (their cost is < 2 % of a step).
+// hi+lo weight planes AND read their activations as fp16 hi|lo planes (fp32-class, like F16_X3): they are < 2 % of a
+// step's FLOPs but sit where a rounding goes straight into the state (input) or into eps (output).
 int dsvc_denoiser::finalize_t() {
     const int M = cfg.mel_bins, C = cfg.channels, L = cfg.layers;
     Cp = round_up(C, 128); Mp = round_up(M, 128);
@@ -314,7 +319,7 @@ int dsvc_denoiser::finalize_t() {
     {
         GET(w, "input_projection.weight", C * M);
         GET(b, "input_projection.bias", C);
-        DSVC_TRY(tpack(in_t, *w, C, M, 1, C / 32, 2, 1, 1.0f, 11u,
+        DSVC_TRY(tpack(in_t, *w, C, M, 1, C / 32, 2, 1, 1.0f, 11u, true,
                        [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, b->data(), C));
     }
     dil_t.resize(L); out_t.resize(L);
@@ -324,17 +329,17 @@ int dsvc_denoiser::finalize_t() {
         GET(wo, q + "output_projection.weight", 2 * C * C);
         GET(bo, q + "output_projection.bias", 2 * C);
         // gate kernel: tile mt holds g-channels 16*mt .. +15: rows 0..15 gate (conv channel c), 16..31 filter (C + c)
-        DSVC_TRY(tpack(dil_t[l], *wd, 2 * C, C, 3, C / 16, planes, nvar, 1.0f, 1000u + 2 * l,
+        DSVC_TRY(tpack(dil_t[l], *wd, 2 * C, C, 3, C / 16, planes, nvar, 1.0f, 1000u + 2 * l, false,
                        [&](int r) { const int mt = r >> 5, i = r & 31; return (i >> 4) * C + mt * 16 + trow_to_ch8(i & 15); },
                        bo->data(), 1));
         // output 1x1: tiles 0..C/32-1 residual half (conv channels 0..C-1), then the skip half (C..2C-1)
-        DSVC_TRY(tpack(out_t[l], *wo, 2 * C, C, 1, 2 * C / 32, planes, nvar, 1.0f, 1001u + 2 * l,
+        DSVC_TRY(tpack(out_t[l], *wo, 2 * C, C, 1, 2 * C / 32, planes, nvar, 1.0f, 1001u + 2 * l, false,
                        [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, bo->data(), 2 * C));
     }
     {
         GET(w, "skip_projection.weight", C * C);
         GET(b, "skip_projection.bias", C);
-        DSVC_TRY(tpack(skip_t, *w, C, C, 1, C / 32, 2, 1, 1.0f / sqrtf((float)L), 12u,          // sum(skip)/sqrt(L) (net.py:131)
+        DSVC_TRY(tpack(skip_t, *w, C, C, 1, C / 32, 2, 1, 1.0f / sqrtf((float)L), 12u, true,    // sum(skip)/sqrt(L) (net.py:131)
                        [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, b->data(), C));
     }
     {
@@ -343,7 +348,7 @@ int dsvc_denoiser::finalize_t() {
         const int mt = ceil_div(M, 32);
         std::vector<float> bias(mt * 32, 0.f);
         for (int i = 0; i < M; ++i) bias[i] = (*b)[i];
-        DSVC_TRY(tpack(fin_t, *w, M, C, 1, mt, 2, 1, 1.0f, 13u,
+        DSVC_TRY(tpack(fin_t, *w, M, C, 1, mt, 2, 1, 1.0f, 13u, true,
                        [&](int r) { const int c = (r >> 5) * 32 + trow_to_ch16(r & 31); return c < M ? c : -1; }, bias.data(), mt * 32));
     }
 #undef GET
@@ -367,9 +372,9 @@ int dsvc_denoiser::ensure_ws(int B, int T) {
     if (tpath) {
         // fp16 operands: zero once -- gap rows, guard rows and pad columns are never written afterwards
         const size_t nxh = (r + 2 * (size_t)guard) * Cp * 2, nh = r * Cp * 2, ns = r * Mp * 2;
-        DSVC_TRY(xh.alloc(nxh)); DSVC_TRY(gh.alloc(nh)); DSVC_TRY(skiph.alloc(nh)); DSVC_TRY(s2h.alloc(nh)); DSVC_TRY(xsh.alloc(ns));
-        DSVC_HIP(hipMemset(xh.p, 0, nxh)); DSVC_HIP(hipMemset(gh.p, 0, nh)); DSVC_HIP(hipMemset(skiph.p, 0, nh));
-        DSVC_HIP(hipMemset(s2h.p, 0, nh)); DSVC_HIP(hipMemset(xsh.p, 0, ns));
+        DSVC_TRY(xh.alloc(nxh)); DSVC_TRY(gh.alloc(nh)); DSVC_TRY(skiph.alloc(2 * nh)); DSVC_TRY(s2h.alloc(2 * nh)); DSVC_TRY(xsh.alloc(2 * ns));
+        DSVC_HIP(hipMemset(xh.p, 0, nxh)); DSVC_HIP(hipMemset(gh.p, 0, nh)); DSVC_HIP(hipMemset(skiph.p, 0, 2 * nh));   // hi|lo planes
+        DSVC_HIP(hipMemset(s2h.p, 0, 2 * nh)); DSVC_HIP(hipMemset(xsh.p, 0, 2 * ns));
         DSVC_HIP(hipMemset(xres.p, 0, r * C * 4)); DSVC_HIP(hipMemset(skip.p, 0, r * C * 4));
         DSVC_HIP(hipMemset(condT.p, 0, r * H * 4)); DSVC_HIP(hipMemset(cproj.p, 0, r * 2 * C * L * 4));
     } else {
@@ -465,7 +470,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         hipLaunchKernelGGL(k_rows_to_half, dim3(ceil_div(rows * (M / 4), 256) < 2048 ? ceil_div(rows * (M / 4), 256) : 2048), dim3(256), 0, st,
                            x_fm, xsh.as<_Float16>(), M, Mp, rm, rows);
     {   // K1: input projection + ReLU (net.py:120-123); emits layer 0's operand xh = fp16(x + film_0)
-        TGemmArgs a = targs(xsh.as<_Float16>(), Mp, in_t, 1, 1);
+        TGemmArgs a = targs(xsh.as<_Float16>(), 2 * Mp, in_t, 1, 1);
         TEpiInProj::Args e{xres.as<float>(), xh_row0(), in_t.bias.as<float>(), film.as<float>(), L * C, step, C, Cp, rm};
         DSVC_TRY(tlaunch_prec<TEpiInProj>(a, e, 2, rows_alloc, st));
     }
@@ -488,12 +493,12 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         }
     }
     {   // K9a: skip projection + ReLU (net.py:132-133)
-        TGemmArgs a = targs(skiph.as<_Float16>(), Cp, skip_t, 1, 1);
+        TGemmArgs a = targs(skiph.as<_Float16>(), 2 * Cp, skip_t, 1, 1);
         TEpiReluHalf::Args e{s2h.as<_Float16>(), Cp, skip_t.bias.as<float>(), C};
         DSVC_TRY(tlaunch_prec<TEpiReluHalf>(a, e, 2, rows_alloc, st));
     }
     {   // K9b: output projection (net.py:134), optionally fused with the DDPM update (K10)
-        TGemmArgs a = targs(s2h.as<_Float16>(), Cp, fin_t, 1, 1);
+        TGemmArgs a = targs(s2h.as<_Float16>(), 2 * Cp, fin_t, 1, 1);
         if (tail == TAIL_DDPM) {
             TEpiDdpm::Args e{ddpm->x, xsh.as<_Float16>(), fin_t.bias.as<float>(), M, Mp, ddpm->tab, step, rm, ddpm->seed, ddpm->clip0};
             DSVC_TRY(tlaunch_prec<TEpiDdpm>(a, e, 2, rows_alloc, st));
@@ -737,7 +742,7 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
     else if (n == "xres") { b = &d->xres; width = C; }
     else if (n == "g") { if (d->tpath) { hb = &d->gh; hld = d->Cp; } else b = &d->g; width = C; }
     else if (n == "skip") { b = &d->skip; width = C; }
-    else if (n == "s2") { if (d->tpath) { hb = &d->s2h; hld = d->Cp; } else b = &d->s2; width = C; }
+    else if (n == "s2") { if (d->tpath) { hb = &d->s2h; hld = 2 * d->Cp; } else b = &d->s2; width = C; }
     else if (n == "xh") { if (!d->tpath) return fail(DSVC_EINVAL, "'xh' exists on the tgemm path only"); hb = &d->xh; hld = d->Cp; hoff = (size_t)d->guard * d->Cp; width = C; }
     else if (n == "eps") { b = &d->eps; width = M; }
     else if (n == "condT") { b = &d->condT; width = H; }
@@ -836,7 +841,19 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
     for (int it = -2; it < iters; ++it) {                 // two untimed warm-up rounds
         for (int l = 0; l < L; ++l) {
             DSVC_HIP(hipEventRecord(e0, st));
-            if (d->tpath) {
+            const char* which = getenv("DSVC_PROFILE_KERNEL");          // "out": time the output projection instead (profiling aid)
+            if (d->tpath && which && which[0] == 'o') {
+                const bool last = l + 1 == L;
+                TGemmArgs a{};
+                a.x = d->gh.as<_Float16>(); a.cin = d->Cp; a.taps = 1; a.dil = 1;
+                a.w = d->out_t[l].w.as<_Float16>(); a.m_tiles = d->out_t[l].m_tiles; a.w_planes = d->out_t[l].planes;
+                a.variant_halfs = (long long)d->out_t[l].variant_halfs; a.n_variants = d->out_t[l].n_variants;
+                a.step_ptr = s->step_dev.as<int>(); a.step_off = 0;
+                TEpiResSkip::Args e{d->xres.as<float>(), last ? nullptr : d->xh_row0(), d->skip.as<float>(), last ? d->skiph.as<_Float16>() : nullptr,
+                                    d->out_t[l].bias.as<float>(), last ? nullptr : d->film.as<float>() + (size_t)(l + 1) * C, L * C,
+                                    StepRef{s->step_dev.as<int>(), 0, 0}, C, d->Cp, l == 0 ? 1 : 0, d->rowmap()};
+                DSVC_TRY(tlaunch_prec<TEpiResSkip>(a, e, d->out_t[l].planes, d->rows_alloc, st));
+            } else if (d->tpath) {
                 TGemmArgs a{};
                 a.x = d->xh_row0(); a.cin = d->Cp; a.taps = 3; a.dil = 1 << (l % d->cfg.dilation_cycle);
                 a.w = d->dil_t[l].w.as<_Float16>(); a.m_tiles = d->dil_t[l].m_tiles; a.w_planes = d->dil_t[l].planes;

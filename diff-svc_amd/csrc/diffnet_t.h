@@ -25,6 +25,20 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ f32x4 ld4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// split 16 fp32 values into fp16 hi and lo (= fp16(v - hi)) and store both planes: dst[0..15] and dst[lo_off..lo_off+15]
+__device__ __forceinline__ void store_hi_lo16(_Float16* dst, int lo_off, const float (&v)[16]) {
+    half8 h0, h1, l0, l1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h0[i] = (_Float16)v[i]; h1[i] = (_Float16)v[8 + i];
+        l0[i] = (_Float16)(v[i] - (float)h0[i]); l1[i] = (_Float16)(v[8 + i] - (float)h1[i]);
+    }
+    *reinterpret_cast<half8*>(dst) = h0;
+    *reinterpret_cast<half8*>(dst + 8) = h1;
+    *reinterpret_cast<half8*>(dst + lo_off) = l0;
+    *reinterpret_cast<half8*>(dst + lo_off + 8) = l1;
+}
+
 // sigmoid(a) * tanh(b) = (1 - E2) / ((1 + E1) * (1 + E2)),  E1 = exp(-a), E2 = exp(-2b)   (net.py:73-77)
 __device__ __forceinline__ float gate_act(float a, float b) {
     b = fminf(fmaxf(b, -15.0f), 15.0f);                    // tanh is +-1 to fp32 precision beyond |b| ~ 9; keeps E2 finite
@@ -71,7 +85,7 @@ struct TEpiResSkip {
         float* x32;             // [rows][C] residual stream (in/out)
         _Float16* xh;           // [rows][ldh] next layer's MFMA operand, row 0 (guard rows precede); null on the last layer
         float* skip;            // [rows][C] running skip sum
-        _Float16* skiph;        // [rows][ldh] fp16(skip) for the skip projection; non-null on the last layer only
+        _Float16* skiph;        // [rows][2*ldh] fp16 hi|lo planes of the skip sum for the skip projection; last layer only
         const float* bias;      // [2C]
         const float* film;      // next layer's FiLM table slice: film[step*film_step_stride + c]; null on the last layer
         int film_step_stride;
@@ -125,12 +139,11 @@ struct TEpiResSkip {
             float* p = (res ? e.x32 : e.skip) + (size_t)frame * e.C + cb;
 #pragma unroll
             for (int q = 0; q < 4; ++q) st4(p + 4 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
-            _Float16* hp = res ? e.xh : e.skiph;
-            if (hp) {
+            if (res && e.xh) {
                 int clip, tl;
                 const bool ok = e.rm.valid(frame, clip, tl);
                 float hv[16];
-                if (ok && res) {
+                if (ok) {
                     const float* fp = e.film + (size_t)e.step.get(clip) * e.film_step_stride + cb;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -140,14 +153,22 @@ struct TEpiResSkip {
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) hv[i] = ok ? v[i] : 0.f;
+                    for (int i = 0; i < 16; ++i) hv[i] = 0.f;
                 }
                 half8 o0, o1;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)hv[i]; o1[i] = (_Float16)hv[8 + i]; }
-                _Float16* q = hp + (size_t)frame * e.ldh + cb;
+                _Float16* q = e.xh + (size_t)frame * e.ldh + cb;
                 *reinterpret_cast<half8*>(q) = o0;
                 *reinterpret_cast<half8*>(q + 8) = o1;
+            }
+            if (!res && e.skiph) {
+                int clip, tl;
+                const bool ok = e.rm.valid(frame, clip, tl);
+                float hv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hv[i] = ok ? v[i] : 0.f;
+                store_hi_lo16(e.skiph + (size_t)frame * (2 * e.ldh) + cb, e.ldh, hv);
             }
         }
     }
@@ -201,9 +222,9 @@ struct TEpiInProj {
     }
 };
 
-// ---- K9a: skip projection + ReLU -> fp16 operand of the final projection ----
+// ---- K9a: skip projection + ReLU -> fp16 hi|lo operand planes of the final projection ----
 struct TEpiReluHalf {
-    struct Args { _Float16* out; int ld; const float* bias; int cout; };
+    struct Args { _Float16* out; int ld; const float* bias; int cout; };   // out [rows][2*ld]: hi plane, lo plane at +ld
     template <int NT_N>
     __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
 #pragma unroll
@@ -221,12 +242,10 @@ struct TEpiReluHalf {
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) {
             const int frame = row0 + 32 * nt + (lane & 31);
-            half8 o0, o1;
+            float v[16];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)fmaxf(acc[nt][i] + b[i], 0.f); o1[i] = (_Float16)fmaxf(acc[nt][8 + i] + b[8 + i], 0.f); }
-            _Float16* q = e.out + (size_t)frame * e.ld + cb;
-            *reinterpret_cast<half8*>(q) = o0;
-            *reinterpret_cast<half8*>(q + 8) = o1;
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[nt][i] + b[i], 0.f);
+            store_hi_lo16(e.out + (size_t)frame * (2 * e.ld) + cb, e.ld, v);
         }
     }
 };
@@ -263,7 +282,7 @@ struct TEpiEps {
 struct TEpiDdpm {
     struct Args {
         float* x;                   // [rows][M] sampler state (in/out)
-        _Float16* xsh;              // [rows][ldh] fp16 copy (zero on gap rows)
+        _Float16* xsh;              // [rows][2*ldh] fp16 hi|lo planes of the state (zero on gap rows)
         const float* bias;          // [M]
         int M, ldh;
         DdpmTables tab;
@@ -317,19 +336,14 @@ struct TEpiDdpm {
                 }
                 st4(px + 4 * q, out);
             }
-            half8 o0, o1;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)hv[i]; o1[i] = (_Float16)hv[8 + i]; }
-            _Float16* hq = e.xsh + (size_t)frame * e.ldh + cb;
-            *reinterpret_cast<half8*>(hq) = o0;
-            *reinterpret_cast<half8*>(hq + 8) = o1;
+            store_hi_lo16(e.xsh + (size_t)frame * (2 * e.ldh) + cb, e.ldh, hv);
         }
     }
 };
 
 // ---- small kernels of the tgemm path ----
 
-// fp32 frame-major [rows][C] -> fp16 [rows][ld] (valid rows only; gap rows and pad columns are left untouched = zero)
+// fp32 frame-major [rows][C] -> fp16 hi|lo planes [rows][2*ld] (valid rows only; gap rows and pad columns stay zero)
 __global__ void k_rows_to_half(const float* __restrict__ src, _Float16* __restrict__ dst, int C, int ld, RowMap rm, int rows) {
     const int per_row = C >> 2;
     const long long n = (long long)rows * per_row;
@@ -338,8 +352,13 @@ __global__ void k_rows_to_half(const float* __restrict__ src, _Float16* __restri
         int clip, tl;
         if (!rm.valid(row, clip, tl)) continue;
         const f32x4 v = ld4(src + (size_t)row * C + c4);
-        _Float16* q = dst + (size_t)row * ld + c4;
-        q[0] = (_Float16)v[0]; q[1] = (_Float16)v[1]; q[2] = (_Float16)v[2]; q[3] = (_Float16)v[3];
+        _Float16* q = dst + (size_t)row * (2 * ld) + c4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const _Float16 h = (_Float16)v[j];
+            q[j] = h;
+            q[ld + j] = (_Float16)(v[j] - (float)h);
+        }
     }
 }
 

@@ -27,6 +27,8 @@
 //     average to w), which keeps 1 MFMA per product inside the 1e-3 bar.
 //   * `MSPLIT` output-channel passes can be spread over blockIdx.y for small batches (B = 1) to fill the chip.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dsvc {
@@ -49,6 +51,8 @@ struct TGemmArgs {
     int n_variants;         // >= 1
     const int* step_ptr;    // device int: current diffusion step (variant = (step - step_off) % n_variants); may be null
     int step_off;
+    int dbg;                // ablation knobs for profiling (env DSVC_TG_DEBUG): 1 = no acc-init loads, 2 = no epilogue,
+                            // 4 = no tile DMA, 8 = no MFMA main loop, 16 = no wave priority split.  0 in production.
 };
 
 // the row <-> channel permutation inside a 32-row output tile that makes a lane's 16 accumulator registers hold 16
@@ -80,7 +84,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         int slot = wave * 64 + lane;
         int r = slot / chunks, c = slot - r * chunks;
         const _Float16* xrow0 = a.x + (long long)(row0 - halo) * a.cin;
-        for (int it = wave; it * 64 < total; it += WAVES) {
+        for (int it = wave; it * 64 < total && !(a.dbg & 4); it += WAVES) {
             const int rc = r < rows_lds ? r : rows_lds - 1;            // lanes past the tile re-read its last row
             const _Float16* src = xrow0 + (long long)rc * a.cin + ((c ^ (rc & a.swz)) << 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -105,7 +109,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
 
     // two waves share a SIMD (waves w and w + 4): give one of them priority so the pair drifts apart and one wave's
     // epilogue / memory waits sit under the other's MFMAs instead of both stalling together
-    if (WAVES > 4 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+    if (WAVES > 4 && wave >= WAVES / 2 && !(a.dbg & 16)) __builtin_amdgcn_s_setprio(1);
 
     auto load_group = [&](half8 (&ring)[KG][NW], const _Float16* p) {
 #pragma unroll
@@ -120,11 +124,12 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     auto compute_group = [&](const half8 (&ring)[KG][NW], f32x16 (&acc)[NT_N], int g) {
         const int tap = g / gpt, kb = (g - tap * gpt) * KG;
         const int rr = halo + (tap - (a.taps >> 1)) * a.dil + (lane & 31);      // LDS row of this lane's frame, N-tile 0
-        // chunk of k16-step k, half h, row r lives at slot (2k + h) ^ (r & swz); kb is a multiple of 8, so only the low
-        // 4 chunk bits are touched:  byte offset = (kb << 5) + ((kk << 5) ^ xs),  xs = ((r & swz) ^ h) << 4
-        const unsigned xs = (unsigned)(((rr & a.swz) ^ (lane >> 5)) << 4);
+        // chunk of k16-step k, half h, row r lives at slot (2k + h) ^ (r & swz), i.e. at byte offset
+        // (k << 5) ^ xs with xs = ((r & swz) ^ h) << 4.  The group's first step kb is a multiple of KG and kk < KG, so
+        // ((kb + kk) << 5) ^ xs = ((kb << 5) ^ xs) ^ (kk << 5): one per-group VALU, then an immediate XOR per step.
+        const unsigned xs = (unsigned)(((rr & a.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5);
         unsigned base[NT_N];
-        base[0] = lds0 + (unsigned)rr * (unsigned)row_bytes + ((unsigned)kb << 5);
+        base[0] = lds0 + (unsigned)rr * (unsigned)row_bytes;
 #pragma unroll
         for (int nt = 1; nt < NT_N; ++nt) base[nt] = base[nt - 1] + nt_stride;
         // keep the per-group bases materialised: without this LLVM re-derives every address from scratch (4-5 VALU per ds_read)
@@ -165,14 +170,21 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     bool active = mt < a.m_tiles;                        // wave-uniform
     if (active) {
         load_group(ringA, wbase + (long long)mt * tile_halfs);
-        epi.init(ea, mt, row0, lane, acc);
+        if (a.dbg & 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+        } else {
+            epi.init(ea, mt, row0, lane, acc);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA'd tile (and the first operands) have landed
     __syncthreads();
 
     while (active) {
         const _Float16* wp = wbase + (long long)mt * tile_halfs;
-        int g = 0;
+        int g = (a.dbg & 8) ? G : 0;
         for (; g + 1 < G; g += 2) {     // straight-line body (no branch): IR-level sinking cannot move a prefetch below its group
             load_group(ringB, wp + (long long)(g + 1) * GROUP_HALFS);          // ringB <- group g+1, under group g's MFMAs
             __builtin_amdgcn_sched_barrier(0);
@@ -191,9 +203,17 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         f32x16 nxt[NT_N];
         if (active_n) {
             load_group(ringA, wbase + (long long)mt_n * tile_halfs);
-            epi.init(ea, mt_n, row0, lane, nxt);
+            if (a.dbg & 1) {
+#pragma unroll
+                for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) nxt[nt][i] = 0.f;
+            } else {
+                epi.init(ea, mt_n, row0, lane, nxt);
+            }
         }
-        epi.finish(ea, mt, row0, lane, acc);
+        if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
+        else asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT_N - 1][15]));
         if (!active_n) break;
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) acc[nt] = nxt[nt];
@@ -221,6 +241,8 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
     if (n_rows % (32 * NT_N) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N);
     if (a.w_planes != NW) return fail(DSVC_EINVAL, "tgemm: weights packed with %d plane(s), kernel streams %d", a.w_planes, NW);
     a.swz = tgemm_swizzle_mask(a.cin);
+    const char* dbg_s = getenv("DSVC_TG_DEBUG");           // profiling ablations only; results are WRONG when set
+    a.dbg = dbg_s ? atoi(dbg_s) : 0;
     auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi>;
     const size_t smem = tgemm_smem<NT_N>(a.taps, a.dil, a.cin);
     if (smem > 160 * 1024) return fail(DSVC_EINVAL, "tgemm: %zu B of LDS requested", smem);
@@ -242,7 +264,8 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
 //   src [O][I][taps] fp32 in the checkpoint's Conv1d layout; rowmap[m_tiles*32] gives the source output channel of
 //   every packed row (or -1 = zero row) -- the caller folds the tile-row permutation (trow_to_ch16 / trow_to_ch8)
 //   into it.  Layout [variant][m_tile][tap][k16][plane][lane][8]; lane l of a fragment holds packed row (l & 31),
-//   k = k16*16 + 8*(l >> 5) + e.  plane 0 = fp16(w), plane 1 = fp16(w - plane0).
+//   k = k16*16 + 8*(l >> 5) + e.  plane 0 = fp16(w), plane 1 = fp16(w - plane0).  fold > 0 packs K = 2*fold input
+//   channels whose upper half repeats the lower one: the matching activation buffer holds [x_hi | x_lo] planes.
 //   Variant v of n rounds w to fp16 DOWN or UP so that the mean over the variants is w +- ulp/(2n): round up iff
 //   frac(w) > ((v' + 0.5)/n + phase(element)) mod 1, v' = bit-reversed v (consecutive diffusion steps use far-apart
 //   thresholds), phase = a per-element hash.  n == 1 is plain round-to-nearest.
@@ -277,7 +300,7 @@ __device__ inline _Float16 tg_round_dither(float w, float thresh) {
 }
 
 __global__ void k_tpack(const float* __restrict__ src, const int* __restrict__ rowmap, _Float16* __restrict__ dst,
-                        int I, int taps, int cin_pad, int m_tiles, int planes, int n_variants, float scale, unsigned salt) {
+                        int I, int taps, int cin_pad, int fold, int m_tiles, int planes, int n_variants, float scale, unsigned salt) {
     const int nk16 = cin_pad >> 4;
     const long long per_variant = (long long)m_tiles * taps * nk16 * 512;      // elements of ONE plane
     const long long total = per_variant * n_variants;
@@ -293,7 +316,8 @@ __global__ void k_tpack(const float* __restrict__ src, const int* __restrict__ r
         const int mt = (int)(r / taps);
         const int row = mt * 32 + (l & 31), ci = k * 16 + 8 * (l >> 5) + e;
         const int o = rowmap[row];
-        const float w = (o >= 0 && ci < I) ? src[((size_t)o * I + ci) * taps + tap] * scale : 0.f;
+        const int cs = fold > 0 ? ci % fold : ci;          // fold: input channels [fold, 2*fold) repeat [0, fold) -- the lo plane of a
+        const float w = (o >= 0 && cs < I) ? src[((size_t)o * I + cs) * taps + tap] * scale : 0.f;   // split activation sees the same weights
         _Float16 hi;
         if (n_variants > 1) {
             int vr = 0;

@@ -9,6 +9,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+import torch
+
+# the oracle's small CPU convolutions collapse when oneDNN fans them out over a GPU host's 256 hardware threads
+# (measured: 50 s per DiffNet evaluation at T=861 instead of 0.1 s); a modest pool is fastest everywhere
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

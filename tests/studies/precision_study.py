@@ -71,7 +71,11 @@ class Net:
         p = lambda k: sd[P + k]
         C = self.C
         act = (lambda v: v) if self.scheme == "f32" else r16
-        x = F.relu(F.conv1d(spec[:, 0], p("input_projection.weight"), p("input_projection.bias")))
+        flags = os.environ.get("STUDY_ROUND", "state,skip,s2").split(",")      # which of the small projections see fp16 inputs
+        a_state = act if "state" in flags else (lambda v: v)
+        a_skip = act if "skip" in flags else (lambda v: v)
+        a_s2 = act if "s2" in flags else (lambda v: v)
+        x = F.relu(F.conv1d(a_state(spec[:, 0]), p("input_projection.weight"), p("input_projection.bias")))   # tgemm path: fp16 state copy
         emb = O.step_embedding(sd, t)
         skip = torch.zeros_like(x)
         k = self.order[int(t[0]) % self.K]
@@ -84,9 +88,8 @@ class Net:
             o = F.conv1d(act(z), self.wo[l][k % len(self.wo[l])], q("output_projection.bias"))
             x = (x + o[:, :C]) / math.sqrt(2.0)
             skip = skip + o[:, C:]
-        s = skip / math.sqrt(self.L)
-        s = F.relu(F.conv1d(s, p("skip_projection.weight"), p("skip_projection.bias")))
-        return F.conv1d(s, p("output_projection.weight"), p("output_projection.bias"))[:, None]
+        s = F.relu(F.conv1d(a_skip(skip), p("skip_projection.weight") / math.sqrt(self.L), p("skip_projection.bias")))   # fp16(skip), 1/sqrt(L) in the weights
+        return F.conv1d(a_s2(s), p("output_projection.weight"), p("output_projection.bias"))[:, None]
 
 def chain(net, sd, hp, cond_t, x, seed, clips, T, steps, K_total):
     M = hp["audio_num_mel_bins"]

@@ -14,6 +14,17 @@ pytestmark = pytest.mark.gpu
 FWD_TOL = {"f16": 2e-2, "f16_w2": 6e-3, "f16_x3": 3e-4}
 
 
+_CHAIN_CACHE = {}
+
+
+def oracle_chain_1000():
+    """The 1000-step oracle chain the full-chain tests share (44.1 kHz architecture, T=64): computed once per session."""
+    if "r" not in _CHAIN_CACHE:
+        hp = dict(synth.HPARAMS_44K)
+        _CHAIN_CACHE["r"] = oracle_sample(hp, synth.acoustic_state(hp, 0), [0], 64, 37, 1, 2024, 1000)
+    return _CHAIN_CACHE["r"]
+
+
 def make_handles(hp, wseed, precision):
     from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
     sd = synth.acoustic_state(hp, wseed)
@@ -80,8 +91,11 @@ def test_sampler_vs_reference_golden(name, tol, precision):
     rounding, hence the looser bar there.  f16_x3 runs on the conv_gemm engine, f16_w2 on the tgemm engine."""
     g = load_golden(name)
     hp = dict(hp_for(name), K_step=int(g["K_step"]))
-    if precision == "f16_w2" and "plms" in name:
-        tol = 4e-3          # fp16 activations, no clamp between the extrapolated steps
+    if precision == "f16_w2":
+        # fp16 activations: the 1e-3 bar is the north star for the 44.1 kHz architecture over a 1000-step chain (see
+        # test_full_chain_1000_steps_*); the coarse 50-step schedules of these short goldens amplify a single
+        # rounding more, and PLMS has no clamp between its extrapolated steps
+        tol = 4e-3 if "plms" in name else 2e-3
     sd, den, smp = make_handles(hp, int(g["wseed"]), precision)
     clips = [int(c) for c in g["clips"]]
     cond = torch.from_numpy(g["decoder_inp"]).transpose(1, 2).contiguous().cuda()
@@ -128,8 +142,7 @@ def test_full_chain_1000_steps_w2_within_mel_bar():
     (f16_w2), mel within 1e-3 max-abs of the oracle -- at a frame count the oracle finishes in ~20 s."""
     hp = dict(synth.HPARAMS_44K)
     sd, den, smp = make_handles(hp, 0, "f16_w2")
-    T, n_units = 64, 37
-    r = oracle_sample(hp, sd, [0], T, n_units, 1, 2024, 1000)
+    r = oracle_chain_1000()
     mel = smp.sample(r["cond_t"].cuda(), 1000, mel2ph=r["mel2ph"].cuda(), seed=2024, first_clip=0, use_graph=True)
     err = (mel.cpu() - r["mel_out"]).abs().max().item()
     assert err < 1e-3, err
@@ -140,8 +153,7 @@ def test_full_chain_1000_steps_dithered_f16_within_mel_bar():
     as above, same bar."""
     hp = dict(synth.HPARAMS_44K)
     sd, den, smp = make_handles(hp, 0, "f16_d64")
-    T, n_units = 64, 37
-    r = oracle_sample(hp, sd, [0], T, n_units, 1, 2024, 1000)
+    r = oracle_chain_1000()
     mel = smp.sample(r["cond_t"].cuda(), 1000, mel2ph=r["mel2ph"].cuda(), seed=2024, first_clip=0, use_graph=True)
     err = (mel.cpu() - r["mel_out"]).abs().max().item()
     assert err < 1e-3, err
@@ -152,8 +164,7 @@ def test_plain_f16_fails_the_bar_dither_is_needed():
     (systematic rounding error), so 'f16' is not a shippable precision for the headline configuration."""
     hp = dict(synth.HPARAMS_44K)
     sd, den, smp = make_handles(hp, 0, "f16")
-    T, n_units = 64, 37
-    r = oracle_sample(hp, sd, [0], T, n_units, 1, 2024, 1000)
+    r = oracle_chain_1000()
     mel = smp.sample(r["cond_t"].cuda(), 1000, mel2ph=r["mel2ph"].cuda(), seed=2024, first_clip=0, use_graph=True)
     err = (mel.cpu() - r["mel_out"]).abs().max().item()
     assert 1e-3 < err < 5e-2, err

@@ -1,0 +1,20 @@
+"""Sampler-only workload for rocprofv3: python tools/prof_sampler.py <B> <steps> <precision> [graph]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import diffsvc_amd
+from diffsvc_amd import synth
+from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
+B, steps, prec = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+graph = len(sys.argv) > 4 and sys.argv[4] == "graph"
+hp = dict(synth.HPARAMS_44K)
+sd = synth.acoustic_state(hp, 0)
+den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=prec, prefix="denoise_fn.")
+smp = SamplerHandle(den, sd)
+cond = torch.randn(B, 256, 861, device="cuda") * 0.5
+smp.sample(cond, 25, seed=1, use_graph=graph)
+torch.cuda.synchronize(); t0 = time.time()
+smp.sample(cond, steps, seed=2, use_graph=graph)
+torch.cuda.synchronize(); dt = time.time() - t0
+print("B=%d %s steps=%d graph=%d: %.3f ms/step" % (B, prec, steps, graph, dt / steps * 1e3))
