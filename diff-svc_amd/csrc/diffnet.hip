@@ -394,8 +394,13 @@ int dsvc_denoiser::prepare_cond(const float* cond_bht, int B, int T, hipStream_t
         a.x = condT.as<float>(); a.ldx = H; a.n_rows = rows; a.clip_stride = Tp; a.clip_len = T;
         a.cin = H; a.taps = 1; a.dil = 1; a.w = condp[l].w.as<_Float16>(); a.n_ctiles = condp[l].n_ctiles; a.w_planes = 2;
         a.in_slope = 1.0f;
-        EpiBias::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, 2 * C, condp[l].bias.as<float>(), 2 * C};
-        DSVC_TRY(dispatch_prec<EpiBias>(a, e, DSVC_PREC_F16_X3, st));
+        if (tpath) {
+            EpiBiasTiled::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, 2 * C / 32, condp[l].bias.as<float>(), 2 * C};
+            DSVC_TRY((dispatch_tiling<EpiBiasTiled, 2, 2>(a, e, st)));
+        } else {
+            EpiBias::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, 2 * C, condp[l].bias.as<float>(), 2 * C};
+            DSVC_TRY(dispatch_prec<EpiBias>(a, e, DSVC_PREC_F16_X3, st));
+        }
     }
     cond_ready = true;
     return DSVC_OK;
@@ -757,6 +762,12 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
         if (hb) {
             if ((size_t)numel < (size_t)r_ws * width) return fail(DSVC_EINVAL, "debug buffer '%s' needs %zu elements", name, (size_t)r_ws * width);
             hipLaunchKernelGGL(k_half_to_rows, dim3(1024), dim3(256), 0, 0, hb->as<_Float16>() + hoff, dst, width, hld, r_ws);
+            DSVC_HIP(hipGetLastError());
+            DSVC_HIP(hipDeviceSynchronize());
+        } else if (d->tpath && (n == "xres" || n == "skip" || n == "cproj")) {
+            const int nr = (n == "cproj") ? r_ws * d->cfg.layers : r_ws;       // every layer slab is a whole number of frame tiles
+            if ((size_t)numel < (size_t)nr * width) return fail(DSVC_EINVAL, "debug buffer '%s' needs %zu elements", name, (size_t)nr * width);
+            hipLaunchKernelGGL(k_untile, dim3(2048), dim3(256), 0, 0, b->as<float>(), dst, width, nr, n == "cproj" ? 1 : 0);
             DSVC_HIP(hipGetLastError());
             DSVC_HIP(hipDeviceSynchronize());
         } else {

@@ -78,6 +78,19 @@ struct EpiBias {
     }
 };
 
+// ---- hoisted conditioner projection for the tgemm path: same math as EpiBias, written in the accumulator-tiled layout
+//      the gate kernel initialises its accumulators from (diffnet_t.h: tiled_off; column p = 32*block + 16*half + 8*h + r')
+struct EpiBiasTiled {
+    static constexpr bool PAIRED = false;
+    struct Args { float* out; int n_mtiles; const float* bias; int cout; };
+    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
+        if (col >= e.cout) return;
+        const int mt = col >> 5, w = col & 31;
+        const int h = (w >> 3) & 1, r = 8 * (w >> 4) + (w & 7);
+        e.out[(((size_t)(row >> 5) * e.n_mtiles + mt) * 4 + (r >> 2)) * 256 + (size_t)((row & 31) + 32 * h) * 4 + (r & 3)] = v + e.bias[col];
+    }
+};
+
 // ---- K9b+K10: final 1x1 fused with the DDPM posterior step (diffusion.py:131-163) ----
 struct DdpmTables {
     const float* sqrt_recip_ac;     // sqrt_recip_alphas_cumprod

@@ -21,6 +21,20 @@ struct RowMap {
     }
 };
 
+// "accumulator-tiled" fp32 layout of the buffers that only the tgemm epilogues touch (residual stream, skip sum,
+// hoisted conditioner projection): [frame tile of 32][m_tile][q = reg/4][lane 64][4 floats], i.e. exactly the order
+// in which a wave's accumulator registers hold a 32-channel x 32-frame tile.  Every accumulator-init load and every
+// epilogue store is then ONE fully coalesced 1 KiB access per instruction (a frame-major layout would touch 32
+// different 128-B lines with 32 useful bytes each).  Element (frame, m_tile, reg r, half h) lives at
+//   ((frame/32 * n_mtiles + m_tile) * 4 + r/4) * 256 + ((frame%32) + 32*h) * 4 + r%4
+__host__ __device__ __forceinline__ size_t tiled_off(int frame, int n_mtiles, int mt, int r, int h) {
+    return (((size_t)(frame >> 5) * n_mtiles + mt) * 4 + (r >> 2)) * 256 + (size_t)((frame & 31) + 32 * h) * 4 + (r & 3);
+}
+// pointer to register quad 0 of (frame tile containing `frame`, m_tile) for this lane; quad q is at + q*256 floats
+__device__ __forceinline__ size_t tiled_lane_base(int frame, int n_mtiles, int mt, int lane) {
+    return ((size_t)(frame >> 5) * n_mtiles + mt) * 1024 + (size_t)lane * 4;
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 ld4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -50,17 +64,17 @@ __device__ __forceinline__ float gate_act(float a, float b) {
 // ---- K4+K5+K6: dilated conv + hoisted conditioner projection + gate -> g (fp16) ----
 struct TEpiGate {
     struct Args {
-        const float* cproj;     // [rows][2*C] per frame: [g-block of 16][gate 16 | filter 16], both biases folded in
+        const float* cproj;     // accumulator-tiled (C/16 m_tiles per frame tile): registers 0..7 gate, 8..15 filter; both biases folded in
         _Float16* g;            // [rows][ldg] fp16
         int C, ldg;
     };
     template <int NT_N>
     __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int n_mt = e.C >> 4;
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) {
-            const int frame = row0 + 32 * nt + (lane & 31);
-            const float* p = e.cproj + (size_t)frame * (2 * e.C) + mt * 32 + 8 * (lane >> 5);
-            const f32x4 v0 = ld4_nt(p), v1 = ld4_nt(p + 4), v2 = ld4_nt(p + 16), v3 = ld4_nt(p + 20);
+            const float* p = e.cproj + tiled_lane_base(row0 + 32 * nt, n_mt, mt, lane);
+            const f32x4 v0 = ld4_nt(p), v1 = ld4_nt(p + 256), v2 = ld4_nt(p + 512), v3 = ld4_nt(p + 768);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc[nt][i] = v0[i]; acc[nt][4 + i] = v1[i]; acc[nt][8 + i] = v2[i]; acc[nt][12 + i] = v3[i]; }
         }
@@ -82,9 +96,9 @@ struct TEpiGate {
 //      xh = fp16(x + film_next), skip half accumulates ----
 struct TEpiResSkip {
     struct Args {
-        float* x32;             // [rows][C] residual stream (in/out)
+        float* x32;             // residual stream (in/out), accumulator-tiled with C/32 m_tiles
         _Float16* xh;           // [rows][ldh] next layer's MFMA operand, row 0 (guard rows precede); null on the last layer
-        float* skip;            // [rows][C] running skip sum
+        float* skip;            // running skip sum, accumulator-tiled with C/32 m_tiles
         _Float16* skiph;        // [rows][2*ldh] fp16 hi|lo planes of the skip sum for the skip projection; last layer only
         const float* bias;      // [2C]
         const float* film;      // next layer's FiLM table slice: film[step*film_step_stride + c]; null on the last layer
@@ -100,15 +114,15 @@ struct TEpiResSkip {
         const bool res = mt < rt;
         const int cb = (res ? mt : mt - rt) * 32 + 16 * (lane >> 5);
         const float* base = res ? e.x32 : e.skip;
+        const int tl_mt = res ? mt : mt - rt;
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) {
-            const int frame = row0 + 32 * nt + (lane & 31);
             if (!res && e.first) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
             } else {
-                const float* p = base + (size_t)frame * e.C + cb;
-                const f32x4 v0 = ld4(p), v1 = ld4(p + 4), v2 = ld4(p + 8), v3 = ld4(p + 12);
+                const float* p = base + tiled_lane_base(row0 + 32 * nt, rt, tl_mt, lane);
+                const f32x4 v0 = ld4(p), v1 = ld4(p + 256), v2 = ld4(p + 512), v3 = ld4(p + 768);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { acc[nt][i] = v0[i]; acc[nt][4 + i] = v1[i]; acc[nt][8 + i] = v2[i]; acc[nt][12 + i] = v3[i]; }
             }
@@ -136,9 +150,9 @@ struct TEpiResSkip {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = acc[nt][i] + b[i];
             }
-            float* p = (res ? e.x32 : e.skip) + (size_t)frame * e.C + cb;
+            float* p = (res ? e.x32 : e.skip) + tiled_lane_base(row0 + 32 * nt, rt, res ? mt : mt - rt, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) st4(p + 4 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+            for (int q = 0; q < 4; ++q) st4(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
             if (res && e.xh) {
                 int clip, tl;
                 const bool ok = e.rm.valid(frame, clip, tl);
@@ -201,9 +215,9 @@ struct TEpiInProj {
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[nt][i] + b[i], 0.f);
-            float* p = e.x32 + (size_t)frame * e.C + cb;
+            float* p = e.x32 + tiled_lane_base(row0 + 32 * nt, e.C >> 5, mt, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) st4(p + 4 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+            for (int q = 0; q < 4; ++q) st4(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
             int clip, tl;
             const bool ok = e.rm.valid(frame, clip, tl);
             half8 o0, o1;
@@ -359,6 +373,21 @@ __global__ void k_rows_to_half(const float* __restrict__ src, _Float16* __restri
             q[j] = h;
             q[ld + j] = (_Float16)(v[j] - (float)h);
         }
+    }
+}
+
+// accumulator-tiled fp32 -> frame-major [rows][width]  (debug taps).  paired = the gate kernel's register meaning
+// (m_tile = 16 channels: regs 0..7 gate, 8..15 filter; output column = the conv_gemm-free order [block 16][gate|filter])
+__global__ void k_untile(const float* __restrict__ src, float* __restrict__ dst, int width, int rows, int paired) {
+    const long long n = (long long)rows * width;
+    const int n_mt = width >> 5;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / width), c = (int)(i - (long long)row * width);
+        const int mt = c >> 5, w = c & 31;
+        int h, r;
+        if (paired) { h = (w >> 3) & 1; r = 8 * (w >> 4) + (w & 7); }
+        else { h = w >> 4; r = w & 15; }
+        dst[i] = src[tiled_off(row, n_mt, mt, r, h)];
     }
 }
 

@@ -52,7 +52,8 @@ struct TGemmArgs {
     const int* step_ptr;    // device int: current diffusion step (variant = (step - step_off) % n_variants); may be null
     int step_off;
     int dbg;                // ablation knobs for profiling (env DSVC_TG_DEBUG): 1 = no acc-init loads, 2 = no epilogue,
-                            // 4 = no tile DMA, 8 = no MFMA main loop, 16 = no wave priority split.  0 in production.
+                            // 4 = no tile DMA, 8 = no MFMA main loop, 16 = no wave priority split, 32 = all tiles stream
+                            // tile 0's weights (L2-hot), 64 = no pass rotation.  0 in production.
 };
 
 // the row <-> channel permutation inside a 32-row output tile that makes a lane's 16 accumulator registers hold 16
@@ -165,11 +166,20 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     Epi epi;
     f32x16 acc[NT_N];
     half8 ringA[KG][NW], ringB[KG][NW];
-    int pass = blockIdx.y;
-    int mt = pass * WAVES + wave;
-    bool active = mt < a.m_tiles;                        // wave-uniform
-    if (active) {
-        load_group(ringA, wbase + (long long)mt * tile_halfs);
+    // output-channel passes are visited in a per-workgroup rotated order: all workgroups stream the SAME weights, and
+    // without the rotation they all miss L2 on the same fragment at the same moment (the whole chip then advances at
+    // first-touch latency); rotated, a tile's first toucher warms it for the other two thirds
+    const int rot = gridDim.y == 1 && !(a.dbg & 64) ? (int)(blockIdx.x % (unsigned)passes) : 0;
+    auto tile_of = [&](int pi) { const int p = pi + rot; return (p < passes ? p : p - passes) * WAVES + wave; };
+    auto next_active = [&](int pi) {                      // next position of this workgroup's sequence where this wave has a tile
+        for (; pi < passes; pi += gridDim.y)
+            if (tile_of(pi) < a.m_tiles) return pi;
+        return -1;
+    };
+    int pi = next_active(blockIdx.y);
+    int mt = pi >= 0 ? tile_of(pi) : 0;
+    if (pi >= 0) {
+        load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt) * tile_halfs);
         if (a.dbg & 1) {
 #pragma unroll
             for (int nt = 0; nt < NT_N; ++nt)
@@ -182,8 +192,8 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA'd tile (and the first operands) have landed
     __syncthreads();
 
-    while (active) {
-        const _Float16* wp = wbase + (long long)mt * tile_halfs;
+    while (pi >= 0) {
+        const _Float16* wp = wbase + (long long)((a.dbg & 32) ? 0 : mt) * tile_halfs;      // dbg 32: every tile streams tile 0 (L2-hot)
         int g = (a.dbg & 8) ? G : 0;
         for (; g + 1 < G; g += 2) {     // straight-line body (no branch): IR-level sinking cannot move a prefetch below its group
             load_group(ringB, wp + (long long)(g + 1) * GROUP_HALFS);          // ringB <- group g+1, under group g's MFMAs
@@ -195,14 +205,13 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
             compute_group(ringB, acc, g + 1);
         }
         if (g < G) compute_group(ringA, acc, g);                               // odd group count: the tail group
-        // next pass of this workgroup: start its weight stream and its accumulator-init loads before this pass's
+        // next tile of this wave: start its weight stream and its accumulator-init loads before this tile's
         // epilogue, so their latency sits under the epilogue's VALU and stores
-        const int pass_n = pass + gridDim.y;
-        const int mt_n = pass_n * WAVES + wave;
-        const bool active_n = pass_n < passes && mt_n < a.m_tiles;
+        const int pn = next_active(pi + gridDim.y);
+        const int mt_n = pn >= 0 ? tile_of(pn) : 0;
         f32x16 nxt[NT_N];
-        if (active_n) {
-            load_group(ringA, wbase + (long long)mt_n * tile_halfs);
+        if (pn >= 0) {
+            load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt_n) * tile_halfs);
             if (a.dbg & 1) {
 #pragma unroll
                 for (int nt = 0; nt < NT_N; ++nt)
@@ -214,10 +223,10 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         }
         if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
         else asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT_N - 1][15]));
-        if (!active_n) break;
+        if (pn < 0) break;
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) acc[nt] = nxt[nt];
-        pass = pass_n; mt = mt_n;
+        pi = pn; mt = mt_n;
     }
 }
 
