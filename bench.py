@@ -92,7 +92,8 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=1)
     ap.add_argument("--ddpm-steps", type=int, default=1000)
     ap.add_argument("--speedup", type=int, default=1, help="pndm_speedup (>1 = PLMS); the headline config is 1")
-    ap.add_argument("--precision", default="f16_w2", choices=["f16", "f16_w2", "f16_x3"])
+    ap.add_argument("--precision", default="f16_d64",
+                    help="f16_dN (fp16 operands, N time-dithered weight roundings; default, parity-tested), f16_w2, f16_x3, f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the extra batched (32 clips/GPU) measurement")
     args = ap.parse_args()
@@ -157,7 +158,7 @@ def main():
         us, rows = pipe.model._handle().profile_gate_kernel(B, T_FRAMES, 5)
         flop = FLOP_PER_FRAME_DILATED * B * T_FRAMES                 # algorithmic: valid frames only, one product per MAC
         achieved = flop / (us * 1e-6) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_gemm<EpiGate> (dilated k=3 conv + FiLM + gate, one residual layer)",
+        roof = {"bound": "mfma", "kernel": "tgemm_kernel<TEpiGate> (dilated k=3 conv + hoisted cond projection + gate, one residual layer)",
                 "achieved": achieved, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_F16,
                 "avg_launch_us": us, "frames_per_launch": B * T_FRAMES, "traffic": None}
         result = {
@@ -165,7 +166,7 @@ def main():
                 args.ddpm_steps, "DDPM" if args.speedup <= 1 else "PLMS/%d" % args.speedup),
             "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 operands (%s) / f32 accumulate" % args.precision, "data": "synthetic",
+            "dtype": "f16", "dtype_detail": "fp16 MFMA operands (%s), fp32 accumulate, fp32 residual/skip/state" % args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: single 10 s clip per GPU, 44.1 kHz, full %d-step DDPM + NSF-HiFiGAN" % args.ddpm_steps,
                        "clips_per_gpu": B, "mel_frames": T_FRAMES, "content_frames": N_UNITS, "sampler_steps": args.ddpm_steps,
                        "pndm_speedup": args.speedup, "precision": args.precision, "vocoder_precision": "f16_x3",
@@ -185,9 +186,12 @@ def main():
             torch.cuda.synchronize(); tb = time.perf_counter() - tb
             usb, _ = pipe.model._handle().profile_gate_kernel(Bb, T_FRAMES, 3)
             ach = FLOP_PER_FRAME_DILATED * Bb * T_FRAMES / (usb * 1e-6) / 1e12
-            result["batched"] = {"clips_per_gpu": Bb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
-                                 "s_per_batch": tb, "gate_kernel_us": usb, "gate_kernel_tflops": ach,
-                                 "gate_kernel_frac_of_peak": ach / PEAK_TFLOPS_F16}
+            result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
+                                 "clips_per_gpu": Bb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
+                                 "s_per_batch": tb,
+                                 "roofline": {"bound": "mfma", "kernel": roof["kernel"], "achieved": ach, "peak": PEAK_TFLOPS_F16,
+                                              "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_F16, "avg_launch_us": usb,
+                                              "frames_per_launch": Bb * T_FRAMES, "traffic": None}}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(hp, sd, vs, h)
         else:

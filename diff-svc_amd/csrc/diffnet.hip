@@ -850,8 +850,10 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
     double total = 0;
     int count = 0;
     for (int it = -2; it < iters; ++it) {                 // two untimed warm-up rounds
+        // the L launches of one evaluation go back to back between two events (a per-launch event pair would add the
+        // ~6 us host launch latency to every sample); the quotient includes the ~1.5 us inter-kernel gaps
+        DSVC_HIP(hipEventRecord(e0, st));
         for (int l = 0; l < L; ++l) {
-            DSVC_HIP(hipEventRecord(e0, st));
             const char* which = getenv("DSVC_PROFILE_KERNEL");          // "out": time the output projection instead (profiling aid)
             if (d->tpath && which && which[0] == 'o') {
                 const bool last = l + 1 == L;
@@ -881,12 +883,12 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
                 EpiGate::Args e{d->cproj.as<float>() + (size_t)l * d->rows_alloc * 2 * C, d->g.as<float>(), C};
                 DSVC_TRY(dispatch_prec<EpiGate>(a, e, d->cfg.precision, st));
             }
-            DSVC_HIP(hipEventRecord(e1, st));
-            DSVC_HIP(hipEventSynchronize(e1));
-            float ms = 0;
-            DSVC_HIP(hipEventElapsedTime(&ms, e0, e1));
-            if (it >= 0) { total += ms; ++count; }
         }
+        DSVC_HIP(hipEventRecord(e1, st));
+        DSVC_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        DSVC_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (it >= 0) { total += ms; count += L; }
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_us = (float)(total * 1000.0 / count);
