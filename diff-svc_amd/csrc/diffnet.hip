@@ -852,6 +852,9 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
     for (int it = -2; it < iters; ++it) {                 // two untimed warm-up rounds
         // the L launches of one evaluation go back to back between two events (a per-launch event pair would add the
         // ~6 us host launch latency to every sample); the quotient includes the ~1.5 us inter-kernel gaps
+        // a different diffusion step per round: with dithered weights every step streams its own variant from HBM, and
+        // a fixed step would time the kernels on L2/MALL-warm weights instead
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, s->step_dev.as<int>(), ((it + 2) * 37) % s->K);
         DSVC_HIP(hipEventRecord(e0, st));
         for (int l = 0; l < L; ++l) {
             const char* which = getenv("DSVC_PROFILE_KERNEL");          // "out": time the output projection instead (profiling aid)
