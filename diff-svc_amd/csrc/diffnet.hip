@@ -96,7 +96,8 @@ struct TPacked {
 // split_act: the activation operand is stored as [x_hi | x_lo] fp16 planes (K = 2 * padded I, same weights for both)
 template <class FR>
 int tpack(TPacked& tp, const std::vector<float>& src, int O, int I, int taps, int m_tiles, int planes, int n_variants,
-          float scale, unsigned salt, bool split_act, FR&& rowmap, const float* bias, int nbias) {
+          float scale, unsigned salt, bool split_act, FR&& rowmap, const float* bias, int nbias,
+          const std::vector<float>* rowscale = nullptr) {
     const int fold = split_act ? round_up(I, 128) : 0;
     tp.m_tiles = m_tiles; tp.taps = taps; tp.cin_pad = split_act ? 2 * fold : round_up(I, 128); tp.planes = planes; tp.n_variants = n_variants;
     tp.variant_halfs = tpacked_halfs(m_tiles, taps, tp.cin_pad, planes, 1);
@@ -106,17 +107,21 @@ int tpack(TPacked& tp, const std::vector<float>& src, int O, int I, int taps, in
         rm[r] = rowmap(r);
         if (rm[r] >= O) return fail(DSVC_EINVAL, "tpack: row map out of range");
     }
-    DevBuf dsrc, drm;
+    DevBuf dsrc, drm, drs;
     DSVC_TRY(upload(dsrc, src.data(), src.size() * 4));
     DSVC_TRY(upload(drm, rm.data(), rm.size() * 4));
+    if (rowscale) {
+        if ((int)rowscale->size() != m_tiles * 32) return fail(DSVC_EINVAL, "tpack: row scale table has the wrong size");
+        DSVC_TRY(upload(drs, rowscale->data(), rowscale->size() * 4));
+    }
     DSVC_TRY(tp.w.alloc(tp.variant_halfs * n_variants * sizeof(_Float16)));
     const long long total = (long long)tp.variant_halfs / planes * n_variants;
     const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
-    hipLaunchKernelGGL(k_tpack, dim3(blocks), dim3(256), 0, 0, dsrc.as<float>(), drm.as<int>(), tp.w.as<_Float16>(), I, taps,
-                       tp.cin_pad, fold, m_tiles, planes, n_variants, scale, salt);
+    hipLaunchKernelGGL(k_tpack, dim3(blocks), dim3(256), 0, 0, dsrc.as<float>(), drm.as<int>(), rowscale ? drs.as<float>() : nullptr,
+                       tp.w.as<_Float16>(), I, taps, tp.cin_pad, fold, m_tiles, planes, n_variants, scale, salt);
     DSVC_HIP(hipGetLastError());
     DSVC_HIP(hipDeviceSynchronize());
-    dsrc.release(); drm.release();
+    dsrc.release(); drm.release(); drs.release();
     return upload(tp.bias, bias, (size_t)nbias * 4);
 }
 
@@ -133,7 +138,7 @@ int tlaunch(const TGemmArgs& a_in, const typename Epi::Args& e, int rows_alloc, 
         if (tgemm_smem<4>(a.taps, a.dil, a.cin) <= 160 * 1024) {
             static const int waves12 = getenv("DSVC_TG_WAVES12") ? atoi(getenv("DSVC_TG_WAVES12")) : 0;     // tuning knob
             if constexpr (NW == 1) {
-                if (waves12) {        // 12 waves (3 per SIMD, <= 168 VGPRs): more waves to hide each other's memory phases
+                if (waves12) {        // 12 waves (3 per SIMD, <= 168 VGPRs).  Measured slower (B=32: 2.50 vs 2.38 ms/step): off by default
                     const int p12 = ceil_div(a.m_tiles, 12);
                     int m12 = 256 / tiles; m12 = m12 < 1 ? 1 : (m12 > p12 ? p12 : m12);
                     return tgemm_launch<4, 12, 3, 4, NW, Epi>(a, e, rows_alloc, m12, st);
@@ -265,9 +270,11 @@ int dsvc_denoiser::finalize() {
         const bool tp = tpath;
         auto chan = [C, tp](int p) { return tp ? ((p >> 4) & 1) * C + (p >> 5) * 16 + (p & 15) : ((p >> 5) & 1) * C + (p >> 6) * 32 + (p & 31); };
         // cproj carries BOTH biases (conditioner + dilated conv)
+        // tgemm path: pre-scaled like the gate kernel's weights (gate_act_scaled)
+        auto csc = [C, tp](int ch) { return !tp ? 1.0f : (ch < C ? GATE_SCALE : FILT_SCALE); };
         DSVC_TRY(pack_conv(condp[l], 2 * C, 1, H,
-                           [&](int p, int, int ci) { return (*wc)[(size_t)chan(p) * H + ci]; },
-                           [&](int p) { return (*bc)[chan(p)] + (*bd)[chan(p)]; }));
+                           [&](int p, int, int ci) { return (*wc)[(size_t)chan(p) * H + ci] * csc(chan(p)); },
+                           [&](int p) { return ((*bc)[chan(p)] + (*bd)[chan(p)]) * csc(chan(p)); }));
         if (!tpath) {
             GET(wd, q + "dilated_conv.weight", 2 * C * C * 3);
             GET(wo, q + "output_projection.weight", 2 * C * C);
@@ -342,9 +349,11 @@ int dsvc_denoiser::finalize_t() {
         GET(wo, q + "output_projection.weight", 2 * C * C);
         GET(bo, q + "output_projection.bias", 2 * C);
         // gate kernel: tile mt holds g-channels 16*mt .. +15: rows 0..15 gate (conv channel c), 16..31 filter (C + c)
+        std::vector<float> gsc((size_t)(C / 16) * 32);                  // gate rows * -log2(e), filter rows * -2 log2(e) (gate_act_scaled)
+        for (size_t r = 0; r < gsc.size(); ++r) gsc[r] = ((r & 31) < 16) ? GATE_SCALE : FILT_SCALE;
         DSVC_TRY(tpack(dil_t[l], *wd, 2 * C, C, 3, C / 16, planes, nvar, 1.0f, 1000u + 2 * l, false,
                        [&](int r) { const int mt = r >> 5, i = r & 31; return (i >> 4) * C + mt * 16 + trow_to_ch8(i & 15); },
-                       bo->data(), 1));
+                       bo->data(), 1, &gsc));
         // output 1x1: tiles 0..C/32-1 residual half (conv channels 0..C-1), then the skip half (C..2C-1)
         DSVC_TRY(tpack(out_t[l], *wo, 2 * C, C, 1, 2 * C / 32, planes, nvar, 1.0f, 1001u + 2 * l, false,
                        [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, bo->data(), 2 * C));
@@ -477,7 +486,9 @@ int dsvc_denoiser::eval_conv(const float* x_fm, const StepRef& step, Tail tail, 
 int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st) {
     const int M = cfg.mel_bins, C = cfg.channels, L = cfg.layers;
     const RowMap rm = rowmap();
-    static const int pf_wgs = getenv("DSVC_TG_PREFETCH_WGS") ? atoi(getenv("DSVC_TG_PREFETCH_WGS")) & ~7 : 128;
+    // measured on MI355X (B = 1, profiles/r01i_ab.txt): 0 -> 0.353 ms/step, 64 -> 0.523, 128 -> 0.410, 256 -> 0.390: the warm-up
+    // workgroups outlive the compute workgroups and stretch every kernel, so it stays OFF; the knob is kept for re-tuning
+    static const int pf_wgs = getenv("DSVC_TG_PREFETCH_WGS") ? atoi(getenv("DSVC_TG_PREFETCH_WGS")) & ~7 : 0;
     // `next`: the kernel that runs after this one -- its weights are warmed into L2 by this launch (small batches)
     auto targs = [&](const _Float16* x, int cin_pad, const TPacked& tp, int taps, int dil, const TPacked* next) {
         TGemmArgs a{};
@@ -490,6 +501,8 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         }
         return a;
     };
+    static const int stream_env = getenv("DSVC_TG_STREAM") ? atoi(getenv("DSVC_TG_STREAM")) : -1;      // tuning knob
+    const int stream_big = stream_env >= 0 ? stream_env : (rows_alloc >= 6144 ? 1 : 0);
     if (!state_half_fresh)
         hipLaunchKernelGGL(k_rows_to_half, dim3(ceil_div(rows * (M / 4), 256) < 2048 ? ceil_div(rows * (M / 4), 256) : 2048), dim3(256), 0, st,
                            x_fm, xsh.as<_Float16>(), M, Mp, rm, rows);
@@ -512,7 +525,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
             TGemmArgs a = targs(gh.as<_Float16>(), Cp, out_t[l], 1, 1, last ? &skip_t : &dil_t[l + 1]);
             TEpiResSkip::Args e{xres.as<float>(), last ? nullptr : xh_row0(), skip.as<float>(), last ? skiph.as<_Float16>() : nullptr,
                                 out_t[l].bias.as<float>(), last ? nullptr : film.as<float>() + (size_t)(l + 1) * C, L * C, step, C, Cp,
-                                l == 0 ? 1 : 0, rm};
+                                l == 0 ? 1 : 0, rm, stream_big};
             DSVC_TRY(tlaunch_prec<TEpiResSkip>(a, e, out_t[l].planes, rows_alloc, st));
         }
     }
@@ -886,7 +899,7 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
                 a.step_ptr = s->step_dev.as<int>(); a.step_off = 0;
                 TEpiResSkip::Args e{d->xres.as<float>(), last ? nullptr : d->xh_row0(), d->skip.as<float>(), last ? d->skiph.as<_Float16>() : nullptr,
                                     d->out_t[l].bias.as<float>(), last ? nullptr : d->film.as<float>() + (size_t)(l + 1) * C, L * C,
-                                    StepRef{s->step_dev.as<int>(), 0, 0}, C, d->Cp, l == 0 ? 1 : 0, d->rowmap()};
+                                    StepRef{s->step_dev.as<int>(), 0, 0}, C, d->Cp, l == 0 ? 1 : 0, d->rowmap(), d->rows_alloc >= 6144 ? 1 : 0};
                 DSVC_TRY(tlaunch_prec<TEpiResSkip>(a, e, d->out_t[l].planes, d->rows_alloc, st));
             } else if (d->tpath) {
                 TGemmArgs a{};

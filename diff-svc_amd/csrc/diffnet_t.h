@@ -38,6 +38,7 @@ __device__ __forceinline__ size_t tiled_lane_base(int frame, int n_mtiles, int m
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 ld4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 
 // split 16 fp32 values into fp16 hi and lo (= fp16(v - hi)) and store both planes: dst[0..15] and dst[lo_off..lo_off+15]
 __device__ __forceinline__ void store_hi_lo16(_Float16* dst, int lo_off, const float (&v)[16]) {
@@ -53,18 +54,24 @@ __device__ __forceinline__ void store_hi_lo16(_Float16* dst, int lo_off, const f
     *reinterpret_cast<half8*>(dst + lo_off + 8) = l1;
 }
 
-// sigmoid(a) * tanh(b) = (1 - E2) / ((1 + E1) * (1 + E2)),  E1 = exp(-a), E2 = exp(-2b)   (net.py:73-77)
-__device__ __forceinline__ float gate_act(float a, float b) {
-    b = fminf(fmaxf(b, -15.0f), 15.0f);                    // tanh is +-1 to fp32 precision beyond |b| ~ 9; keeps E2 finite
-    const float e1 = __expf(-a);
-    const float e2 = __expf(-2.0f * b);
-    return (1.0f - e2) * __frcp_rn((1.0f + e1) * (1.0f + e2));
+// sigmoid(a) * tanh(b) = (1 - E2) / ((1 + E1) * (1 + E2)),  E1 = exp(-a), E2 = exp(-2b)   (net.py:73-77).
+// The gate kernel's weights and conditioner projection are packed PRE-SCALED (gate rows by -log2(e), filter rows by
+// -2 log2(e)), so its accumulators already hold ag = -a*log2(e) and bf = -2b*log2(e): 9 VALU per output, 3 of them
+// transcendental (v_exp_f32 x2, v_rcp_f32), instead of the ~30 the libm forms expand to.
+constexpr float GATE_SCALE = -1.4426950408889634f;        // -log2(e)
+constexpr float FILT_SCALE = -2.8853900817779268f;        // -2 log2(e)
+__device__ __forceinline__ float gate_act_scaled(float ag, float bf) {
+    bf = __builtin_amdgcn_fmed3f(bf, -43.28f, 43.28f);     // |b| <= 15: tanh is +-1 to fp32 precision beyond |b| ~ 9; keeps E2 finite
+    const float e1 = __builtin_amdgcn_exp2f(ag);
+    const float e2 = __builtin_amdgcn_exp2f(bf);
+    return (1.0f - e2) * __builtin_amdgcn_rcpf((1.0f + e1) * (1.0f + e2));
 }
 
 // ---- K4+K5+K6: dilated conv + hoisted conditioner projection + gate -> g (fp16) ----
 struct TEpiGate {
     struct Args {
-        const float* cproj;     // accumulator-tiled (C/16 m_tiles per frame tile): registers 0..7 gate, 8..15 filter; both biases folded in
+        const float* cproj;     // accumulator-tiled (C/16 m_tiles per frame tile): registers 0..7 gate, 8..15 filter; both biases
+                                // folded in, pre-scaled like the weights (see gate_act_scaled)
         _Float16* g;            // [rows][ldg] fp16
         int C, ldg;
     };
@@ -86,7 +93,7 @@ struct TEpiGate {
             const int frame = row0 + 32 * nt + (lane & 31);
             half8 o;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) o[r] = (_Float16)gate_act(acc[nt][r], acc[nt][8 + r]);
+            for (int r = 0; r < 8; ++r) o[r] = (_Float16)gate_act_scaled(acc[nt][r], acc[nt][8 + r]);
             *reinterpret_cast<half8*>(e.g + (size_t)frame * e.ldg + mt * 16 + 8 * (lane >> 5)) = o;
         }
     }
@@ -107,6 +114,8 @@ struct TEpiResSkip {
         int C, ldh;
         int first;              // layer 0: skip = s (no read)
         RowMap rm;
+        int stream;             // large batches: the fp32 residual / skip tiles are touched once per layer and do not fit any
+                                // cache -> non-temporal loads and stores (no dirty-line build-up to flush at the kernel boundary)
     };
     template <int NT_N>
     __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
@@ -122,7 +131,9 @@ struct TEpiResSkip {
                 for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
             } else {
                 const float* p = base + tiled_lane_base(row0 + 32 * nt, rt, tl_mt, lane);
-                const f32x4 v0 = ld4(p), v1 = ld4(p + 256), v2 = ld4(p + 512), v3 = ld4(p + 768);
+                f32x4 v0, v1, v2, v3;
+                if (e.stream) { v0 = ld4_nt(p); v1 = ld4_nt(p + 256); v2 = ld4_nt(p + 512); v3 = ld4_nt(p + 768); }
+                else { v0 = ld4(p); v1 = ld4(p + 256); v2 = ld4(p + 512); v3 = ld4(p + 768); }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { acc[nt][i] = v0[i]; acc[nt][4 + i] = v1[i]; acc[nt][8 + i] = v2[i]; acc[nt][12 + i] = v3[i]; }
             }
@@ -151,8 +162,13 @@ struct TEpiResSkip {
                 for (int i = 0; i < 16; ++i) v[i] = acc[nt][i] + b[i];
             }
             float* p = (res ? e.x32 : e.skip) + tiled_lane_base(row0 + 32 * nt, rt, res ? mt : mt - rt, lane);
+            if (e.stream) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) st4(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+                for (int q = 0; q < 4; ++q) st4_nt(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st4(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+            }
             if (res && e.xh) {
                 int clip, tl;
                 const bool ok = e.rm.valid(frame, clip, tl);

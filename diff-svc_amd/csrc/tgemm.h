@@ -321,7 +321,7 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
 // Packing (on the device: a 64-variant dithered DiffNet is 3 GB of fragments).
 //   src [O][I][taps] fp32 in the checkpoint's Conv1d layout; rowmap[m_tiles*32] gives the source output channel of
 //   every packed row (or -1 = zero row) -- the caller folds the tile-row permutation (trow_to_ch16 / trow_to_ch8)
-//   into it.  Layout [variant][m_tile][tap][k16][plane][lane][8]; lane l of a fragment holds packed row (l & 31),
+//   into it; rowscale (optional) multiplies a packed row (the gate kernel folds -log2(e) / -2 log2(e) into its rows).  Layout [variant][m_tile][tap][k16][plane][lane][8]; lane l of a fragment holds packed row (l & 31),
 //   k = k16*16 + 8*(l >> 5) + e.  plane 0 = fp16(w), plane 1 = fp16(w - plane0).  fold > 0 packs K = 2*fold input
 //   channels whose upper half repeats the lower one: the matching activation buffer holds [x_hi | x_lo] planes.
 //   Variant v of n rounds w to fp16 DOWN or UP so that the mean over the variants is w +- ulp/(2n): round up iff
@@ -357,8 +357,9 @@ __device__ inline _Float16 tg_round_dither(float w, float thresh) {
     return frac > thresh ? hi : lo;
 }
 
-__global__ void k_tpack(const float* __restrict__ src, const int* __restrict__ rowmap, _Float16* __restrict__ dst,
-                        int I, int taps, int cin_pad, int fold, int m_tiles, int planes, int n_variants, float scale, unsigned salt) {
+__global__ void k_tpack(const float* __restrict__ src, const int* __restrict__ rowmap, const float* __restrict__ rowscale,
+                        _Float16* __restrict__ dst, int I, int taps, int cin_pad, int fold, int m_tiles, int planes, int n_variants,
+                        float scale, unsigned salt) {
     const int nk16 = cin_pad >> 4;
     const long long per_variant = (long long)m_tiles * taps * nk16 * 512;      // elements of ONE plane
     const long long total = per_variant * n_variants;
@@ -375,7 +376,7 @@ __global__ void k_tpack(const float* __restrict__ src, const int* __restrict__ r
         const int row = mt * 32 + (l & 31), ci = k * 16 + 8 * (l >> 5) + e;
         const int o = rowmap[row];
         const int cs = fold > 0 ? ci % fold : ci;          // fold: input channels [fold, 2*fold) repeat [0, fold) -- the lo plane of a
-        const float w = (o >= 0 && cs < I) ? src[((size_t)o * I + cs) * taps + tap] * scale : 0.f;   // split activation sees the same weights
+        const float w = (o >= 0 && cs < I) ? src[((size_t)o * I + cs) * taps + tap] * scale * (rowscale ? rowscale[row] : 1.0f) : 0.f;   // split activation sees the same weights
         _Float16 hi;
         if (n_variants > 1) {
             int vr = 0;

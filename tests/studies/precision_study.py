@@ -50,8 +50,13 @@ class Net:
         self.L = hp["residual_layers"]; self.C = hp["residual_channels"]; self.cyc = hp["dilation_cycle_length"]
         self.K = 1
         p = "denoise_fn.residual_layers.%d.%s"
+        self.hold = 1
         if scheme.startswith("dither"):
-            self.K = int(scheme[6:])
+            body = scheme[6:]
+            if "h" in body:                     # ditherNhR: each variant is kept for R consecutive steps
+                body, hold = body.split("h")
+                self.hold = int(hold)
+            self.K = int(body)
         self.wd, self.wo = [], []
         for l in range(self.L):
             wd, wo = sd[p % (l, "dilated_conv.weight")], sd[p % (l, "output_projection.weight")]
@@ -78,7 +83,7 @@ class Net:
         x = F.relu(F.conv1d(a_state(spec[:, 0]), p("input_projection.weight"), p("input_projection.bias")))   # tgemm path: fp16 state copy
         emb = O.step_embedding(sd, t)
         skip = torch.zeros_like(x)
-        k = self.order[int(t[0]) % self.K]
+        k = self.order[(int(t[0]) // self.hold) % self.K]
         for l in range(self.L):
             q = lambda s: p("residual_layers.%d.%s" % (l, s))
             d = 2 ** (l % self.cyc)

@@ -16,6 +16,20 @@ if files:
     print("%-92s %8s %12s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:25]:
         print("%-92s %8d %12.1f %10.2f %7.2f" % (k, len(v), sum(v) / 1e3, sum(v) / len(v) / 1e3, 100.0 * sum(v) / tot))
+if files and len(sys.argv) > 2 and sys.argv[2] == "gaps":
+    ev = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+    ev.sort()
+    gaps = collections.defaultdict(list)
+    for (s0, e0, n0), (s1, e1, n1) in zip(ev, ev[1:]):
+        if "tgemm" in n0 and "tgemm" in n1:
+            gaps[n0[-40:] + " -> " + n1[-40:]].append(s1 - e0)
+    print("gap after kernel -> next kernel (ns): count mean p50 p90")
+    for k, v in sorted(gaps.items(), key=lambda kv: -len(kv[1]))[:8]:
+        v = sorted(v)
+        print("  %-84s %6d %8.0f %8d %8d" % (k, len(v), sum(v) / len(v), v[len(v) // 2], v[int(len(v) * 0.9)]))
 if pmcf:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in pmcf:
