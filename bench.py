@@ -174,6 +174,23 @@ def main():
             "finite_output": ok,
             "roofline": roof,
         }
+        # PMC-derived HBM traffic of the same kernel (a separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` pass over this very
+        # command: tools/gpu_round.sh + tools/rocprof_traffic.py; counters cannot be read from inside the process)
+        tpath = os.path.join(ROOT, "profiles", "gate_traffic.json")
+        if os.path.exists(tpath) and B == 1 and args.precision == "f16_d64":
+            with open(tpath) as f:
+                tj = json.load(f)
+            roof["traffic"] = tj.get("bytes_per_launch")
+            roof["traffic_source"] = tj.get("source")
+        if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched:
+            # BASELINE configs[2]: the same clip with the 50-iteration PLMS sampler (pndm_speedup=20, 51 denoiser evaluations)
+            pipe.infer(hub, m2p, f0, speedup=20, seed=7)
+            torch.cuda.synchronize(); tp0 = time.perf_counter()
+            for i in range(3):
+                pipe.infer(hub, m2p, f0, speedup=20, seed=8 + i)
+            torch.cuda.synchronize(); tpl = (time.perf_counter() - tp0) / 3
+            result["plms_50"] = {"workload": "BASELINE configs[2]: single 10 s clip, 50-iteration PLMS (pndm_speedup=20) + NSF-HiFiGAN",
+                                 "value": CLIP_SECONDS / tpl, "unit": "audio-sec/wall-sec", "ms_per_clip": tpl * 1e3}
         if not args.no_batched and world == 1 and B == 1:
             # the throughput configuration (BASELINE configs[3] per-GPU share): 32 clips in one batch
             Bb = 32

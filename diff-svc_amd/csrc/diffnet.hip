@@ -128,30 +128,17 @@ int tpack(TPacked& tp, const std::vector<float>& src, int O, int I, int taps, in
 // tiling choice of the tgemm path: 128-frame tiles x 8 waves when the batch fills the chip, otherwise 32-frame tiles
 // x 4 waves with the output-channel passes spread over blockIdx.y
 template <class Epi, int NW>
-int tlaunch(const TGemmArgs& a_in, const typename Epi::Args& e, int rows_alloc, hipStream_t st) {
+int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hipStream_t st) {
     constexpr int KG = NW == 2 ? 4 : 8;                  // two planes: half the ring depth, same bytes in flight
     if (rows_alloc / 128 >= 48) {
-        TGemmArgs a = a_in;
-        a.pf_wgs = 0; a.pf_ptr = nullptr;                // big batches: kernels are long, the warm-up would only take CUs away
         const int tiles = rows_alloc / 128, passes = ceil_div(a.m_tiles, 8);
         int ms = 256 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
-        if (tgemm_smem<4>(a.taps, a.dil, a.cin) <= 160 * 1024) {
-            static const int waves12 = getenv("DSVC_TG_WAVES12") ? atoi(getenv("DSVC_TG_WAVES12")) : 0;     // tuning knob
-            if constexpr (NW == 1) {
-                if (waves12) {        // 12 waves (3 per SIMD, <= 168 VGPRs).  Measured slower (B=32: 2.50 vs 2.38 ms/step): off by default
-                    const int p12 = ceil_div(a.m_tiles, 12);
-                    int m12 = 256 / tiles; m12 = m12 < 1 ? 1 : (m12 > p12 ? p12 : m12);
-                    return tgemm_launch<4, 12, 3, 4, NW, Epi>(a, e, rows_alloc, m12, st);
-                }
-            }
-            return tgemm_launch<4, 8, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
-        }
+        if (tgemm_smem<4>(a.taps, a.dil, a.cin) <= 160 * 1024) return tgemm_launch<4, 8, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
         return tgemm_launch<2, 8, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);       // K too wide for a 128-frame tile in LDS
     }
-    const TGemmArgs& a = a_in;
     const int tiles = rows_alloc / 32, passes = ceil_div(a.m_tiles, 4);
     int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
-    return tgemm_launch<1, 4, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);    // (the only tiling that runs weight warm-up workgroups)
+    return tgemm_launch<1, 4, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
 }
 
 template <class Epi>
@@ -486,28 +473,19 @@ int dsvc_denoiser::eval_conv(const float* x_fm, const StepRef& step, Tail tail, 
 int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st) {
     const int M = cfg.mel_bins, C = cfg.channels, L = cfg.layers;
     const RowMap rm = rowmap();
-    // measured on MI355X (B = 1, profiles/r01i_ab.txt): 0 -> 0.353 ms/step, 64 -> 0.523, 128 -> 0.410, 256 -> 0.390: the warm-up
-    // workgroups outlive the compute workgroups and stretch every kernel, so it stays OFF; the knob is kept for re-tuning
-    static const int pf_wgs = getenv("DSVC_TG_PREFETCH_WGS") ? atoi(getenv("DSVC_TG_PREFETCH_WGS")) & ~7 : 0;
-    // `next`: the kernel that runs after this one -- its weights are warmed into L2 by this launch (small batches)
-    auto targs = [&](const _Float16* x, int cin_pad, const TPacked& tp, int taps, int dil, const TPacked* next) {
+    auto targs = [&](const _Float16* x, int cin_pad, const TPacked& tp, int taps, int dil) {
         TGemmArgs a{};
         a.x = x; a.cin = cin_pad; a.taps = taps; a.dil = dil; a.w = tp.w.as<_Float16>(); a.m_tiles = tp.m_tiles;
         a.w_planes = tp.planes; a.variant_halfs = (long long)tp.variant_halfs; a.n_variants = tp.n_variants;
         a.step_ptr = step.ptr; a.step_off = step.off;
-        if (next && pf_wgs > 0) {
-            a.pf_ptr = next->w.as<_Float16>(); a.pf_bytes = (long long)next->variant_halfs * 2;
-            a.pf_variant_halfs = (long long)next->variant_halfs; a.pf_n_variants = next->n_variants; a.pf_wgs = pf_wgs;
-        }
         return a;
     };
-    static const int stream_env = getenv("DSVC_TG_STREAM") ? atoi(getenv("DSVC_TG_STREAM")) : -1;      // tuning knob
-    const int stream_big = stream_env >= 0 ? stream_env : (rows_alloc >= 6144 ? 1 : 0);
+    const int stream_big = rows_alloc >= 6144 ? 1 : 0;   // (non-temporal residual/skip traffic measured neutral: 2.41 vs 2.42 ms/step)
     if (!state_half_fresh)
         hipLaunchKernelGGL(k_rows_to_half, dim3(ceil_div(rows * (M / 4), 256) < 2048 ? ceil_div(rows * (M / 4), 256) : 2048), dim3(256), 0, st,
                            x_fm, xsh.as<_Float16>(), M, Mp, rm, rows);
     {   // K1: input projection + ReLU (net.py:120-123); emits layer 0's operand xh = fp16(x + film_0)
-        TGemmArgs a = targs(xsh.as<_Float16>(), 2 * Mp, in_t, 1, 1, &dil_t[0]);
+        TGemmArgs a = targs(xsh.as<_Float16>(), 2 * Mp, in_t, 1, 1);
         TEpiInProj::Args e{xres.as<float>(), xh_row0(), in_t.bias.as<float>(), film.as<float>(), L * C, step, C, Cp, rm};
         DSVC_TRY(tlaunch_prec<TEpiInProj>(a, e, 2, rows_alloc, st));
     }
@@ -516,13 +494,13 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
     for (int l = 0; l < L; ++l) {
         if (stop_after >= 0 && l >= stop_after) return DSVC_OK;
         {   // K5+K6 (+ hoisted K4, K3 already folded into xh): dilated conv, gate (net.py:67-77)
-            TGemmArgs a = targs(xh_row0(), Cp, dil_t[l], 3, 1 << (l % cfg.dilation_cycle), &out_t[l]);
+            TGemmArgs a = targs(xh_row0(), Cp, dil_t[l], 3, 1 << (l % cfg.dilation_cycle));
             TEpiGate::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, gh.as<_Float16>(), C, Cp};
             DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, dil_t[l].planes, rows_alloc, st));
         }
         {   // K7+K8: output projection, residual / skip (net.py:79-84,131) + next layer's FiLM (K3)
             const bool last = l + 1 == L;
-            TGemmArgs a = targs(gh.as<_Float16>(), Cp, out_t[l], 1, 1, last ? &skip_t : &dil_t[l + 1]);
+            TGemmArgs a = targs(gh.as<_Float16>(), Cp, out_t[l], 1, 1);
             TEpiResSkip::Args e{xres.as<float>(), last ? nullptr : xh_row0(), skip.as<float>(), last ? skiph.as<_Float16>() : nullptr,
                                 out_t[l].bias.as<float>(), last ? nullptr : film.as<float>() + (size_t)(l + 1) * C, L * C, step, C, Cp,
                                 l == 0 ? 1 : 0, rm, stream_big};
@@ -530,12 +508,12 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         }
     }
     {   // K9a: skip projection + ReLU (net.py:132-133)
-        TGemmArgs a = targs(skiph.as<_Float16>(), 2 * Cp, skip_t, 1, 1, &fin_t);
+        TGemmArgs a = targs(skiph.as<_Float16>(), 2 * Cp, skip_t, 1, 1);
         TEpiReluHalf::Args e{s2h.as<_Float16>(), Cp, skip_t.bias.as<float>(), C};
         DSVC_TRY(tlaunch_prec<TEpiReluHalf>(a, e, 2, rows_alloc, st));
     }
     {   // K9b: output projection (net.py:134), optionally fused with the DDPM update (K10)
-        TGemmArgs a = targs(s2h.as<_Float16>(), 2 * Cp, fin_t, 1, 1, &in_t);
+        TGemmArgs a = targs(s2h.as<_Float16>(), 2 * Cp, fin_t, 1, 1);
         if (tail == TAIL_DDPM) {
             TEpiDdpm::Args e{ddpm->x, xsh.as<_Float16>(), fin_t.bias.as<float>(), M, Mp, ddpm->tab, step, rm, ddpm->seed, ddpm->clip0};
             DSVC_TRY(tlaunch_prec<TEpiDdpm>(a, e, 2, rows_alloc, st));

@@ -51,11 +51,6 @@ struct TGemmArgs {
     int n_variants;         // >= 1
     const int* step_ptr;    // device int: current diffusion step (variant = (step - step_off) % n_variants); may be null
     int step_off;
-    // optional L2 warm-up of the NEXT kernel's weights (small batches only: a layer kernel then lasts a few us and the
-    // ~2 us first-touch HBM latency of its own weight stream is a quarter of it).  pf_wgs extra workgroups are appended
-    // to grid.x; those that land on XCD i (block id % 8, by observed dispatch order -- placement only affects speed)
-    // read the whole range [pf_ptr, pf_ptr + pf_bytes) between them.
-    const _Float16* pf_ptr; long long pf_bytes; long long pf_variant_halfs; int pf_n_variants; int pf_wgs;
     int dbg;                // ablation knobs for profiling (env DSVC_TG_DEBUG): 1 = no acc-init loads, 2 = no epilogue,
                             // 4 = no tile DMA, 8 = no MFMA main loop, 16 = no wave priority split, 32 = all tiles stream
                             // tile 0's weights (L2-hot), 64 = no pass rotation.  0 in production.
@@ -75,27 +70,6 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
-    if (a.pf_wgs > 0 && (int)blockIdx.x >= (int)gridDim.x - a.pf_wgs) {          // weight warm-up workgroup (no barrier below this point yet)
-        if (blockIdx.y == 0 && a.pf_ptr) {
-            int variant = 0;
-            if (a.pf_n_variants > 1 && a.step_ptr) {
-                variant = (*a.step_ptr - a.step_off) % a.pf_n_variants;
-                if (variant < 0) variant += a.pf_n_variants;
-            }
-            const char* base = reinterpret_cast<const char*>(a.pf_ptr + (long long)variant * a.pf_variant_halfs);
-            const int p = (int)blockIdx.x - ((int)gridDim.x - a.pf_wgs);
-            const int per_xcd = a.pf_wgs >> 3, rank = p >> 3;                     // blocks p, p+8, p+16, ... share an XCD
-            const long long chunk = ((a.pf_bytes / per_xcd + 4095) / 4096) * 4096;
-            const long long lo = (long long)rank * chunk, hi = lo + chunk < a.pf_bytes ? lo + chunk : a.pf_bytes;
-            unsigned sx = 0;
-            for (long long off = lo + (long long)tid * 16; off < hi; off += (long long)(64 * WAVES) * 16) {
-                const uint4 v = *reinterpret_cast<const uint4*>(base + off);
-                sx ^= v.x ^ v.y ^ v.z ^ v.w;
-            }
-            asm volatile("" :: "v"(sx));                                          // keep the loads alive
-        }
-        return;
-    }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * TN;
@@ -136,10 +110,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
 
     // two waves share a SIMD (waves w and w + 4): give one of them priority so the pair drifts apart and one wave's
     // epilogue / memory waits sit under the other's MFMAs instead of both stalling together
-    if (WAVES > 4 && !(a.dbg & 16)) {                     // waves w, w+4, w+8 share SIMD (w & 3)
-        if (wave >= 8) __builtin_amdgcn_s_setprio(2);
-        else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    }
+    if (WAVES > 4 && wave >= 4 && !(a.dbg & 16)) __builtin_amdgcn_s_setprio(1);     // waves w and w+4 share SIMD (w & 3)
 
     auto load_group = [&](half8 (&ring)[KG][NW], const _Float16* p) {
 #pragma unroll
@@ -165,30 +136,40 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         // keep the per-group bases materialised: without this LLVM re-derives every address from scratch (4-5 VALU per ds_read)
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) asm volatile("" : "+v"(base[nt]));
-        half8 bq[2][NT_N];                               // B fragments: step kk in bq[kk & 1], step kk+1 being read
+        // B fragments: BQ-deep software pipeline -- step kk computes from bq[kk % BQ] while steps kk+1 .. kk+BQ-1 are in flight
+        constexpr int BQ = 2;                            // (3-deep measured slower on MI355X: 2.44 vs 2.33 ms/step at 32 clips)
+        half8 bq[BQ][NT_N];
 #pragma unroll
-        for (int nt = 0; nt < NT_N; ++nt) bq[0][nt] = *(lds_frag_ptr)(size_t)(base[nt] + xs);
+        for (int d = 0; d < BQ - 1; ++d) {
+            if (d < KG) {
+                const unsigned off = ((unsigned)d << 5) ^ xs;
+#pragma unroll
+                for (int nt = 0; nt < NT_N; ++nt) bq[d][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < KG; ++kk) {
-            if (kk + 1 < KG) {
-                const unsigned off = ((unsigned)(kk + 1) << 5) ^ xs;
+            if (kk + BQ - 1 < KG) {
+                const unsigned off = ((unsigned)(kk + BQ - 1) << 5) ^ xs;
 #pragma unroll
-                for (int nt = 0; nt < NT_N; ++nt) bq[(kk + 1) & 1][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
+                for (int nt = 0; nt < NT_N; ++nt) bq[(kk + BQ - 1) % BQ][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
             }
 #pragma unroll
             for (int nt = 0; nt < NT_N; ++nt) {
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][0], bq[kk & 1][nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][0], bq[kk % BQ][nt], acc[nt], 0, 0, 0);
                 if constexpr (NW == 2)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][1], bq[kk & 1][nt], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][1], bq[kk % BQ][nt], acc[nt], 0, 0, 0);
             }
         }
         // pin the software pipeline: left alone, the scheduler sinks every ds_read to just above its MFMA (register
         // pressure heuristic) and the wave then eats the full LDS latency once per MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, NT_N, 0);                     // B fragments of step 0
+#pragma unroll
+        for (int d = 0; d < BQ - 1; ++d)
+            if (d < KG) __builtin_amdgcn_sched_group_barrier(0x100, NT_N, 0);         // B fragments of the first BQ-1 steps
 #pragma unroll
         for (int kk = 0; kk < KG; ++kk) {
-            if (kk + 1 < KG) __builtin_amdgcn_sched_group_barrier(0x100, NT_N, 0);  // ... of step kk+1, issued ahead of
-            __builtin_amdgcn_sched_group_barrier(0x008, NT_N * NW, 0);              // the MFMAs of step kk
+            if (kk + BQ - 1 < KG) __builtin_amdgcn_sched_group_barrier(0x100, NT_N, 0);  // ... of step kk+BQ-1, issued ahead of
+            __builtin_amdgcn_sched_group_barrier(0x008, NT_N * NW, 0);                   // the MFMAs of step kk
         }
     };
 
@@ -238,42 +219,25 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         // epilogue, so their latency sits under the epilogue's VALU and stores
         const int pn = next_active(pi + gridDim.y);
         const int mt_n = pn >= 0 ? tile_of(pn) : 0;
-        if constexpr (WAVES <= 8) {
-            // start the next tile's weight stream and accumulator-init loads BEFORE this tile's epilogue, so their
-            // latency sits under the epilogue's VALU and stores (costs a second accumulator set for the epilogue's duration)
-            f32x16 nxt[NT_N];
-            if (pn >= 0) {
-                load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt_n) * tile_halfs);
-                if (a.dbg & 1) {
-#pragma unroll
-                    for (int nt = 0; nt < NT_N; ++nt)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) nxt[nt][i] = 0.f;
-                } else {
-                    epi.init(ea, mt_n, row0, lane, nxt);
-                }
-            }
-            if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
-            else asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT_N - 1][15]));
-            if (pn < 0) break;
-#pragma unroll
-            for (int nt = 0; nt < NT_N; ++nt) acc[nt] = nxt[nt];
-        } else {
-            // three waves per SIMD (168 VGPRs): no room for a second accumulator set; the other two waves of the SIMD
-            // cover this wave's epilogue and init latency instead
-            if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
-            else asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT_N - 1][15]));
-            if (pn < 0) break;
+        // start the next tile's weight stream and accumulator-init loads BEFORE this tile's epilogue, so their
+        // latency sits under the epilogue's VALU and stores (costs a second accumulator set for the epilogue's duration)
+        f32x16 nxt[NT_N];
+        if (pn >= 0) {
             load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt_n) * tile_halfs);
             if (a.dbg & 1) {
 #pragma unroll
                 for (int nt = 0; nt < NT_N; ++nt)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+                    for (int i = 0; i < 16; ++i) nxt[nt][i] = 0.f;
             } else {
-                epi.init(ea, mt_n, row0, lane, acc);
+                epi.init(ea, mt_n, row0, lane, nxt);
             }
         }
+        if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
+        else asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT_N - 1][15]));
+        if (pn < 0) break;
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) acc[nt] = nxt[nt];
         pi = pn; mt = mt_n;
     }
 }
@@ -311,8 +275,7 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
     const int passes = ceil_div(a.m_tiles, WAVES);
     if (m_split < 1) m_split = 1;
     if (m_split > passes) m_split = passes;
-    if (a.pf_wgs & 7) return fail(DSVC_EINVAL, "tgemm: pf_wgs must be a multiple of 8");
-    hipLaunchKernelGGL(kern, dim3(n_rows / (32 * NT_N) + a.pf_wgs, m_split), dim3(64 * WAVES), smem, stream, a, ea);
+    hipLaunchKernelGGL(kern, dim3(n_rows / (32 * NT_N), m_split), dim3(64 * WAVES), smem, stream, a, ea);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
