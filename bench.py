@@ -96,6 +96,8 @@ def main():
                     help="f16_dN (fp16 operands, N time-dithered weight roundings; default, parity-tested), f16_w2, f16_x3, f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the extra batched (32 clips/GPU) measurement")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch the sampler steps eagerly (rocprofv3 --pmc segfaults on hipGraph replays on this stack)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +129,7 @@ def main():
     def one_step(seed):
         # clips of a rank are strided (i % world), so Philox clip ids go through first_clip = rank, stride world:
         # with one clip per GPU the id is just the rank; for B > 1 ids are rank-local but unique per (rank, b).
-        wav = pipe.infer(hub, m2p, f0, speedup=args.speedup, seed=seed, first_clip=rank * B, use_graph=True)
+        wav = pipe.infer(hub, m2p, f0, speedup=args.speedup, seed=seed, first_clip=rank * B, use_graph=not args.no_graph)
         if world > 1:
             wav = gather_pcm(wav, my_clips, n_clips)
         return wav

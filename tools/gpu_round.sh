@@ -20,7 +20,7 @@ F=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1)
 [ -n "$F" ] && head -30 "$F" > $OUT/${TAG}_kernel_stats.csv && cat $OUT/${TAG}_kernel_stats.csv
 # PMC passes (own runs, no other trace domains) for the gate kernel's HBM traffic
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --no-batched --no-cpu-baseline > $OUT/${TAG}_pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --no-batched --no-cpu-baseline --no-graph > $OUT/${TAG}_pmc_$c.log 2>&1
 done
 python $ROOT/tools/rocprof_traffic.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE "TEpiGate" $OUT/${TAG}_gate_traffic.json
 rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
