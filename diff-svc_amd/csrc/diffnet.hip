@@ -536,6 +536,10 @@ struct dsvc_sampler {
     DevBuf xstate, hist, xpred, step_dev;
     int wsB = 0, wsT = 0;
 
+    // captured PLMS iteration (one denoiser evaluation + Adams-Bashforth update; t and the history count live on the device)
+    hipGraphExec_t gexec_plms = nullptr;
+    int pB = 0, pT = 0, p_prec = -1, p_interval = 0;
+    const void* p_key = nullptr;
     // captured DDPM graph
     hipGraphExec_t gexec = nullptr;
     hipStream_t cap_stream = nullptr;
@@ -545,6 +549,7 @@ struct dsvc_sampler {
 
     ~dsvc_sampler() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (gexec_plms) (void)hipGraphExecDestroy(gexec_plms);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (DevBuf* b : {&alphas_cumprod, &sqrt_recip, &sqrt_recipm1, &coef1, &coef2, &sigma, &spec_min, &spec_max,
                           &xstate, &hist, &xpred, &step_dev})
@@ -602,6 +607,7 @@ int dsvc_sampler::ensure_ws(int B, int T) {
     DSVC_HIP(hipMemset(xstate.p, 0, n)); DSVC_HIP(hipMemset(xpred.p, 0, n)); DSVC_HIP(hipMemset(hist.p, 0, 4 * n));
     wsB = B; wsT = T;
     if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+    if (gexec_plms) { (void)hipGraphExecDestroy(gexec_plms); gexec_plms = nullptr; }
     return DSVC_OK;
 }
 
@@ -666,29 +672,60 @@ int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
     const int interval = a->speedup;
     const size_t n = (size_t)den->rows * den->cfg.mel_bins;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    int n_hist = 0;
-    int first = ((a->t_start - 1) / interval) * interval;
-    for (int i = first; i >= a->t_stop; i -= interval) {
+    int* sdev = step_dev.as<int>();                      // sdev[0] = t, sdev[1] = predictions stored so far
+    PlmsArgs p{};
+    p.x = xstate.as<float>(); p.eps = den->eps.as<float>(); p.hist = hist.as<float>(); p.x_pred = xpred.as<float>();
+    p.alphas_cumprod = alphas_cumprod.as<float>(); p.n = n; p.interval = interval;
+    int i = ((a->t_start - 1) / interval) * interval;
+    if (i < a->t_stop) return DSVC_OK;
+    {   // first iteration: no history yet -> improved Euler with a second evaluation at t_prev (diffusion.py:184-187)
         const int t_prev = i - interval > 0 ? i - interval : 0;
-        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), i);
-        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, st));
-        PlmsArgs p{};
-        p.x = xstate.as<float>(); p.eps = den->eps.as<float>(); p.hist = hist.as<float>(); p.x_pred = xpred.as<float>();
-        p.alphas_cumprod = alphas_cumprod.as<float>(); p.n = n; p.t = i; p.t_prev = t_prev; p.n_hist = n_hist;
-        if (n_hist == 0) {
-            p.phase = 0;
-            hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
-            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), t_prev);
-            DSVC_TRY(den->eval(xpred.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, st));
-            p.phase = 1;
-            hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
-            n_hist = 1;
-        } else {
-            p.phase = 2;
-            hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
-            n_hist += 1;
-        }
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, sdev, i);
+        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, st));
+        p.t = i; p.t_prev = t_prev; p.n_hist = 0; p.phase = 0;
+        hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, sdev, t_prev);
+        DSVC_TRY(den->eval(xpred.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, st));
+        p.phase = 1;
+        hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
+        i -= interval;
     }
+    if (i < a->t_stop) { DSVC_HIP(hipGetLastError()); return DSVC_OK; }
+    // remaining iterations: eps = denoiser(x, t); x = x_pred(x, AB(eps, history), t); one body, state on the device
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, sdev, i);
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, sdev + 1, 1);
+    p.phase = 2; p.state_dev = sdev;
+    auto body = [&](hipStream_t s2) -> int {
+        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, s2));
+        hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, s2, p);
+        hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s2, sdev, -interval);
+        hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s2, sdev + 1, 1);
+        return DSVC_OK;
+    };
+    int iters = (i - a->t_stop) / interval + 1;
+    if (a->use_graph && iters >= 4) {
+        const bool stale = !gexec_plms || pB != a->B || pT != a->T || p_prec != den->cfg.precision || p_interval != interval ||
+                           p_key != den->cproj.p;
+        if (stale) {
+            if (gexec_plms) { (void)hipGraphExecDestroy(gexec_plms); gexec_plms = nullptr; }
+            DSVC_TRY(body(st));                          // one eager iteration first: sets every function attribute outside the capture
+            iters -= 1;
+            if (!cap_stream) DSVC_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+            DSVC_HIP(hipStreamSynchronize(st));
+            DSVC_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+            const int rc = body(cap_stream);
+            hipGraph_t graph = nullptr;
+            hipError_t ce = hipStreamEndCapture(cap_stream, &graph);
+            if (rc != DSVC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (ce != hipSuccess) return fail(DSVC_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+            ce = hipGraphInstantiate(&gexec_plms, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ce != hipSuccess) { gexec_plms = nullptr; return fail(DSVC_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ce)); }
+            pB = a->B; pT = a->T; p_prec = den->cfg.precision; p_interval = interval; p_key = den->cproj.p;
+        }
+        for (; iters > 0; --iters) DSVC_HIP(hipGraphLaunch(gexec_plms, st));
+    }
+    for (; iters > 0; --iters) DSVC_TRY(body(st));
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }

@@ -244,6 +244,8 @@ struct PlmsArgs {
     size_t n;                // rows*M
     int t, t_prev;           // t, max(t - interval, 0)
     int n_hist;              // predictions stored so far
+    const int* state_dev;    // phase 2 under graph replay: {t, n_hist} live on the device (state_dev[0], state_dev[1]); null = use the fields
+    int interval;            // ... and t_prev = max(t - interval, 0)
     int phase;               // 0: x_pred = xpred(x, eps, t)                 (first iteration, before the 2nd eval)
                              // 1: eps' = (hist[0] + eps)/2 ; x = xpred(x, eps', t)   (first iteration, after the 2nd eval; hist[0] holds eps_0)
                              // 2: eps' = AB(eps, hist); x = xpred(x, eps', t); push eps
@@ -257,7 +259,10 @@ __device__ __forceinline__ float plms_xpred(float x, float e, float a_t, float a
 }
 
 __global__ void k_plms(const PlmsArgs a) {
-    const float a_t = a.alphas_cumprod[a.t], a_p = a.alphas_cumprod[a.t_prev];
+    const int t = a.state_dev ? a.state_dev[0] : a.t;
+    const int t_prev = a.state_dev ? (t - a.interval > 0 ? t - a.interval : 0) : a.t_prev;
+    const int n_hist = a.state_dev ? a.state_dev[1] : a.n_hist;
+    const float a_t = a.alphas_cumprod[t], a_p = a.alphas_cumprod[t_prev];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
         const float e = a.eps[i];
         const float x = a.x[i];
@@ -268,7 +273,7 @@ __global__ void k_plms(const PlmsArgs a) {
             const float ep = (a.hist[i] + e) / 2.0f;
             a.x[i] = plms_xpred(x, ep, a_t, a_p);
         } else {
-            const int nh = a.n_hist;
+            const int nh = n_hist;
             const float h1 = a.hist[(size_t)((nh - 1) & 3) * a.n + i];
             float ep;
             if (nh == 1) {

@@ -123,6 +123,21 @@ def test_ddpm_graph_replay_equals_eager_and_oracle():
     assert (eager.cpu() - r["mel_out"]).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize("precision", ["f16_x3", "f16_d16"])
+def test_plms_graph_replay_equals_eager_and_oracle(precision):
+    """PLMS with the per-iteration body replayed from a hipGraph (t and the history count live on the device):
+    bit-identical to eager launches, and within the PLMS bar of the oracle."""
+    hp = synth.tiny_hparams(K=100)
+    sd, den, smp = make_handles(hp, 3, precision)
+    r = oracle_sample(hp, sd, [0, 1], 40, 23, 5, 321, 100)
+    cond, m2p = r["cond_t"].cuda(), r["mel2ph"].cuda()
+    eager = smp.sample(cond, 100, speedup=5, mel2ph=m2p, seed=321, first_clip=0, use_graph=False)
+    graph = smp.sample(cond, 100, speedup=5, mel2ph=m2p, seed=321, first_clip=0, use_graph=True)
+    again = smp.sample(cond, 100, speedup=5, mel2ph=m2p, seed=321, first_clip=0, use_graph=True)     # cached graph
+    assert torch.equal(eager, graph) and torch.equal(graph, again)
+    assert (eager.cpu() - r["mel_out"]).abs().max().item() < (2e-3 if precision == "f16_x3" else 6e-3)
+
+
 def test_batch_equals_per_clip():
     """Clips of a batch are independent: a batched call reproduces the B=1 calls bit for bit
     when the tiling is the same."""
