@@ -133,7 +133,14 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
     if (rows_alloc / 128 >= 48) {
         const int tiles = rows_alloc / 128, passes = ceil_div(a.m_tiles, 8);
         int ms = 256 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
-        if (tgemm_smem<4>(a.taps, a.dil, a.cin) <= 160 * 1024) return tgemm_launch<4, 8, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
+        if (tgemm_smem<4>(a.taps, a.dil, a.cin) <= 160 * 1024) {
+            static const int sched = getenv("DSVC_TG_SCHED") ? atoi(getenv("DSVC_TG_SCHED")) : 1;       // tuning knob
+            if constexpr (NW == 1) {
+                if (sched == 2) return tgemm_launch<4, 8, 2, 8, NW, Epi, 2>(a, e, rows_alloc, ms, st);
+                if (sched == 3) return tgemm_launch<4, 8, 2, 8, NW, Epi, 3>(a, e, rows_alloc, ms, st);
+            }
+            return tgemm_launch<4, 8, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
+        }
         return tgemm_launch<2, 8, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);       // K too wide for a 128-frame tile in LDS
     }
     const int tiles = rows_alloc / 32, passes = ceil_div(a.m_tiles, 4);

@@ -53,7 +53,8 @@ struct TGemmArgs {
     int step_off;
     int dbg;                // ablation knobs for profiling (env DSVC_TG_DEBUG): 1 = no acc-init loads, 2 = no epilogue,
                             // 4 = no tile DMA, 8 = no MFMA main loop, 16 = no wave priority split, 32 = all tiles stream
-                            // tile 0's weights (L2-hot), 64 = no pass rotation.  0 in production.
+                            // tile 0's weights (L2-hot), 64 = no pass rotation, 128 = next-tile init loads issued at the
+                            // end of the pass (both waves of a SIMD together) instead of staggered inside it.  0 in production.
 };
 
 // the row <-> channel permutation inside a 32-row output tile that makes a lane's 16 accumulator registers hold 16
@@ -137,7 +138,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) asm volatile("" : "+v"(base[nt]));
         // B fragments: BQ-deep software pipeline -- step kk computes from bq[kk % BQ] while steps kk+1 .. kk+BQ-1 are in flight
-        constexpr int BQ = 2;                            // (3-deep measured slower on MI355X: 2.44 vs 2.33 ms/step at 32 clips)
+        constexpr int BQ = SCHED == 2 ? 3 : (SCHED == 3 ? 4 : 2);     // SCHED 2/3: deeper B-fragment pipelines (tuning variants)
         half8 bq[BQ][NT_N];
 #pragma unroll
         for (int d = 0; d < BQ - 1; ++d) {
@@ -211,28 +212,19 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA'd tile (and the first operands) have landed
     __syncthreads();
 
+    // The accumulator-init loads of a wave's NEXT tile are issued in the middle of its current tile's main loop: they are a
+    // burst from HBM (the conditioner projection / the residual stream), vmcnt is in-order, so whenever they are issued the
+    // wave's next weight-ring wait stalls until they have landed.  The two waves of a SIMD (w and w+4) issue theirs at
+    // DIFFERENT points of the pass (first vs middle group pair), so one of them always has MFMAs to issue while the other
+    // sits behind its burst, and the chip-wide HBM demand is spread instead of arriving from every workgroup at once.
+    const int g_issue = (WAVES > 4 && wave >= WAVES / 2) ? ((G / 2) & ~1) : 0;
     while (pi >= 0) {
         const _Float16* wp = wbase + (long long)((a.dbg & 32) ? 0 : mt) * tile_halfs;      // dbg 32: every tile streams tile 0 (L2-hot)
-        int g = (a.dbg & 8) ? G : 0;
-        for (; g + 1 < G; g += 2) {     // straight-line body (no branch): IR-level sinking cannot move a prefetch below its group
-            load_group(ringB, wp + (long long)(g + 1) * GROUP_HALFS);          // ringB <- group g+1, under group g's MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group(ringA, acc, g);
-            const int gn = g + 2 < G ? g + 2 : G - 1;
-            load_group(ringA, wp + (long long)gn * GROUP_HALFS);               // ringA <- group g+2, under group g+1's MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group(ringB, acc, g + 1);
-        }
-        if (g < G) compute_group(ringA, acc, g);                               // odd group count: the tail group
-        // next tile of this wave: start its weight stream and its accumulator-init loads before this tile's
-        // epilogue, so their latency sits under the epilogue's VALU and stores
         const int pn = next_active(pi + gridDim.y);
         const int mt_n = pn >= 0 ? tile_of(pn) : 0;
-        // start the next tile's weight stream and accumulator-init loads BEFORE this tile's epilogue, so their
-        // latency sits under the epilogue's VALU and stores (costs a second accumulator set for the epilogue's duration)
         f32x16 nxt[NT_N];
-        if (pn >= 0) {
-            load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt_n) * tile_halfs);
+        bool nxt_issued = false;
+        auto issue_next_init = [&]() {
             if (a.dbg & 1) {
 #pragma unroll
                 for (int nt = 0; nt < NT_N; ++nt)
@@ -241,6 +233,23 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
             } else {
                 epi.init(ea, mt_n, row0, lane, nxt);
             }
+        };
+        int g = ((a.dbg & 8) || ((a.dbg & 256) && wave >= WAVES / 2)) ? G : 0;      // dbg 256: half the waves skip their MFMAs
+        for (; g + 1 < G; g += 2) {     // straight-line body (no branch around the prefetches): IR-level sinking cannot move one below its group
+            load_group(ringB, wp + (long long)(g + 1) * GROUP_HALFS);          // ringB <- group g+1, under group g's MFMAs
+            if (g == g_issue && pn >= 0 && !(a.dbg & 128)) { issue_next_init(); nxt_issued = true; }
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group(ringA, acc, g);
+            const int gn = g + 2 < G ? g + 2 : G - 1;
+            load_group(ringA, wp + (long long)gn * GROUP_HALFS);               // ringA <- group g+2, under group g+1's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group(ringB, acc, g + 1);
+        }
+        if (g < G) compute_group(ringA, acc, g);                               // odd group count: the tail group
+        // the next tile's weight stream starts before this tile's epilogue, so its latency sits under the epilogue
+        if (pn >= 0) {
+            load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt_n) * tile_halfs);
+            if (!nxt_issued) issue_next_init();                                // short K loops (or dbg 128): issue here instead
         }
         if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
         else asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT_N - 1][15]));

@@ -6,7 +6,10 @@ in libdsvc_hip.so.  Register it in the reference's seam with
 
     DIFF_DECODERS['wavenet'] = lambda hp: DiffNetHip(hp['audio_num_mel_bins'])
 
-(infer_tools/infer_tool.py:107-111).  Inference only: there is no autograd through the HIP kernels, so
+(infer_tools/infer_tool.py:107-111).  ``precision`` selects the operand scheme of the two big per-layer contractions
+(include/dsvc.h): the default ``"f16_d64"`` is one fp16 MFMA per product with 64 time-dithered weight roundings (the
+configuration bench.py measures and the 1000-step parity test covers); ``"f16_w2"`` / ``"f16_x3"`` spend 2 / 3 MFMAs.
+Inference only: there is no autograd through the HIP kernels, so
 ``infer=False`` training keeps using the reference module.
 """
 import math
@@ -38,7 +41,7 @@ class _ResidualBlockParams(nn.Module):
 
 
 class DiffNetHip(nn.Module):
-    def __init__(self, in_dims=80, hparams=None, precision="f16_w2"):
+    def __init__(self, in_dims=80, hparams=None, precision="f16_d64"):
         super().__init__()
         hp = hparams if hparams is not None else get_hparams()
         self.in_dims = in_dims

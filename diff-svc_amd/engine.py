@@ -30,7 +30,7 @@ class DenoiserHandle:
     """dsvc_denoiser: DiffNet weights packed for the MFMA kernels + per-step FiLM tables."""
 
     def __init__(self, state, mel_bins, hidden, channels, layers, dilation_cycle, max_steps,
-                 precision="f16_w2", prefix=""):
+                 precision="f16_d64", prefix=""):
         self._h = ctypes.c_void_p(0)
         prec, variants = parse_precision(precision)
         self.cfg = _lib.DenoiserCfg(mel_bins, hidden, channels, layers, dilation_cycle, max_steps, prec, variants)
