@@ -240,3 +240,56 @@ def clip_inputs(clip, T=861, n_units=500, H=256, seed=1234):
     elif uv.any():
         f0[uv] = np.interp(np.where(uv)[0], np.where(~uv)[0], f0[~uv])
     return hub, align_units(T, n_units), f0.astype(np.float32), f0_hz
+
+
+def slicer_case(seed, sr=22050, seconds=20.0, floor_db=-62.0, lead_silence=False, tail_silence=False, dense=False,
+                mode="mixed"):
+    """Synthetic audio for the slicer KATs: voiced bursts (two partials + noise, random level) separated by pauses whose
+    level sits at ``floor_db``; ``dense`` makes some voiced pieces shorter than the slicer's min_length so the merge
+    branch is taken.  mode 'silent' / 'loud' give the two degenerate signals.  float32 [N]."""
+    g = _rng("slicer", seed)
+    n = int(sr * seconds)
+    t = np.arange(n) / sr
+    floor = 10.0 ** (floor_db / 20.0)
+    x = g.standard_normal(n) * floor
+    if mode == "silent":
+        return x.astype(np.float32)
+    env = np.zeros(n)
+    pos = int(sr * g.uniform(0.6, 1.5)) if lead_silence else 0
+    while pos < n:
+        dur = int(sr * (g.uniform(0.4, 2.0) if dense else g.uniform(2.0, 7.0)))
+        if mode == "loud":
+            dur = n
+        lvl = 10.0 ** (g.uniform(-18.0, -3.0) / 20.0)
+        end = min(n, pos + dur)
+        ramp = min(int(0.01 * sr), max(1, (end - pos) // 4))
+        e = np.full(end - pos, lvl)
+        e[:ramp] *= np.linspace(0, 1, ramp); e[-ramp:] *= np.linspace(1, 0, ramp)
+        env[pos:end] = e
+        pos = end + int(sr * g.uniform(0.35, 1.4))
+    if tail_silence:
+        env[n - int(sr * g.uniform(0.5, 1.2)):] = 0.0
+    f1, f2 = g.uniform(110, 330), g.uniform(400, 900)
+    voiced = 0.6 * np.sin(2 * np.pi * f1 * t) + 0.3 * np.sin(2 * np.pi * f2 * t + 1.0) + 0.1 * g.standard_normal(n)
+    return (x + env * voiced).astype(np.float32)
+
+
+SLICER_CASES = [
+    dict(seed=1, sr=22050, seconds=22.6, args=dict(db_threshold=-40)),
+    dict(seed=2, sr=44100, seconds=12.0, args=dict(db_threshold=-30)),
+    dict(seed=3, sr=22050, seconds=18.0, lead_silence=True, tail_silence=True, args=dict(db_threshold=-40)),
+    dict(seed=4, sr=22050, seconds=25.0, dense=True, args=dict(db_threshold=-40)),
+    dict(seed=5, sr=44100, seconds=15.0, dense=True, lead_silence=True, args=dict(db_threshold=-30, min_length=3000)),
+    dict(seed=6, sr=22050, seconds=8.0, mode="silent", args=dict(db_threshold=-40)),
+    dict(seed=7, sr=22050, seconds=8.0, mode="loud", args=dict(db_threshold=-40)),
+    dict(seed=8, sr=22050, seconds=4.0, args=dict(db_threshold=-40)),                               # <= min_length: returned whole
+    dict(seed=9, sr=16000, seconds=30.0, tail_silence=True, args=dict(db_threshold=-35, win_l=400, win_s=30, max_silence_kept=800)),
+    dict(seed=10, sr=22050, seconds=20.0, floor_db=-130.0, args=dict(db_threshold=-40)),          # digital silence: clipped levels tie
+    dict(seed=11, sr=24000, seconds=40.0, dense=True, tail_silence=True, args=dict(db_threshold=-40, min_length=8000)),
+    dict(seed=12, sr=22050, seconds=16.0, floor_db=-45.0, args=dict(db_threshold=-40)),           # noise floor close to the threshold
+]
+
+
+def slicer_audio(case):
+    kw = {k: v for k, v in case.items() if k not in ("args",)}
+    return slicer_case(**kw)

@@ -7,6 +7,7 @@ oracle/refshim.py) on synthetic checkpoints and seeded inputs.  Container-only: 
 Random draws of the reference (torch.randn in diffusion.py:34-37,160,265-268 and models.py:192,271) are
 replaced by the Philox streams of oracle/dsvc_oracle.py so that a GPU kernel can reproduce them.
 """
+import json
 import os
 import sys
 
@@ -207,6 +208,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "--keys-only" in sys.argv:
         return golden_state_keys()
+    if "--24k-only" in sys.argv:
+        return golden_24k()
+    if "--slicer-only" in sys.argv:
+        return golden_slicer()
     golden_state_keys()
     golden_vocoder("vocoder_tiny", synth.tiny_vocoder(), 5, clips=[0, 3], T=24, seed=90)
     golden_vocoder("vocoder_44k", dict(synth.VOCODER_44K), 1, clips=[1], T=12, seed=91)
@@ -221,6 +226,33 @@ def main():
     golden_sampler("plms_tiny_s5", tiny, 3, clips=[1], T=52, n_units=30, speedup=5, seed=79)
     golden_sampler("ddpm_44k_k20", dict(full, K_step=20), 0, clips=[0], T=32, n_units=19, speedup=1, seed=80)
     golden_sampler("plms_44k_k100_s20", dict(full, K_step=100), 0, clips=[4], T=32, n_units=19, speedup=20, seed=81)
+    golden_24k()
+    golden_slicer()
+
+
+def golden_slicer():
+    """Slicer KATs: the real ``infer_tools.slicer.Slicer`` on the synthetic signals of synth.SLICER_CASES."""
+    import contextlib, io
+    refshim.install()
+    from infer_tools.slicer import Slicer
+    out = []
+    for case in synth.SLICER_CASES:
+        audio = synth.slicer_audio(case)
+        with contextlib.redirect_stdout(io.StringIO()):
+            chunks = Slicer(sr=case["sr"], **case["args"]).slice(audio)
+        out.append({"case": case, "n_samples": int(audio.shape[0]), "chunks": chunks})
+        print("slicer seed", case["seed"], len(chunks), "chunks", [v["split_time"] for v in chunks.values()][:6])
+    with open(os.path.join(OUT, "slicer_kat.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
+def golden_24k():
+    """BASELINE configs[0] shapes: the 24 kHz demo architecture (training/config.yaml: M=80, C=256) with the full
+    1000-step schedule and pndm_speedup=50 (20 PLMS iterations / 21 denoiser evaluations), plus one DDPM tail."""
+    b = dict(synth.HPARAMS_24K)
+    golden_diffnet("diffnet_24k", b, 2, B=2, T=37)
+    golden_sampler("plms_24k_s50", b, 2, clips=[3], T=36, n_units=21, speedup=50, seed=82)
+    golden_sampler("ddpm_24k_k30", dict(b, K_step=30), 2, clips=[6], T=36, n_units=21, speedup=1, seed=83)
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@ def make_handles(hp, wseed, precision):
 
 
 @pytest.mark.parametrize("precision", ["f16_x3", "f16_w2", "f16"])
-@pytest.mark.parametrize("name", ["diffnet_tiny", "diffnet_44k"])
+@pytest.mark.parametrize("name", ["diffnet_tiny", "diffnet_44k", "diffnet_24k"])
 def test_denoiser_forward_vs_reference_golden(name, precision):
     g = load_golden(name)
     hp = hp_for(name)
@@ -85,7 +85,8 @@ def test_denoiser_batched_throughput_tiling_matches_oracle():
 
 @pytest.mark.parametrize("precision", ["f16_x3", "f16_w2"])
 @pytest.mark.parametrize("name,tol", [("ddpm_tiny", 1e-3), ("plms_tiny_s10", 2e-3), ("plms_tiny_s5", 2e-3),
-                                      ("ddpm_44k_k20", 1e-3), ("plms_44k_k100_s20", 2e-3)])
+                                      ("ddpm_44k_k20", 1e-3), ("plms_44k_k100_s20", 2e-3),
+                                      ("ddpm_24k_k30", 1e-3), ("plms_24k_s50", 2e-3)])
 def test_sampler_vs_reference_golden(name, tol, precision):
     """mel within 1e-3 max-abs of the reference (north_star); PLMS' unclamped extrapolation amplifies
     rounding, hence the looser bar there.  f16_x3 runs on the conv_gemm engine, f16_w2 on the tgemm engine."""
@@ -106,7 +107,10 @@ def test_sampler_vs_reference_golden(name, tol, precision):
         mel = smp.sample(cond[i:i + 1], int(g["K_step"]), speedup=int(g["speedup"]), mel2ph=m2p[i:i + 1].cuda(),
                          seed=int(g["seed"]), first_clip=c, use_graph=False)
         mels.append(mel.cpu())
-    err = (torch.cat(mels) - torch.from_numpy(g["mel_out"])).abs().max().item()
+    # (the 24 kHz demo config's 20-iteration PNDM overshoots the mel range by orders of magnitude with random-init weights,
+    #  in the reference itself: its error is taken relative to the reference's own range)
+    scale = max(1.0, float(np.abs(g["mel_out"]).max()) / 5.0)
+    err = (torch.cat(mels) - torch.from_numpy(g["mel_out"])).abs().max().item() / scale
     assert err < tol, err
 
 

@@ -151,3 +151,36 @@ def test_product_sources_never_import_the_oracle():
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert not re.search(r"^\s*(import|from)\s+(dsvc_oracle|refshim|oracle)\b", src, re.M), f
                 assert "/root/reference" not in src, f
+
+
+# ------------------------------------------------------------------------------------------------
+# slicer (host-side integer work in front of the path: bit-exact bar)
+def _slicer_kats():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "slicer_kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_slicer_indices_bit_exact_vs_reference(i):
+    from diffsvc_amd.slicer import Slicer
+    kat = _slicer_kats()[i]
+    case = kat["case"]
+    audio = synth.slicer_audio(case)
+    assert audio.shape[0] == kat["n_samples"]
+    got = Slicer(sr=case["sr"], **case["args"]).slice(audio)
+    assert got == kat["chunks"]
+
+
+def test_slicer_chunks_tile_the_signal_and_reject_bad_windows():
+    from diffsvc_amd.slicer import Slicer, cut_samples, chunks_of
+    audio = synth.slicer_audio(synth.SLICER_CASES[3])
+    chunks = cut_samples(np.stack([audio, audio]), 22050, db_thresh=-40)
+    spans = [tuple(int(x) for x in v["split_time"].split(",")) for v in chunks.values()]
+    assert spans[0][0] == 0 and spans[-1][1] == audio.shape[0]
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert sum(len(x) for _, x in chunks_of(chunks, audio)) == audio.shape[0]
+    with pytest.raises(ValueError):
+        Slicer(sr=22050, min_length=100, win_l=300)
+    with pytest.raises(ValueError):
+        Slicer(sr=22050, win_s=20, max_silence_kept=10)

@@ -9,7 +9,7 @@ import dsvc_oracle as O
 from util import hp_for, load_golden, oracle_sample
 
 
-@pytest.mark.parametrize("name", ["diffnet_tiny", "diffnet_44k"])
+@pytest.mark.parametrize("name", ["diffnet_tiny", "diffnet_44k", "diffnet_24k"])
 def test_diffnet_forward_matches_reference(name):
     g = load_golden(name)
     hp = hp_for(name)
@@ -21,7 +21,8 @@ def test_diffnet_forward_matches_reference(name):
     assert err < 2e-5, err          # fp32 summation-order noise only
 
 
-@pytest.mark.parametrize("name", ["ddpm_tiny", "plms_tiny_s10", "plms_tiny_s5", "ddpm_44k_k20", "plms_44k_k100_s20"])
+@pytest.mark.parametrize("name", ["ddpm_tiny", "plms_tiny_s10", "plms_tiny_s5", "ddpm_44k_k20", "plms_44k_k100_s20",
+                                  "plms_24k_s50", "ddpm_24k_k30"])
 def test_sampler_matches_reference(name):
     g = load_golden(name)
     hp = dict(hp_for(name), K_step=int(g["K_step"]))
@@ -31,7 +32,10 @@ def test_sampler_matches_reference(name):
     assert np.array_equal(r["pitch"].numpy()[..., None], g["pitch"])                      # index work: bit-exact
     assert np.array_equal(r["f0_denorm"].numpy(), g["f0_denorm"])
     assert np.abs(r["cond"].numpy() - g["decoder_inp"]).max() == 0.0
-    err = np.abs(r["mel_out"].numpy() - g["mel_out"]).max()
+    # random-init weights make the 20-iteration PNDM of the 24 kHz demo config (BASELINE configs[0]) overshoot the mel
+    # range by orders of magnitude in the reference itself: compare relative to the reference's own range there
+    scale = max(1.0, float(np.abs(g["mel_out"]).max()) / 5.0)
+    err = np.abs(r["mel_out"].numpy() - g["mel_out"]).max() / scale
     assert err < 5e-4, err
 
 

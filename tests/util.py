@@ -19,6 +19,8 @@ def load_golden(name):
 def hp_for(name):
     if "tiny" in name:
         return synth.tiny_hparams()
+    if "24k" in name:
+        return dict(synth.HPARAMS_24K)
     return dict(synth.HPARAMS_44K)
 
 
