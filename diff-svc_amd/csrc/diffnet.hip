@@ -145,6 +145,10 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
     }
     const int tiles = rows_alloc / 32, passes = ceil_div(a.m_tiles, 4);
     int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
+    // at most one workgroup per CU (a single 10 s clip): a lone wave per SIMD issues its loads, LDS reads and MFMAs one after
+    // the other (~85 cycles per k-step measured), so the tile's K loop is split over three waves that reduce through LDS
+    static const int ksplit = getenv("DSVC_TG_KS") ? atoi(getenv("DSVC_TG_KS")) : 3;       // tuning knob (1 = off)
+    if (ms == passes && tiles * passes <= 256 && ksplit == 3) return tgemm_launch<1, 4, 3, KG, NW, Epi, 1, 3>(a, e, rows_alloc, ms, st);
     return tgemm_launch<1, 4, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
 }
 
@@ -484,7 +488,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         TGemmArgs a{};
         a.x = x; a.cin = cin_pad; a.taps = taps; a.dil = dil; a.w = tp.w.as<_Float16>(); a.m_tiles = tp.m_tiles;
         a.w_planes = tp.planes; a.variant_halfs = (long long)tp.variant_halfs; a.n_variants = tp.n_variants;
-        a.step_ptr = step.ptr; a.step_off = step.off;
+        a.step_ptr = step.ptr; a.step_off = step.off; a.clip_rows = Tp;
         return a;
     };
     const int stream_big = rows_alloc >= 6144 ? 1 : 0;   // (non-temporal residual/skip traffic measured neutral: 2.41 vs 2.42 ms/step)
@@ -918,7 +922,7 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
                 a.x = d->gh.as<_Float16>(); a.cin = d->Cp; a.taps = 1; a.dil = 1;
                 a.w = d->out_t[l].w.as<_Float16>(); a.m_tiles = d->out_t[l].m_tiles; a.w_planes = d->out_t[l].planes;
                 a.variant_halfs = (long long)d->out_t[l].variant_halfs; a.n_variants = d->out_t[l].n_variants;
-                a.step_ptr = s->step_dev.as<int>(); a.step_off = 0;
+                a.step_ptr = s->step_dev.as<int>(); a.step_off = 0; a.clip_rows = d->Tp;
                 TEpiResSkip::Args e{d->xres.as<float>(), last ? nullptr : d->xh_row0(), d->skip.as<float>(), last ? d->skiph.as<_Float16>() : nullptr,
                                     d->out_t[l].bias.as<float>(), last ? nullptr : d->film.as<float>() + (size_t)(l + 1) * C, L * C,
                                     StepRef{s->step_dev.as<int>(), 0, 0}, C, d->Cp, l == 0 ? 1 : 0, d->rowmap(), d->rows_alloc >= 6144 ? 1 : 0};
@@ -928,7 +932,7 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
                 a.x = d->xh_row0(); a.cin = d->Cp; a.taps = 3; a.dil = 1 << (l % d->cfg.dilation_cycle);
                 a.w = d->dil_t[l].w.as<_Float16>(); a.m_tiles = d->dil_t[l].m_tiles; a.w_planes = d->dil_t[l].planes;
                 a.variant_halfs = (long long)d->dil_t[l].variant_halfs; a.n_variants = d->dil_t[l].n_variants;
-                a.step_ptr = s->step_dev.as<int>(); a.step_off = 0;
+                a.step_ptr = s->step_dev.as<int>(); a.step_off = 0; a.clip_rows = d->Tp;
                 TEpiGate::Args e{d->cproj.as<float>() + (size_t)l * d->rows_alloc * 2 * C, d->gh.as<_Float16>(), C, d->Cp};
                 DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, d->dil_t[l].planes, d->rows_alloc, st));
             } else {

@@ -27,7 +27,11 @@
 //     average to w), which keeps 1 MFMA per product inside the 1e-3 bar.
 //   * `MSPLIT` output-channel passes can be spread over blockIdx.y for small batches (B = 1) to fill the chip.
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -51,10 +55,13 @@ struct TGemmArgs {
     int n_variants;         // >= 1
     const int* step_ptr;    // device int: current diffusion step (variant = (step - step_off) % n_variants); may be null
     int step_off;
+    int clip_rows;          // rows per clip (clip stride) or 0: the K-loop stagger is keyed on a tile's position inside its clip, so a
+                            // clip computes bit-identically alone and inside a batch
+    unsigned long long* stamps;   // profiling: per-wave phase time stamps (s_memrealtime, 100 MHz), 16 per wave; null in production
     int dbg;                // ablation knobs for profiling (env DSVC_TG_DEBUG): 1 = no acc-init loads, 2 = no epilogue,
                             // 4 = no tile DMA, 8 = no MFMA main loop, 16 = no wave priority split, 32 = all tiles stream
                             // tile 0's weights (L2-hot), 64 = no pass rotation, 128 = next-tile init loads issued at the
-                            // end of the pass (both waves of a SIMD together) instead of staggered inside it.  0 in production.
+                            // end of the pass (both waves of a SIMD together) instead of staggered inside it, 1024 = no K-loop stagger.  0 in production.
 };
 
 // the row <-> channel permutation inside a 32-row output tile that makes a lane's 16 accumulator registers hold 16
@@ -64,16 +71,26 @@ __host__ __device__ inline int trow_to_ch16(int i) { return 16 * ((i >> 2) & 1) 
 // row i (< 16) = 4h + 8j + e  <->  channel 8h + 4j + e
 __host__ __device__ inline int trow_to_ch8(int i) { return 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3); }
 
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1>
-__global__ void __launch_bounds__(64 * WAVES, MINW) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+// KS > 1 (small batches only, one output tile per wave): the K loop of a tile is split over KS waves, which reduce through
+// LDS before the epilogue -- a lone wave per SIMD issues its loads, LDS reads and MFMAs strictly one after the other
+// (measured ~85 cycles per k-step), so at B = 1 the way to shorten a kernel is more waves per tile, not a better loop.
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1>
+__global__ void __launch_bounds__(64 * WAVES * KS, MINW) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     constexpr int TN = 32 * NT_N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = KS > 1 ? wave_all % WAVES : wave_all;      // which output tile of the pass
+    const int ks = KS > 1 ? wave_all / WAVES : 0;               // which slice of the K loop
     const int row0 = blockIdx.x * TN;
+    auto stamp = [&](int i) {
+        if (a.stamps && lane == 0)
+            a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (WAVES * KS) + wave_all) * 16 + i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
     const int halo = (a.taps >> 1) * a.dil;
     const int rows_lds = TN + 2 * halo;
     const int chunks = a.cin >> 3;                       // 16-B chunks per row
@@ -82,11 +99,11 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     // ---- stage the time tile: HBM/L2 -> LDS by DMA, swizzled on the source side ----
     {
         const int total = rows_lds * chunks;             // 16-B slots
-        const int dq = (WAVES * 64) / chunks, dr = (WAVES * 64) - dq * chunks;
-        int slot = wave * 64 + lane;
+        const int dq = (WAVES * KS * 64) / chunks, dr = (WAVES * KS * 64) - dq * chunks;
+        int slot = wave_all * 64 + lane;
         int r = slot / chunks, c = slot - r * chunks;
         const _Float16* xrow0 = a.x + (long long)(row0 - halo) * a.cin;
-        for (int it = wave; it * 64 < total && !(a.dbg & 4); it += WAVES) {
+        for (int it = wave_all; it * 64 < total && !(a.dbg & 4); it += WAVES * KS) {
             const int rc = r < rows_lds ? r : rows_lds - 1;            // lanes past the tile re-read its last row
             const _Float16* src = xrow0 + (long long)rc * a.cin + ((c ^ (rc & a.swz)) << 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -96,12 +113,14 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         }
     }
 
+    stamp(12);
     int variant = 0;
     if (a.n_variants > 1 && a.step_ptr) {
         const int st = *a.step_ptr - a.step_off;
         variant = st % a.n_variants;
         if (variant < 0) variant += a.n_variants;
     }
+    if (a.stamps) { asm volatile("" :: "s"(variant)); stamp(13); }
     constexpr int GROUP_HALFS = KG * NW * TFRAG_HALFS;   // one ring refill = KG k16-steps of one output tile
     const _Float16* wbase = a.w + (long long)variant * a.variant_halfs + lane * 8;
     const int gpt = (a.cin >> 4) / KG;                   // groups per tap
@@ -196,10 +215,80 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
             if (tile_of(pi) < a.m_tiles) return pi;
         return -1;
     };
+    // ... and the K loop of a tile starts at a per-workgroup group offset (and wraps): the workgroups of different frame
+    // tiles stream the SAME fragments, and started together they all wait on the same few KB at any moment -- at B = 1
+    // the unique bytes in flight are then 24 tiles x 16 KB and the 1.8 MB weight variant (HBM-cold under time-dithering)
+    // arrives at latency x 0.4 MB instead of at bandwidth.  Staggered starts multiply the unique bytes in flight by G.
+    const unsigned tiles_pc = (a.clip_rows > 0 && a.clip_rows % TN == 0) ? (unsigned)(a.clip_rows / TN) : 0u;
+    const int rk = (a.dbg & 1024) ? 0 : (int)((tiles_pc ? blockIdx.x % tiles_pc : blockIdx.x) % (unsigned)G);
+    auto gmap = [&](int g) { const int x = g + rk; return x >= G ? x - G : x; };
+    if constexpr (KS > 1) {
+        // ---- split-K flow: one tile per wave triple, gridDim.y == passes (host-checked), reduction through LDS ----
+        const int mt = blockIdx.y * WAVES + wave;
+        const bool active = mt < a.m_tiles;
+        const int g0 = ks * G / KS, n = (ks + 1) * G / KS - g0;
+        const _Float16* wp = wbase + (long long)(active ? mt : 0) * tile_halfs;
+        if (active && n > 0) load_group(ringA, wp + (long long)gmap(g0) * GROUP_HALFS);
+        stamp(14);
+        if (active && ks == 0 && !(a.dbg & 1)) {
+            epi.init(ea, mt, row0, lane, acc);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+        }
+        stamp(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(2);
+        __syncthreads();
+        stamp(3);
+        if (active && !(a.dbg & 8)) {
+            int i = 0;
+            for (; i + 1 < n; i += 2) {
+                load_group(ringB, wp + (long long)gmap(g0 + i + 1) * GROUP_HALFS);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_group(ringA, acc, gmap(g0 + i));
+                const int in = i + 2 < n ? i + 2 : n - 1;
+                load_group(ringA, wp + (long long)gmap(g0 + in) * GROUP_HALFS);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_group(ringB, acc, gmap(g0 + i + 1));
+            }
+            if (i < n) compute_group(ringA, acc, gmap(g0 + i));
+        }
+        stamp(9);
+        // partial sums of slices 1 .. KS-1 -> LDS [slice][tile wave][N-tile][quad][lane] (16 B per lane: conflict-free)
+        f32x4* red = reinterpret_cast<f32x4*>(smem + (((size_t)rows_lds * row_bytes + 1023) & ~(size_t)1023));
+        if (ks > 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    red[((((ks - 1) * WAVES + wave) * NT_N + nt) * 4 + q) * 64 + lane] =
+                        f32x4{acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+        }
+        __syncthreads();
+        if (ks == 0 && active) {
+#pragma unroll
+            for (int s2 = 1; s2 < KS; ++s2)
+#pragma unroll
+                for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = red[((((s2 - 1) * WAVES + wave) * NT_N + nt) * 4 + q) * 64 + lane];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[nt][4 * q + i] += v[i];
+                    }
+            if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
+            if (a.stamps) { stamp(10); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(11); }
+        } else if (a.stamps) { stamp(10); stamp(11); }
+        return;
+    }
     int pi = next_active(blockIdx.y);
     int mt = pi >= 0 ? tile_of(pi) : 0;
     if (pi >= 0) {
-        load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt) * tile_halfs);
+        load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt) * tile_halfs + (long long)gmap(0) * GROUP_HALFS);
+        stamp(14);
         if (a.dbg & 1) {
 #pragma unroll
             for (int nt = 0; nt < NT_N; ++nt)
@@ -209,8 +298,11 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
             epi.init(ea, mt, row0, lane, acc);
         }
     }
+    stamp(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA'd tile (and the first operands) have landed
+    stamp(2);
     __syncthreads();
+    stamp(3);
 
     // The accumulator-init loads of a wave's NEXT tile are issued in the middle of its current tile's main loop: they are a
     // burst from HBM (the conditioner projection / the residual stream), vmcnt is in-order, so whenever they are issued the
@@ -236,23 +328,36 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         };
         int g = ((a.dbg & 8) || ((a.dbg & 256) && wave >= WAVES / 2)) ? G : 0;      // dbg 256: half the waves skip their MFMAs
         for (; g + 1 < G; g += 2) {     // straight-line body (no branch around the prefetches): IR-level sinking cannot move one below its group
-            load_group(ringB, wp + (long long)(g + 1) * GROUP_HALFS);          // ringB <- group g+1, under group g's MFMAs
+            if (a.dbg & 2048) {                                                // profiling: no weight stream inside the loop
+                compute_group(ringA, acc, gmap(g));
+                compute_group(ringA, acc, gmap(g + 1));
+                if (a.stamps && g < 8) stamp(4 + (g >> 1));
+                continue;
+            }
+            load_group(ringB, wp + (long long)gmap(g + 1) * GROUP_HALFS);      // ringB <- group g+1, under group g's MFMAs
             if (g == g_issue && pn >= 0 && !(a.dbg & 128)) { issue_next_init(); nxt_issued = true; }
             __builtin_amdgcn_sched_barrier(0);
-            compute_group(ringA, acc, g);
+            compute_group(ringA, acc, gmap(g));
             const int gn = g + 2 < G ? g + 2 : G - 1;
-            load_group(ringA, wp + (long long)gn * GROUP_HALFS);               // ringA <- group g+2, under group g+1's MFMAs
+            load_group(ringA, wp + (long long)gmap(gn) * GROUP_HALFS);         // ringA <- group g+2, under group g+1's MFMAs
             __builtin_amdgcn_sched_barrier(0);
-            compute_group(ringB, acc, g + 1);
+            compute_group(ringB, acc, gmap(g + 1));
+            if (a.stamps && g < 8) stamp(4 + (g >> 1));
         }
-        if (g < G) compute_group(ringA, acc, g);                               // odd group count: the tail group
+        if (g < G) compute_group(ringA, acc, gmap(g));                         // odd group count: the tail group
+        stamp(9);
         // the next tile's weight stream starts before this tile's epilogue, so its latency sits under the epilogue
         if (pn >= 0) {
-            load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt_n) * tile_halfs);
+            load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt_n) * tile_halfs + (long long)gmap(0) * GROUP_HALFS);
             if (!nxt_issued) issue_next_init();                                // short K loops (or dbg 128): issue here instead
         }
         if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
         else asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT_N - 1][15]));
+        if (a.stamps) {
+            stamp(10);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(11);
+        }
         if (pn < 0) break;
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) acc[nt] = nxt[nt];
@@ -273,8 +378,31 @@ inline int tgemm_swizzle_mask(int cin) {
     return m;
 }
 
+// profiling aid (env DSVC_TG_STAMPS=<path prefix>): the first `slots` tgemm launches of the process record 16 s_memrealtime
+// stamps per wave (see stamp() in the kernel); when the last slot is used the log is written to <prefix>.bin (u64) and
+// <prefix>.meta (one line per launch: kernel, grid x, grid y, waves).  tools/stamps_report.py reads it.
+struct TStampLog {
+    unsigned long long* dev = nullptr;
+    int slots = 172, used = 0;
+    size_t per_slot = (size_t)2048 * 16;              // waves per launch (upper bound) x stamps
+    std::string meta;
+    bool done = false;
+};
+inline TStampLog& tstamp_log() { static TStampLog l; return l; }
+inline void tstamp_dump(const char* prefix) {
+    TStampLog& L = tstamp_log();
+    if (L.done || !L.dev) return;
+    L.done = true;
+    if (hipDeviceSynchronize() != hipSuccess) return;
+    std::vector<unsigned long long> host((size_t)L.used * L.per_slot);
+    if (hipMemcpy(host.data(), L.dev, host.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    std::string p(prefix);
+    if (FILE* f = fopen((p + ".bin").c_str(), "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+    if (FILE* f = fopen((p + ".meta").c_str(), "w")) { fputs(L.meta.c_str(), f); fclose(f); }
+}
+
 // n_rows must be a multiple of 32*NT_N; m_split = number of blockIdx.y slices the output-channel passes are dealt over
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1>
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1>
 inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, int m_split, hipStream_t stream) {
     if (a.cin % (16 * KG) != 0) return fail(DSVC_EINVAL, "tgemm: cin %d not a multiple of %d", a.cin, 16 * KG);
     if (n_rows % (32 * NT_N) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N);
@@ -282,8 +410,8 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
     a.swz = tgemm_swizzle_mask(a.cin);
     const char* dbg_s = getenv("DSVC_TG_DEBUG");           // profiling ablations only; results are WRONG when set
     a.dbg = dbg_s ? atoi(dbg_s) : 0;
-    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED>;
-    const size_t smem = tgemm_smem<NT_N>(a.taps, a.dil, a.cin);
+    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS>;
+    const size_t smem = tgemm_smem<NT_N>(a.taps, a.dil, a.cin) + (size_t)(KS - 1) * WAVES * NT_N * 4096;
     if (smem > 160 * 1024) return fail(DSVC_EINVAL, "tgemm: %zu B of LDS requested", smem);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {
@@ -293,8 +421,26 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
     const int passes = ceil_div(a.m_tiles, WAVES);
     if (m_split < 1) m_split = 1;
     if (m_split > passes) m_split = passes;
-    hipLaunchKernelGGL(kern, dim3(n_rows / (32 * NT_N), m_split), dim3(64 * WAVES), smem, stream, a, ea);
+    if (KS > 1 && m_split != passes) return fail(DSVC_EINVAL, "tgemm: the split-K tiling needs one output tile per wave (m_split %d, passes %d)", m_split, passes);
+    static const char* stamp_path = getenv("DSVC_TG_STAMPS");
+    if (stamp_path) {
+        TStampLog& L = tstamp_log();
+        const size_t waves = (size_t)(n_rows / (32 * NT_N)) * m_split * WAVES * KS;
+        if (!L.dev && !L.done) {
+            DSVC_HIP(hipMalloc(&L.dev, (size_t)L.slots * L.per_slot * 8));
+            DSVC_HIP(hipMemset(L.dev, 0, (size_t)L.slots * L.per_slot * 8));
+        }
+        if (!L.done && L.used < L.slots && waves * 16 <= L.per_slot) {
+            a.stamps = L.dev + (size_t)L.used * L.per_slot;
+            char line[512];
+            snprintf(line, sizeof line, "%s|%d|%d|%d\n", __PRETTY_FUNCTION__, n_rows / (32 * NT_N), m_split, WAVES * KS);
+            L.meta += line;
+            L.used++;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(n_rows / (32 * NT_N), m_split), dim3(64 * WAVES * KS), smem, stream, a, ea);
     DSVC_HIP(hipGetLastError());
+    if (stamp_path && tstamp_log().used == tstamp_log().slots) tstamp_dump(stamp_path);
     return DSVC_OK;
 }
 

@@ -135,7 +135,8 @@ def test_vocoder_plugin_contract(tmp_path):
 def test_full_size_clip_properties():
     """BASELINE clip size (T=861, 44.1 kHz architecture), 24 DDPM steps -- properties that need no oracle run:
     (1) a chain split at an arbitrary step composes exactly (noise is keyed by (seed, clip, step));
-    (2) a batch of clips equals the per-clip runs bit for bit; (3) graph replay == eager; (4) output is finite
+    (2) a batch of clips equals the per-clip runs up to fp32 summation order (a single clip uses the split-K tiling, a
+    batch does not; tests/test_gpu_diffnet.py::test_batch_equals_per_clip checks bit-equality under one tiling); (3) graph replay == eager; (4) output is finite
     and inside the denormalised range [spec_min, spec_max] (x0 is clamped to [-1, 1] at t=0)."""
     from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
     hp = dict(synth.HPARAMS_44K)
@@ -151,7 +152,7 @@ def test_full_size_clip_properties():
     rest, xr = smp.sample(cond, 9, x_init=xp, seed=5, first_clip=0, use_graph=False, return_x=True)
     assert torch.equal(xr, xf) and torch.equal(rest, full)
     one = smp.sample(cond[1:2], K, seed=5, first_clip=1, use_graph=False)
-    assert torch.equal(one[0], full[1])
+    assert (one[0] - full[1]).abs().max().item() < 2e-4, (one[0] - full[1]).abs().max().item()
     graph = smp.sample(cond, K, seed=5, first_clip=0, use_graph=True)
     assert torch.equal(graph, full)
     assert torch.isfinite(full).all()
