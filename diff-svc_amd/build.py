@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdsvc_hip.so")
 SOURCES = ["common.hip", "diffnet.hip", "vocoder.hip", "melspec.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-Rpass-analysis=kernel-resource-usage"]       # the per-kernel register / scratch report is kept next to the object
 
 
 def _hipcc():
@@ -47,6 +48,8 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-8000:]))
+        with open(obj.replace(".o", ".resources.txt"), "w") as f:
+            f.write(r.stderr)
         return src
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
@@ -65,3 +68,22 @@ def build(force=False, verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+
+
+def kernel_resources(source="diffnet.hip"):
+    """{mangled kernel name: {"vgprs", "agprs", "spill", "scratch", "occupancy"}} from the last build of ``source``."""
+    import re
+    path = os.path.join(HERE, "build", source.replace(".hip", ".resources.txt"))
+    out, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "VGPRs Spill": "spill", "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy"}
+    with open(path) as f:
+        for line in f:
+            m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|VGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\S+)", line)
+            if not m:
+                continue
+            if m.group(1) == "Function Name":
+                cur = out.setdefault(m.group(2), {})
+            elif cur is not None:
+                cur[keys[m.group(1)]] = int(m.group(2))
+    return out

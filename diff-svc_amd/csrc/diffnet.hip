@@ -145,10 +145,13 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
     }
     const int tiles = rows_alloc / 32, passes = ceil_div(a.m_tiles, 4);
     int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
-    // at most one workgroup per CU (a single 10 s clip): a lone wave per SIMD issues its loads, LDS reads and MFMAs one after
-    // the other (~85 cycles per k-step measured), so the tile's K loop is split over three waves that reduce through LDS
+    // a single 10 s clip (fewer workgroups than CUs): the kernels are bound by what ONE CU can pull through its vector-memory
+    // path (every wave streams its own weights: ~40 B/clk measured against 64 peak) and by in-order issue of a lone wave per
+    // SIMD (~85 cycles per k-step).  So the work is cut finer: 3 output tiles per workgroup (224 workgroups for the layer
+    // kernels instead of 168) and each tile's K loop split over 3 waves that reduce through LDS (9 waves per workgroup).
     static const int ksplit = getenv("DSVC_TG_KS") ? atoi(getenv("DSVC_TG_KS")) : 3;       // tuning knob (1 = off)
-    if (ms == passes && tiles * passes <= 256 && ksplit == 3) return tgemm_launch<1, 4, 3, KG, NW, Epi, 1, 3>(a, e, rows_alloc, ms, st);
+    if (ksplit == 3 && tiles * ceil_div(a.m_tiles, 3) <= 256)
+        return tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 3>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st);
     return tgemm_launch<1, 4, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
 }
 

@@ -86,8 +86,10 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     const int wave = KS > 1 ? wave_all % WAVES : wave_all;      // which output tile of the pass
     const int ks = KS > 1 ? wave_all / WAVES : 0;               // which slice of the K loop
     const int row0 = blockIdx.x * TN;
+    constexpr bool STAMPS = NT_N == 1;                    // the phase stamps exist only in the small-batch kernels: in the 128-frame
+                                                          // tiling their few SGPRs/VGPRs tip the register allocation into spills
     auto stamp = [&](int i) {
-        if (a.stamps && lane == 0)
+        if constexpr (STAMPS) if (a.stamps && lane == 0)
             a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (WAVES * KS) + wave_all) * 16 + i] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
@@ -120,7 +122,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         variant = st % a.n_variants;
         if (variant < 0) variant += a.n_variants;
     }
-    if (a.stamps) { asm volatile("" :: "s"(variant)); stamp(13); }
+    if constexpr (STAMPS) if (a.stamps) { asm volatile("" :: "s"(variant)); stamp(13); }
     constexpr int GROUP_HALFS = KG * NW * TFRAG_HALFS;   // one ring refill = KG k16-steps of one output tile
     const _Float16* wbase = a.w + (long long)variant * a.variant_halfs + lane * 8;
     const int gpt = (a.cin >> 4) / KG;                   // groups per tap
@@ -219,9 +221,12 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     // tiles stream the SAME fragments, and started together they all wait on the same few KB at any moment -- at B = 1
     // the unique bytes in flight are then 24 tiles x 16 KB and the 1.8 MB weight variant (HBM-cold under time-dithering)
     // arrives at latency x 0.4 MB instead of at bandwidth.  Staggered starts multiply the unique bytes in flight by G.
+    // (small tilings only: in the 128-frame tiling the stream is bandwidth-, not latency-bound -- measured neutral -- and the
+    //  extra index arithmetic tips its 256-register allocation into spills)
+    constexpr bool STAGGER = NT_N < 4;
     const unsigned tiles_pc = (a.clip_rows > 0 && a.clip_rows % TN == 0) ? (unsigned)(a.clip_rows / TN) : 0u;
-    const int rk = (a.dbg & 1024) ? 0 : (int)((tiles_pc ? blockIdx.x % tiles_pc : blockIdx.x) % (unsigned)G);
-    auto gmap = [&](int g) { const int x = g + rk; return x >= G ? x - G : x; };
+    const int rk = (!STAGGER || (a.dbg & 1024)) ? 0 : (int)((tiles_pc ? blockIdx.x % tiles_pc : blockIdx.x) % (unsigned)G);
+    auto gmap = [&](int g) { if constexpr (!STAGGER) return g; const int x = g + rk; return x >= G ? x - G : x; };
     if constexpr (KS > 1) {
         // ---- split-K flow: one tile per wave triple, gridDim.y == passes (host-checked), reduction through LDS ----
         const int mt = blockIdx.y * WAVES + wave;
@@ -229,6 +234,9 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         const int g0 = ks * G / KS, n = (ks + 1) * G / KS - g0;
         const _Float16* wp = wbase + (long long)(active ? mt : 0) * tile_halfs;
         if (active && n > 0) load_group(ringA, wp + (long long)gmap(g0) * GROUP_HALFS);
+        // the second group is put in flight before the barrier too: a ring refill issued inside the loop is waited for at full
+        // L2/HBM latency, there is no other work in a 3-group slice to hide it behind
+        if (active && n > 1) load_group(ringB, wp + (long long)gmap(g0 + 1) * GROUP_HALFS);
         stamp(14);
         if (active && ks == 0 && !(a.dbg & 1)) {
             epi.init(ea, mt, row0, lane, acc);
@@ -246,11 +254,10 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         if (active && !(a.dbg & 8)) {
             int i = 0;
             for (; i + 1 < n; i += 2) {
-                load_group(ringB, wp + (long long)gmap(g0 + i + 1) * GROUP_HALFS);
+                if (i > 0) load_group(ringB, wp + (long long)gmap(g0 + i + 1) * GROUP_HALFS);
                 __builtin_amdgcn_sched_barrier(0);
                 compute_group(ringA, acc, gmap(g0 + i));
-                const int in = i + 2 < n ? i + 2 : n - 1;
-                load_group(ringA, wp + (long long)gmap(g0 + in) * GROUP_HALFS);
+                if (i + 2 < n) load_group(ringA, wp + (long long)gmap(g0 + i + 2) * GROUP_HALFS);
                 __builtin_amdgcn_sched_barrier(0);
                 compute_group(ringB, acc, gmap(g0 + i + 1));
             }
@@ -280,8 +287,8 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
                         for (int i = 0; i < 4; ++i) acc[nt][4 * q + i] += v[i];
                     }
             if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
-            if (a.stamps) { stamp(10); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(11); }
-        } else if (a.stamps) { stamp(10); stamp(11); }
+            if constexpr (STAMPS) if (a.stamps) { stamp(10); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(11); }
+        } else if constexpr (STAMPS) { if (a.stamps) { stamp(10); stamp(11); } }
         return;
     }
     int pi = next_active(blockIdx.y);
@@ -328,10 +335,10 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         };
         int g = ((a.dbg & 8) || ((a.dbg & 256) && wave >= WAVES / 2)) ? G : 0;      // dbg 256: half the waves skip their MFMAs
         for (; g + 1 < G; g += 2) {     // straight-line body (no branch around the prefetches): IR-level sinking cannot move one below its group
-            if (a.dbg & 2048) {                                                // profiling: no weight stream inside the loop
+            if constexpr (STAMPS) if (a.dbg & 2048) {                         // profiling: no weight stream inside the loop
                 compute_group(ringA, acc, gmap(g));
                 compute_group(ringA, acc, gmap(g + 1));
-                if (a.stamps && g < 8) stamp(4 + (g >> 1));
+                if constexpr (STAMPS) if (a.stamps && g < 8) stamp(4 + (g >> 1));
                 continue;
             }
             load_group(ringB, wp + (long long)gmap(g + 1) * GROUP_HALFS);      // ringB <- group g+1, under group g's MFMAs
@@ -342,7 +349,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
             load_group(ringA, wp + (long long)gmap(gn) * GROUP_HALFS);         // ringA <- group g+2, under group g+1's MFMAs
             __builtin_amdgcn_sched_barrier(0);
             compute_group(ringB, acc, gmap(g + 1));
-            if (a.stamps && g < 8) stamp(4 + (g >> 1));
+            if constexpr (STAMPS) if (a.stamps && g < 8) stamp(4 + (g >> 1));
         }
         if (g < G) compute_group(ringA, acc, gmap(g));                         // odd group count: the tail group
         stamp(9);
@@ -353,7 +360,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         }
         if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
         else asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT_N - 1][15]));
-        if (a.stamps) {
+        if constexpr (STAMPS) if (a.stamps) {
             stamp(10);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(11);

@@ -33,3 +33,20 @@ def test_error_convention_without_gpu():
     assert rc != 0 and b"null" in lib.dsvc_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(rc)
+
+
+def test_hot_kernels_do_not_spill():
+    """Register budget guard (CPU: read from the compiler's resource report of the last build).  The two per-layer kernels of
+    the 128-frame tiling sit at the 256-VGPR limit of two waves per SIMD: an innocent edit (a profiling hook, an index
+    computation) tips them into scratch spills and costs 12 % of the batched throughput without failing any parity test."""
+    from diffsvc_amd import build
+    build.build(verbose=False)
+    res = build.kernel_resources("diffnet.hip")
+    hot = {k: v for k, v in res.items() if "tgemm_kernelILi4ELi8ELi2ELi8ELi1E" in k and k.endswith("ELi1ELi1EEEvNS_9TGemmArgsENT4_4ArgsE")}
+    gate = [v for k, v in hot.items() if "TEpiGate" in k]
+    out = [v for k, v in hot.items() if "TEpiResSkip" in k]
+    assert len(gate) == 1 and len(out) == 1, sorted(hot)
+    assert gate[0]["spill"] == 0 and gate[0]["scratch"] == 0, gate
+    assert out[0]["spill"] <= 2, out
+    small = [v for k, v in res.items() if "tgemm_kernelILi1ELi3ELi3E" in k]
+    assert small and all(v["spill"] == 0 for v in small), small
