@@ -227,6 +227,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     const unsigned tiles_pc = (a.clip_rows > 0 && a.clip_rows % TN == 0) ? (unsigned)(a.clip_rows / TN) : 0u;
     const int rk = (!STAGGER || (a.dbg & 1024)) ? 0 : (int)((tiles_pc ? blockIdx.x % tiles_pc : blockIdx.x) % (unsigned)G);
     auto gmap = [&](int g) { if constexpr (!STAGGER) return g; const int x = g + rk; return x >= G ? x - G : x; };
+    auto wgrp = [&](int g) { return (a.dbg & 4096) ? 0 : gmap(g); };    // dbg 4096: the ring re-reads group 0 (L1-hot weight stream)
     if constexpr (KS > 1) {
         // ---- split-K flow: one tile per wave triple, gridDim.y == passes (host-checked), reduction through LDS ----
         const int mt = blockIdx.y * WAVES + wave;
@@ -341,12 +342,12 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
                 if constexpr (STAMPS) if (a.stamps && g < 8) stamp(4 + (g >> 1));
                 continue;
             }
-            load_group(ringB, wp + (long long)gmap(g + 1) * GROUP_HALFS);      // ringB <- group g+1, under group g's MFMAs
+            load_group(ringB, wp + (long long)wgrp(g + 1) * GROUP_HALFS);      // ringB <- group g+1, under group g's MFMAs
             if (g == g_issue && pn >= 0 && !(a.dbg & 128)) { issue_next_init(); nxt_issued = true; }
             __builtin_amdgcn_sched_barrier(0);
             compute_group(ringA, acc, gmap(g));
             const int gn = g + 2 < G ? g + 2 : G - 1;
-            load_group(ringA, wp + (long long)gmap(gn) * GROUP_HALFS);         // ringA <- group g+2, under group g+1's MFMAs
+            load_group(ringA, wp + (long long)wgrp(gn) * GROUP_HALFS);         // ringA <- group g+2, under group g+1's MFMAs
             __builtin_amdgcn_sched_barrier(0);
             compute_group(ringB, acc, gmap(g + 1));
             if constexpr (STAMPS) if (a.stamps && g < 8) stamp(4 + (g >> 1));
