@@ -100,6 +100,7 @@ def main():
                     help="launch the sampler steps eagerly (rocprofv3 --pmc segfaults on hipGraph replays on this stack)")
     args = ap.parse_args()
 
+    SHARE_DEVICE = os.environ.get("DSVC_BENCH_SHARE_DEVICE") == "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -107,8 +108,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if SHARE_DEVICE:        # launch-contract test on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device: the product path has no CPU fallback"
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -148,7 +153,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev)
+        tmax = torch.tensor([elapsed], device="cpu" if SHARE_DEVICE else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ok = bool(torch.isfinite(wav).all().item())

@@ -58,10 +58,13 @@ def gather_pcm(local_wav, clip_ids, n_clips, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return local_wav
+    dev = local_wav.device
+    if dist.get_backend(group) == "gloo" and local_wav.is_cuda:     # CPU test rigs: gloo gathers host tensors
+        local_wav = local_wav.cpu()
     out = [torch.empty_like(local_wav) for _ in range(world)]
     dist.all_gather(out, local_wav.contiguous(), group=group)
-    full = torch.empty(n_clips, local_wav.shape[1], dtype=local_wav.dtype, device=local_wav.device)
+    full = torch.empty(n_clips, local_wav.shape[1], dtype=local_wav.dtype, device=dev)
     for r in range(world):
         ids = shard_clips(n_clips, r, world)
-        full[ids] = out[r][:len(ids)]
+        full[ids] = out[r][:len(ids)].to(dev)
     return full

@@ -174,3 +174,22 @@ def test_full_size_vocoder_properties():
     short = voc.vocode(mel[:, :64].contiguous(), f0[:, :64].contiguous(), seed=1, first_clip=0)
     n = (64 - 24) * 512                                     # receptive field of the generator < 24 frames
     assert (short[0, :n] - wav[0, :n]).abs().max().item() < 1e-5
+
+
+def test_bench_launch_contract_two_ranks_share_the_device():
+    """The driver's N > 1 launch line (torch.distributed.run, one rank per GPU) exercised on a 1-GPU box: both ranks on
+    cuda:0, gloo instead of RCCL.  Checks rendezvous, clip sharding, the gather, the max-over-ranks clock and the JSON line."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, DSVC_BENCH_SHARE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--ddpm-steps", "20", "--no-cpu-baseline", "--no-batched"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["finite_output"] and d["value"] > 0
+    assert d["config"]["parallelism"].startswith("utterance-sharded x2")
