@@ -96,8 +96,16 @@ class SamplerHandle:
                use_graph=True, return_x=False):
         """cond [B,H,T] -> mel_out [B,T,M] (denormalised, masked).  See dsvc_sample_args."""
         _need_cuda(cond, x_init, mel2ph)
+        if cond.dim() != 3:
+            raise RuntimeError("cond must be [B, hidden, T], got %s" % (tuple(cond.shape),))
         B, H, T = cond.shape
         M = self.den.mel_bins
+        if H != self.den.hidden:
+            raise RuntimeError("cond has %d channels, the denoiser was built for hidden_size %d" % (H, self.den.hidden))
+        if x_init is not None and tuple(x_init.shape) != (B, 1, M, T):
+            raise RuntimeError("x_init must be [B,1,M,T] = %s, got %s" % ((B, 1, M, T), tuple(x_init.shape)))
+        if mel2ph is not None and tuple(mel2ph.shape) != (B, T):
+            raise RuntimeError("mel2ph must be [B,T] = %s, got %s" % ((B, T), tuple(mel2ph.shape)))
         cond = cond.contiguous().float()
         mel = torch.empty(B, T, M, device=cond.device, dtype=torch.float32)
         xo = torch.empty(B, 1, M, T, device=cond.device, dtype=torch.float32) if return_x else None

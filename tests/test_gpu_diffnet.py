@@ -187,3 +187,35 @@ def test_plain_f16_fails_the_bar_dither_is_needed():
     mel = smp.sample(r["cond_t"].cuda(), 1000, mel2ph=r["mel2ph"].cuda(), seed=2024, first_clip=0, use_graph=True)
     err = (mel.cpu() - r["mel_out"]).abs().max().item()
     assert 1e-3 < err < 5e-2, err
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 5), (3, 31), (2, 33), (5, 64), (1, 97)])
+def test_ragged_and_tiny_clip_lengths_vs_oracle(B, T):
+    """Edge sizes: a single frame, lengths around the 32-frame tile, an odd batch -- 12-step DDPM on the tiny architecture
+    against the oracle (gap rows between clips must behave as the convs' zero padding at every length)."""
+    hp = synth.tiny_hparams(K=12)
+    sd, den, smp = make_handles(hp, 4, "f16_x3")
+    clips = list(range(B))
+    n_units = max(1, T // 2)
+    r = oracle_sample(hp, sd, clips, T, n_units, 1, 31, 12)
+    _, m2p, _ = clip_batch(hp, clips, T, n_units)
+    for graph in (False, True):
+        mel = smp.sample(r["cond_t"].cuda(), 12, mel2ph=m2p.cuda(), seed=31, first_clip=0, use_graph=graph).cpu()
+        assert mel.shape == r["mel_out"].shape
+        err = (mel - r["mel_out"]).abs().max().item()
+        assert err < 1e-3, (B, T, graph, err)
+
+
+def test_sampler_rejects_bad_arguments():
+    """Error behaviour of the C ABI: codes, never a crash."""
+    hp = synth.tiny_hparams(K=12)
+    sd, den, smp = make_handles(hp, 4, "f16_x3")
+    cond = torch.zeros(1, hp["hidden_size"], 8, device="cuda")
+    with pytest.raises(RuntimeError):
+        smp.sample(cond, 13, seed=1)                    # more steps than the schedule has
+    with pytest.raises(RuntimeError):
+        smp.sample(cond, 0, seed=1)
+    with pytest.raises(RuntimeError):
+        smp.sample(cond.cpu(), 4, seed=1)               # host pointer
+    with pytest.raises(RuntimeError):
+        smp.sample(torch.zeros(1, hp["hidden_size"] + 1, 8, device="cuda"), 4, seed=1)
