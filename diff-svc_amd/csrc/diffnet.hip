@@ -216,12 +216,13 @@ struct dsvc_denoiser {
 
     enum Tail { TAIL_EPS = 0, TAIL_DDPM = 1 };
     // what the fused DDPM tail needs from the sampler (the epilogue-specific Args are built inside eval)
-    struct DdpmCtx { float* x; DdpmTables tab; unsigned long long seed; int clip0; };
+    struct DdpmCtx { float* x; DdpmTables tab; const unsigned long long* seedp; const int* clip0p; };
     // one denoiser evaluation on the frame-major state `x_fm` [rows][M]; `state_half_fresh`: the fp16 copy of the
     // state (tgemm path) is already up to date (the previous DDPM tail wrote it)
-    int eval(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st);
+    // host_step >= 0: the caller knows the diffusion step (mod the dither period) at launch time -> variants are passed by value
+    int eval(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step = -1);
     int eval_conv(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, hipStream_t st);
-    int eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st);
+    int eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step);
     int finalize_t();
 };
 
@@ -429,8 +430,8 @@ int dsvc_denoiser::prepare_cond(const float* cond_bht, int B, int T, hipStream_t
     return DSVC_OK;
 }
 
-int dsvc_denoiser::eval(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st) {
-    return tpath ? eval_t(x_fm, step, tail, ddpm, state_half_fresh, st) : eval_conv(x_fm, step, tail, ddpm, st);
+int dsvc_denoiser::eval(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step) {
+    return tpath ? eval_t(x_fm, step, tail, ddpm, state_half_fresh, st, host_step) : eval_conv(x_fm, step, tail, ddpm, st);
 }
 
 int dsvc_denoiser::eval_conv(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, hipStream_t st) {
@@ -473,7 +474,7 @@ int dsvc_denoiser::eval_conv(const float* x_fm, const StepRef& step, Tail tail, 
         if (tail == TAIL_DDPM) {
             EpiDdpm::Args e{};
             e.x = ddpm->x; e.bias = fin_proj.bias.as<float>(); e.M = M; e.tab = ddpm->tab; e.step = step;
-            e.clip_stride = Tp; e.clip_len = wsT; e.seed = ddpm->seed; e.clip0 = ddpm->clip0;
+            e.clip_stride = Tp; e.clip_len = wsT; e.seedp = ddpm->seedp; e.clip0p = ddpm->clip0p;
             DSVC_TRY(dispatch_prec<EpiDdpm>(a, e, DSVC_PREC_F16_X3, st));
         } else {
             EpiBias::Args e{eps.as<float>(), M, fin_proj.bias.as<float>(), M};
@@ -484,7 +485,7 @@ int dsvc_denoiser::eval_conv(const float* x_fm, const StepRef& step, Tail tail, 
 }
 
 // the tgemm path: every contraction reads fp16 activations that the previous kernel's epilogue left in HBM/L2
-int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st) {
+int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step) {
     const int M = cfg.mel_bins, C = cfg.channels, L = cfg.layers;
     const RowMap rm = rowmap();
     auto targs = [&](const _Float16* x, int cin_pad, const TPacked& tp, int taps, int dil) {
@@ -492,6 +493,10 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         a.x = x; a.cin = cin_pad; a.taps = taps; a.dil = dil; a.w = tp.w.as<_Float16>(); a.m_tiles = tp.m_tiles;
         a.w_planes = tp.planes; a.variant_halfs = (long long)tp.variant_halfs; a.n_variants = tp.n_variants;
         a.step_ptr = step.ptr; a.step_off = step.off; a.clip_rows = Tp;
+        if (host_step >= 0 && tp.n_variants > 1 && step.per_clip == 0) {      // variant known at launch: pass it by value
+            a.w += (size_t)(host_step % tp.n_variants) * tp.variant_halfs;
+            a.n_variants = 1;
+        }
         return a;
     };
     const int stream_big = rows_alloc >= 6144 ? 1 : 0;   // (non-temporal residual/skip traffic measured neutral: 2.41 vs 2.42 ms/step)
@@ -529,7 +534,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
     {   // K9b: output projection (net.py:134), optionally fused with the DDPM update (K10)
         TGemmArgs a = targs(s2h.as<_Float16>(), 2 * Cp, fin_t, 1, 1);
         if (tail == TAIL_DDPM) {
-            TEpiDdpm::Args e{ddpm->x, xsh.as<_Float16>(), fin_t.bias.as<float>(), M, Mp, ddpm->tab, step, rm, ddpm->seed, ddpm->clip0};
+            TEpiDdpm::Args e{ddpm->x, xsh.as<_Float16>(), fin_t.bias.as<float>(), M, Mp, ddpm->tab, step, rm, ddpm->seedp, ddpm->clip0p};
             DSVC_TRY(tlaunch_prec<TEpiDdpm>(a, e, 2, rows_alloc, st));
         } else {
             TEpiEps::Args e{eps.as<float>(), M, fin_t.bias.as<float>()};
@@ -557,8 +562,7 @@ struct dsvc_sampler {
     // captured DDPM graph
     hipGraphExec_t gexec = nullptr;
     hipStream_t cap_stream = nullptr;
-    int g_unroll = 0, gB = 0, gT = 0, g_prec = -1, g_clip0 = -1;
-    unsigned long long g_seed = 0;
+    int g_unroll = 0, gB = 0, gT = 0, g_prec = -1;
     const void* g_key = nullptr;
 
     ~dsvc_sampler() {
@@ -571,7 +575,7 @@ struct dsvc_sampler {
     }
     int finalize();
     int ensure_ws(int B, int T);
-    dsvc_denoiser::DdpmCtx ddpm_ctx(unsigned long long seed, int clip0);
+    dsvc_denoiser::DdpmCtx ddpm_ctx();
     int run_ddpm(const dsvc_sample_args* a, hipStream_t st);
     int run_plms(const dsvc_sample_args* a, hipStream_t st);
 };
@@ -625,37 +629,49 @@ int dsvc_sampler::ensure_ws(int B, int T) {
     return DSVC_OK;
 }
 
-dsvc_denoiser::DdpmCtx dsvc_sampler::ddpm_ctx(unsigned long long seed, int clip0) {
+dsvc_denoiser::DdpmCtx dsvc_sampler::ddpm_ctx() {
     dsvc_denoiser::DdpmCtx c{};
     c.x = xstate.as<float>();
     c.tab = DdpmTables{sqrt_recip.as<float>(), sqrt_recipm1.as<float>(), coef1.as<float>(), coef2.as<float>(), sigma.as<float>()};
-    c.seed = seed; c.clip0 = clip0;
+    // step_dev: [0] t, [1] PLMS history count, bytes 8..15 the Philox seed, [4] clip id of slot 0
+    c.seedp = reinterpret_cast<const unsigned long long*>(step_dev.as<char>() + 8);
+    c.clip0p = step_dev.as<int>() + 4;
     return c;
 }
 
 int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
     int n = a->t_start - a->t_stop;
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), a->t_start - 1);
-    constexpr int UNROLL = 10;
+    int t = a->t_start - 1;                               // the host mirrors the device-side step counter
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), t);
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>() + 2, (int)(unsigned)(a->seed & 0xffffffffull));
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>() + 3, (int)(unsigned)(a->seed >> 32));
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>() + 4, a->first_clip);
+    auto eager_step = [&]() -> int {
+        dsvc_denoiser::DdpmCtx e = ddpm_ctx();
+        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, st, t));
+        hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), -1);
+        --n; --t;
+        return DSVC_OK;
+    };
+    // The captured segment is one period of the dither schedule (64 steps for f16_d64) replayed from a period-aligned step, so
+    // every kernel node knows its weight variant at capture time and passes it by value: the alternative -- a scalar load of the
+    // step in front of every kernel's weight stream -- costs ~0.4 us x 43 kernels per step in the single-clip regime.
+    const int nvar = (den->tpath && den->cfg.precision == DSVC_PREC_F16 && den->cfg.weight_variants > 1) ? den->cfg.weight_variants : 1;
+    const int UNROLL = (nvar > 1 && nvar <= 64) ? nvar : 10;
+    const bool aligned = UNROLL == nvar && nvar > 1;
     if (a->use_graph && n >= 2 * UNROLL) {
-        const bool stale = !gexec || gB != a->B || gT != a->T || g_prec != den->cfg.precision || g_seed != a->seed ||
-                           g_clip0 != a->first_clip || g_key != den->cproj.p;
+        const bool stale = !gexec || g_unroll != UNROLL || gB != a->B || gT != a->T || g_prec != den->cfg.precision || g_key != den->cproj.p;
         if (stale) {
             if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
-            // one eager step first: sets every function attribute outside the capture
-            {
-                dsvc_denoiser::DdpmCtx e = ddpm_ctx(a->seed, a->first_clip);
-                DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, st));
-                hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), -1);
-                n -= 1;
-            }
+            DSVC_TRY(eager_step());                       // one eager step first: sets every function attribute outside the capture
             if (!cap_stream) DSVC_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
             DSVC_HIP(hipStreamSynchronize(st));
             DSVC_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
             int rc = DSVC_OK;
             for (int u = 0; u < UNROLL && rc == DSVC_OK; ++u) {
-                dsvc_denoiser::DdpmCtx e = ddpm_ctx(a->seed, a->first_clip);
-                rc = den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), u, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, cap_stream);
+                dsvc_denoiser::DdpmCtx e = ddpm_ctx();
+                rc = den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), u, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, cap_stream,
+                               aligned ? UNROLL - 1 - u : -1);
             }
             if (rc == DSVC_OK) hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, cap_stream, step_dev.as<int>(), -UNROLL);
             hipGraph_t graph = nullptr;
@@ -665,19 +681,17 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
             ce = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             if (ce != hipSuccess) { gexec = nullptr; return fail(DSVC_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ce)); }
-            g_unroll = UNROLL; gB = a->B; gT = a->T; g_prec = den->cfg.precision; g_seed = a->seed; g_clip0 = a->first_clip;
+            g_unroll = UNROLL; gB = a->B; gT = a->T; g_prec = den->cfg.precision;
             g_key = den->cproj.p;
         }
+        if (aligned)
+            while (n > 0 && (t % UNROLL) != UNROLL - 1) DSVC_TRY(eager_step());     // walk to the period boundary
         while (n >= g_unroll) {
             DSVC_HIP(hipGraphLaunch(gexec, st));
-            n -= g_unroll;
+            n -= g_unroll; t -= g_unroll;
         }
     }
-    for (; n > 0; --n) {
-        dsvc_denoiser::DdpmCtx e = ddpm_ctx(a->seed, a->first_clip);
-        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, st));
-        hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), -1);
-    }
+    while (n > 0) DSVC_TRY(eager_step());
     return DSVC_OK;
 }
 

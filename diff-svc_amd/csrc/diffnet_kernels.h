@@ -109,8 +109,8 @@ struct EpiDdpm {
         DdpmTables tab;
         StepRef step;
         int clip_stride, clip_len;
-        unsigned long long seed;
-        int clip0;                  // Philox clip id of slot 0
+        const unsigned long long* seedp;   // device: Philox seed and clip id of slot 0 live in memory so that a captured
+        const int* clip0p;                 // graph serves every call (they change per call, the graph does not)
     };
     __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
         if (col >= e.M) return;
@@ -126,7 +126,7 @@ struct EpiDdpm {
         float out = e.tab.coef1[t] * x0 + e.tab.coef2[t] * xt;
         if (t > 0) {
             const unsigned el = (unsigned)tl * (unsigned)e.M + (unsigned)col;
-            const float z = philox_normal_lane(el >> 2, (unsigned)t, (unsigned)(e.clip0 + clip), PURPOSE_DDPM_NOISE, e.seed, el & 3);
+            const float z = philox_normal_lane(el >> 2, (unsigned)t, (unsigned)(*e.clip0p + clip), PURPOSE_DDPM_NOISE, *e.seedp, el & 3);
             out += e.tab.sigma[t] * z;
         }
         *px = out;

@@ -318,8 +318,8 @@ struct TEpiDdpm {
         DdpmTables tab;
         StepRef step;
         RowMap rm;
-        unsigned long long seed;
-        int clip0;
+        const unsigned long long* seedp;   // device (see EpiDdpm)
+        const int* clip0p;
     };
     template <int NT_N>
     __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
@@ -351,7 +351,7 @@ struct TEpiDdpm {
                 float z[4] = {0.f, 0.f, 0.f, 0.f};
                 if (t > 0) {
                     const unsigned el = (unsigned)tl * (unsigned)e.M + (unsigned)(cb + 4 * q);
-                    philox_normal4(el >> 2, (unsigned)t, (unsigned)(e.clip0 + clip), PURPOSE_DDPM_NOISE, e.seed, z);
+                    philox_normal4(el >> 2, (unsigned)t, (unsigned)(*e.clip0p + clip), PURPOSE_DDPM_NOISE, *e.seedp, z);
                 }
                 f32x4 out;
 #pragma unroll

@@ -54,7 +54,8 @@ struct TGemmArgs {
     long long variant_halfs;// stride between dither variants
     int n_variants;         // >= 1
     const int* step_ptr;    // device int: current diffusion step (variant = (step - step_off) % n_variants); may be null
-    int step_off;
+    int step_off;           // (a launcher that knows the step passes w already offset to the variant and n_variants = 1: that takes the
+                            //  dependent scalar load, ~0.4 us per kernel in the single-clip regime, out of the front of the weight stream)
     int clip_rows;          // rows per clip (clip stride) or 0: the K-loop stagger is keyed on a tile's position inside its clip, so a
                             // clip computes bit-identically alone and inside a batch
     unsigned long long* stamps;   // profiling: per-wave phase time stamps (s_memrealtime, 100 MHz), 16 per wave; null in production
