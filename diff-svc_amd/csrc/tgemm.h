@@ -25,7 +25,9 @@
 //     the systematic weight-rounding error would cost ~6e-3 of mel after 1000 DDPM steps, so the packer can emit
 //     n_variants differently-rounded copies (time-dithered rounding: step t uses copy t % n_variants; the copies
 //     average to w), which keeps 1 MFMA per product inside the 1e-3 bar.
-//   * `MSPLIT` output-channel passes can be spread over blockIdx.y for small batches (B = 1) to fill the chip.
+//   * small batches: the output-channel passes are spread over blockIdx.y, frame tiles start their K loop at staggered
+//     groups, and for a single clip (KS = 3) a tile's K loop is split over three waves that reduce through LDS -- the
+//     latency regime, analysed with the in-kernel stamps (DSVC_TG_STAMPS) in DESIGN.md 4.1.
 #pragma once
 #include <stdio.h>
 #include <stdlib.h>
