@@ -42,15 +42,7 @@ template <class Epi, int NW, int NA>
 int dispatch_tiling(const ConvGemmArgs& a, const typename Epi::Args& e, hipStream_t st) {
     //                                                              WM WN WK KCB PF SPT
     if (a.n_rows >= 6144 && a.cin % 64 == 0) return conv_gemm_launch<4, 4, 1, 64, 4, 5, NW, NA, Epi>(a, e, st);
-    if (a.cin % 384 == 0) {
-        static const int stile = getenv("DSVC_STILE") ? atoi(getenv("DSVC_STILE")) : 0;      // tuning knob
-        switch (stile) {
-            case 1: return conv_gemm_launch<2, 1, 4, 384, 2, 6, NW, NA, Epi>(a, e, st);
-            case 2: return conv_gemm_launch<1, 1, 8, 384, 3, 5, NW, NA, Epi>(a, e, st);
-            case 3: return conv_gemm_launch<1, 2, 4, 384, 3, 5, NW, NA, Epi>(a, e, st);
-            default: return conv_gemm_launch<1, 1, 4, 384, 3, 5, NW, NA, Epi>(a, e, st);
-        }
-    }
+    if (a.cin % 384 == 0) return conv_gemm_launch<1, 1, 4, 384, 3, 5, NW, NA, Epi>(a, e, st);
     if (a.cin % 128 == 0) return conv_gemm_launch<1, 1, 4, 128, 2, 3, NW, NA, Epi>(a, e, st);
     return conv_gemm_launch<1, 2, 1, 16, 1, 2, NW, NA, Epi>(a, e, st);
 }
@@ -134,11 +126,6 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
         const int tiles = rows_alloc / 128, passes = ceil_div(a.m_tiles, 8);
         int ms = 256 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
         if (tgemm_smem<4>(a.taps, a.dil, a.cin) <= 160 * 1024) {
-            static const int sched = getenv("DSVC_TG_SCHED") ? atoi(getenv("DSVC_TG_SCHED")) : 1;       // tuning knob
-            if constexpr (NW == 1) {
-                if (sched == 2) return tgemm_launch<4, 8, 2, 8, NW, Epi, 2>(a, e, rows_alloc, ms, st);
-                if (sched == 3) return tgemm_launch<4, 8, 2, 8, NW, Epi, 3>(a, e, rows_alloc, ms, st);
-            }
             return tgemm_launch<4, 8, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
         }
         return tgemm_launch<2, 8, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);       // K too wide for a 128-frame tile in LDS

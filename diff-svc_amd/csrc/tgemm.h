@@ -162,7 +162,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) asm volatile("" : "+v"(base[nt]));
         // B fragments: BQ-deep software pipeline -- step kk computes from bq[kk % BQ] while steps kk+1 .. kk+BQ-1 are in flight
-        constexpr int BQ = SCHED == 2 ? 3 : (SCHED == 3 ? 4 : 2);     // SCHED 2/3: deeper B-fragment pipelines (tuning variants)
+        constexpr int BQ = 2;                                          // (3- and 4-deep pipelines measured 3-4 % slower)
         half8 bq[BQ][NT_N];
 #pragma unroll
         for (int d = 0; d < BQ - 1; ++d) {
