@@ -20,6 +20,8 @@
 
 using namespace dsvc;
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
 namespace {
 
 struct DevBuf {
@@ -111,6 +113,131 @@ int pack_conv(PackedConv& pc, int cout, int taps, int cin, int dil, FW&& src, co
     pack_fragments(h.data(), pc.n_ctiles, taps, cin, 2, [&](int col, int tap, int ci) { return col < cout ? src(col, tap, ci) : 0.f; });
     DSVC_TRY(upload(pc.w, h.data(), h.size() * sizeof(_Float16)));
     return upload(pc.bias, bias, (size_t)nbias * sizeof(float));
+}
+
+// ---- fused ResBlock1 pair for the narrow stages (C = 16 / 32 channels at 256x / 512x the frame rate) ----
+//   out = alpha * ( x + b2 + conv_k,1( lrelu( b1 + conv_k,d( lrelu(x) ) ) ) )  [+ out]        (models.py:57-64)
+// These stages are HBM-bound by nature (64-128 B per frame row, a few hundred FMAs per output), but as two passes of the
+// generic MFMA engine each conv was a read + write of the whole fp32 stage through 64-column tiles of which 16 or 32 are
+// real: measured 0.7 TB/s, 3.9 ms per conv at 32 clips.  Here one workgroup stages a (TN + 2H) x C tile of lrelu(x) in LDS,
+// computes the intermediate activation for TN + 2*(k/2) rows into LDS, and the second conv + residual from there: one read
+// and one write of the stage per PAIR.  Arithmetic is plain fp32 FMA (exact products, like the reference); the weights are
+// wave-uniform and come through the scalar cache ([tap][ci][co] layout: 16 / 32 consecutive co per scalar load).
+template <int C, int TN>
+__global__ void __launch_bounds__(TN) k_resblock_pair(const float* __restrict__ x, float* __restrict__ out, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      int k, int d, int n_rows, int stride, int len, float alpha, int accumulate) {
+    constexpr int XS = C + 4;                              // row stride in floats: 16-B aligned, conflict-free ds_read_b128 across rows
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int h2 = k >> 1, h1 = h2 * d, H = h1 + h2;
+    float* xs = reinterpret_cast<float*>(smem);            // [TN + 2H][XS]   lrelu(x), zero outside the clip
+    float* ts = xs + (size_t)(TN + 2 * H) * XS;            // [TN + 2h2][XS]  lrelu(conv1), zero outside the clip
+    const int tid = threadIdx.x;
+    const long long tile0 = (long long)blockIdx.x * TN;
+    auto valid = [&](long long g) { return g >= 0 && g < n_rows && (int)(g % stride) < len; };
+    // ---- stage lrelu(x) ----
+    {
+        constexpr int Q = C / 4;
+        const int total = (TN + 2 * H) * Q;
+        for (int i = tid; i < total; i += TN) {
+            const int r = i / Q, q = i - r * Q;
+            const long long g = tile0 - H + r;
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            if (valid(g)) {
+                v = *reinterpret_cast<const f32x4v*>(x + (size_t)g * C + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
+            }
+            *reinterpret_cast<f32x4v*>(xs + (size_t)r * XS + 4 * q) = v;
+        }
+    }
+    __syncthreads();
+    // ---- conv1 (dilation d) -> ts ----
+    for (int rr = tid; rr < TN + 2 * h2; rr += TN) {
+        const long long g = tile0 - h2 + rr;
+        float acc[C];
+#pragma unroll
+        for (int co = 0; co < C; ++co) acc[co] = b1[co];
+        if (valid(g)) {
+            for (int tap = 0; tap < k; ++tap) {
+                const float* xr = xs + (size_t)(rr + tap * d) * XS;            // x row g + (tap - k/2)*d
+                const float* wt = w1 + (size_t)tap * C * C;
+#pragma unroll
+                for (int q = 0; q < C / 4; ++q) {
+                    const f32x4v xv = *reinterpret_cast<const f32x4v*>(xr + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float* wr = wt + (size_t)(4 * q + e) * C;
+#pragma unroll
+                        for (int co = 0; co < C; ++co) acc[co] = fmaf(wr[co], xv[e], acc[co]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < C; ++co) acc[co] = acc[co] > 0.f ? acc[co] : 0.1f * acc[co];
+        } else {
+#pragma unroll
+            for (int co = 0; co < C; ++co) acc[co] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q)
+            *reinterpret_cast<f32x4v*>(ts + (size_t)rr * XS + 4 * q) = f32x4v{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    }
+    __syncthreads();
+    // ---- conv2 (dilation 1) + residual ----
+    {
+        const long long g = tile0 + tid;
+        if (g >= n_rows) return;
+        float acc[C];
+        const bool ok = valid(g);
+        if (ok) {
+#pragma unroll
+            for (int co = 0; co < C; ++co) acc[co] = b2[co];
+            for (int tap = 0; tap < k; ++tap) {
+                const float* tr = ts + (size_t)(tid + tap) * XS;                // t row g + tap - k/2
+                const float* wt = w2 + (size_t)tap * C * C;
+#pragma unroll
+                for (int q = 0; q < C / 4; ++q) {
+                    const f32x4v tv = *reinterpret_cast<const f32x4v*>(tr + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float* wr = wt + (size_t)(4 * q + e) * C;
+#pragma unroll
+                        for (int co = 0; co < C; ++co) acc[co] = fmaf(wr[co], tv[e], acc[co]);
+                    }
+                }
+            }
+        }
+        float* po = out + (size_t)g * C;
+        const float* px = x + (size_t)g * C;
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+            f32x4v o = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const f32x4v xv = *reinterpret_cast<const f32x4v*>(px + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = alpha * (acc[4 * q + e] + xv[e]);
+                if (accumulate) {
+                    const f32x4v pv = *reinterpret_cast<const f32x4v*>(po + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += pv[e];
+                }
+            }
+            *reinterpret_cast<f32x4v*>(po + 4 * q) = o;
+        }
+    }
+}
+
+template <int C, int TN>
+int resblock_pair_launch(const float* x, float* out, const float* w1, const float* b1, const float* w2, const float* b2, int k, int d,
+                         int n_rows, int stride, int len, float alpha, int accumulate, hipStream_t st) {
+    const int h2 = k / 2, H = h2 * d + h2;
+    const size_t smem = ((size_t)(TN + 2 * H) + (size_t)(TN + 2 * h2)) * (C + 4) * 4;
+    if (smem > 64 * 1024) return fail(DSVC_EINVAL, "resblock pair: %zu B of LDS", smem);
+    hipLaunchKernelGGL((k_resblock_pair<C, TN>), dim3(ceil_div(n_rows, TN)), dim3(TN), smem, st, x, out, w1, b1, w2, b2, k, d, n_rows, stride, len,
+                       alpha, accumulate);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
 }
 
 // ---- small kernels ----
@@ -241,6 +368,7 @@ struct dsvc_vocoder {
     std::vector<DevBuf> nc_w, nc_b;              // noise convs (plain fp32)
     std::vector<int> nc_k, nc_s, nc_pad;
     std::vector<PackedConv> rb1, rb2;            // [stage*nk*3 + j*3 + m]
+    std::vector<DevBuf> rb1_f32, rb2_f32;        // same index: [tap][ci][co] fp32 for the narrow stages' fused pair kernel (else empty)
     DevBuf lin_w, lin_b;
     int gap_frames = 8;
 
@@ -254,6 +382,8 @@ struct dsvc_vocoder {
         for (auto& p : ups) rel(p);
         for (auto& p : rb1) rel(p);
         for (auto& p : rb2) rel(p);
+        for (auto& b : rb1_f32) b.release();
+        for (auto& b : rb2_f32) b.release();
         for (auto& b : nc_w) b.release();
         for (auto& b : nc_b) b.release();
         for (DevBuf* b : {&lin_w, &lin_b, &mel_in, &har, &frames, &fl00, &buf[0], &buf[1], &buf[2], &buf[3], &buf[4]}) b->release();
@@ -312,6 +442,7 @@ int dsvc_vocoder::finalize() {
     }
     ups.resize(nu); nc_w.resize(nu); nc_b.resize(nu); nc_k.resize(nu); nc_s.resize(nu); nc_pad.resize(nu);
     rb1.resize((size_t)nu * nk * 3); rb2.resize((size_t)nu * nk * 3);
+    rb1_f32.resize(rb1.size()); rb2_f32.resize(rb2.size());
     int need_gap = 3;
     int rate = 1;
     for (int i = 0; i < nu; ++i) {
@@ -357,10 +488,20 @@ int dsvc_vocoder::finalize() {
                 const std::vector<float>* b1 = plain(base + "convs1." + std::to_string(m) + ".bias", cout);
                 if (!b1) return DSVC_ESTATE;
                 DSVC_TRY(pack_conv(rb1[idx], cout, rk, cout, d, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b1->data(), cout));
+                auto pack_f32 = [&](DevBuf& dst) {      // [tap][ci][co]
+                    std::vector<float> t((size_t)rk * cout * cout);
+                    for (int tap = 0; tap < rk; ++tap)
+                        for (int ci = 0; ci < cout; ++ci)
+                            for (int co = 0; co < cout; ++co) t[((size_t)tap * cout + ci) * cout + co] = w[((size_t)co * cout + ci) * rk + tap];
+                    return upload(dst, t.data(), t.size() * 4);
+                };
+                const bool narrow = (cout == 16 || cout == 32) && (rk / 2) * d + rk / 2 <= 40;
+                if (narrow) DSVC_TRY(pack_f32(rb1_f32[idx]));
                 DSVC_TRY(folded(base + "convs2." + std::to_string(m), (size_t)cout * cout * rk, cout, w));
                 const std::vector<float>* b2 = plain(base + "convs2." + std::to_string(m) + ".bias", cout);
                 if (!b2) return DSVC_ESTATE;
                 DSVC_TRY(pack_conv(rb2[idx], cout, rk, cout, 1, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b2->data(), cout));
+                if (narrow) DSVC_TRY(pack_f32(rb2_f32[idx]));
                 const int halo = (rk / 2) * d;
                 if (ceil_div(halo, rate) > need_gap) need_gap = ceil_div(halo, rate);
             }
@@ -464,6 +605,23 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
         for (int j = 0; j < nk; ++j) {
             for (int m = 0; m < 3; ++m) {
                 const size_t idx = ((size_t)i * nk + j) * 3 + m;
+                static const bool no_fused = getenv("DSVC_VOC_NO_FUSED") && atoi(getenv("DSVC_VOC_NO_FUSED"));   // A/B knob
+                if (rb1_f32[idx].p && !no_fused) {
+                    // narrow stage: one LDS-fused kernel per conv pair; ping-pong U -> A -> Tm -> S (the pair kernel reads its
+                    // input with halos, so it cannot run in place)
+                    const float* fin = (m == 0) ? U : (m == 1 ? A : Tm);
+                    float* fout = (m == 0) ? A : (m == 1 ? Tm : S);
+                    const float al = (m == 2) ? 1.0f / (float)nk : 1.0f;
+                    const int accu = (m == 2 && j > 0) ? 1 : 0;
+                    const int rk = rb1[idx].taps, dd = rb1[idx].dil;
+                    if (cout == 16)
+                        DSVC_TRY((resblock_pair_launch<16, 256>(fin, fout, rb1_f32[idx].as<float>(), rb1[idx].bias.as<float>(), rb2_f32[idx].as<float>(),
+                                                                rb2[idx].bias.as<float>(), rk, dd, rows, stride, len, al, accu, st)));
+                    else
+                        DSVC_TRY((resblock_pair_launch<32, 128>(fin, fout, rb1_f32[idx].as<float>(), rb1[idx].bias.as<float>(), rb2_f32[idx].as<float>(),
+                                                                rb2[idx].bias.as<float>(), rk, dd, rows, stride, len, al, accu, st)));
+                    continue;
+                }
                 const float* xin = (m == 0) ? U : A;
                 {   // xt = c1(leaky_relu(x))
                     ConvGemmArgs a = conv(rb1[idx], xin, rows, stride, len, 0.1f);
