@@ -184,3 +184,25 @@ def test_slicer_chunks_tile_the_signal_and_reject_bad_windows():
         Slicer(sr=22050, min_length=100, win_l=300)
     with pytest.raises(ValueError):
         Slicer(sr=22050, win_s=20, max_silence_kept=10)
+
+
+def test_committed_bench_line_follows_the_driver_contract():
+    """The last committed bench line (profiles/*_bench.json, produced by bench.py on the GPU box) carries every field the
+    driver and the judge read: the metric contract, `roofline` and `cpu_baseline`."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench.json")))
+    assert files, "no bench line committed under profiles/"
+    with open(files[-1]) as f:
+        d = json.loads(f.read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "audio-sec/wall-sec" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and "workload" in d["config"] and "model" not in d["config"] and d["data"] == "synthetic"
+    r = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and r["bound"] in ("hbm", "mfma")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("port", "reference") and c["cores"] >= 1
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 10.0) < 0.05          # one 10 s clip per step
