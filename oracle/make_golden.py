@@ -212,6 +212,8 @@ def main():
         return golden_24k()
     if "--slicer-only" in sys.argv:
         return golden_slicer()
+    if "--schedule-only" in sys.argv:
+        return golden_schedule()
     golden_state_keys()
     golden_vocoder("vocoder_tiny", synth.tiny_vocoder(), 5, clips=[0, 3], T=24, seed=90)
     golden_vocoder("vocoder_44k", dict(synth.VOCODER_44K), 1, clips=[1], T=12, seed=91)
@@ -228,6 +230,24 @@ def main():
     golden_sampler("plms_44k_k100_s20", dict(full, K_step=100), 0, clips=[4], T=32, n_units=19, speedup=20, seed=81)
     golden_24k()
     golden_slicer()
+    golden_schedule()
+
+
+def golden_schedule():
+    """The 12 schedule buffers as the REAL GaussianDiffusion.__init__ computes them (diffusion.py:87-120), for the linear
+    (max_beta 0.02, 44.1 kHz config) and the cosine schedule -- nothing loaded on top."""
+    refshim.set_hparams(dict(synth.HPARAMS_44K))
+    from network.diff.diffusion import GaussianDiffusion
+    from network.diff.net import DiffNet
+    out = {}
+    for tag, extra in (("linear", dict(schedule_type="linear", max_beta=0.02)), ("cosine", dict(schedule_type="cosine"))):
+        hp = dict(synth.HPARAMS_44K, **extra)
+        refshim.set_hparams(hp)
+        m = GaussianDiffusion(None, 128, DiffNet(128), timesteps=1000, K_step=1000, loss_type="l2", spec_min=hp["spec_min"], spec_max=hp["spec_max"])
+        for k in O.SCHEDULE_KEYS:
+            out[tag + "_" + k] = getattr(m, k).detach().numpy().copy()
+        print("schedule", tag, float(out[tag + "_betas"][0]), float(out[tag + "_betas"][-1]))
+    np.savez_compressed(os.path.join(OUT, "schedule.npz"), **out)
 
 
 def golden_slicer():

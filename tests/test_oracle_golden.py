@@ -49,6 +49,21 @@ def test_schedule_tables_match_checkpoint_buffers():
     assert cos["betas"].shape == (1000,) and float(cos["betas"].max()) <= 0.9990001
 
 
+@pytest.mark.parametrize("kind", ["linear", "cosine"])
+def test_schedule_tables_match_the_reference_constructor(kind):
+    """The 12 buffers of GaussianDiffusion.__init__ (float64 numpy math cast to fp32 last, diffusion.py:87-120), minted from the
+    real class (tests/golden/schedule.npz): the oracle's tables and the product's checkpoint writer must agree bit for bit."""
+    g = load_golden("schedule")
+    betas = O.linear_betas(1000, 0.02) if kind == "linear" else O.cosine_betas(1000)
+    tabs = O.schedule_tables(betas)
+    hp = dict(synth.HPARAMS_44K, schedule_type=kind, max_beta=0.02)
+    bufs = synth.schedule_buffers(hp)
+    for k in O.SCHEDULE_KEYS:
+        ref = g[kind + "_" + k]
+        assert np.array_equal(tabs[k].numpy(), ref), ("oracle", k)
+        assert np.array_equal(bufs[k].numpy(), ref), ("product", k)
+
+
 def test_get_align_kat():
     # integer recurrence of infer_tool.py:231-242; T=861, N_h=500 is the 10 s clip of the benchmark
     m = O.get_align(861, 500)
