@@ -219,3 +219,20 @@ def test_sampler_rejects_bad_arguments():
         smp.sample(cond.cpu(), 4, seed=1)               # host pointer
     with pytest.raises(RuntimeError):
         smp.sample(torch.zeros(1, hp["hidden_size"] + 1, 8, device="cuda"), 4, seed=1)
+
+
+@pytest.mark.parametrize("precision,steps", [("f16_d64", 210), ("f16_d16", 70)])
+def test_period_aligned_ddpm_graph_equals_eager(precision, steps):
+    """The dithered DDPM graph is one period of the rounding schedule with every kernel's weight variant passed by value, replayed
+    from a period-aligned step after an eager walk to the boundary; seed and clip id reach the captured kernels through device
+    memory.  Same kernels, same variants, same noise as the eager loop: bit-identical, also for a second call with another seed
+    and clip id on the SAME captured graph, and from an unaligned start."""
+    hp = dict(synth.HPARAMS_44K)
+    sd, den, smp = make_handles(hp, 0, precision)
+    g = np.random.Generator(np.random.PCG64(3))
+    cond = torch.from_numpy((g.standard_normal((2, 256, 40)) * 0.5).astype(np.float32)).cuda()
+    for t_start, seed, clip0 in ((1000, 5, 0), (1000 - 7, 6, 3)):
+        eager = smp.sample(cond, t_start, seed=seed, first_clip=clip0, t_stop=t_start - steps, use_graph=False, return_x=True)[1]
+        graph = smp.sample(cond, t_start, seed=seed, first_clip=clip0, t_stop=t_start - steps, use_graph=True, return_x=True)[1]
+        assert torch.isfinite(graph).all()
+        assert torch.equal(eager, graph), (precision, t_start)
