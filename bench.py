@@ -210,12 +210,19 @@ def main():
             torch.cuda.synchronize(); tb = time.perf_counter() - tb
             usb, _ = pipe.model._handle().profile_gate_kernel(Bb, T_FRAMES, 3)
             ach = FLOP_PER_FRAME_DILATED * Bb * T_FRAMES / (usb * 1e-6) / 1e12
+            btraffic, bsrc = None, None
+            bpath = os.path.join(ROOT, "profiles", "gate_traffic_b32.json")       # tools/gpu_traffic_b32.sh (separate PMC passes)
+            if os.path.exists(bpath) and args.precision == "f16_d64":
+                with open(bpath) as f:
+                    tj = json.load(f)
+                btraffic, bsrc = tj.get("bytes_per_launch"), tj.get("source")
             result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
                                  "clips_per_gpu": Bb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
                                  "s_per_batch": tb,
                                  "roofline": {"bound": "mfma", "kernel": roof["kernel"], "achieved": ach, "peak": PEAK_TFLOPS_F16,
                                               "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_F16, "avg_launch_us": usb,
-                                              "frames_per_launch": Bb * T_FRAMES, "traffic": None}}
+                                              "frames_per_launch": Bb * T_FRAMES, "traffic": btraffic, "traffic_source": bsrc,
+                                              "algorithmic_bytes": 4.7e3 * Bb * T_FRAMES + 1.77e6}}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(hp, sd, vs, h)
         else:

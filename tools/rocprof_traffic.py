@@ -11,11 +11,12 @@ def mean_counter(d, name, sub):
                 vals.append(float(r["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 fd, wd, sub, out = sys.argv[1:5]
+cmd = sys.argv[5] if len(sys.argv) > 5 else "bench.py --steps 1 --warmup 1 --no-batched --no-cpu-baseline --no-graph"
 f, nf = mean_counter(fd, "FETCH_SIZE", sub)
 w, nw = mean_counter(wd, "WRITE_SIZE", sub)
 res = {"kernel": sub, "launches_sampled": [nf, nw], "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
        "bytes_per_launch": (2.0 * f * 1024 + w * 1024) if f is not None and w is not None else None,
-       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 --no-batched --no-cpu-baseline --no-graph`; "
+       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `" + cmd + "`; "
                  "read side doubled per the gfx950 FETCH_SIZE correction"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
