@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(HERE, "libdsvc_hip.so")
 
 PREC_F16, PREC_F16_W2, PREC_F16_X3 = 0, 1, 2
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def parse_precision(p):
@@ -37,7 +37,8 @@ class DenoiserCfg(ctypes.Structure):
 class SampleArgs(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("T", ctypes.c_int32), ("cond", ctypes.c_void_p), ("x_init", ctypes.c_void_p),
                 ("ref_mel", ctypes.c_void_p), ("mel2ph", ctypes.c_void_p), ("seed", ctypes.c_uint64),
-                ("first_clip", ctypes.c_int32), ("t_start", ctypes.c_int32), ("t_stop", ctypes.c_int32),
+                ("first_clip", ctypes.c_int32), ("clip_ids", ctypes.c_void_p), ("clip_lens", ctypes.c_void_p),
+                ("t_start", ctypes.c_int32), ("t_stop", ctypes.c_int32),
                 ("speedup", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("mel_out", ctypes.c_void_p),
                 ("x_out", ctypes.c_void_p)]
 
@@ -78,7 +79,7 @@ SYMBOLS = [
     ("dsvc_vocoder_load_tensor", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64]),
     ("dsvc_vocoder_finalize", ctypes.c_int, [_VP]),
     ("dsvc_vocoder_destroy", None, [_VP]),
-    ("dsvc_vocode", ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int32, _VP]),
+    ("dsvc_vocode", ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int32, _VP, _VP]),
     ("dsvc_melspec_create", ctypes.c_int, [ctypes.POINTER(MelspecCfg), _VP, ctypes.POINTER(_VP)]),
     ("dsvc_melspec_destroy", None, [_VP]),
     ("dsvc_melspec_frames", ctypes.c_int, [_VP, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]),

@@ -39,6 +39,7 @@ struct ConvGemmArgs {
     int n_rows;            // batch * clip_stride
     int clip_stride;       // rows per clip slot (>= 32)
     int clip_len;          // valid rows per slot
+    const int* clip_lens;  // optional device [n_rows/clip_stride]: per-clip valid rows (overrides clip_len)
     int cin;               // input channels, multiple of KCB
     int taps, dil;         // tap offset = (tap - taps/2) * dil rows
     const _Float16* w;     // fragment-packed weights
@@ -156,7 +157,10 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
                 const int c8 = (it - rr * IPR) * 8;
                 const int r = row0 - halo + rr;
                 bool valid = (r >= 0) && (r < a.n_rows);
-                if (valid) valid = clip_local(r, a.clip_stride) < a.clip_len;
+                if (valid) {
+                    const int clip = r / a.clip_stride;
+                    valid = (r - clip * a.clip_stride) < (a.clip_lens ? a.clip_lens[clip] : a.clip_len);
+                }
                 if (valid) {
                     const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)r * a.ldx + c0 + c8);
                     sr[u][0] = src[0];

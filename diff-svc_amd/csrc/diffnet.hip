@@ -169,10 +169,13 @@ struct dsvc_denoiser {
     // workspace for (B, T)
     int wsB = 0, wsT = 0, Tp = 0, rows = 0, rows_alloc = 0;
     DevBuf xin, xres, g, skip, s2, eps, condT, cproj, tsteps;
+    DevBuf lens, clipid;  // int [B]: valid frames per clip (zero padding beyond), Philox clip id per batch element
+    DevBuf rowclip;       // int [rows_alloc]: clip of a row, -1 on gap / padded rows (RowMap)
     bool cond_ready = false;
+    unsigned ws_gen = 0;  // bumped whenever the workspace is (re)built: captured graphs bake its pointers and are keyed on this
 
     ~dsvc_denoiser() {
-        for (DevBuf* b : {&film, &xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps, &xh, &gh, &skiph, &s2h, &xsh}) b->release();
+        for (DevBuf* b : {&film, &xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps, &lens, &clipid, &rowclip, &xh, &gh, &skiph, &s2h, &xsh}) b->release();
         auto rel = [](PackedConv& p) { p.w.release(); p.bias.release(); };
         rel(in_proj); rel(skip_proj); rel(fin_proj);
         for (auto& p : dil) rel(p);
@@ -184,7 +187,7 @@ struct dsvc_denoiser {
         for (auto& p : out_t) relt(p);
     }
 
-    RowMap rowmap() const { return RowMap{Tp, wsT, rows}; }
+    RowMap rowmap() const { return RowMap{Tp, rowclip.as<int>()}; }
     _Float16* xh_row0() const { return xh.as<_Float16>() + (size_t)guard * Cp; }
 
     const std::vector<float>* get(const std::string& k, size_t numel) {
@@ -198,12 +201,14 @@ struct dsvc_denoiser {
     }
 
     int finalize();
-    int ensure_ws(int B, int T);
+    int ensure_ws(int B, int T, hipStream_t st);
+    // per-call clip metadata: Philox ids (ids_dev [B] or first + b) and valid lengths (lens_dev [B] or T for every clip)
+    int set_clip_meta(const int32_t* ids_dev, int first, const int32_t* lens_dev, hipStream_t st);
     int prepare_cond(const float* cond_bht, int B, int T, hipStream_t st);
 
     enum Tail { TAIL_EPS = 0, TAIL_DDPM = 1 };
     // what the fused DDPM tail needs from the sampler (the epilogue-specific Args are built inside eval)
-    struct DdpmCtx { float* x; DdpmTables tab; const unsigned long long* seedp; const int* clip0p; };
+    struct DdpmCtx { float* x; DdpmTables tab; const unsigned long long* seedp; const int* clipid; };
     // one denoiser evaluation on the frame-major state `x_fm` [rows][M]; `state_half_fresh`: the fp16 copy of the
     // state (tgemm path) is already up to date (the previous DDPM tail wrote it)
     // host_step >= 0: the caller knows the diffusion step (mod the dither period) at launch time -> variants are passed by value
@@ -217,7 +222,12 @@ int dsvc_denoiser::finalize() {
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers, K = cfg.max_steps;
     if (M % 16 || H % 16 || C % 64) return fail(DSVC_EINVAL, "denoiser: need mel_bins%%16==0, hidden%%16==0, channels%%64==0 (got %d,%d,%d)", M, H, C);
     if (L < 1 || K < 1 || cfg.dilation_cycle < 1) return fail(DSVC_EINVAL, "denoiser: bad layers/steps/cycle");
-    if ((1 << ((L - 1) % cfg.dilation_cycle)) > 64 && cfg.dilation_cycle > 7) return fail(DSVC_EINVAL, "denoiser: dilation too large");
+    {   // largest dilation over ALL layers (2^(l % cycle)): the time tiles stage 2*dil halo rows in LDS and clips are separated by
+        // >= dil zero gap rows
+        int max_dil = 1;
+        for (int l = 0; l < L; ++l) { const int d = 1 << ((l % cfg.dilation_cycle) < 30 ? (l % cfg.dilation_cycle) : 30); if (d > max_dil) max_dil = d; }
+        if (max_dil > 64) return fail(DSVC_EINVAL, "denoiser: dilation %d > 64 is not supported (dilation_cycle_length %d over %d layers)", max_dil, cfg.dilation_cycle, L);
+    }
     // F16 (optionally time-dithered) and F16_W2 run on the tgemm engine; F16_X3 (split activations) on conv_gemm
     tpath = cfg.precision != DSVC_PREC_F16_X3 && !getenv("DSVC_FORCE_CONV_GEMM");
 #define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
@@ -366,7 +376,7 @@ int dsvc_denoiser::finalize_t() {
     return DSVC_OK;
 }
 
-int dsvc_denoiser::ensure_ws(int B, int T) {
+int dsvc_denoiser::ensure_ws(int B, int T, hipStream_t st) {
     if (B == wsB && T == wsT) return DSVC_OK;
     if (B < 1 || T < 1) return fail(DSVC_EINVAL, "bad batch/frames %d/%d", B, T);
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
@@ -378,21 +388,38 @@ int dsvc_denoiser::ensure_ws(int B, int T) {
     const size_t r = (size_t)rows_alloc;
     DSVC_TRY(xin.alloc(r * M * 4)); DSVC_TRY(xres.alloc(r * C * 4)); DSVC_TRY(skip.alloc(r * C * 4)); DSVC_TRY(eps.alloc(r * M * 4));
     DSVC_TRY(condT.alloc(r * H * 4)); DSVC_TRY(cproj.alloc(r * 2 * C * L * 4)); DSVC_TRY(tsteps.alloc((size_t)B * 4 + 16));
-    DSVC_HIP(hipMemset(xin.p, 0, r * M * 4));
-    DSVC_HIP(hipMemset(eps.p, 0, r * M * 4));
+    DSVC_TRY(lens.alloc((size_t)B * 4 + 16)); DSVC_TRY(clipid.alloc((size_t)B * 4 + 16)); DSVC_TRY(rowclip.alloc(r * 4));
+    ++ws_gen;
+    // zero fills go on the CALLER's stream: the null stream does not order against non-blocking streams (PyTorch's)
+    DSVC_HIP(hipMemsetAsync(xin.p, 0, r * M * 4, st));
+    DSVC_HIP(hipMemsetAsync(eps.p, 0, r * M * 4, st));
+    hipLaunchKernelGGL(k_iota_int, dim3(ceil_div(B, 256)), dim3(256), 0, st, lens.as<int>(), T, 0, B);
+    hipLaunchKernelGGL(k_iota_int, dim3(ceil_div(B, 256)), dim3(256), 0, st, clipid.as<int>(), 0, 1, B);
+    hipLaunchKernelGGL(k_build_rowclip, dim3(ceil_div(rows_alloc, 256)), dim3(256), 0, st, rowclip.as<int>(), lens.as<int>(), Tp, rows, rows_alloc);
     if (tpath) {
         // fp16 operands: zero once -- gap rows, guard rows and pad columns are never written afterwards
         const size_t nxh = (r + 2 * (size_t)guard) * Cp * 2, nh = r * Cp * 2, ns = r * Mp * 2;
         DSVC_TRY(xh.alloc(nxh)); DSVC_TRY(gh.alloc(nh)); DSVC_TRY(skiph.alloc(2 * nh)); DSVC_TRY(s2h.alloc(2 * nh)); DSVC_TRY(xsh.alloc(2 * ns));
-        DSVC_HIP(hipMemset(xh.p, 0, nxh)); DSVC_HIP(hipMemset(gh.p, 0, nh)); DSVC_HIP(hipMemset(skiph.p, 0, 2 * nh));   // hi|lo planes
-        DSVC_HIP(hipMemset(s2h.p, 0, 2 * nh)); DSVC_HIP(hipMemset(xsh.p, 0, 2 * ns));
-        DSVC_HIP(hipMemset(xres.p, 0, r * C * 4)); DSVC_HIP(hipMemset(skip.p, 0, r * C * 4));
-        DSVC_HIP(hipMemset(condT.p, 0, r * H * 4)); DSVC_HIP(hipMemset(cproj.p, 0, r * 2 * C * L * 4));
+        DSVC_HIP(hipMemsetAsync(xh.p, 0, nxh, st)); DSVC_HIP(hipMemsetAsync(gh.p, 0, nh, st)); DSVC_HIP(hipMemsetAsync(skiph.p, 0, 2 * nh, st));   // hi|lo planes
+        DSVC_HIP(hipMemsetAsync(s2h.p, 0, 2 * nh, st)); DSVC_HIP(hipMemsetAsync(xsh.p, 0, 2 * ns, st));
+        DSVC_HIP(hipMemsetAsync(xres.p, 0, r * C * 4, st)); DSVC_HIP(hipMemsetAsync(skip.p, 0, r * C * 4, st));
+        DSVC_HIP(hipMemsetAsync(condT.p, 0, r * H * 4, st)); DSVC_HIP(hipMemsetAsync(cproj.p, 0, r * 2 * C * L * 4, st));
     } else {
         DSVC_TRY(g.alloc(r * C * 4)); DSVC_TRY(s2.alloc(r * C * 4));
     }
     wsB = B; wsT = T;
     cond_ready = false;
+    return DSVC_OK;
+}
+
+int dsvc_denoiser::set_clip_meta(const int32_t* ids_dev, int first, const int32_t* lens_dev, hipStream_t st) {
+    const int B = wsB, nb = ceil_div(B, 256);
+    if (ids_dev) DSVC_HIP(hipMemcpyAsync(clipid.p, ids_dev, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    else hipLaunchKernelGGL(k_iota_int, dim3(nb), dim3(256), 0, st, clipid.as<int>(), first, 1, B);
+    if (lens_dev) hipLaunchKernelGGL(k_clamp_copy_int, dim3(nb), dim3(256), 0, st, lens.as<int>(), lens_dev, 0, wsT, B);
+    else hipLaunchKernelGGL(k_iota_int, dim3(nb), dim3(256), 0, st, lens.as<int>(), wsT, 0, B);
+    hipLaunchKernelGGL(k_build_rowclip, dim3(ceil_div(rows_alloc, 256)), dim3(256), 0, st, rowclip.as<int>(), lens.as<int>(), Tp, rows, rows_alloc);
+    DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
 
@@ -402,7 +429,7 @@ int dsvc_denoiser::prepare_cond(const float* cond_bht, int B, int T, hipStream_t
                        cond_bht, condT.as<float>(), B, H, T, Tp, 1.0f);
     for (int l = 0; l < L; ++l) {
         ConvGemmArgs a{};
-        a.x = condT.as<float>(); a.ldx = H; a.n_rows = rows; a.clip_stride = Tp; a.clip_len = T;
+        a.x = condT.as<float>(); a.ldx = H; a.n_rows = rows; a.clip_stride = Tp; a.clip_len = T;      // (cond is zero on padded frames already)
         a.cin = H; a.taps = 1; a.dil = 1; a.w = condp[l].w.as<_Float16>(); a.n_ctiles = condp[l].n_ctiles; a.w_planes = 2;
         a.in_slope = 1.0f;
         if (tpath) {
@@ -425,7 +452,7 @@ int dsvc_denoiser::eval_conv(const float* x_fm, const StepRef& step, Tail tail, 
     const int M = cfg.mel_bins, C = cfg.channels, L = cfg.layers;
     auto base = [&](const float* x, int ldx, int cin, const PackedConv& pc) {
         ConvGemmArgs a{};
-        a.x = x; a.ldx = ldx; a.n_rows = rows; a.clip_stride = Tp; a.clip_len = wsT;
+        a.x = x; a.ldx = ldx; a.n_rows = rows; a.clip_stride = Tp; a.clip_len = wsT; a.clip_lens = lens.as<int>();
         a.cin = cin; a.taps = pc.taps; a.dil = 1; a.w = pc.w.as<_Float16>(); a.n_ctiles = pc.n_ctiles; a.w_planes = 2;
         a.in_slope = 1.0f;
         return a;
@@ -461,7 +488,7 @@ int dsvc_denoiser::eval_conv(const float* x_fm, const StepRef& step, Tail tail, 
         if (tail == TAIL_DDPM) {
             EpiDdpm::Args e{};
             e.x = ddpm->x; e.bias = fin_proj.bias.as<float>(); e.M = M; e.tab = ddpm->tab; e.step = step;
-            e.clip_stride = Tp; e.clip_len = wsT; e.seedp = ddpm->seedp; e.clip0p = ddpm->clip0p;
+            e.clip_stride = Tp; e.lens = lens.as<int>(); e.seedp = ddpm->seedp; e.clipid = ddpm->clipid;
             DSVC_TRY(dispatch_prec<EpiDdpm>(a, e, DSVC_PREC_F16_X3, st));
         } else {
             EpiBias::Args e{eps.as<float>(), M, fin_proj.bias.as<float>(), M};
@@ -521,7 +548,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
     {   // K9b: output projection (net.py:134), optionally fused with the DDPM update (K10)
         TGemmArgs a = targs(s2h.as<_Float16>(), 2 * Cp, fin_t, 1, 1);
         if (tail == TAIL_DDPM) {
-            TEpiDdpm::Args e{ddpm->x, xsh.as<_Float16>(), fin_t.bias.as<float>(), M, Mp, ddpm->tab, step, rm, ddpm->seedp, ddpm->clip0p};
+            TEpiDdpm::Args e{ddpm->x, xsh.as<_Float16>(), fin_t.bias.as<float>(), M, Mp, ddpm->tab, step, rm, ddpm->seedp, ddpm->clipid};
             DSVC_TRY(tlaunch_prec<TEpiDdpm>(a, e, 2, rows_alloc, st));
         } else {
             TEpiEps::Args e{eps.as<float>(), M, fin_t.bias.as<float>()};
@@ -545,12 +572,12 @@ struct dsvc_sampler {
     // captured PLMS iteration (one denoiser evaluation + Adams-Bashforth update; t and the history count live on the device)
     hipGraphExec_t gexec_plms = nullptr;
     int pB = 0, pT = 0, p_prec = -1, p_interval = 0, p_first = -1, p_iters = 0;
-    const void* p_key = nullptr;
+    unsigned p_gen = 0;
     // captured DDPM graph
     hipGraphExec_t gexec = nullptr;
     hipStream_t cap_stream = nullptr;
     int g_unroll = 0, gB = 0, gT = 0, g_prec = -1;
-    const void* g_key = nullptr;
+    unsigned g_gen = 0;
 
     ~dsvc_sampler() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
@@ -561,7 +588,7 @@ struct dsvc_sampler {
             b->release();
     }
     int finalize();
-    int ensure_ws(int B, int T);
+    int ensure_ws(int B, int T, hipStream_t st);
     dsvc_denoiser::DdpmCtx ddpm_ctx();
     int run_ddpm(const dsvc_sample_args* a, hipStream_t st);
     int run_plms(const dsvc_sample_args* a, hipStream_t st);
@@ -604,12 +631,12 @@ int dsvc_sampler::finalize() {
     return DSVC_OK;
 }
 
-int dsvc_sampler::ensure_ws(int B, int T) {
-    DSVC_TRY(den->ensure_ws(B, T));
+int dsvc_sampler::ensure_ws(int B, int T, hipStream_t st) {
+    DSVC_TRY(den->ensure_ws(B, T, st));
     if (B == wsB && T == wsT) return DSVC_OK;
     const size_t n = (size_t)den->rows_alloc * den->cfg.mel_bins * 4;
     DSVC_TRY(xstate.alloc(n)); DSVC_TRY(hist.alloc(4 * n)); DSVC_TRY(xpred.alloc(n));
-    DSVC_HIP(hipMemset(xstate.p, 0, n)); DSVC_HIP(hipMemset(xpred.p, 0, n)); DSVC_HIP(hipMemset(hist.p, 0, 4 * n));
+    DSVC_HIP(hipMemsetAsync(xstate.p, 0, n, st)); DSVC_HIP(hipMemsetAsync(xpred.p, 0, n, st)); DSVC_HIP(hipMemsetAsync(hist.p, 0, 4 * n, st));
     wsB = B; wsT = T;
     if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
     if (gexec_plms) { (void)hipGraphExecDestroy(gexec_plms); gexec_plms = nullptr; }
@@ -620,9 +647,9 @@ dsvc_denoiser::DdpmCtx dsvc_sampler::ddpm_ctx() {
     dsvc_denoiser::DdpmCtx c{};
     c.x = xstate.as<float>();
     c.tab = DdpmTables{sqrt_recip.as<float>(), sqrt_recipm1.as<float>(), coef1.as<float>(), coef2.as<float>(), sigma.as<float>()};
-    // step_dev: [0] t, [1] PLMS history count, bytes 8..15 the Philox seed, [4] clip id of slot 0
+    // step_dev: [0] t, [1] PLMS history count, bytes 8..15 the Philox seed; the clip ids live in the denoiser's workspace
     c.seedp = reinterpret_cast<const unsigned long long*>(step_dev.as<char>() + 8);
-    c.clip0p = step_dev.as<int>() + 4;
+    c.clipid = den->clipid.as<int>();
     return c;
 }
 
@@ -632,7 +659,6 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>(), t);
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>() + 2, (int)(unsigned)(a->seed & 0xffffffffull));
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>() + 3, (int)(unsigned)(a->seed >> 32));
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, step_dev.as<int>() + 4, a->first_clip);
     auto eager_step = [&]() -> int {
         dsvc_denoiser::DdpmCtx e = ddpm_ctx();
         DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, st, t));
@@ -647,7 +673,7 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
     const int UNROLL = (nvar > 1 && nvar <= 64) ? nvar : 10;
     const bool aligned = UNROLL == nvar && nvar > 1;
     if (a->use_graph && n >= 2 * UNROLL) {
-        const bool stale = !gexec || g_unroll != UNROLL || gB != a->B || gT != a->T || g_prec != den->cfg.precision || g_key != den->cproj.p;
+        const bool stale = !gexec || g_unroll != UNROLL || gB != a->B || gT != a->T || g_prec != den->cfg.precision || g_gen != den->ws_gen;
         if (stale) {
             if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
             DSVC_TRY(eager_step());                       // one eager step first: sets every function attribute outside the capture
@@ -669,7 +695,7 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
             (void)hipGraphDestroy(graph);
             if (ce != hipSuccess) { gexec = nullptr; return fail(DSVC_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ce)); }
             g_unroll = UNROLL; gB = a->B; gT = a->T; g_prec = den->cfg.precision;
-            g_key = den->cproj.p;
+            g_gen = den->ws_gen;
         }
         if (aligned)
             while (n > 0 && (t % UNROLL) != UNROLL - 1) DSVC_TRY(eager_step());     // walk to the period boundary
@@ -723,7 +749,7 @@ int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
     if (a->use_graph && iters >= 4) {
         // the whole remaining chain is ONE graph (51 evaluations for pndm_speedup = 20: ~2300 nodes), keyed by its schedule
         const bool stale = !gexec_plms || pB != a->B || pT != a->T || p_prec != den->cfg.precision || p_interval != interval ||
-                           p_first != i || p_iters != iters - 1 || p_key != den->cproj.p;
+                           p_first != i || p_iters != iters - 1 || p_gen != den->ws_gen;
         DSVC_TRY(body(st, i));                           // first of them eagerly: sets every function attribute outside a capture
         iters -= 1; i -= interval;
         if (stale) {
@@ -741,7 +767,7 @@ int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
             (void)hipGraphDestroy(graph);
             if (ce != hipSuccess) { gexec_plms = nullptr; return fail(DSVC_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ce)); }
             pB = a->B; pT = a->T; p_prec = den->cfg.precision; p_interval = interval; p_first = i + interval; p_iters = iters;
-            p_key = den->cproj.p;
+            p_gen = den->ws_gen;
         }
         DSVC_HIP(hipGraphLaunch(gexec_plms, st));
         iters = 0;
@@ -791,7 +817,8 @@ int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t,
     hipStream_t st = (hipStream_t)stream;
     const int M = d->cfg.mel_bins;
     const bool fresh = !(B == d->wsB && T == d->wsT);
-    DSVC_TRY(d->ensure_ws(B, T));
+    DSVC_TRY(d->ensure_ws(B, T, st));
+    DSVC_TRY(d->set_clip_meta(nullptr, 0, nullptr, st));
     if (fresh || cond_changed || !d->cond_ready) DSVC_TRY(d->prepare_cond(cond, B, T, st));
     hipLaunchKernelGGL(k_to_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st, spec,
                        d->xin.as<float>(), B, M, T, d->Tp, 1.0f);
@@ -879,16 +906,22 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
     dsvc_denoiser* d = s->den;
     const int B = a->B, T = a->T, M = d->cfg.mel_bins;
     if ((T * M) % 4) return fail(DSVC_EINVAL, "T*mel_bins must be a multiple of 4");
-    DSVC_TRY(s->ensure_ws(B, T));
+    DSVC_TRY(s->ensure_ws(B, T, st));
+    DSVC_TRY(d->set_clip_meta(a->clip_ids, a->first_clip, a->clip_lens, st));
     DSVC_TRY(d->prepare_cond(a->cond, B, T, st));
     float* xs = s->xstate.as<float>();
     if (a->ref_mel) {
-        // use_gt_mel start (diffusion.py:255-261): x = q_sample(norm_spec(ref_mel), t_start-1)
-        return fail(DSVC_EINVAL, "ref_mel start is handled by the Python host (norm_spec + q_sample into x_init)");
+        // use_gt_mel start (diffusion.py:255-261): x = q_sample(norm_spec(ref_mel), t_start - 1, noise)   (:200-205, :286-287)
+        const size_t nm = (size_t)B * T * M;
+        const int nb = (int)((nm + 255) / 256 < 4096 ? (nm + 255) / 256 : 4096);
+        hipLaunchKernelGGL(k_norm_ref_mel, dim3(nb), dim3(256), 0, st, a->ref_mel, xs, s->spec_min.as<float>(), s->spec_max.as<float>(),
+                           s->n_spec, B, T, M, d->Tp);
+        hipLaunchKernelGGL(k_q_sample, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, xs, B, T, M, d->Tp,
+                           s->h_sqrt_ac[a->t_start - 1], s->h_sqrt_1mac[a->t_start - 1], a->seed, d->clipid.as<int>());
     } else if (a->x_init) {
         hipLaunchKernelGGL(k_to_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st, a->x_init, xs, B, M, T, d->Tp, 1.0f);
     } else {
-        hipLaunchKernelGGL(k_x_init, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, xs, B, T, M, d->Tp, a->seed, a->first_clip);
+        hipLaunchKernelGGL(k_x_init, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, xs, B, T, M, d->Tp, a->seed, d->clipid.as<int>());
     }
     if (d->tpath)      // fp16 copy of the state for the first input projection; every DDPM tail refreshes it afterwards
         hipLaunchKernelGGL(k_rows_to_half, dim3(ceil_div(d->rows * (M / 4), 256) < 2048 ? ceil_div(d->rows * (M / 4), 256) : 2048), dim3(256), 0, st,
@@ -897,7 +930,7 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
     else DSVC_TRY(s->run_ddpm(a, st));
     const size_t n = (size_t)B * T * M;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_finish_mel, dim3(blocks), dim3(256), 0, st, xs, a->mel_out, a->mel2ph, s->spec_min.as<float>(),
+    hipLaunchKernelGGL(k_finish_mel, dim3(blocks), dim3(256), 0, st, xs, a->mel_out, a->mel2ph, d->lens.as<int>(), s->spec_min.as<float>(),
                        s->spec_max.as<float>(), s->n_spec, B, T, M, d->Tp);
     if (a->x_out)
         hipLaunchKernelGGL(k_from_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st, xs, a->x_out, B, M, T, d->Tp);
@@ -909,7 +942,8 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
     if (!s || !avg_us || !rows || iters < 1) return fail(DSVC_EINVAL, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     dsvc_denoiser* d = s->den;
-    DSVC_TRY(s->ensure_ws(B, T));
+    DSVC_TRY(s->ensure_ws(B, T, st));
+    DSVC_TRY(d->set_clip_meta(nullptr, 0, nullptr, st));
     if (!d->cond_ready) DSVC_HIP(hipMemsetAsync(d->cproj.p, 0, d->cproj.bytes, st));
     const int C = d->cfg.channels, L = d->cfg.layers;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, s->step_dev.as<int>(), 0);
@@ -947,7 +981,7 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
                 DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, d->dil_t[l].planes, d->rows_alloc, st));
             } else {
                 ConvGemmArgs a{};
-                a.x = d->xres.as<float>(); a.ldx = C; a.n_rows = d->rows; a.clip_stride = d->Tp; a.clip_len = d->wsT;
+                a.x = d->xres.as<float>(); a.ldx = C; a.n_rows = d->rows; a.clip_stride = d->Tp; a.clip_len = d->wsT; a.clip_lens = d->lens.as<int>();
                 a.cin = C; a.taps = 3; a.dil = 1 << (l % d->cfg.dilation_cycle); a.w = d->dil[l].w.as<_Float16>();
                 a.n_ctiles = d->dil[l].n_ctiles; a.w_planes = 2; a.in_slope = 1.0f;
                 a.film = d->film.as<float>() + (size_t)l * C; a.film_step_stride = L * C; a.step_ptr = s->step_dev.as<int>();

@@ -108,15 +108,16 @@ struct EpiDdpm {
         int M;
         DdpmTables tab;
         StepRef step;
-        int clip_stride, clip_len;
-        const unsigned long long* seedp;   // device: Philox seed and clip id of slot 0 live in memory so that a captured
-        const int* clip0p;                 // graph serves every call (they change per call, the graph does not)
+        int clip_stride;
+        const int* lens;                   // device [B]: valid frames per clip
+        const unsigned long long* seedp;   // device: the Philox seed and the clip ids live in memory so that a captured
+        const int* clipid;                 // graph serves every call (they change per call, the graph does not); [B]
     };
     __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
         if (col >= e.M) return;
         const int clip = row / e.clip_stride;
         const int tl = row - clip * e.clip_stride;
-        if (tl >= e.clip_len) return;
+        if (tl >= e.lens[clip]) return;
         const int t = e.step.get(clip);
         const float eps = v + e.bias[col];
         float* px = e.x + (size_t)row * e.M + col;
@@ -126,7 +127,7 @@ struct EpiDdpm {
         float out = e.tab.coef1[t] * x0 + e.tab.coef2[t] * xt;
         if (t > 0) {
             const unsigned el = (unsigned)tl * (unsigned)e.M + (unsigned)col;
-            const float z = philox_normal_lane(el >> 2, (unsigned)t, (unsigned)(*e.clip0p + clip), PURPOSE_DDPM_NOISE, *e.seedp, el & 3);
+            const float z = philox_normal_lane(el >> 2, (unsigned)t, (unsigned)e.clipid[clip], PURPOSE_DDPM_NOISE, *e.seedp, el & 3);
             out += e.tab.sigma[t] * z;
         }
         *px = out;
@@ -172,20 +173,20 @@ __global__ void k_from_frame_major(const float* __restrict__ src, float* __restr
 }
 
 // x_T ~ N(0,1) straight into the frame-major state (diffusion.py:265-268 with our Philox stream)
-__global__ void k_x_init(float* __restrict__ x, int B, int T, int M, int stride, unsigned long long seed, int clip0) {
+__global__ void k_x_init(float* __restrict__ x, int B, int T, int M, int stride, unsigned long long seed, const int* __restrict__ clipid) {
     const int quads = T * M / 4;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (q >= quads) return;
     float z[4];
-    philox_normal4((unsigned)q, 0u, (unsigned)(clip0 + b), PURPOSE_X_INIT, seed, z);
+    philox_normal4((unsigned)q, 0u, (unsigned)clipid[b], PURPOSE_X_INIT, seed, z);
     float* p = x + (size_t)b * stride * M + (size_t)q * 4;       // rows of a clip are contiguous: t*M+m == q*4
     *reinterpret_cast<float4*>(p) = make_float4(z[0], z[1], z[2], z[3]);
 }
 
 // K12: denorm + mask + layout: state [B*stride][M] -> mel_out [B][T][M]   (diffusion.py:279-290)
 __global__ void k_finish_mel(const float* __restrict__ x, float* __restrict__ mel, const int* __restrict__ mel2ph,
-                             const float* __restrict__ spec_min, const float* __restrict__ spec_max, int n_spec,
+                             const int* __restrict__ lens, const float* __restrict__ spec_min, const float* __restrict__ spec_max, int n_spec,
                              int B, int T, int M, int stride) {
     const size_t n = (size_t)B * T * M;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -195,11 +196,22 @@ __global__ void k_finish_mel(const float* __restrict__ x, float* __restrict__ me
         const float lo = spec_min[n_spec == 1 ? 0 : m], hi = spec_max[n_spec == 1 ? 0 : m];
         float v = (x[((size_t)b * stride + t) * M + m] + 1.0f) / 2.0f * (hi - lo) + lo;
         if (mel2ph && mel2ph[bt] <= 0) v = v * 0.0f;
+        if (t >= lens[b]) v = 0.0f;                          // zero padding beyond the clip's own length
         mel[i] = v;
     }
 }
 
 __global__ void k_set_int(int* p, int v) { *p = v; }
+// p[i] = base + i*stride  (clip ids first_clip + b; stride 0 fills a constant: the default per-clip length)
+__global__ void k_iota_int(int* p, int base, int stride, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = base + i * stride;
+}
+// p[i] = min(max(src[i], lo), hi)  (caller-supplied per-clip lengths, clamped to the workspace)
+__global__ void k_clamp_copy_int(int* p, const int* __restrict__ src, int lo, int hi, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int v = src[i]; p[i] = v < lo ? lo : (v > hi ? hi : v); }
+}
 __global__ void k_add_int(int* p, int d) { *p += d; }
 
 // ---- step-embedding tables (K2, K3): depend on the integer step only => built once per checkpoint ----
@@ -292,15 +304,28 @@ __global__ void k_plms(const PlmsArgs a) {
     }
 }
 
+// norm_spec (diffusion.py:286-287) of a reference mel [B][T][M] (log10) into the frame-major state [B*stride][M]
+__global__ void k_norm_ref_mel(const float* __restrict__ mel, float* __restrict__ x, const float* __restrict__ spec_min,
+                               const float* __restrict__ spec_max, int n_spec, int B, int T, int M, int stride) {
+    const size_t n = (size_t)B * T * M;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % M);
+        const size_t bt = i / M;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const float lo = spec_min[n_spec == 1 ? 0 : m], hi = spec_max[n_spec == 1 ? 0 : m];
+        x[((size_t)b * stride + t) * M + m] = (mel[i] - lo) / (hi - lo) * 2.0f - 1.0f;
+    }
+}
+
 // q_sample (diffusion.py:200-205) in place on the frame-major state: x = sa*x0 + sb*noise(Philox X_INIT stream)
 __global__ void k_q_sample(float* __restrict__ x, int B, int T, int M, int stride, float sa, float sb,
-                           unsigned long long seed, int clip0) {
+                           unsigned long long seed, const int* __restrict__ clipid) {
     const int quads = T * M / 4;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (q >= quads) return;
     float z[4];
-    philox_normal4((unsigned)q, 0u, (unsigned)(clip0 + b), PURPOSE_X_INIT, seed, z);
+    philox_normal4((unsigned)q, 0u, (unsigned)clipid[b], PURPOSE_X_INIT, seed, z);
     float4* p = reinterpret_cast<float4*>(x + (size_t)b * stride * M + (size_t)q * 4);
     float4 v = *p;
     v.x = sa * v.x + sb * z[0]; v.y = sa * v.y + sb * z[1]; v.z = sa * v.z + sb * z[2]; v.w = sa * v.w + sb * z[3];

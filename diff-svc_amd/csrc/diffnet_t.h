@@ -11,15 +11,26 @@
 
 namespace dsvc {
 
-// which rows of the frame-major buffers are real frames: row = clip*clip_stride + t, t < clip_len, row < n_valid
+// which rows of the frame-major buffers are real frames: rowclip[row] = the clip a row belongs to, or -1 for a gap / padded row
+// (row = clip*clip_stride + t with t < that clip's own length).  The table is rebuilt per call from the per-clip lengths
+// (k_build_rowclip): the epilogues pay one 4-byte load per row instead of an integer division, and a clip shorter than the
+// batch's T gets true zero padding (dsvc_sample_args.clip_lens).
 struct RowMap {
-    int clip_stride, clip_len, n_valid;
+    int clip_stride;
+    const int* rowclip;         // device [rows_alloc]
     __device__ __forceinline__ bool valid(int row, int& clip, int& tl) const {
-        clip = row / clip_stride;
+        clip = rowclip[row];
         tl = row - clip * clip_stride;
-        return row < n_valid && tl < clip_len;
+        return clip >= 0;
     }
 };
+
+__global__ void k_build_rowclip(int* __restrict__ rowclip, const int* __restrict__ lens, int clip_stride, int rows, int rows_alloc) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows_alloc) return;
+    const int clip = row / clip_stride, tl = row - clip * clip_stride;
+    rowclip[row] = (row < rows && tl < lens[clip]) ? clip : -1;
+}
 
 // "accumulator-tiled" fp32 layout of the buffers that only the tgemm epilogues touch (residual stream, skip sum,
 // hoisted conditioner projection): [frame tile of 32][m_tile][q = reg/4][lane 64][4 floats], i.e. exactly the order
@@ -319,7 +330,7 @@ struct TEpiDdpm {
         StepRef step;
         RowMap rm;
         const unsigned long long* seedp;   // device (see EpiDdpm)
-        const int* clip0p;
+        const int* clipid;
     };
     template <int NT_N>
     __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
@@ -351,7 +362,7 @@ struct TEpiDdpm {
                 float z[4] = {0.f, 0.f, 0.f, 0.f};
                 if (t > 0) {
                     const unsigned el = (unsigned)tl * (unsigned)e.M + (unsigned)(cb + 4 * q);
-                    philox_normal4(el >> 2, (unsigned)t, (unsigned)(*e.clip0p + clip), PURPOSE_DDPM_NOISE, *e.seedp, z);
+                    philox_normal4(el >> 2, (unsigned)t, (unsigned)e.clipid[clip], PURPOSE_DDPM_NOISE, *e.seedp, z);
                 }
                 f32x4 out;
 #pragma unroll
@@ -375,6 +386,8 @@ struct TEpiDdpm {
 
 // fp32 frame-major [rows][C] -> fp16 hi|lo planes [rows][2*ld] (valid rows only; gap rows and pad columns stay zero)
 __global__ void k_rows_to_half(const float* __restrict__ src, _Float16* __restrict__ dst, int C, int ld, RowMap rm, int rows) {
+    // (rows beyond a clip's own length are skipped: they keep whatever an earlier call left there, which no valid frame ever reads --
+    //  the projections that consume this buffer are 1x1)
     const int per_row = C >> 2;
     const long long n = (long long)rows * per_row;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {

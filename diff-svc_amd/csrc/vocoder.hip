@@ -262,12 +262,13 @@ __global__ void k_prep_mel(const float* __restrict__ mel, float* __restrict__ ds
 struct SrcFrame { double base; double flprev; double delta_acc; };
 
 __global__ void k_source_frames(const float* __restrict__ f0, SrcFrame* __restrict__ fr, float* __restrict__ fl00,
-                                int T, int hop, int dim, float sr, unsigned long long seed, int clip0) {
+                                int T, int hop, int dim, float sr, unsigned long long seed, int clip0, const int* __restrict__ clip_ids) {
     const int b = blockIdx.x, h = threadIdx.x;
     if (h >= dim) return;
+    const unsigned cid = (unsigned)(clip_ids ? clip_ids[b] : clip0 + b);
     float ini = 0.f;
     if (h > 0) {
-        const u32x4 r = philox4x32((unsigned)(h >> 2), 0u, (unsigned)(clip0 + b), PURPOSE_SINE_PHASE, seed);
+        const u32x4 r = philox4x32((unsigned)(h >> 2), 0u, cid, PURPOSE_SINE_PHASE, seed);
         const unsigned w = (h & 3) == 0 ? r.x : (h & 3) == 1 ? r.y : (h & 3) == 2 ? r.z : r.w;
         ini = u01_open_high(w);
     }
@@ -298,8 +299,9 @@ __global__ void k_source_frames(const float* __restrict__ f0, SrcFrame* __restri
 __global__ void k_source_samples(const float* __restrict__ f0, const SrcFrame* __restrict__ fr, const float* __restrict__ fl00,
                                  const float* __restrict__ lin_w, const float* __restrict__ lin_b, float* __restrict__ har,
                                  int T, int hop, int dim, float sr, int stride_samples, unsigned long long seed, int clip0,
-                                 float sine_amp, float noise_std) {
+                                 const int* __restrict__ clip_ids, float sine_amp, float noise_std) {
     const int b = blockIdx.y;
+    const unsigned cid = (unsigned)(clip_ids ? clip_ids[b] : clip0 + b);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T * hop) return;
     const int f = i / hop, j = i - f * hop;
@@ -308,7 +310,7 @@ __global__ void k_source_samples(const float* __restrict__ f0, const SrcFrame* _
     const float noise_amp = uv * noise_std + ((1.f - uv) * sine_amp) / 3.f;
     float zs[12];
     for (int q = 0; q < (dim + 3) / 4; ++q)
-        philox_normal4((unsigned)i, (unsigned)q, (unsigned)(clip0 + b), PURPOSE_SINE_NOISE, seed, zs + 4 * q);
+        philox_normal4((unsigned)i, (unsigned)q, cid, PURPOSE_SINE_NOISE, seed, zs + 4 * q);
     float acc = 0.f;
     for (int h = 0; h < dim; ++h) {
         const float fh = f0v * (float)(h + 1);
@@ -421,7 +423,7 @@ struct dsvc_vocoder {
 
     int finalize();
     int ensure_ws(int B, int T);
-    int run(const float* mel, const float* f0, float* wav, int B, int T, unsigned long long seed, int clip0, hipStream_t st);
+    int run(const float* mel, const float* f0, float* wav, int B, int T, unsigned long long seed, int clip0, const int* clip_ids, hipStream_t st);
 };
 
 int dsvc_vocoder::finalize() {
@@ -550,7 +552,7 @@ int dsvc_vocoder::ensure_ws(int B, int T) {
     return DSVC_OK;
 }
 
-int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int T, unsigned long long seed, int clip0, hipStream_t st) {
+int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int T, unsigned long long seed, int clip0, const int* clip_ids, hipStream_t st) {
     DSVC_TRY(ensure_ws(B, T));
     const int nu = cfg.n_ups, nk = cfg.n_kernels, ch0 = cfg.upsample_initial_channel, M = cfg.num_mels;
     const int prec = cfg.precision;
@@ -560,9 +562,9 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
     }
     // excitation (models.py:363-366)
     hipLaunchKernelGGL(k_source_frames, dim3(B), dim3(32), 0, st, f0, frames.as<SrcFrame>(), fl00.as<float>(), T, hop, dim,
-                       (float)cfg.sampling_rate, seed, clip0);
+                       (float)cfg.sampling_rate, seed, clip0, clip_ids);
     hipLaunchKernelGGL(k_source_samples, dim3(ceil_div(T * hop, 256), B), dim3(256), 0, st, f0, frames.as<SrcFrame>(), fl00.as<float>(),
-                       lin_w.as<float>(), lin_b.as<float>(), har.as<float>(), T, hop, dim, (float)cfg.sampling_rate, Tp * hop, seed, clip0,
+                       lin_w.as<float>(), lin_b.as<float>(), har.as<float>(), T, hop, dim, (float)cfg.sampling_rate, Tp * hop, seed, clip0, clip_ids,
                        0.1f, 0.003f);
     auto conv = [&](const PackedConv& pc, const float* x, int rows, int stride, int len, float slope) {
         ConvGemmArgs a{};
@@ -678,10 +680,10 @@ int dsvc_vocoder_finalize(dsvc_vocoder* v) {
 void dsvc_vocoder_destroy(dsvc_vocoder* v) { delete v; }
 
 int dsvc_vocode(dsvc_vocoder* v, const float* mel, const float* f0, float* wav, int32_t B, int32_t T, uint64_t seed,
-                int32_t first_clip, void* stream) {
+                int32_t first_clip, const int32_t* clip_ids, void* stream) {
     if (!v || !mel || !f0 || !wav) return fail(DSVC_EINVAL, "null argument");
     if (!v->finalized) return fail(DSVC_ESTATE, "vocoder not finalized");
-    return v->run(mel, f0, wav, B, T, seed, first_clip, (hipStream_t)stream);
+    return v->run(mel, f0, wav, B, T, seed, first_clip, clip_ids, (hipStream_t)stream);
 }
 
 }  // extern "C"

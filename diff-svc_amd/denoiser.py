@@ -62,7 +62,8 @@ class DiffNetHip(nn.Module):
         nn.init.zeros_(self.output_projection.weight)           # net.py:110
         self._handle = None
         self._handle_key = None
-        self._cond_key = None
+        self._cond_ref = None          # the cond tensor whose hoisted projections the C handle holds (a strong reference, so the
+        self._cond_ver = -1            # caching allocator cannot hand its address to a different tensor: no ABA on data_ptr)
 
     # -- C handle management: rebuilt whenever a parameter tensor changes (load_state_dict, .to(), in-place edits)
     def _params_key(self):
@@ -74,14 +75,19 @@ class DiffNetHip(nn.Module):
             self._handle = DenoiserHandle(self.state_dict(), self.in_dims, self.encoder_hidden, self.channels, self.n_layers,
                                           self.dilation_cycle, self.max_steps, precision=self.precision)
             self._handle_key = key
-            self._cond_key = None
+            self.invalidate_cond()
         return self._handle
+
+    def invalidate_cond(self):
+        """Forget which cond the C handle's hoisted conditioner projections belong to (the sampler path overwrites them)."""
+        self._cond_ref, self._cond_ver = None, -1
 
     def forward(self, spec, diffusion_step, cond):
         """spec [B,1,M,T], diffusion_step [B] (long), cond [B,H,T] -> [B,1,M,T]   (net.py:112-135)"""
         h = self.handle()
-        ckey = (cond.data_ptr(), cond._version, tuple(cond.shape))
-        changed = ckey != self._cond_key                      # the sampler calls with the same cond 1000 times
+        # a sampler loop calls with the SAME cond tensor 1000 times: the hoisted conditioner projections are recomputed only
+        # when the tensor object or its version counter changes (identity, not address: see __init__)
+        changed = not (cond is self._cond_ref and cond._version == self._cond_ver)
         out = h.forward(spec, diffusion_step.reshape(-1), cond, cond_changed=changed)
-        self._cond_key = ckey
+        self._cond_ref, self._cond_ver = cond, cond._version
         return out

@@ -56,6 +56,13 @@ class DenoiserHandle:
         spec = spec.contiguous().float()
         cond = cond.contiguous().float()
         t32 = t.to(torch.int32).contiguous()
+        if t32.numel() != B:
+            raise ValueError("diffusion_step must hold one step per clip (%d), got %d" % (B, t32.numel()))
+        # the step embedding / FiLM path is TABULATED for the integer steps 0 .. timesteps-1 (net.py:32-44,99-103 evaluated at
+        # load): anything else would index outside the table.  (The sampler never leaves the range; this guards direct callers.)
+        lo, hi = int(t32.min().item()), int(t32.max().item())
+        if lo < 0 or hi >= self.cfg.max_steps:
+            raise ValueError("diffusion_step must be an integer in [0, %d), got %d..%d" % (self.cfg.max_steps, lo, hi))
         out = torch.empty_like(spec)
         check(lib().dsvc_denoiser_forward(self._h, ptr(spec), ptr(t32), ptr(cond), ptr(out), B, T,
                                           1 if cond_changed else 0, stream_ptr()))
@@ -93,9 +100,11 @@ class SamplerHandle:
         check(lib().dsvc_sampler_finalize(self._h))
 
     def sample(self, cond, t_start, speedup=1, x_init=None, mel2ph=None, seed=0, first_clip=0, t_stop=0,
-               use_graph=True, return_x=False):
-        """cond [B,H,T] -> mel_out [B,T,M] (denormalised, masked).  See dsvc_sample_args."""
-        _need_cuda(cond, x_init, mel2ph)
+               use_graph=True, return_x=False, ref_mel=None, clip_ids=None, clip_lens=None):
+        """cond [B,H,T] -> mel_out [B,T,M] (denormalised, masked).  See dsvc_sample_args.
+        ref_mel [B,T,M]: use_gt_mel start (q_sample at t_start-1); clip_ids [B]: explicit Philox clip ids; clip_lens [B]: valid
+        frames per clip (frames beyond are the convs' zero padding, as if the clip ran alone)."""
+        _need_cuda(cond, x_init, mel2ph, ref_mel, clip_ids, clip_lens)
         if cond.dim() != 3:
             raise RuntimeError("cond must be [B, hidden, T], got %s" % (tuple(cond.shape),))
         B, H, T = cond.shape
@@ -111,8 +120,23 @@ class SamplerHandle:
         xo = torch.empty(B, 1, M, T, device=cond.device, dtype=torch.float32) if return_x else None
         xi = x_init.contiguous().float() if x_init is not None else None
         m2p = mel2ph.to(torch.int32).contiguous() if mel2ph is not None else None
-        a = _lib.SampleArgs(B, T, cond.data_ptr(), xi.data_ptr() if xi is not None else None, None,
-                            m2p.data_ptr() if m2p is not None else None, seed, first_clip, t_start, t_stop,
+        if ref_mel is not None and tuple(ref_mel.shape) != (B, T, M):
+            raise RuntimeError("ref_mel must be [B,T,M] = %s, got %s" % ((B, T, M), tuple(ref_mel.shape)))
+        rm = ref_mel.contiguous().float() if ref_mel is not None else None
+        ids = lens = None
+        if clip_ids is not None:
+            ids = clip_ids.to(torch.int32).contiguous()
+            if ids.numel() != B:
+                raise RuntimeError("clip_ids must hold %d entries" % B)
+        if clip_lens is not None:
+            lens = clip_lens.to(torch.int32).contiguous()
+            if lens.numel() != B:
+                raise RuntimeError("clip_lens must hold %d entries" % B)
+        a = _lib.SampleArgs(B, T, cond.data_ptr(), xi.data_ptr() if xi is not None else None,
+                            rm.data_ptr() if rm is not None else None,
+                            m2p.data_ptr() if m2p is not None else None, seed, first_clip,
+                            ids.data_ptr() if ids is not None else None, lens.data_ptr() if lens is not None else None,
+                            t_start, t_stop,
                             int(speedup), 1 if use_graph else 0, mel.data_ptr(), xo.data_ptr() if xo is not None else None)
         check(lib().dsvc_sample(self._h, ctypes.byref(a), stream_ptr()))
         return (mel, xo) if return_x else mel
@@ -167,16 +191,19 @@ class VocoderHandle:
             check(lib().dsvc_vocoder_load_tensor(self._h, k.encode(), p, hbuf.numel()))
         check(lib().dsvc_vocoder_finalize(self._h))
 
-    def vocode(self, mel, f0, seed=0, first_clip=0):
-        """mel [B,T,M] log10, f0 [B,T] Hz (0 = unvoiced) -> wav [B, T*hop]."""
-        _need_cuda(mel, f0)
+    def vocode(self, mel, f0, seed=0, first_clip=0, clip_ids=None):
+        """mel [B,T,M] log10, f0 [B,T] Hz (0 = unvoiced) -> wav [B, T*hop].  clip_ids [B]: explicit Philox clip ids."""
+        _need_cuda(mel, f0, clip_ids)
         B, T, M = mel.shape
         if M != self.num_mels or f0.shape != (B, T):
             raise ValueError("shape mismatch: mel %s f0 %s" % (tuple(mel.shape), tuple(f0.shape)))
         mel = mel.contiguous().float()
         f0 = f0.contiguous().float()
         wav = torch.empty(B, T * self.hop, device=mel.device, dtype=torch.float32)
-        check(lib().dsvc_vocode(self._h, ptr(mel), ptr(f0), ptr(wav), B, T, seed, first_clip, stream_ptr()))
+        ids = clip_ids.to(torch.int32).contiguous() if clip_ids is not None else None
+        if ids is not None and ids.numel() != B:
+            raise ValueError("clip_ids must hold %d entries" % B)
+        check(lib().dsvc_vocode(self._h, ptr(mel), ptr(f0), ptr(wav), B, T, seed, first_clip, ptr(ids), stream_ptr()))
         return wav
 
     def __del__(self):

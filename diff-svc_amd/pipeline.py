@@ -37,18 +37,64 @@ class SvcPipeline:
         self.vocoder = VocoderHandle(vocoder_state, vocoder_cfg, precision=vocoder_precision)
 
     @torch.no_grad()
-    def infer(self, hubert, mel2ph, f0, speedup=1, seed=0, first_clip=0, use_graph=True, return_mel=False):
+    def infer(self, hubert, mel2ph, f0, speedup=1, seed=0, first_clip=0, clip_ids=None, use_graph=True, return_mel=False,
+              return_lens=False):
         """hubert [B,N,H], mel2ph [B,T] long, f0 [B,T] log2 (interpolated) -- all device tensors.
-        Returns PCM [B, T*hop] on the device (and mel [B,T,M] if asked)."""
+        Returns PCM [B, T*hop] on the device (and mel [B,T,M] / the per-clip sample counts if asked).
+
+        Clips of different lengths are padded to a common T with ``mel2ph == 0`` frames at the end.  The reference runs every
+        clip alone (B=1, infer_tool.py:277), so a padded batch must equal the per-clip runs: trailing padded frames are the
+        convs' ZERO PADDING inside the sampler (``clip_lens``), and the host glue of ``Svc.after_infer``
+        (infer_tool.py:177-191) is reproduced per clip -- frames whose predicted mel row is all-zero are dropped (``mel_out``
+        is masked by ``mel2ph > 0``, diffusion.py:280-281, so those are exactly the ``mel2ph == 0`` frames), the mel is clipped to
+        [mel_vmin, mel_vmax], f0 is cut with the same mask -- before the vocoder sees it.  PCM rows are zero beyond a clip's own
+        ``kept_frames * hop`` samples."""
         hp = dict(self.hp, pndm_speedup=speedup)
         self.model.hp = hp
         self.model.fs2.hp = hp
-        ret = self.model(hubert, mel2ph=mel2ph, f0=f0.clone(), infer=True, seed=seed, first_clip=first_clip, use_graph=use_graph)
+        B, T = mel2ph.shape
+        valid = mel2ph > 0
+        ragged = not bool(valid.all().item())                  # one tiny D2H before anything is launched
+        clip_lens = None
+        if ragged:
+            ar = torch.arange(1, T + 1, device=mel2ph.device)
+            last = (valid * ar).amax(dim=1)                      # frames up to the last content frame (interior gaps stay inside)
+            clip_lens = last.clamp(min=1).to(torch.int32)
+        ret = self.model(hubert, mel2ph=mel2ph, f0=f0.clone(), infer=True, seed=seed, first_clip=first_clip, clip_ids=clip_ids,
+                         clip_lens=clip_lens, use_graph=use_graph)
         mel = ret["mel_out"]
-        # host glue of Svc.after_infer (infer_tool.py:177-183): clip the mel, f0 for the NSF source is f0_denorm
         mel_c = torch.clamp(mel, hp["mel_vmin"], hp["mel_vmax"])
-        wav = self.vocoder.vocode(mel_c, ret["f0_denorm"], seed=seed, first_clip=first_clip)
-        return (wav, mel) if return_mel else wav
+        hop = self.vocoder.hop
+        if not ragged:
+            wav = self.vocoder.vocode(mel_c, ret["f0_denorm"], seed=seed, first_clip=first_clip, clip_ids=clip_ids)
+            lens = torch.full((B,), T * hop, dtype=torch.int64, device=wav.device)
+        else:
+            wav, lens = self._vocode_ragged(mel_c, ret["f0_denorm"], valid, seed, first_clip, clip_ids)
+        out = (wav,)
+        if return_mel:
+            out += (mel,)
+        if return_lens:
+            out += (lens,)
+        return out if len(out) > 1 else wav
+
+    def _vocode_ragged(self, mel_c, f0_hz, valid, seed, first_clip, clip_ids):
+        """after_infer's frame drop per clip, then one vocoder call per group of equal kept length."""
+        B, T, M = mel_c.shape
+        hop = self.vocoder.hop
+        kept = valid.sum(dim=1).tolist()
+        ids = clip_ids.tolist() if clip_ids is not None else [first_clip + b for b in range(B)]
+        wav = torch.zeros(B, T * hop, device=mel_c.device, dtype=torch.float32)
+        groups = {}
+        for b, n in enumerate(kept):
+            if n > 0:
+                groups.setdefault(n, []).append(b)
+        for n, members in sorted(groups.items()):
+            mg = torch.stack([mel_c[b][valid[b]] for b in members])             # [g, n, M]: mel_pred[mel_pred_mask]
+            fg = torch.stack([f0_hz[b][valid[b]] for b in members])             # f0_pred[mel_pred_mask]
+            gid = torch.tensor([ids[b] for b in members], dtype=torch.int32, device=mel_c.device)
+            w = self.vocoder.vocode(mg.contiguous(), fg.contiguous(), seed=seed, clip_ids=gid)
+            wav[torch.tensor(members, device=wav.device), :n * hop] = w
+        return wav, torch.tensor([n * hop for n in kept], dtype=torch.int64, device=wav.device)
 
 
 def gather_pcm(local_wav, clip_ids, n_clips, group=None):

@@ -95,18 +95,20 @@ class GaussianDiffusionHip(nn.Module):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         smp = self._handle()
-        x_init = None
+        x_init = ref = None
         if kwargs.get("use_gt_mel"):
-            t = kwargs["add_noise_step"]                         # diffusion.py:255-261
-            x0 = self.norm_spec(ref_mels).transpose(1, 2)[:, None, :, :]
-            noise = torch.randn_like(x0)
-            x_init = (self.sqrt_alphas_cumprod[t - 1] * x0 + self.sqrt_one_minus_alphas_cumprod[t - 1] * noise).contiguous()
+            # diffusion.py:255-261: x = q_sample(norm_spec(ref_mels), t-1); norm_spec, q_sample and the noise draw (x_T Philox
+            # stream) all happen inside dsvc_sample (dsvc_sample_args.ref_mel)
+            t = int(kwargs["add_noise_step"])
+            ref = ref_mels
         else:
             t = self.K_step
             x_init = kwargs.get("x_init")
         speedup = hp.get("pndm_speedup") or 1
+        self.denoise_fn.invalidate_cond()        # dsvc_sample recomputes the handle's hoisted conditioner projections for THIS cond
         mel = smp.sample(cond, t, speedup=speedup if speedup > 1 else 1, x_init=x_init, mel2ph=mel2ph, seed=seed,
-                         first_clip=kwargs.get("first_clip", 0), use_graph=kwargs.get("use_graph", True))
+                         first_clip=kwargs.get("first_clip", 0), use_graph=kwargs.get("use_graph", True), ref_mel=ref,
+                         clip_ids=kwargs.get("clip_ids"), clip_lens=kwargs.get("clip_lens"))
         ret["mel_out"] = mel
         return ret
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DSVC_ABI_VERSION 2
+#define DSVC_ABI_VERSION 3
 
 enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM = 4 };
 
@@ -94,10 +94,17 @@ typedef struct {
     int32_t B, T;              /* clips, mel frames per clip                                               */
     const float* cond;         /* [B,H,T] device: ret['decoder_inp'].transpose(1,2)  (diffusion.py:232-234) */
     const float* x_init;       /* [B,1,M,T] device, or NULL: x_T ~ N(0,1) from Philox(seed, clip)          */
-    const float* ref_mel;      /* [B,T,M] device or NULL: use_gt_mel start (diffusion.py:255-261)          */
+    const float* ref_mel;      /* [B,T,M] device (log10 mel) or NULL: use_gt_mel start (diffusion.py:255-261):
+                                * x = q_sample(norm_spec(ref_mel), t_start - 1, noise) (diffusion.py:200-205,286-287) with the
+                                * noise drawn from the x_T Philox stream; takes precedence over x_init                  */
     const int32_t* mel2ph;     /* [B,T] device or NULL: output mask (mel2ph > 0)      (diffusion.py:280-281) */
     uint64_t seed;             /* Philox key for x_T and the per-step noise z                                */
     int32_t first_clip;        /* Philox clip id of batch element 0 (clip b uses first_clip + b)             */
+    const int32_t* clip_ids;   /* [B] device or NULL: explicit Philox clip id per batch element (overrides first_clip) -- a
+                                * clip keeps its noise stream wherever a sharded job places it                */
+    const int32_t* clip_lens;  /* [B] device or NULL: valid frames per clip (1..T).  Frames >= clip_lens[b] are the convs'
+                                * ZERO PADDING, exactly as if clip b had been run alone at its own length (the reference is
+                                * B=1, infer_tool.py:277); their mel_out rows are 0.  NULL = every clip has T frames.       */
     int32_t t_start;           /* K_step, or add_noise_step with ref_mel: runs t = t_start-1 ... 0           */
     int32_t t_stop;            /* normally 0; tests may stop the chain early (runs down to t_stop)           */
     int32_t speedup;           /* hparams['pndm_speedup']: <= 1 -> DDPM, > 1 -> PLMS with that interval      */
@@ -140,9 +147,10 @@ int dsvc_vocoder_finalize(dsvc_vocoder* v);
 void dsvc_vocoder_destroy(dsvc_vocoder* v);
 
 /* Generator.forward(2.30259 * mel^T, f0)   mel [B,T,M] log10 device, f0 [B,T] Hz device -> wav [B, T*hop] device.
- * The source module's random draws (models.py:192,271) come from Philox(seed, first_clip + b). */
+ * The source module's random draws (models.py:192,271) come from Philox(seed, clip id), clip id = clip_ids[b] (device [B]) or,
+ * when clip_ids is NULL, first_clip + b. */
 int dsvc_vocode(dsvc_vocoder* v, const float* mel, const float* f0, float* wav, int32_t B, int32_t T,
-                uint64_t seed, int32_t first_clip, void* stream);
+                uint64_t seed, int32_t first_clip, const int32_t* clip_ids, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mel front-end -- replaces modules/nsf_hifigan/nvSTFT.py:72-104 (STFT.get_mel) + the log10 scale of

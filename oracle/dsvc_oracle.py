@@ -209,6 +209,7 @@ def diffnet_forward(sd, spec, t, cond, dilation_cycle, prefix="denoise_fn.", tap
         if taps is not None:
             taps["g%d" % l] = z.clone()
             taps["x%d" % l] = x.clone()
+            taps["s%d" % l] = skip_sum.clone()          # running (unscaled) skip sum after layer l
     s = skip_sum / math.sqrt(L)
     if taps is not None:
         taps["skip"] = s.clone()

@@ -118,10 +118,10 @@ def vocoder_inputs(h, clips, T):
     return np.stack(mels), np.stack(f0s)
 
 
-def golden_vocoder(name, h, wseed, clips, T, seed):
+def run_reference_vocoder(h, wseed, mel, f0, clips, seed):
     """Generator.forward of the REAL reference (weight-normed checkpoint -> load_state_dict ->
     remove_weight_norm, models.py:14-30) with the source module's torch.rand / randn_like replaced by the
-    Philox streams."""
+    Philox streams.  mel [B,T,M] log10 numpy, f0 [B,T] Hz numpy -> wav [B, T*hop] numpy."""
     refshim.install()
     import modules.nsf_hifigan.models as NM
     from modules.nsf_hifigan.env import AttrDict
@@ -130,7 +130,7 @@ def golden_vocoder(name, h, wseed, clips, T, seed):
     gen.load_state_dict(sdw, strict=True)
     gen.eval()
     gen.remove_weight_norm()
-    mel, f0 = vocoder_inputs(h, clips, T)
+    T = mel.shape[1]
     hop = int(np.prod(h["upsample_rates"]))
     ini, nz = O.vocoder_rng(seed, clips, T * hop)
     orig_rand, orig_randn_like = torch.rand, torch.randn_like
@@ -151,9 +151,41 @@ def golden_vocoder(name, h, wseed, clips, T, seed):
             wav = gen(c, torch.from_numpy(f0))
     finally:
         torch.rand, torch.randn_like = orig_rand, orig_randn_like
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), mel=mel, f0=f0, wav=wav.numpy().reshape(len(clips), -1),
+    return wav.numpy().reshape(len(clips), -1)
+
+
+def golden_vocoder(name, h, wseed, clips, T, seed):
+    mel, f0 = vocoder_inputs(h, clips, T)
+    wav = run_reference_vocoder(h, wseed, mel, f0, clips, seed)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), mel=mel, f0=f0, wav=wav,
                         wseed=wseed, clips=np.array(clips), seed=seed)
-    print(name, "wav rms %.4f max %.3f" % (wav.pow(2).mean().sqrt().item(), wav.abs().max().item()))
+    print(name, "wav rms %.4f max %.3f" % (float(np.sqrt((wav ** 2).mean())), float(np.abs(wav).max())))
+
+
+def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500, seed=2026, wseed=0, vseed=1, K=1000, speedup=1):
+    """The BENCHMARKED configuration (BASELINE configs[1]: 10 s clip, T=861, 44.1 kHz architecture, full 1000-step DDPM) through
+    the REAL reference end to end: GaussianDiffusion.forward(infer=True) (diffusion.py:227-284) -> the host glue of
+    Svc.after_infer (clip to [mel_vmin, mel_vmax], infer_tool.py:177-183) -> Generator.forward (models.py:361-387) for the first
+    clip.  ~2 x 1000 reference denoiser evaluations at T=861: minutes on 8 cores.  Inputs are regenerated from synth.clip_inputs
+    on the test side (the cond builder is pinned bit for bit elsewhere), so only the outputs are stored."""
+    import time
+    clips = list(clips)
+    hp = dict(synth.HPARAMS_44K, K_step=K)
+    sd = synth.acoustic_state(hp, wseed)
+    model = build_reference_model(hp, sd)
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    t0 = time.time()
+    ret = run_reference_sampler(model, hp, hub, m2p, f0, clips, speedup, seed)
+    mel = ret["mel_out"].numpy()
+    print(name, "sampler %.0f s, mel range %.3f..%.3f" % (time.time() - t0, mel.min(), mel.max()))
+    h = dict(synth.VOCODER_44K)
+    mel_c = np.clip(mel[:1], hp["mel_vmin"], hp["mel_vmax"])
+    f0_hz = ret["f0_denorm"].numpy()[:1]
+    wav = run_reference_vocoder(h, vseed, mel_c, f0_hz, clips[:1], seed)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), mel_out=mel, wav0=wav[0], f0_denorm=ret["f0_denorm"].numpy(),
+                        pitch=ret["pitch_pred"].numpy().astype(np.int16), wseed=wseed, vseed=vseed, clips=np.array(clips), T=T,
+                        n_units=n_units, speedup=speedup, seed=seed, K_step=K)
+    print(name, "wav rms %.4f max %.3f" % (float(np.sqrt((wav ** 2).mean())), float(np.abs(wav).max())))
 
 
 def golden_melspec(name, sr, n_fft, win, hop, n_mels, fmin, fmax, n_samples):
@@ -214,6 +246,8 @@ def main():
         return golden_slicer()
     if "--schedule-only" in sys.argv:
         return golden_schedule()
+    if "--headline-only" in sys.argv:
+        return golden_headline()
     golden_state_keys()
     golden_vocoder("vocoder_tiny", synth.tiny_vocoder(), 5, clips=[0, 3], T=24, seed=90)
     golden_vocoder("vocoder_44k", dict(synth.VOCODER_44K), 1, clips=[1], T=12, seed=91)

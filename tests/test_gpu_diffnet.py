@@ -83,7 +83,7 @@ def test_denoiser_batched_throughput_tiling_matches_oracle():
             assert (out[b:b + 1] - ref).abs().max() < 3e-4, b
 
 
-@pytest.mark.parametrize("precision", ["f16_x3", "f16_w2"])
+@pytest.mark.parametrize("precision", ["f16_x3", "f16_w2", "f16_d64"])
 @pytest.mark.parametrize("name,tol", [("ddpm_tiny", 1e-3), ("plms_tiny_s10", 2e-3), ("plms_tiny_s5", 2e-3),
                                       ("ddpm_44k_k20", 1e-3), ("plms_44k_k100_s20", 2e-3),
                                       ("ddpm_24k_k30", 1e-3), ("plms_24k_s50", 2e-3)])
@@ -92,7 +92,7 @@ def test_sampler_vs_reference_golden(name, tol, precision):
     rounding, hence the looser bar there.  f16_x3 runs on the conv_gemm engine, f16_w2 on the tgemm engine."""
     g = load_golden(name)
     hp = dict(hp_for(name), K_step=int(g["K_step"]))
-    if precision == "f16_w2":
+    if precision in ("f16_w2", "f16_d64"):
         # fp16 activations: the 1e-3 bar is the north star for the 44.1 kHz architecture over a 1000-step chain (see
         # test_full_chain_1000_steps_*); the coarse 50-step schedules of these short goldens amplify a single
         # rounding more, and PLMS has no clamp between its extrapolated steps

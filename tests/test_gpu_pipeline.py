@@ -66,7 +66,8 @@ def test_denoiser_module_seam():
 
 
 def test_sampler_module_use_gt_mel_start():
-    """use_gt_mel / add_noise_step (diffusion.py:255-261): the chain starts from q_sample(norm_spec(ref_mel), t-1)."""
+    """use_gt_mel / add_noise_step (diffusion.py:255-261): the chain starts from q_sample(norm_spec(ref_mel), t-1); norm_spec,
+    q_sample and the noise draw run inside the C ABI (dsvc_sample_args.ref_mel)."""
     from diffsvc_amd.denoiser import DiffNetHip
     from diffsvc_amd.sampler import GaussianDiffusionHip
     hp = synth.tiny_hparams(K=50)
@@ -81,15 +82,12 @@ def test_sampler_module_use_gt_mel_start():
     hub, m2p, f0 = clip_batch(hp, [0], T, n_units)
     g = np.random.Generator(np.random.PCG64(4))
     ref_mel = torch.from_numpy((g.standard_normal((1, T, M)) * 0.7 - 2.5).astype(np.float32))
-    x0_dev = model.norm_spec(ref_mel.cuda()).transpose(1, 2)[:, None, :, :]
-    torch.manual_seed(99)
-    noise = torch.randn_like(x0_dev)                          # the very draw forward() makes (same shape and strides)
-    torch.manual_seed(99)
     ret = model(hub.cuda(), mel2ph=m2p.cuda(), f0=f0.clone().cuda(), ref_mels=ref_mel.cuda(), infer=True,
                 use_gt_mel=True, add_noise_step=steps, seed=seed)
     cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
     x0 = O.norm_spec(sd, ref_mel).transpose(1, 2)[:, None]
-    x = O.q_sample(sd, x0, torch.tensor([steps - 1]), noise.cpu())
+    noise = O.ddpm_noise_ref_layout(seed, [0], 0, T, M, O.PURPOSE_X_INIT)     # dsvc_sample draws q_sample's noise from the x_T stream
+    x = O.q_sample(sd, x0, torch.tensor([steps - 1]), noise)
     x = O.sample_ddpm(sd, cond.transpose(1, 2).contiguous(), x, lambda i: O.ddpm_noise_ref_layout(seed, [0], i, T, M),
                       hp["dilation_cycle_length"], t_start=steps)
     assert (ret["mel_out"].cpu() - O.finish_mel(sd, x, m2p)).abs().max().item() < 1e-3
@@ -193,3 +191,98 @@ def test_bench_launch_contract_two_ranks_share_the_device():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["finite_output"] and d["value"] > 0
     assert d["config"]["parallelism"].startswith("utterance-sharded x2")
+
+
+def _ragged_inputs(hp, clips, lens, n_units_of, T):
+    """Clips of different lengths padded to a common T the way a batched caller pads them: mel2ph == 0, f0 = 0 and zero content
+    rows beyond a clip's own frames."""
+    N = max(n_units_of(l) for l in lens)
+    hub = torch.zeros(len(clips), N, hp["hidden_size"])
+    m2p = torch.zeros(len(clips), T, dtype=torch.long)
+    f0 = torch.zeros(len(clips), T)
+    per = []
+    for i, (c, l) in enumerate(zip(clips, lens)):
+        h, m, f, _ = synth.clip_inputs(int(c), T=l, n_units=n_units_of(l), H=hp["hidden_size"])
+        hub[i, :h.shape[0]] = torch.from_numpy(h); m2p[i, :l] = torch.from_numpy(m); f0[i, :l] = torch.from_numpy(f)
+        per.append((torch.from_numpy(h)[None], torch.from_numpy(m)[None], torch.from_numpy(f)[None]))
+    return hub, m2p, f0, per
+
+
+@pytest.mark.parametrize("speedup", [1, 10])
+def test_ragged_batch_equals_per_clip_reference_runs(speedup):
+    """Variable-length clips in one padded batch (Svc.after_infer, infer_tool.py:177-191): the reference processes every clip
+    ALONE at its own length, so the batch must reproduce those runs -- trailing padded frames act as the convs' zero padding
+    inside the sampler, all-zero mel frames are dropped and f0 is cut with the same mask before the vocoder.  Checked against
+    the oracle run per clip at the clip's own length: mel (1e-3) and PCM end to end (1e-4 RMS)."""
+    pipe, hp, h, sd, vs = tiny_pipeline(K=30)
+    clips, lens, T, seed = [4, 1, 7, 2], [40, 33, 40, 21], 40, 19
+    n_units_of = lambda l: max(2, (l * 23) // 40)
+    hub, m2p, f0, per = _ragged_inputs(hp, clips, lens, n_units_of, T)
+    ids = torch.tensor(clips, dtype=torch.int32, device="cuda")
+    wav, mel, wlens = pipe.infer(hub.cuda(), m2p.cuda(), f0.cuda(), speedup=speedup, seed=seed, clip_ids=ids, return_mel=True, return_lens=True)
+    hop = int(np.prod(h["upsample_rates"]))
+    gw = O.fold_weight_norm(vs)
+    assert wlens.tolist() == [l * hop for l in lens]
+    for i, (c, l) in enumerate(zip(clips, lens)):
+        r = oracle_sample(hp, sd, [c], l, n_units_of(l), speedup, seed, hp["K_step"])
+        err = (mel[i, :l].cpu() - r["mel_out"][0]).abs().max().item()
+        assert err < (1e-3 if speedup == 1 else 2e-3), (i, err)
+        assert (mel[i, l:] == 0).all() and (wav[i, l * hop:] == 0).all()
+        mel_k, f0_k = O.after_infer_mel(r["mel_out"][0].numpy(), r["f0_denorm"][0].numpy(), hp)
+        assert mel_k.shape[0] == l
+        ini, nz = O.vocoder_rng(seed, [c], l * hop)
+        ref = O.spec2wav(gw, h, mel_k, f0_k, ini, nz)
+        rms = (wav[i, :l * hop].cpu() - ref).pow(2).mean().sqrt().item()
+        assert rms < (1e-4 if speedup == 1 else 3e-4), (i, rms)
+
+
+def test_clip_ids_keep_a_clips_noise_stream_wherever_it_is_placed():
+    """Philox streams are keyed by the GLOBAL clip id (dsvc_sample_args.clip_ids / dsvc_vocode's clip_ids): a clip produces the
+    same PCM alone, inside a batch, and at any batch position -- what makes an N-GPU sharded job equal the 1-GPU job per clip."""
+    pipe, hp, h, sd, vs = tiny_pipeline(K=20, precision="f16_w2")
+    T, n_units, seed = 40, 23, 3
+    clips = [9, 2, 5]
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    ids = torch.tensor(clips, dtype=torch.int32, device="cuda")
+    full = pipe.infer(hub.cuda(), m2p.cuda(), f0.cuda(), seed=seed, clip_ids=ids)
+    perm = [2, 0, 1]
+    shuf = pipe.infer(hub[perm].cuda(), m2p[perm].cuda(), f0[perm].cuda(), seed=seed, clip_ids=ids[perm])
+    assert torch.equal(shuf, full[perm])
+    for i, c in enumerate(clips):
+        one = pipe.infer(hub[i:i + 1].cuda(), m2p[i:i + 1].cuda(), f0[i:i + 1].cuda(), seed=seed, first_clip=c)
+        assert torch.equal(one[0], full[i]), c
+
+
+def test_denoiser_seam_recomputes_cond_projections_for_a_new_tensor_at_a_recycled_address():
+    """DiffNetHip caches the hoisted conditioner projections per cond TENSOR (identity + version), not per address: a fresh cond
+    of the same shape that the caching allocator places at the freed address of the previous one must not reuse them."""
+    from diffsvc_amd.denoiser import DiffNetHip
+    hp = synth.tiny_hparams()
+    sd = synth.acoustic_state(hp, 3)
+    den = DiffNetHip(hp["audio_num_mel_bins"], hparams=hp, precision="f16_x3")
+    den.load_state_dict({k[len("denoise_fn."):]: v for k, v in sd.items() if k.startswith("denoise_fn.")}, strict=True)
+    den.cuda()
+    g = np.random.Generator(np.random.PCG64(8))
+    spec = torch.from_numpy(g.standard_normal((1, 1, 16, 33)).astype(np.float32))
+    t = torch.tensor([11], dtype=torch.long)
+    conds = [torch.from_numpy((g.standard_normal((1, 32, 33)) * 0.5).astype(np.float32)) for _ in range(2)]
+    c0 = conds[0].cuda()
+    p0 = c0.data_ptr()
+    den(spec.cuda(), t.cuda(), cond=c0)
+    del c0
+    c1 = conds[1].cuda()                                    # same shape, freshly allocated: normally lands on p0
+    recycled = c1.data_ptr() == p0
+    out = den(spec.cuda(), t.cuda(), cond=c1).cpu()
+    with torch.no_grad():
+        ref = O.diffnet_forward(sd, spec, t, conds[1], hp["dilation_cycle_length"])
+    assert (out - ref).abs().max().item() < 3e-4, recycled
+    # in-place edit of the SAME tensor bumps its version: also recomputed
+    c1.mul_(0.5)
+    out = den(spec.cuda(), t.cuda(), cond=c1).cpu()
+    with torch.no_grad():
+        ref = O.diffnet_forward(sd, spec, t, conds[1] * 0.5, hp["dilation_cycle_length"])
+    assert (out - ref).abs().max().item() < 3e-4
+    with pytest.raises(ValueError):                          # steps are tabulated for 0 .. timesteps-1 only
+        den(spec.cuda(), torch.tensor([hp["timesteps"]]).cuda(), cond=c1)
+    with pytest.raises(ValueError):
+        den(spec.cuda(), torch.tensor([-1]).cuda(), cond=c1)
