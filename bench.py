@@ -11,6 +11,8 @@ Default workload = BASELINE.json configs[1]: a single clip per GPU, full 1000-st
 Rank 0 prints ONE JSON line (see README of the task for the contract) with `roofline` and `cpu_baseline`.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -31,6 +33,28 @@ T_FRAMES = 861            # floor((441000 - 512) / 512) + 1   (nvSTFT.py:92-96)
 N_UNITS = 500
 FLOP_PER_FRAME_DILATED = 2 * 384 * 768 * 3        # the k=3 dilated conv of one residual layer
 PEAK_TFLOPS_F16 = 2500.0                           # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def kernel_sources_sha():
+    """sha256 of the HIP sources the kernels are built from: a PMC traffic file measured on other sources is stale."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "diff-svc_amd", "csrc", "*"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(name):
+    """(bytes_per_launch, source) of a committed PMC measurement, or (None, why) when it is missing or was taken on other kernel
+    sources (tools/rocprof_traffic.py stamps the file with kernel_sources_sha())."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, "no PMC pass committed (%s)" % name
+    with open(path) as f:
+        tj = json.load(f)
+    if tj.get("csrc_sha16") != kernel_sources_sha():
+        return None, "stale: %s was measured on kernel sources %s, this tree is %s" % (name, tj.get("csrc_sha16"), kernel_sources_sha())
+    return tj.get("bytes_per_launch"), tj.get("source")
 
 
 def make_inputs(clips, device):
@@ -89,7 +113,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips-per-gpu", type=int, default=1)
+    ap.add_argument("--clips-per-gpu", type=int, default=0,
+                    help="default: 1 at --gpus 1 (BASELINE configs[1], the single-clip headline), 32 at --gpus N > 1 "
+                         "(BASELINE configs[3]: 256 clips over 8 GPUs)")
     ap.add_argument("--ddpm-steps", type=int, default=1000)
     ap.add_argument("--speedup", type=int, default=1, help="pndm_speedup (>1 = PLMS); the headline config is 1")
     ap.add_argument("--precision", default="f16_d64",
@@ -126,15 +152,15 @@ def main():
     vs = synth.vocoder_state(h, 1)
     pipe = SvcPipeline(hp, sd, vs, h, precision=args.precision, vocoder_precision="f16_x3")
 
-    B = args.clips_per_gpu
+    B = args.clips_per_gpu if args.clips_per_gpu > 0 else (1 if world == 1 else 32)
     n_clips = B * world
     my_clips = shard_clips(n_clips, rank, world) if world > 1 else list(range(B))
     hub, m2p, f0 = make_inputs(my_clips, dev)
+    clip_ids = torch.tensor(my_clips, dtype=torch.int32, device=dev)
 
     def one_step(seed):
-        # clips of a rank are strided (i % world), so Philox clip ids go through first_clip = rank, stride world:
-        # with one clip per GPU the id is just the rank; for B > 1 ids are rank-local but unique per (rank, b).
-        wav = pipe.infer(hub, m2p, f0, speedup=args.speedup, seed=seed, first_clip=rank * B, use_graph=not args.no_graph)
+        # noise streams are keyed by the GLOBAL clip index: clip i produces the same PCM on 1 GPU and on any rank of N GPUs
+        wav = pipe.infer(hub, m2p, f0, speedup=args.speedup, seed=seed, clip_ids=clip_ids, use_graph=not args.no_graph)
         if world > 1:
             wav = gather_pcm(wav, my_clips, n_clips)
         return wav
@@ -162,7 +188,7 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel (dilated conv + gate), HIP events on the launch stream ----
-        us, rows = pipe.model._handle().profile_gate_kernel(B, T_FRAMES, 5)
+        us, rows = pipe.model._handle().profile_gate_kernel(B, T_FRAMES, 5 if B == 1 else 3)
         flop = FLOP_PER_FRAME_DILATED * B * T_FRAMES                 # algorithmic: valid frames only, one product per MAC
         achieved = flop / (us * 1e-6) / 1e12
         roof = {"bound": "mfma", "kernel": "tgemm_kernel<TEpiGate> (dilated k=3 conv + hoisted cond projection + gate, one residual layer)",
@@ -174,21 +200,24 @@ def main():
             "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "dtype_detail": "fp16 MFMA operands (%s), fp32 accumulate, fp32 residual/skip/state" % args.precision, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: single 10 s clip per GPU, 44.1 kHz, full %d-step DDPM + NSF-HiFiGAN" % args.ddpm_steps,
+            "config": {"workload": ("BASELINE configs[1]: single 10 s clip per GPU, 44.1 kHz, full %d-step DDPM + NSF-HiFiGAN" % args.ddpm_steps) if B == 1 else
+                                   ("BASELINE configs[3] share: %d x 10 s clips per GPU in one batch (%d clips over %d GPU(s)), 44.1 kHz, full %d-step DDPM "
+                                    "+ NSF-HiFiGAN, gather of the PCM; the same per-GPU workload on 1 GPU is `batched.value` of the --gpus 1 line"
+                                    % (B, n_clips, world, args.ddpm_steps)),
                        "clips_per_gpu": B, "mel_frames": T_FRAMES, "content_frames": N_UNITS, "sampler_steps": args.ddpm_steps,
                        "pndm_speedup": args.speedup, "precision": args.precision, "vocoder_precision": "f16_x3",
                        "weights": "random-init (synthetic checkpoint, seeds 0/1)", "parallelism": "utterance-sharded x%d, gather of PCM" % world},
             "finite_output": ok,
             "roofline": roof,
         }
+        if os.environ.get("DSVC_BENCH_PCM_STATS") == "1":       # test hook: per-clip moments of the gathered PCM of the last step
+            w64 = wav.double()
+            result["pcm_stats"] = [[int(i), float(w64[i].sum()), float((w64[i] ** 2).sum())] for i in range(w64.shape[0])]
         # PMC-derived HBM traffic of the same kernel (a separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` pass over this very
         # command: tools/gpu_round.sh + tools/rocprof_traffic.py; counters cannot be read from inside the process)
-        tpath = os.path.join(ROOT, "profiles", "gate_traffic.json")
-        if os.path.exists(tpath) and B == 1 and args.precision == "f16_d64":
-            with open(tpath) as f:
-                tj = json.load(f)
-            roof["traffic"] = tj.get("bytes_per_launch")
-            roof["traffic_source"] = tj.get("source")
+        if args.precision == "f16_d64" and B in (1, 32):
+            roof["traffic"], roof["traffic_source"] = load_traffic("gate_traffic.json" if B == 1 else "gate_traffic_b32.json")
+        roof["algorithmic_bytes"] = 4.7e3 * B * T_FRAMES + 1.77e6
         if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched:
             # BASELINE configs[2]: the same clip with the 50-iteration PLMS sampler (pndm_speedup=20, 51 denoiser evaluations)
             pipe.infer(hub, m2p, f0, speedup=20, seed=7)
@@ -210,12 +239,7 @@ def main():
             torch.cuda.synchronize(); tb = time.perf_counter() - tb
             usb, _ = pipe.model._handle().profile_gate_kernel(Bb, T_FRAMES, 3)
             ach = FLOP_PER_FRAME_DILATED * Bb * T_FRAMES / (usb * 1e-6) / 1e12
-            btraffic, bsrc = None, None
-            bpath = os.path.join(ROOT, "profiles", "gate_traffic_b32.json")       # tools/gpu_traffic_b32.sh (separate PMC passes)
-            if os.path.exists(bpath) and args.precision == "f16_d64":
-                with open(bpath) as f:
-                    tj = json.load(f)
-                btraffic, bsrc = tj.get("bytes_per_launch"), tj.get("source")
+            btraffic, bsrc = load_traffic("gate_traffic_b32.json") if args.precision == "f16_d64" else (None, None)   # tools/gpu_traffic_b32.sh
             result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
                                  "clips_per_gpu": Bb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
                                  "s_per_batch": tb,
@@ -223,6 +247,19 @@ def main():
                                               "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_F16, "avg_launch_us": usb,
                                               "frames_per_launch": Bb * T_FRAMES, "traffic": btraffic, "traffic_source": bsrc,
                                               "algorithmic_bytes": 4.7e3 * Bb * T_FRAMES + 1.77e6}}
+        if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched and args.precision != "f16_x3":
+            # like-for-like operand precision with the fp32 reference: the same clip at f16_x3 (split fp16 operands, 3 MFMAs per
+            # product, 1e-5-class single evaluations) -- what the path costs when nothing is traded for the fp16 operand rounding
+            del pipe
+            torch.cuda.empty_cache()
+            pipe3 = SvcPipeline(hp, sd, vs, h, precision="f16_x3", vocoder_precision="f16_x3")
+            pipe3.infer(hub, m2p, f0, seed=3, clip_ids=clip_ids)
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            pipe3.infer(hub, m2p, f0, seed=4, clip_ids=clip_ids)
+            torch.cuda.synchronize(); t3 = time.perf_counter() - t3
+            result["fp32_class"] = {"precision": "f16_x3", "value": CLIP_SECONDS / t3, "unit": "audio-sec/wall-sec", "ms_per_clip": t3 * 1e3,
+                                    "workload": "BASELINE configs[1] at split-fp16 (fp32-class) operands"}
+            del pipe3
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(hp, sd, vs, h)
         else:

@@ -174,23 +174,38 @@ def test_full_size_vocoder_properties():
     assert (short[0, :n] - wav[0, :n]).abs().max().item() < 1e-5
 
 
-def test_bench_launch_contract_two_ranks_share_the_device():
-    """The driver's N > 1 launch line (torch.distributed.run, one rank per GPU) exercised on a 1-GPU box: both ranks on
-    cuda:0, gloo instead of RCCL.  Checks rendezvous, clip sharding, the gather, the max-over-ranks clock and the JSON line."""
-    import json, os, socket, subprocess, sys
+def _run_bench(nproc, clips_per_gpu, extra_env=None):
+    import json, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, DSVC_BENCH_SHARE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--ddpm-steps", "20", "--no-cpu-baseline", "--no-batched"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    env = dict(os.environ, DSVC_BENCH_SHARE_DEVICE="1", DSVC_BENCH_PCM_STATS="1", **(extra_env or {}))
+    tail = [os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "1", "--warmup", "1", "--ddpm-steps", "20",
+            "--clips-per-gpu", str(clips_per_gpu), "--no-cpu-baseline", "--no-batched"]
+    if nproc > 1:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_launch_contract_two_ranks_share_the_device():
+    """The driver's N > 1 launch line (torch.distributed.run, one rank per GPU) exercised on a 1-GPU box: both ranks on
+    cuda:0, gloo instead of RCCL.  Checks rendezvous, clip sharding, the gather, the max-over-ranks clock and the JSON line --
+    and that the gathered PCM of the 2-rank job equals the 1-rank job clip for clip (noise streams are keyed by the global clip
+    index; 2 clips per rank vs 4 clips on one rank run the same tiling family, so only the vocoder's batch-size dependent tiling
+    can differ by summation order)."""
+    d = _run_bench(2, 2)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["finite_output"] and d["value"] > 0
-    assert d["config"]["parallelism"].startswith("utterance-sharded x2")
+    assert d["config"]["parallelism"].startswith("utterance-sharded x2") and d["config"]["clips_per_gpu"] == 2
+    one = _run_bench(1, 4)
+    assert [s[0] for s in d["pcm_stats"]] == [0, 1, 2, 3] == [s[0] for s in one["pcm_stats"]]
+    for a, b in zip(d["pcm_stats"], one["pcm_stats"]):
+        assert abs(a[1] - b[1]) <= 1e-3 + 1e-5 * abs(b[1]) and abs(a[2] - b[2]) <= 1e-5 * b[2], (a, b)
 
 
 def _ragged_inputs(hp, clips, lens, n_units_of, T):
