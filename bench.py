@@ -32,7 +32,45 @@ CLIP_SECONDS = 10.0
 T_FRAMES = 861            # floor((441000 - 512) / 512) + 1   (nvSTFT.py:92-96)
 N_UNITS = 500
 FLOP_PER_FRAME_DILATED = 2 * 384 * 768 * 3        # the k=3 dilated conv of one residual layer
+FLOP_PER_FRAME_OUTPROJ = 2 * 384 * 768            # ... and its 1x1 output projection (residual + skip halves)
 PEAK_TFLOPS_F16 = 2500.0                           # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0                              # HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
+# algorithmic HBM bytes per frame of one residual layer, C = 384, fp16 operands / fp32 residual + skip + cproj:
+#   gate kernel alone : xh in 768*(1 + 2d/128 averaged over d = 1,2,4,8 -> 1.06) + cproj 3072 + g out 768
+#   fused layer kernel: xh in 814 + cproj 3072 + x32 in/out 3072 + skip in/out 3072 + next xh out 768   (g never leaves the CU)
+BYTES_PER_FRAME_GATE = 814 + 3072 + 768
+BYTES_PER_FRAME_LAYER = 814 + 3072 + 3072 + 3072 + 768
+WEIGHT_BYTES_GATE = 768 * 1152 * 2
+WEIGHT_BYTES_LAYER = WEIGHT_BYTES_GATE + 768 * 384 * 2
+
+
+def dominant_kernel_roofline(handle, B, precision):
+    """HIP-event timing of the dominant kernel at this batch size (dsvc_sampler_profile_gate_kernel) against its roofline.
+    Small batches run a layer as two launches and the gate kernel dominates (MFMA-shaped: 1.77 MFLOP per frame); the throughput
+    tiling runs the whole layer as one kernel whose HBM bytes (10.8 KB per frame) take longer at the HBM peak than its 2.36 MFLOP
+    per frame take at the MFMA peak: that kernel is priced against the HBM roof, with the MFMA fraction beside it."""
+    us, rows, kind = handle.profile_gate_kernel(B, T_FRAMES, 5 if B == 1 else 3)
+    frames = B * T_FRAMES
+    if kind == 0:
+        ach = FLOP_PER_FRAME_DILATED * frames / (us * 1e-6) / 1e12
+        roof = {"bound": "mfma", "kernel": "tgemm_kernel<TEpiGate> (dilated k=3 conv + hoisted cond projection + gate, one residual layer)",
+                "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_F16,
+                "avg_launch_us": us, "frames_per_launch": frames, "traffic": None,
+                "algorithmic_bytes": BYTES_PER_FRAME_GATE * frames + WEIGHT_BYTES_GATE}
+        tfile = {1: "gate_traffic.json", 32: "gate_traffic_b32.json"}.get(B)
+    else:
+        nbytes = BYTES_PER_FRAME_LAYER * frames + WEIGHT_BYTES_LAYER
+        ach = nbytes / (us * 1e-6) / 1e9
+        tf = (FLOP_PER_FRAME_DILATED + FLOP_PER_FRAME_OUTPROJ) * frames / (us * 1e-6) / 1e12
+        roof = {"bound": "hbm", "kernel": "tlayer_kernel (one residual layer in one launch: dilated conv + cond projection + gate -> g in LDS -> "
+                                         "output 1x1 + residual/skip update + next layer's FiLM'd fp16 operand)",
+                "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                "avg_launch_us": us, "frames_per_launch": frames, "traffic": None, "algorithmic_bytes": nbytes,
+                "mfma_tflops": tf, "mfma_frac": tf / PEAK_TFLOPS_F16}
+        tfile = {32: "layer_traffic_b32.json"}.get(B)
+    if precision == "f16_d64" and tfile:
+        roof["traffic"], roof["traffic_source"] = load_traffic(tfile)
+    return roof
 
 
 def kernel_sources_sha():
@@ -188,12 +226,7 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel (dilated conv + gate), HIP events on the launch stream ----
-        us, rows = pipe.model._handle().profile_gate_kernel(B, T_FRAMES, 5 if B == 1 else 3)
-        flop = FLOP_PER_FRAME_DILATED * B * T_FRAMES                 # algorithmic: valid frames only, one product per MAC
-        achieved = flop / (us * 1e-6) / 1e12
-        roof = {"bound": "mfma", "kernel": "tgemm_kernel<TEpiGate> (dilated k=3 conv + hoisted cond projection + gate, one residual layer)",
-                "achieved": achieved, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_F16,
-                "avg_launch_us": us, "frames_per_launch": B * T_FRAMES, "traffic": None}
+        roof = dominant_kernel_roofline(pipe.model._handle(), B, args.precision)
         result = {
             "metric": "audio-sec/wall-sec (RTF) end-to-end 44.1kHz %d-step %s + NSF-HiFiGAN" % (
                 args.ddpm_steps, "DDPM" if args.speedup <= 1 else "PLMS/%d" % args.speedup),
@@ -215,9 +248,6 @@ def main():
             result["pcm_stats"] = [[int(i), float(w64[i].sum()), float((w64[i] ** 2).sum())] for i in range(w64.shape[0])]
         # PMC-derived HBM traffic of the same kernel (a separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` pass over this very
         # command: tools/gpu_round.sh + tools/rocprof_traffic.py; counters cannot be read from inside the process)
-        if args.precision == "f16_d64" and B in (1, 32):
-            roof["traffic"], roof["traffic_source"] = load_traffic("gate_traffic.json" if B == 1 else "gate_traffic_b32.json")
-        roof["algorithmic_bytes"] = 4.7e3 * B * T_FRAMES + 1.77e6
         if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched:
             # BASELINE configs[2]: the same clip with the 50-iteration PLMS sampler (pndm_speedup=20, 51 denoiser evaluations)
             pipe.infer(hub, m2p, f0, speedup=20, seed=7)
@@ -237,16 +267,10 @@ def main():
             torch.cuda.synchronize(); tb = time.perf_counter()
             pipe.infer(hb, mb, fb, seed=2)
             torch.cuda.synchronize(); tb = time.perf_counter() - tb
-            usb, _ = pipe.model._handle().profile_gate_kernel(Bb, T_FRAMES, 3)
-            ach = FLOP_PER_FRAME_DILATED * Bb * T_FRAMES / (usb * 1e-6) / 1e12
-            btraffic, bsrc = load_traffic("gate_traffic_b32.json") if args.precision == "f16_d64" else (None, None)   # tools/gpu_traffic_b32.sh
+            broof = dominant_kernel_roofline(pipe.model._handle(), Bb, args.precision)
             result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
                                  "clips_per_gpu": Bb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
-                                 "s_per_batch": tb,
-                                 "roofline": {"bound": "mfma", "kernel": roof["kernel"], "achieved": ach, "peak": PEAK_TFLOPS_F16,
-                                              "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_F16, "avg_launch_us": usb,
-                                              "frames_per_launch": Bb * T_FRAMES, "traffic": btraffic, "traffic_source": bsrc,
-                                              "algorithmic_bytes": 4.7e3 * Bb * T_FRAMES + 1.77e6}}
+                                 "s_per_batch": tb, "roofline": broof}
         if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched and args.precision != "f16_x3":
             # like-for-like operand precision with the fp32 reference: the same clip at f16_x3 (split fp16 operands, 3 MFMAs per
             # product, 1e-5-class single evaluations) -- what the path costs when nothing is traded for the fp16 operand rounding

@@ -74,7 +74,7 @@ SYMBOLS = [
     ("dsvc_sampler_destroy", None, [_VP]),
     ("dsvc_sample", ctypes.c_int, [_VP, ctypes.POINTER(SampleArgs), _VP]),
     ("dsvc_sampler_profile_gate_kernel", ctypes.c_int,
-     [_VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64), _VP]),
+     [_VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64), c_i32p, _VP]),
     ("dsvc_vocoder_create", ctypes.c_int, [ctypes.POINTER(VocoderCfg), ctypes.POINTER(_VP)]),
     ("dsvc_vocoder_load_tensor", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64]),
     ("dsvc_vocoder_finalize", ctypes.c_int, [_VP]),

@@ -10,6 +10,7 @@
 
 #include "../../include/dsvc.h"
 #include "diffnet_t.h"
+#include "tlayer.h"
 
 using namespace dsvc;
 
@@ -165,6 +166,8 @@ struct dsvc_denoiser {
     TPacked in_t, skip_t, fin_t;
     std::vector<TPacked> dil_t, out_t;
     DevBuf xh, gh, skiph, s2h, xsh;   // fp16: layer operand (with guard rows), gate output, skip sum, relu(skip proj), sampler state
+    DevBuf xh2;                       // second layer-operand buffer: the fused layer kernel (tlayer.h) reads xh of layer l while other
+                                      // workgroups of the SAME launch already write layer l+1's, so consecutive layers alternate buffers
 
     // workspace for (B, T)
     int wsB = 0, wsT = 0, Tp = 0, rows = 0, rows_alloc = 0;
@@ -175,7 +178,7 @@ struct dsvc_denoiser {
     unsigned ws_gen = 0;  // bumped whenever the workspace is (re)built: captured graphs bake its pointers and are keyed on this
 
     ~dsvc_denoiser() {
-        for (DevBuf* b : {&film, &xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps, &lens, &clipid, &rowclip, &xh, &gh, &skiph, &s2h, &xsh}) b->release();
+        for (DevBuf* b : {&film, &xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps, &lens, &clipid, &rowclip, &xh, &xh2, &gh, &skiph, &s2h, &xsh}) b->release();
         auto rel = [](PackedConv& p) { p.w.release(); p.bias.release(); };
         rel(in_proj); rel(skip_proj); rel(fin_proj);
         for (auto& p : dil) rel(p);
@@ -189,6 +192,7 @@ struct dsvc_denoiser {
 
     RowMap rowmap() const { return RowMap{Tp, rowclip.as<int>()}; }
     _Float16* xh_row0() const { return xh.as<_Float16>() + (size_t)guard * Cp; }
+    _Float16* xh_buf(int i) const { return ((i & 1) ? xh2 : xh).as<_Float16>() + (size_t)guard * Cp; }
 
     const std::vector<float>* get(const std::string& k, size_t numel) {
         auto it = host.find(k);
@@ -216,6 +220,9 @@ struct dsvc_denoiser {
     int eval_conv(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, hipStream_t st);
     int eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step);
     int finalize_t();
+    // the whole residual layer as one kernel (tlayer.h) -- the throughput tiling only
+    bool fused_layer_ok() const;
+    int launch_fused_layer(int l, const StepRef& step, hipStream_t st, int host_step);
 };
 
 int dsvc_denoiser::finalize() {
@@ -399,7 +406,8 @@ int dsvc_denoiser::ensure_ws(int B, int T, hipStream_t st) {
     if (tpath) {
         // fp16 operands: zero once -- gap rows, guard rows and pad columns are never written afterwards
         const size_t nxh = (r + 2 * (size_t)guard) * Cp * 2, nh = r * Cp * 2, ns = r * Mp * 2;
-        DSVC_TRY(xh.alloc(nxh)); DSVC_TRY(gh.alloc(nh)); DSVC_TRY(skiph.alloc(2 * nh)); DSVC_TRY(s2h.alloc(2 * nh)); DSVC_TRY(xsh.alloc(2 * ns));
+        DSVC_TRY(xh.alloc(nxh)); DSVC_TRY(xh2.alloc(nxh)); DSVC_TRY(gh.alloc(nh));
+        DSVC_HIP(hipMemsetAsync(xh2.p, 0, nxh, st)); DSVC_TRY(skiph.alloc(2 * nh)); DSVC_TRY(s2h.alloc(2 * nh)); DSVC_TRY(xsh.alloc(2 * ns));
         DSVC_HIP(hipMemsetAsync(xh.p, 0, nxh, st)); DSVC_HIP(hipMemsetAsync(gh.p, 0, nh, st)); DSVC_HIP(hipMemsetAsync(skiph.p, 0, 2 * nh, st));   // hi|lo planes
         DSVC_HIP(hipMemsetAsync(s2h.p, 0, 2 * nh, st)); DSVC_HIP(hipMemsetAsync(xsh.p, 0, 2 * ns, st));
         DSVC_HIP(hipMemsetAsync(xres.p, 0, r * C * 4, st)); DSVC_HIP(hipMemsetAsync(skip.p, 0, r * C * 4, st));
@@ -524,8 +532,13 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
     }
     const char* stop_env = getenv("DSVC_DEBUG_STOP_AFTER_LAYERS");      // parity-debugging aid: run only the first n layers
     const int stop_after = stop_env ? atoi(stop_env) : -1;
+    const bool fused = fused_layer_ok();
     for (int l = 0; l < L; ++l) {
         if (stop_after >= 0 && l >= stop_after) return DSVC_OK;
+        if (fused) {   // K3..K8 of the layer in one launch: g never leaves the CU (tlayer.h)
+            DSVC_TRY(launch_fused_layer(l, step, st, host_step));
+            continue;
+        }
         {   // K5+K6 (+ hoisted K4, K3 already folded into xh): dilated conv, gate (net.py:67-77)
             TGemmArgs a = targs(xh_row0(), Cp, dil_t[l], 3, 1 << (l % cfg.dilation_cycle));
             TEpiGate::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, gh.as<_Float16>(), C, Cp};
@@ -556,6 +569,39 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         }
     }
     return DSVC_OK;
+}
+
+bool dsvc_denoiser::fused_layer_ok() const {
+    static const bool off = getenv("DSVC_NO_FUSED_LAYER") != nullptr;
+    if (off || !tpath || rows_alloc / 128 < 48) return false;
+    int max_dil = 1;
+    for (int l = 0; l < cfg.layers; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
+    return tlayer_supported(cfg.channels, Cp, max_dil, rows_alloc);
+}
+
+int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st, int host_step) {
+    const int C = cfg.channels, L = cfg.layers;
+    const bool last = l + 1 == L;
+    auto wargs = [&](const TPacked& tp, int taps, int dil) {
+        TGemmArgs a{};
+        a.x = xh_buf(l); a.cin = Cp; a.taps = taps; a.dil = dil; a.w = tp.w.as<_Float16>(); a.m_tiles = tp.m_tiles;
+        a.w_planes = tp.planes; a.variant_halfs = (long long)tp.variant_halfs; a.n_variants = tp.n_variants;
+        a.step_ptr = step.ptr; a.step_off = step.off; a.clip_rows = Tp;
+        if (host_step >= 0 && tp.n_variants > 1 && step.per_clip == 0) {
+            a.w += (size_t)(host_step % tp.n_variants) * tp.variant_halfs;
+            a.n_variants = 1;
+        }
+        return a;
+    };
+    // layer l reads xh buffer l & 1 and writes layer l+1's operand into the other one (see xh2)
+    const TGemmArgs ga = wargs(dil_t[l], 3, 1 << (l % cfg.dilation_cycle));
+    const TGemmArgs oa = wargs(out_t[l], 1, 1);
+    const float* cp = cproj.as<float>() + (size_t)l * rows_alloc * 2 * C;
+    TEpiResSkip::Args oe{xres.as<float>(), last ? nullptr : xh_buf(l + 1), skip.as<float>(), last ? skiph.as<_Float16>() : nullptr,
+                         out_t[l].bias.as<float>(), last ? nullptr : film.as<float>() + (size_t)(l + 1) * C, L * C, step, C, Cp,
+                         l == 0 ? 1 : 0, rowmap(), 1};
+    static const int pf = getenv("DSVC_FUSED_PF") ? atoi(getenv("DSVC_FUSED_PF")) : 0;
+    return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st);
 }
 
 // =================================================================================================
@@ -938,7 +984,7 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
     return DSVC_OK;
 }
 
-int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters, float* avg_us, int64_t* rows, void* stream) {
+int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters, float* avg_us, int64_t* rows, int32_t* kind, void* stream) {
     if (!s || !avg_us || !rows || iters < 1) return fail(DSVC_EINVAL, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     dsvc_denoiser* d = s->den;
@@ -960,7 +1006,9 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
         DSVC_HIP(hipEventRecord(e0, st));
         for (int l = 0; l < L; ++l) {
             const char* which = getenv("DSVC_PROFILE_KERNEL");          // "out": time the output projection instead (profiling aid)
-            if (d->tpath && which && which[0] == 'o') {
+            if (d->fused_layer_ok() && !which) {                        // the product path at this size is the fused layer kernel
+                DSVC_TRY(d->launch_fused_layer(l, StepRef{s->step_dev.as<int>(), 0, 0}, st, -1));
+            } else if (d->tpath && which && which[0] == 'o') {
                 const bool last = l + 1 == L;
                 TGemmArgs a{};
                 a.x = d->gh.as<_Float16>(); a.cin = d->Cp; a.taps = 1; a.dil = 1;
@@ -998,6 +1046,7 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_us = (float)(total * 1000.0 / count);
     *rows = d->rows;
+    if (kind) *kind = (d->fused_layer_ok() && !getenv("DSVC_PROFILE_KERNEL")) ? 1 : 0;
     return DSVC_OK;
 }
 

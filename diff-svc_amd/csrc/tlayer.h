@@ -1,0 +1,320 @@
+// tlayer.h -- one residual layer of DiffNet (net.py:66-84) as ONE kernel in the throughput tiling (gfx950 / CDNA4, wave64).
+//
+//   phase 1  gate GEMM        y[2C][128] = cproj + W_dil[2C][3*C] * xh[frame + (tap-1)*d][C]      (dilated k=3 conv, K4+K5)
+//            epilogue         g = sigmoid(y[:C]) * tanh(y[C:])  -> fp16, kept ON CHIP                 (K6)
+//   phase 2  output 1x1       [r; s][2C][128] = W_out[2C][C] * g,  x <- (x + r)/sqrt(2),  skip += s   (K7+K8)
+//            epilogue         + the NEXT layer's operand xh = fp16(x + film_next)                      (K3 of layer l+1)
+//
+// versus the two tgemm launches it replaces (tgemm.h: TEpiGate, TEpiResSkip) the gate output never travels: 768 B per frame per
+// layer less written and 768 B less read (12 % of the layer's HBM bytes), one kernel boundary and one prologue (kernarg, tile DMA of
+// g, first weight ring) less per layer.  Everything else is tgemm's machinery: the (128 + 2d) x C fp16 time tile DMA'd once into
+// LDS with the source-side XOR swizzle, weights streamed as A fragments through two register rings, accumulator-init loads instead
+// of epilogue reads, 8 waves of [32 output rows x 128 frames].
+//
+// LDS plan (C = 384, d = 8: 143 360 B of the CU's 160 KB):
+//   X  [0, (128+2d)*2C)         the time tile, live through all gate passes
+//   S  [round_up(X), +32 KB)    the g block of the FIRST gate pass (a pass = 8 waves x 16 g-channels = one 128-channel block of
+//                               128 frames x 256 B); written as soon as that pass's epilogue has it
+//   the middle pass's g block waits in 16 VGPRs per lane (there is no room for a second block beside X: 52 KB free, 64 needed)
+//   after the last gate pass: barrier (X is dead) -> the remaining blocks are written over X -> barrier -> phase 2 reads g.
+// A g block is [128 frames][128 channels] fp16, 16-B chunk c of row f at slot c ^ (f & 15): the same conflict-free ds_read_b128
+// pattern as the time tile, and ds_write_b128 of 8 consecutive frames x one chunk is conflict-free too.
+#pragma once
+#include "diffnet_t.h"
+
+namespace dsvc {
+
+constexpr int TL_TN = 128;                 // frames per workgroup
+constexpr int TL_BLOCK_BYTES = TL_TN * 256;   // one g block: 128 frames x 128 channels fp16
+
+// what the fused kernel needs of the two contractions (a trimmed TGemmArgs pair: kernel arguments live in SGPRs, and this kernel
+// sits at the 256-VGPR limit where spilled SGPRs cost vector registers)
+struct TLayerArgs {
+    const _Float16* x;          // fp16 layer operand xh, row 0 (guard rows precede)
+    int cin, swz, dil;          // channels per row (= C), chunk swizzle mask, dilation of the k=3 conv
+    const _Float16* gw;         // gate weights  [variant][C/16 m_tiles][3 taps][C/16][planes][lane][8]
+    const _Float16* ow;         // output 1x1    [variant][2C/32 m_tiles][C/16][planes][lane][8]
+    long long gvar, ovar;       // halfs between dither variants
+    int n_variants;             // > 1: variant = (*step_ptr - step_off) mod n_variants is resolved in the kernel; the sampler passes
+    const int* step_ptr;        //      the variant by value (gw / ow already offset, n_variants = 1)
+    int step_off;
+};
+
+// KG k16-steps of one output tile against 4 N-tiles of 32 frames: tgemm's compute_group with the LDS geometry passed in.
+//   base0     LDS byte address of this lane's row of N-tile 0
+//   nt_stride bytes between N-tiles (32 rows)
+//   xs        (((row & swz) ^ (lane >> 5)) << 4) ^ (first k16 step of the group << 5)
+template <int KG, int NW>
+__device__ __forceinline__ void tl_compute_group(const half8 (&ring)[KG][NW], f32x16 (&acc)[4], unsigned base0, unsigned nt_stride, unsigned xs) {
+    typedef const half8 __attribute__((address_space(3))) * lds_frag_ptr;
+    unsigned base[4];
+    base[0] = base0;
+#pragma unroll
+    for (int nt = 1; nt < 4; ++nt) base[nt] = base[nt - 1] + nt_stride;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(base[nt]));      // keep the bases materialised (see tgemm.h)
+    half8 bq[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bq[0][nt] = *(lds_frag_ptr)(size_t)(base[nt] + xs);
+#pragma unroll
+    for (int kk = 0; kk < KG; ++kk) {
+        if (kk + 1 < KG) {
+            const unsigned off = ((unsigned)(kk + 1) << 5) ^ xs;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bq[(kk + 1) & 1][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][0], bq[kk & 1][nt], acc[nt], 0, 0, 0);
+            if constexpr (NW == 2) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][1], bq[kk & 1][nt], acc[nt], 0, 0, 0);
+        }
+    }
+    // pin the software pipeline: one B-fragment read of step kk+1 behind each MFMA (pair) of step kk
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int kk = 0; kk < KG; ++kk) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NW, 0);
+            if (kk + 1 < KG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+}
+
+template <int KG, int NW>
+__device__ __forceinline__ void tl_load_group(half8 (&ring)[KG][NW], const _Float16* p) {
+#pragma unroll
+    for (int u = 0; u < KG; ++u)
+#pragma unroll
+        for (int q = 0; q < NW; ++q) ring[u][q] = *reinterpret_cast<const half8*>(p + (u * NW + q) * TFRAG_HALFS);
+}
+
+// NB = C / 128 = gate passes = output passes (8 waves x 16 g-channels, 8 waves x 32 output rows of 2C): 2 (C = 256) or 3 (C = 384).
+// PF: prefetch the output projection's first accumulator init (residual stream) already under the LAST gate pass's main loop
+// (64 more live VGPRs there) instead of right after it.
+template <int NB, int KG, int NW, int PF>
+__global__ void __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
+tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiResSkip::Args oe) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * TL_TN;
+    const int halo = ga.dil;                              // taps == 3
+    const int rows_lds = TL_TN + 2 * halo;
+    const int chunks = ga.cin >> 3;
+    const int row_bytes = ga.cin * 2;
+
+    // ---- the time tile: HBM/L2 -> LDS by DMA, swizzled on the source side (tgemm.h) ----
+    {
+        const int total = rows_lds * chunks;
+        const int dq = 512 / chunks, dr = 512 - dq * chunks;
+        int slot = wave * 64 + lane;
+        int r = slot / chunks, c = slot - r * chunks;
+        const _Float16* xrow0 = ga.x + (long long)(row0 - halo) * ga.cin;
+        for (int it = wave; it * 64 < total; it += 8) {
+            const int rc = r < rows_lds ? r : rows_lds - 1;
+            const _Float16* src = xrow0 + (long long)rc * ga.cin + ((c ^ (rc & ga.swz)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + it * 1024), 16, 0, 0);
+            c += dr; r += dq;
+            if (c >= chunks) { c -= chunks; r += 1; }
+        }
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned s_off = (unsigned)(((size_t)rows_lds * row_bytes + 1023) & ~(size_t)1023);
+    auto block_base = [&](int pos) -> unsigned { return lds0 + (pos == 0 ? s_off : (unsigned)(pos - 1) * (unsigned)TL_BLOCK_BYTES); };
+
+    int variant = 0;
+    if (ga.n_variants > 1 && ga.step_ptr) {               // (the sampler passes the variant by value: n_variants == 1 on the hot path)
+        const int st = *ga.step_ptr - ga.step_off;
+        variant = st % ga.n_variants;
+        if (variant < 0) variant += ga.n_variants;
+    }
+    constexpr int GROUP_HALFS = KG * NW * TFRAG_HALFS;
+    // wave-uniform weight bases (SGPRs); the lane's 16-byte slot inside a fragment is added where a ring is loaded
+    const _Float16* gw = ga.gw + (long long)variant * ga.gvar;
+    const _Float16* ow = ga.ow + (long long)variant * ga.ovar;
+    const int lane8 = lane * 8;
+    const int gpt = (ga.cin >> 4) / KG;                   // gate: groups per tap
+    const int G1 = 3 * gpt;                               // gate: groups per output tile
+    const int G2 = gpt;                                   // output projection: groups per tile (K = C)
+    const long long tile1 = (long long)G1 * GROUP_HALFS, tile2 = (long long)G2 * GROUP_HALFS;
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);         // waves w and w+4 share a SIMD: let the pair drift apart (tgemm.h)
+    const int rot = (int)(blockIdx.x % (unsigned)NB);     // per-workgroup rotated pass order (tgemm.h)
+    auto tile_of = [&](int pi) { const int p = pi + rot; return (p < NB ? p : p - NB) * 8 + wave; };
+    const int g_issue = wave >= 4 ? ((G1 / 2) & ~1) : 0;
+
+    TEpiGate gepi;
+    TEpiResSkip oepi;
+    const TEpiGate::Args ge{cproj, nullptr, ga.cin, ga.cin};
+    f32x16 acc[4], nxt[4];
+    half8 ringA[KG][NW], ringB[KG][NW];
+    half8 gmid[4];                                        // the middle gate pass's g block share (NB == 3)
+
+    // first operands in flight before the barrier
+    tl_load_group<KG, NW>(ringA, gw + (long long)tile_of(0) * tile1 + lane8);
+    gepi.init(ge, tile_of(0), row0, lane, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const unsigned nt_stride_x = 32u * (unsigned)row_bytes;
+    // =========================== phase 1: gate passes ===========================
+#pragma unroll
+    for (int pi = 0; pi < NB; ++pi) {
+        const int mt = tile_of(pi);
+        const _Float16* wp = gw + (long long)mt * tile1;
+        const bool last = pi == NB - 1;
+        const int mt_n = last ? tile_of(0) : tile_of(pi + 1);          // last gate pass: the next "tile" is output pass 0
+        bool nxt_issued = false;
+        auto issue_next_init = [&]() {
+            if (!last) gepi.init(ge, mt_n, row0, lane, nxt);
+            else if (PF) oepi.init(oe, mt_n, row0, lane, nxt);
+        };
+        int g = 0;
+        for (; g + 1 < G1; g += 2) {
+            tl_load_group<KG, NW>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
+            if (g == g_issue && (!last || PF)) { issue_next_init(); nxt_issued = true; }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int tap = g / gpt, kb = (g - tap * gpt) * KG;
+                const int rr = halo + (tap - 1) * ga.dil + (lane & 31);
+                tl_compute_group<KG, NW>(ringA, acc, lds0 + (unsigned)rr * (unsigned)row_bytes, nt_stride_x,
+                                         (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5));
+            }
+            const int gn = g + 2 < G1 ? g + 2 : G1 - 1;
+            tl_load_group<KG, NW>(ringA, wp + (long long)gn * GROUP_HALFS + lane8);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int g1 = g + 1, tap = g1 / gpt, kb = (g1 - tap * gpt) * KG;
+                const int rr = halo + (tap - 1) * ga.dil + (lane & 31);
+                tl_compute_group<KG, NW>(ringB, acc, lds0 + (unsigned)rr * (unsigned)row_bytes, nt_stride_x,
+                                         (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5));
+            }
+        }
+        if (g < G1) {
+            const int tap = g / gpt, kb = (g - tap * gpt) * KG;
+            const int rr = halo + (tap - 1) * ga.dil + (lane & 31);
+            tl_compute_group<KG, NW>(ringA, acc, lds0 + (unsigned)rr * (unsigned)row_bytes, nt_stride_x,
+                                     (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5));
+        }
+        // the next tile's weight stream starts before this tile's epilogue
+        if (!last) tl_load_group<KG, NW>(ringA, gw + (long long)mt_n * tile1 + lane8);
+        else tl_load_group<KG, NW>(ringA, ow + (long long)mt_n * tile2 + lane8);
+        if (!nxt_issued && (!last || PF)) issue_next_init();
+        // ---- gate epilogue: g = sigmoid * tanh -> fp16 (TEpiGate::finish, kept on chip) ----
+        half8 gq[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) gq[nt][r] = (_Float16)gate_act_scaled(acc[nt][r], acc[nt][8 + r]);
+        // lane (h = lane >> 5) holds g-channels 16*wave + 8h .. +7 of its block for frames 32*nt + (lane & 31): chunk 2*wave + h
+        auto store_block = [&](int pos, const half8 (&v)[4]) {
+            const unsigned bb = block_base(pos);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const unsigned f = 32u * nt + (unsigned)(lane & 31);
+                const unsigned a = bb + f * 256u + ((((unsigned)(2 * wave) + (unsigned)(lane >> 5)) ^ (f & 15u)) << 4);
+                *(half8 __attribute__((address_space(3)))*)(size_t)a = v[nt];
+            }
+        };
+        if (pi == 0) {
+            store_block(0, gq);                            // S is disjoint from the time tile: no barrier needed
+        } else if (!last) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) gmid[nt] = gq[nt];
+        }
+        if (last) {
+            if (!PF) oepi.init(oe, mt_n, row0, lane, nxt);  // accumulators are dead: the output projection's first init goes out now
+            __syncthreads();                               // every wave is done reading the time tile
+            if (NB == 3) store_block(1, gmid);
+            store_block(NB - 1, gq);
+            __syncthreads();                               // g complete
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = nxt[nt];
+    }
+
+    // =========================== phase 2: output projection passes ===========================
+    const unsigned xs_g = (unsigned)((((lane & 31) & 15) ^ (lane >> 5)) << 4);
+    const int g_issue2 = wave >= 4 ? ((G2 / 2) & ~1) : 0;
+#pragma unroll
+    for (int po = 0; po < NB; ++po) {
+        const int mt = tile_of(po);
+        const _Float16* wp = ow + (long long)mt * tile2;
+        const bool last = po == NB - 1;
+        const int mt_n = last ? 0 : tile_of(po + 1);
+        bool nxt_issued = false;
+        auto group_b = [&](int g, unsigned& base0, unsigned& xs) {
+            const int kb = g * KG;                          // first k16 step of the group; 8 steps per 128-channel block
+            int pos = (kb >> 3) - rot; if (pos < 0) pos += NB;
+            base0 = block_base(pos) + (unsigned)(lane & 31) * 256u;
+            xs = xs_g ^ ((unsigned)(kb & 7) << 5);
+        };
+        int g = 0;
+        for (; g + 1 < G2; g += 2) {
+            tl_load_group<KG, NW>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
+            if (g == g_issue2 && !last) { oepi.init(oe, mt_n, row0, lane, nxt); nxt_issued = true; }
+            __builtin_amdgcn_sched_barrier(0);
+            { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG, NW>(ringA, acc, b0, 32u * 256u, xs); }
+            const int gn = g + 2 < G2 ? g + 2 : G2 - 1;
+            tl_load_group<KG, NW>(ringA, wp + (long long)gn * GROUP_HALFS + lane8);
+            __builtin_amdgcn_sched_barrier(0);
+            { unsigned b0, xs; group_b(g + 1, b0, xs); tl_compute_group<KG, NW>(ringB, acc, b0, 32u * 256u, xs); }
+        }
+        if (g < G2) { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG, NW>(ringA, acc, b0, 32u * 256u, xs); }
+        if (!last) {
+            tl_load_group<KG, NW>(ringA, ow + (long long)mt_n * tile2 + lane8);
+            if (!nxt_issued) oepi.init(oe, mt_n, row0, lane, nxt);
+        }
+        oepi.finish(oe, mt, row0, lane, acc);
+        if (!last) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = nxt[nt];
+        }
+    }
+}
+
+inline size_t tlayer_smem(int dil, int cin) {
+    const size_t x = (((size_t)(TL_TN + 2 * dil) * cin * 2) + 1023) & ~(size_t)1023;
+    return x + TL_BLOCK_BYTES;
+}
+
+// can this layer shape run fused?  C a multiple of 128 with 2 or 3 channel blocks, the time tile + one g block inside 160 KB, and
+// the time tile at least as large as the other g blocks (always true: it holds C channels of >= 128 frames)
+inline bool tlayer_supported(int C, int cin_pad, int dil, int n_rows) {
+    return C == cin_pad && (C == 256 || C == 384) && n_rows % TL_TN == 0 && tlayer_smem(dil, cin_pad) <= 160 * 1024;
+}
+
+template <int NB, int KG, int NW, int PF>
+inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiResSkip::Args& oe, int n_rows, hipStream_t stream) {
+    auto kern = tlayer_kernel<NB, KG, NW, PF>;
+    const size_t smem = tlayer_smem(ga.dil, ga.cin);
+    static thread_local size_t smem_set = 0;
+    if (smem > 64 * 1024 && smem > smem_set) {
+        DSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        smem_set = smem;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_rows / TL_TN), dim3(512), smem, stream, ga, cproj, oe);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+// gate weights `g` (taps 3, m_tiles C/16) + output-projection weights `o` (taps 1, m_tiles 2C/32) of ONE layer, as tgemm would get them
+template <int NW>
+inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs& o, const TEpiResSkip::Args& oe, int C, int n_rows,
+                         int prefetch, hipStream_t stream) {
+    constexpr int KG = NW == 2 ? 4 : 8;
+    if (g.taps != 3 || o.taps != 1 || g.m_tiles != C / 16 || o.m_tiles != 2 * C / 32 || g.cin != C || o.cin != C)
+        return fail(DSVC_EINVAL, "tlayer: unexpected layer geometry");
+    if (g.w_planes != NW || o.w_planes != NW) return fail(DSVC_EINVAL, "tlayer: weight planes");
+    if (g.n_variants != o.n_variants) return fail(DSVC_EINVAL, "tlayer: the two contractions must carry the same number of dither variants");
+    if (!tlayer_supported(C, g.cin, g.dil, n_rows)) return fail(DSVC_EINVAL, "tlayer: shape not supported by the fused layer kernel");
+    TLayerArgs a{};
+    a.x = g.x; a.cin = g.cin; a.swz = tgemm_swizzle_mask(g.cin); a.dil = g.dil; a.gw = g.w; a.ow = o.w;
+    a.gvar = g.variant_halfs; a.ovar = o.variant_halfs; a.n_variants = g.n_variants; a.step_ptr = g.step_ptr; a.step_off = g.step_off;
+    if (C == 384) return prefetch ? tlayer_launch_t<3, KG, NW, 1>(a, cproj, oe, n_rows, stream) : tlayer_launch_t<3, KG, NW, 0>(a, cproj, oe, n_rows, stream);
+    return prefetch ? tlayer_launch_t<2, KG, NW, 1>(a, cproj, oe, n_rows, stream) : tlayer_launch_t<2, KG, NW, 0>(a, cproj, oe, n_rows, stream);
+}
+
+}  // namespace dsvc

@@ -142,10 +142,13 @@ class SamplerHandle:
         return (mel, xo) if return_x else mel
 
     def profile_gate_kernel(self, B, T, iters=5):
+        """(average launch time in us, rows per launch, kind) of the dominant kernel at this batch size; kind 0 = the gate
+        kernel of the two-launch layer, 1 = the fused residual-layer kernel."""
         us = ctypes.c_float(0)
         rows = ctypes.c_int64(0)
-        check(lib().dsvc_sampler_profile_gate_kernel(self._h, B, T, iters, ctypes.byref(us), ctypes.byref(rows), stream_ptr()))
-        return us.value, rows.value
+        kind = ctypes.c_int32(0)
+        check(lib().dsvc_sampler_profile_gate_kernel(self._h, B, T, iters, ctypes.byref(us), ctypes.byref(rows), ctypes.byref(kind), stream_ptr()))
+        return us.value, rows.value, kind.value
 
     def __del__(self):
         try:

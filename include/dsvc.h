@@ -115,11 +115,13 @@ typedef struct {
 
 int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream);
 
-/* per-kernel timing of the last dsvc_sample call, for bench.py's roofline: average duration in
- * microseconds of the dominant kernel (dilated conv + gate) measured with HIP events on the launch
- * stream, and the number of frames (rows) one launch processed. */
+/* per-kernel timing for bench.py's roofline: average duration in microseconds of the dominant kernel at this batch size,
+ * measured with HIP events on the launch stream over back-to-back launches of all layers (a different dither variant per round:
+ * weights as cold as in the real chain), and the number of frames (rows) one launch processed.
+ * kind (may be NULL) receives which kernel that is: 0 = the gate kernel (dilated conv + conditioner projection + gate: small
+ * batches run a layer as two launches), 1 = the fused residual-layer kernel (gate GEMM + output projection: the throughput tiling). */
 int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters,
-                                     float* avg_us, int64_t* rows, void* stream);
+                                     float* avg_us, int64_t* rows, int32_t* kind, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Vocoder -- replaces modules/nsf_hifigan/models.py:325-387 (Generator.forward) + :14-30 (load_model),
