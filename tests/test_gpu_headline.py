@@ -190,3 +190,27 @@ def test_end_to_end_waveform_vs_reference(precision):
     assert wav.shape[1] == ref.shape[0]
     assert mel_err < MEL_BAR, mel_err
     assert rms < WAV_BAR, rms
+
+
+@pytest.mark.parametrize("precision", ["f16_d64", "f16_w2"])
+def test_fused_layer_kernel_equals_the_two_launch_layer_bit_for_bit(precision):
+    """The throughput tiling runs a residual layer as ONE kernel (tlayer.h: gate GEMM -> g in LDS -> output projection).  It issues
+    the same MFMAs on the same operands in the same order as the two tgemm launches it replaces (DSVC_NO_FUSED_LAYER=1), so a
+    20-step DDPM chain at B=8 x T=861 must come out bit-identical -- layer geometry, g hand-off through LDS, the alternating xh
+    buffers and the pass rotation are all covered by one equality."""
+    hp = dict(synth.HPARAMS_44K, K_step=20)
+    sd, den, smp = make_handles(hp, 0, precision)
+    clips, T, n_units, seed = list(range(8)), 861, 500, 77
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    cond = cond.transpose(1, 2).contiguous().cuda()
+    fused = smp.sample(cond, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
+    os.environ["DSVC_NO_FUSED_LAYER"] = "1"
+    try:
+        two = smp.sample(cond, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
+    finally:
+        os.environ.pop("DSVC_NO_FUSED_LAYER", None)
+    assert torch.isfinite(fused).all()
+    d = (fused - two).abs().max().item()
+    print("fused vs two-launch layer (%s): max |diff| %.3e" % (precision, d))
+    assert torch.equal(fused, two), d
