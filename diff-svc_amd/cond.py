@@ -63,16 +63,30 @@ class CondBuilder(nn.Module):
         gathered = torch.gather(padded, 1, idx)                               # [B, T, H]
         nonpad = (mel2ph > 0).float()[:, :, None]
         # ---- index work on the host, bit-exact with the reference CPU path (fs2.py:229-233, pitch_utils.py) ----
+        # The reference runs every clip ALONE as a [1, T_clip] tensor (infer_tool.py:277), and torch's CPU kernels are not
+        # position-independent in the last bit: a vectorised loop handles the last (numel mod 16) elements with the scalar libm
+        # routine and the rest with the SIMD one.  So 2**f0 and the coarse bin are computed per clip on its own [1, T_clip]
+        # slice (frames up to the last content frame), exactly the tensor the reference would have built for that clip --
+        # a clip then gets the same f0_denorm / pitch bins alone, in a batch and at any batch position.
         f0_cpu = f0.detach().to("cpu", torch.float32)
-        pad_cpu = (mel2ph == 0).cpu()
+        m2p_cpu = mel2ph.cpu()
+        pad_cpu = m2p_cpu == 0
         if hp.get("pitch_norm", "log") != "log":
             raise NotImplementedError("pitch_norm must be 'log'")
-        f0_denorm = 2 ** f0_cpu
-        if uv is not None and hp.get("use_uv"):
-            f0_denorm[uv.cpu() > 0] = 0
-        f0_denorm[pad_cpu] = 0
+        B, T = m2p_cpu.shape
+        uv_cpu = uv.cpu() if (uv is not None and hp.get("use_uv")) else None
+        f0_denorm = torch.zeros(B, T, dtype=torch.float32)
+        coarse = torch.ones(B, T, dtype=torch.long)                             # f0_to_coarse(0) == 1 on padded frames
+        ar = torch.arange(1, T + 1)
+        for b in range(B):
+            n = int(((~pad_cpu[b]) * ar).max().item()) if (~pad_cpu[b]).any() else T   # trailing padding excluded (all-padded: whole row)
+            d = 2 ** f0_cpu[b:b + 1, :n]
+            if uv_cpu is not None:
+                d[uv_cpu[b:b + 1, :n] > 0] = 0
+            d[pad_cpu[b:b + 1, :n]] = 0
+            f0_denorm[b, :n] = d[0]
+            coarse[b, :n] = f0_to_coarse(d.clone(), hp)[0]
         f0[(mel2ph == 0)] = 0                                                  # the reference mutates its argument (fs2.py:231)
-        coarse = f0_to_coarse(f0_denorm.clone(), hp)
         ret["f0_denorm"] = f0_denorm.to(dev)
         ret["pitch_pred"] = coarse.unsqueeze(-1).to(dev)
         emb = self.pitch_embed(coarse.to(dev))

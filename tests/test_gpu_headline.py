@@ -149,11 +149,14 @@ def _tap_errors(den, sd, spec, t, cond, rows_of):
     return worst
 
 
-@pytest.mark.parametrize("precision,B,T", [("f16_w2", 1, 45), ("f16_d64", 1, 45), ("f16_d64", 2, 861), ("f16_w2", 8, 861), ("f16_d64", 8, 861)])
-def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T):
+@pytest.mark.parametrize("precision,B,T,fused", [("f16_w2", 1, 45, True), ("f16_d64", 1, 45, True), ("f16_d64", 2, 861, True),
+                                                 ("f16_w2", 8, 861, True), ("f16_d64", 8, 861, True), ("f16_d64", 8, 861, False)])
+def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused):
     """Per-layer localisation on the PRODUCT engine (tgemm): after every residual block the residual stream x_l, the gate
     output g_l and the running skip sum are compared with the oracle -- for the split-K single-clip tiling (T=45 and T=861), the
-    small-batch tiling (B=2) and the 128-frame throughput tiling (B=8 x 861)."""
+    small-batch tiling (B=2) and the 128-frame throughput tiling (B=8 x 861).  The throughput tiling runs a layer as ONE fused
+    kernel whose gate output never leaves the CU (tlayer.h), so g is tapped on its two-launch form (fused=False); x and the skip
+    sum are tapped on both."""
     hp = dict(synth.HPARAMS_44K)
     sd, den, _ = make_handles(hp, 0, precision)
     g = np.random.Generator(np.random.PCG64(5 + B))
@@ -161,13 +164,19 @@ def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T):
     cond = torch.from_numpy((g.standard_normal((B, 256, T)) * 0.5).astype(np.float32))
     t = torch.from_numpy(g.integers(0, 1000, size=(B,)))
     Tp = (T + 8 + 31) // 32 * 32
-    worst = _tap_errors(den, sd, spec, t, cond, lambda b: slice(b * Tp, b * Tp + T))
-    print("tgemm taps %s B=%d T=%d: worst |err| x %.2e (layer %d), g %.2e (layer %d), skip-sum %.2e (layer %d)"
-          % (precision, B, T, worst["x"][0], worst["x"][1], worst["g"][0], worst["g"][1], worst["s"][0], worst["s"][1]))
+    if not fused:
+        os.environ["DSVC_NO_FUSED_LAYER"] = "1"
+    try:
+        worst = _tap_errors(den, sd, spec, t, cond, lambda b: slice(b * Tp, b * Tp + T))
+    finally:
+        os.environ.pop("DSVC_NO_FUSED_LAYER", None)
+    print("tgemm taps %s B=%d T=%d fused=%d: worst |err| x %.2e (layer %d), g %.2e (layer %d), skip-sum %.2e (layer %d)"
+          % (precision, B, T, fused, worst["x"][0], worst["x"][1], worst["g"][0], worst["g"][1], worst["s"][0], worst["s"][1]))
     # fp16 activations: one rounding of an O(1..4) value is 2^-11 relative; 20 layers of it stay well under these bars, a
     # mis-indexed tile or a wrong dilation does not
     tol = 1.5e-2 if precision != "f16_w2" else 1e-2
-    assert worst["x"][0] < tol and worst["g"][0] < tol and worst["s"][0] < 4 * tol, worst
+    g_live = not (fused and B * Tp >= 6144)                  # the fused kernel keeps g in LDS: the debug buffer is not written
+    assert worst["x"][0] < tol and (worst["g"][0] < tol or not g_live) and worst["s"][0] < 4 * tol, worst
 
 
 @pytest.mark.parametrize("precision", ["f16_d64", "f16_w2", "f16_x3"])
