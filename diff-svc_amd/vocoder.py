@@ -40,8 +40,7 @@ def load_generator_checkpoint(model_path):
 
 
 def read_wav(path_or_file, target_sr):
-    """int PCM -> [-1, 1) by the type's magnitude, first channel only (nvSTFT.py:14-44).  Resampling is the
-    caller's job (the reference uses librosa.resample, which is not part of this path)."""
+    """int PCM -> [-1, 1) by the type's magnitude, first channel only, resampled to the model rate (nvSTFT.py:14-44)."""
     try:
         import soundfile as sf
         data, sr = sf.read(path_or_file, always_2d=True)
@@ -54,8 +53,27 @@ def read_wav(path_or_file, target_sr):
             raise RuntimeError("only 16-bit PCM wav is supported without the soundfile package")
         data = np.frombuffer(raw, dtype="<i2").reshape(-1, nch)[:, 0].astype(np.float32) / 32768.0
     if sr != target_sr:
-        raise RuntimeError("wav2spec: file is %d Hz, model expects %d Hz (resample first)" % (sr, target_sr))
+        data = resample(data, sr, target_sr)
     return data
+
+
+def resample(data, sr, target_sr):
+    """The reference resamples with ``librosa.resample`` (nvSTFT.py:38-40).  librosa when it is importable (identical to the
+    reference then); otherwise a polyphase FIR resampler (scipy.signal.resample_poly) -- same band-limited signal, not the same
+    samples bit for bit, so a one-line notice is printed."""
+    try:
+        import librosa
+        return librosa.resample(data, orig_sr=sr, target_sr=target_sr).astype(np.float32)
+    except ImportError:
+        pass
+    try:
+        from math import gcd
+        from scipy.signal import resample_poly
+    except ImportError:
+        raise RuntimeError("wav2spec: file is %d Hz, model expects %d Hz and neither librosa nor scipy is available to resample" % (sr, target_sr))
+    g = gcd(int(sr), int(target_sr))
+    print("| wav2spec: resampling %d -> %d Hz with scipy.signal.resample_poly (librosa, which the reference uses, is not installed)" % (sr, target_sr))
+    return resample_poly(data.astype(np.float64), int(target_sr) // g, int(sr) // g).astype(np.float32)
 
 
 @register_vocoder

@@ -243,6 +243,7 @@ def main():
     if "--24k-only" in sys.argv:
         return golden_24k()
     if "--slicer-only" in sys.argv:
+        golden_slicer_demo_input()
         return golden_slicer()
     if "--schedule-only" in sys.argv:
         return golden_schedule()
@@ -264,6 +265,7 @@ def main():
     golden_sampler("plms_44k_k100_s20", dict(full, K_step=100), 0, clips=[4], T=32, n_units=19, speedup=20, seed=81)
     golden_24k()
     golden_slicer()
+    golden_slicer_demo_input()
     golden_schedule()
 
 
@@ -298,6 +300,26 @@ def golden_slicer():
         print("slicer seed", case["seed"], len(chunks), "chunks", [v["split_time"] for v in chunks.values()][:6])
     with open(os.path.join(OUT, "slicer_kat.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
+
+
+def golden_slicer_demo_input():
+    """The real Slicer on the reference's shipped demo input raw/test_input.wav at six parameter sets."""
+    import contextlib, io, wave
+    refshim.install()
+    from infer_tools.slicer import Slicer
+    with wave.open(os.path.join(refshim.REF_ROOT, "raw", "test_input.wav"), "rb") as w:
+        sr, n = w.getframerate(), w.getnframes()
+        audio = np.frombuffer(w.readframes(n), dtype="<i2").astype(np.float32) / 32768.0
+    cases = []
+    for args in (dict(db_threshold=-40), dict(db_threshold=-30), dict(db_threshold=-40, min_length=3000),
+                 dict(db_threshold=-35, win_l=400, win_s=30, max_silence_kept=800), dict(db_threshold=-50, min_length=8000),
+                 dict(db_threshold=-25, win_l=200, win_s=10, max_silence_kept=300)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            chunks = Slicer(sr=sr, **args).slice(audio)
+        cases.append({"args": args, "chunks": chunks})
+        print("slicer test_input.wav", args, [v["split_time"] for v in chunks.values()][:8])
+    with open(os.path.join(OUT, "slicer_test_input.json"), "w") as f:
+        json.dump({"sr": sr, "n_samples": n, "cases": cases}, f, indent=0, sort_keys=True)
 
 
 def golden_24k():

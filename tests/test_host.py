@@ -206,3 +206,17 @@ def test_committed_bench_line_follows_the_driver_contract():
     c = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("port", "reference") and c["cores"] >= 1
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 10.0) < 0.05          # one 10 s clip per step
+
+
+@pytest.mark.parametrize("tag,extra", [("linear", dict(schedule_type="linear", max_beta=0.02)), ("cosine", dict(schedule_type="cosine"))])
+def test_drop_in_constructor_buffers_match_the_reference_constructor(tag, extra):
+    """GaussianDiffusionHip.__init__ recomputes the 12 schedule buffers (float64 numpy, cast to fp32 last: diffusion.py:87-120) before a
+    checkpoint overwrites them: value-checked bit for bit against the REAL constructor's buffers (tests/golden/schedule.npz)."""
+    g = load_golden("schedule")
+    hp = dict(synth.HPARAMS_44K, **extra)
+    model = GaussianDiffusionHip(None, 128, DiffNetHip(128, hparams=hp), timesteps=1000, K_step=1000, loss_type="l2",
+                                 spec_min=hp["spec_min"], spec_max=hp["spec_max"], hparams=hp)
+    keys = [k[len(tag) + 1:] for k in g if k.startswith(tag + "_")]
+    assert len(keys) == 12
+    for k in keys:
+        assert np.array_equal(getattr(model, k).numpy(), g[tag + "_" + k]), k

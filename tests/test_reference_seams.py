@@ -1,0 +1,46 @@
+"""CPU, container only: the drop-in boundary driven by the REAL reference's own seam code -- the vocoder registry
+(network/vocoders/base_vocoder.py:5-19), the strict checkpoint loader (utils/__init__.py:178-209), the process-global hparams dict
+-- and the slicer against the reference's shipped demo input.  Skipped where /root/reference does not exist (the GPU box)."""
+import json
+import os
+import subprocess
+import sys
+import wave
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("DSVC_REFERENCE_ROOT", "/root/reference")
+needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "network", "diff")), reason="reference tree not present")
+
+
+@needs_ref
+def test_drop_ins_through_the_real_reference_seams():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_seams_driver.py")], capture_output=True, text=True, timeout=600,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, r.stdout[-2000:]
+    d = json.loads(line[-1][7:])
+    assert d["vocoder_cls"] == "NsfHifiGANHip" and d["vocoder_module"].endswith("vocoder")
+    for k in ("registered_bare", "registered_lower", "is_base_vocoder", "by_short_name", "has_contract", "ckpt_keys_equal",
+              "ckpt_values_equal", "same_keys_as_reference_model", "dir_load_ok", "strict_rejects_missing", "shares_global_hparams"):
+        assert d[k] is True, (k, d)
+
+
+@needs_ref
+def test_slicer_on_the_reference_demo_input_matches_the_real_slicer():
+    """raw/test_input.wav (mono 16-bit 22 050 Hz, 22.6 s -- the only real audio the reference ships) through diffsvc_amd.slicer at six
+    parameter sets against chunk dicts minted from the real infer_tools/slicer.py (tests/golden/slicer_test_input.json, written by
+    oracle/make_golden.py --slicer-only).  Sample indices: bit-exact."""
+    from diffsvc_amd.slicer import Slicer
+    with open(os.path.join(ROOT, "tests", "golden", "slicer_test_input.json")) as f:
+        kat = json.load(f)
+    with wave.open(os.path.join(REF, "raw", "test_input.wav"), "rb") as w:
+        sr, n = w.getframerate(), w.getnframes()
+        audio = np.frombuffer(w.readframes(n), dtype="<i2").astype(np.float32) / 32768.0
+    assert sr == kat["sr"] and n == kat["n_samples"]
+    for case in kat["cases"]:
+        got = Slicer(sr=sr, **case["args"]).slice(audio)
+        assert got == case["chunks"], case["args"]
