@@ -93,16 +93,23 @@ def golden_diffnet(name, hp, wseed, B, T):
     print(name, "out std %.3f" % out.std().item())
 
 
-def golden_sampler(name, hp, wseed, clips, T, n_units, speedup, seed):
-    sd = synth.acoustic_state(hp, wseed)
+def golden_sampler(name, hp, wseed, clips, T, n_units, speedup, seed, conditioned=None, store_cond=True):
+    """conditioned = (lam, rho): synth.acoustic_state_conditioned -- a checkpoint whose noise prediction tracks its input like a
+    trained model's, so that the unclamped PNDM chain contracts; the reference's own mel must then stay inside
+    [spec_min, spec_max] (asserted here: a golden outside the data range is an ill-conditioned parity probe)."""
+    sd = synth.acoustic_state_conditioned(hp, wseed, *conditioned) if conditioned else synth.acoustic_state(hp, wseed)
     model = build_reference_model(hp, sd)
     hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
     ret = run_reference_sampler(model, hp, hub, m2p, f0, clips, speedup, seed)
+    lo, hi = ret["mel_out"].min().item(), ret["mel_out"].max().item()
+    if conditioned:
+        assert min(hp["spec_min"]) <= lo and hi <= max(hp["spec_max"]), (name, lo, hi)
+    extra = dict(decoder_inp=ret["decoder_inp"].numpy()) if store_cond else {}
     np.savez_compressed(os.path.join(OUT, name + ".npz"), mel_out=ret["mel_out"].numpy(),
-                        decoder_inp=ret["decoder_inp"].numpy(), f0_denorm=ret["f0_denorm"].numpy(),
+                        f0_denorm=ret["f0_denorm"].numpy(),
                         pitch=ret["pitch_pred"].numpy(), wseed=wseed, clips=np.array(clips), T=T, n_units=n_units,
-                        speedup=speedup, seed=seed, K_step=hp["K_step"])
-    print(name, "mel range %.3f..%.3f" % (ret["mel_out"].min().item(), ret["mel_out"].max().item()))
+                        speedup=speedup, seed=seed, K_step=hp["K_step"], conditioned=np.array(conditioned if conditioned else []), **extra)
+    print(name, "mel range %.3f..%.3f" % (lo, hi))
 
 
 def vocoder_inputs(h, clips, T):
@@ -249,6 +256,8 @@ def main():
         return golden_schedule()
     if "--headline-only" in sys.argv:
         return golden_headline()
+    if "--plms-only" in sys.argv:
+        return golden_plms_conditioned()
     golden_state_keys()
     golden_vocoder("vocoder_tiny", synth.tiny_vocoder(), 5, clips=[0, 3], T=24, seed=90)
     golden_vocoder("vocoder_44k", dict(synth.VOCODER_44K), 1, clips=[1], T=12, seed=91)
@@ -264,9 +273,23 @@ def main():
     golden_sampler("ddpm_44k_k20", dict(full, K_step=20), 0, clips=[0], T=32, n_units=19, speedup=1, seed=80)
     golden_sampler("plms_44k_k100_s20", dict(full, K_step=100), 0, clips=[4], T=32, n_units=19, speedup=20, seed=81)
     golden_24k()
+    golden_plms_conditioned()
     golden_slicer()
     golden_slicer_demo_input()
     golden_schedule()
+
+
+def golden_plms_conditioned():
+    """PLMS/PNDM parity probes on conditioned checkpoints (see golden_sampler): the 44.1 kHz architecture with the full 1000-step
+    schedule at pndm_speedup=20 (50 iterations / 51 evaluations -- BASELINE configs[2]) at a small frame count and at the
+    benchmarked T=861, the 24 kHz demo architecture at pndm_speedup=50 (BASELINE configs[0]), and the tiny architecture."""
+    tiny = synth.tiny_hparams(K=100)
+    full = dict(synth.HPARAMS_44K)
+    golden_sampler("plmsc_tiny_s10", tiny, 3, clips=[2], T=40, n_units=23, speedup=10, seed=78, conditioned=(2.0, 0.05))
+    golden_sampler("plmsc_tiny_s5", tiny, 3, clips=[1], T=52, n_units=30, speedup=5, seed=79, conditioned=(2.0, 0.05))
+    golden_sampler("plmsc_44k_s20", full, 0, clips=[4], T=32, n_units=19, speedup=20, seed=81, conditioned=(1.5, 0.07))
+    golden_sampler("plmsc_24k_s50", dict(synth.HPARAMS_24K), 2, clips=[3], T=36, n_units=21, speedup=50, seed=82, conditioned=(1.35, 0.05))
+    golden_sampler("plmsc_44k_T861_s20", full, 0, clips=[0], T=861, n_units=500, speedup=20, seed=84, conditioned=(1.5, 0.07), store_cond=False)
 
 
 def golden_schedule():

@@ -6,7 +6,7 @@ import torch
 
 from diffsvc_amd import synth
 import dsvc_oracle as O
-from util import hp_for, load_golden, oracle_sample, clip_batch
+from util import golden_state, hp_for, load_golden, oracle_sample, clip_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -25,9 +25,9 @@ def oracle_chain_1000():
     return _CHAIN_CACHE["r"]
 
 
-def make_handles(hp, wseed, precision):
+def make_handles(hp, wseed, precision, sd=None):
     from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
-    sd = synth.acoustic_state(hp, wseed)
+    sd = sd if sd is not None else synth.acoustic_state(hp, wseed)
     den = DenoiserHandle(sd, hp["audio_num_mel_bins"], hp["hidden_size"], hp["residual_channels"],
                          hp["residual_layers"], hp["dilation_cycle_length"], hp["timesteps"],
                          precision=precision, prefix="denoise_fn.")
@@ -84,33 +84,37 @@ def test_denoiser_batched_throughput_tiling_matches_oracle():
 
 
 @pytest.mark.parametrize("precision", ["f16_x3", "f16_w2", "f16_d64"])
-@pytest.mark.parametrize("name,tol", [("ddpm_tiny", 1e-3), ("plms_tiny_s10", 2e-3), ("plms_tiny_s5", 2e-3),
-                                      ("ddpm_44k_k20", 1e-3), ("plms_44k_k100_s20", 2e-3),
-                                      ("ddpm_24k_k30", 1e-3), ("plms_24k_s50", 2e-3)])
-def test_sampler_vs_reference_golden(name, tol, precision):
-    """mel within 1e-3 max-abs of the reference (north_star); PLMS' unclamped extrapolation amplifies
-    rounding, hence the looser bar there.  f16_x3 runs on the conv_gemm engine, f16_w2 on the tgemm engine."""
+@pytest.mark.parametrize("name", ["ddpm_tiny", "plmsc_tiny_s10", "plmsc_tiny_s5", "ddpm_44k_k20", "plmsc_44k_s20",
+                                  "ddpm_24k_k30", "plmsc_24k_s50"])
+def test_sampler_vs_reference_golden(name, precision):
+    """mel within 1e-3 max-abs of the REAL reference (north_star) at every shipped precision, DDPM and PLMS/PNDM alike.  The
+    PLMS goldens (plmsc_*) are minted on conditioned checkpoints whose noise prediction tracks its input like a trained model's
+    (synth.acoustic_state_conditioned), so the unclamped PNDM chain contracts and the reference's own mel stays inside
+    [spec_min, spec_max]: the 44.1 kHz architecture over the full 1000-step schedule at pndm_speedup=20 (BASELINE configs[2]),
+    the 24 kHz demo architecture at pndm_speedup=50 (configs[0]).  f16_x3 runs on the conv_gemm engine, the others on tgemm."""
     g = load_golden(name)
     hp = dict(hp_for(name), K_step=int(g["K_step"]))
-    if precision in ("f16_w2", "f16_d64"):
-        # fp16 activations: the 1e-3 bar is the north star for the 44.1 kHz architecture over a 1000-step chain (see
-        # test_full_chain_1000_steps_*); the coarse 50-step schedules of these short goldens amplify a single
-        # rounding more, and PLMS has no clamp between its extrapolated steps
-        tol = 4e-3 if "plms" in name else 2e-3
-    sd, den, smp = make_handles(hp, int(g["wseed"]), precision)
+    if "tiny" in name:
+        hp["timesteps"] = int(g["K_step"])
+    tol = 1e-3
+    if "ddpm" in name and precision != "f16_x3":
+        tol = 2e-3          # 20-30 coarse DDPM steps from t = K_step-1 of a short schedule amplify one fp16 rounding more than the
+                            # 1000-step chain does (tests/test_gpu_headline.py holds THAT to 1e-3 at the benchmarked size)
+    sd = golden_state(g, hp)
+    _, den, smp = make_handles(hp, int(g["wseed"]), precision, sd=sd)
     clips = [int(c) for c in g["clips"]]
-    cond = torch.from_numpy(g["decoder_inp"]).transpose(1, 2).contiguous().cuda()
     hub, m2p, f0 = clip_batch(hp, clips, int(g["T"]), int(g["n_units"]))
-    assert clips == list(range(clips[0], clips[0] + len(clips))) or len(clips) == 1 or True
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    if "decoder_inp" in g:
+        assert np.array_equal(cond.numpy(), g["decoder_inp"])
+    cond = cond.transpose(1, 2).contiguous().cuda()
     mels = []
     for i, c in enumerate(clips):            # one call per clip: Philox clip ids need not be contiguous
         mel = smp.sample(cond[i:i + 1], int(g["K_step"]), speedup=int(g["speedup"]), mel2ph=m2p[i:i + 1].cuda(),
                          seed=int(g["seed"]), first_clip=c, use_graph=False)
         mels.append(mel.cpu())
-    # (the 24 kHz demo config's 20-iteration PNDM overshoots the mel range by orders of magnitude with random-init weights,
-    #  in the reference itself: its error is taken relative to the reference's own range)
-    scale = max(1.0, float(np.abs(g["mel_out"]).max()) / 5.0)
-    err = (torch.cat(mels) - torch.from_numpy(g["mel_out"])).abs().max().item() / scale
+    err = (torch.cat(mels) - torch.from_numpy(g["mel_out"])).abs().max().item()
+    print("sampler golden %s %s: mel max-abs err %.2e" % (name, precision, err))
     assert err < tol, err
 
 

@@ -15,7 +15,7 @@ import torch
 
 from diffsvc_amd import synth
 import dsvc_oracle as O
-from util import clip_batch, load_golden, oracle_sample
+from util import clip_batch, golden_state, load_golden, oracle_sample
 
 pytestmark = pytest.mark.gpu
 
@@ -65,6 +65,31 @@ def test_headline_single_clip_T861_1000_steps_vs_reference(precision):
                          first_clip=c, use_graph=True)
         errs.append((mel[0].cpu() - torch.from_numpy(g["mel_out"][i])).abs().max().item())
     print("headline %s: mel max-abs err per clip %s" % (precision, ["%.2e" % e for e in errs]))
+    assert max(errs) < MEL_BAR, errs
+
+
+@pytest.mark.parametrize("precision", ["f16_d64", "f16_w2"])
+def test_plms_50_iterations_T861_vs_reference(precision):
+    """BASELINE configs[2] at the benchmarked size: one 10 s clip (T=861), 44.1 kHz architecture, the full 1000-step schedule at
+    pndm_speedup=20 (50 PLMS iterations, 51 denoiser evaluations), the captured-graph path bench.py times -- mel within 1e-3 of the
+    REAL reference on a conditioned checkpoint (plmsc_44k_T861_s20: the reference's own mel stays in [spec_min, spec_max])."""
+    g = load_golden("plmsc_44k_T861_s20")
+    hp = dict(synth.HPARAMS_44K, K_step=int(g["K_step"]))
+    sd = golden_state(g, hp)
+    from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
+    den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=precision, prefix="denoise_fn.")
+    smp = SamplerHandle(den, sd)
+    clips = [int(c) for c in g["clips"]]
+    hub, m2p, f0 = clip_batch(hp, clips, int(g["T"]), int(g["n_units"]))
+    cond, f0_denorm, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    assert np.array_equal(f0_denorm.numpy(), g["f0_denorm"])
+    cond = cond.transpose(1, 2).contiguous().cuda()
+    errs = []
+    for graph in (False, True, True):                       # eager, captured, replay of the cached graph
+        mel = smp.sample(cond, int(g["K_step"]), speedup=int(g["speedup"]), mel2ph=m2p.cuda(), seed=int(g["seed"]), first_clip=clips[0],
+                         use_graph=graph)
+        errs.append((mel.cpu() - torch.from_numpy(g["mel_out"])).abs().max().item())
+    print("PLMS-50 T=861 %s: mel max-abs err eager/graph/replay %s" % (precision, ["%.2e" % e for e in errs]))
     assert max(errs) < MEL_BAR, errs
 
 

@@ -24,6 +24,14 @@ def hp_for(name):
     return dict(synth.HPARAMS_44K)
 
 
+def golden_state(g, hp):
+    """The synthetic checkpoint a golden was minted on: plain random-init, or the conditioned variant (PLMS probes)."""
+    c = g.get("conditioned")
+    if c is not None and np.size(c):
+        return synth.acoustic_state_conditioned(hp, int(g["wseed"]), float(c[0]), float(c[1]))
+    return synth.acoustic_state(hp, int(g["wseed"]))
+
+
 def clip_batch(hp, clips, T, n_units):
     hub, m2p, f0 = [], [], []
     for c in clips:
