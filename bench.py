@@ -156,8 +156,9 @@ def main():
                          "(BASELINE configs[3]: 256 clips over 8 GPUs)")
     ap.add_argument("--ddpm-steps", type=int, default=1000)
     ap.add_argument("--speedup", type=int, default=1, help="pndm_speedup (>1 = PLMS); the headline config is 1")
-    ap.add_argument("--precision", default="f16_d64",
-                    help="f16_dN (fp16 operands, N time-dithered weight roundings; default, parity-tested), f16_w2, f16_x3, f16")
+    ap.add_argument("--precision", default="auto",
+                    help="auto (default: f16_d64 for the DDPM chain, f16_w2 for PLMS -- the precisions the parity tests hold to the "
+                         "1e-3 mel bar at the benchmarked sizes), f16_dN (fp16 operands, N time-dithered weight roundings), f16_w2, f16_x3, f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the extra batched (32 clips/GPU) measurement")
     ap.add_argument("--no-graph", action="store_true",
@@ -190,6 +191,7 @@ def main():
     vs = synth.vocoder_state(h, 1)
     pipe = SvcPipeline(hp, sd, vs, h, precision=args.precision, vocoder_precision="f16_x3")
 
+    prec = pipe.model.denoise_fn.precision_for("plms" if args.speedup > 1 else "ddpm", args.speedup)      # what the timed chain runs at
     B = args.clips_per_gpu if args.clips_per_gpu > 0 else (1 if world == 1 else 32)
     n_clips = B * world
     my_clips = shard_clips(n_clips, rank, world) if world > 1 else list(range(B))
@@ -226,19 +228,19 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel (dilated conv + gate), HIP events on the launch stream ----
-        roof = dominant_kernel_roofline(pipe.model._handle(), B, args.precision)
+        roof = dominant_kernel_roofline(pipe.model._handle("plms" if args.speedup > 1 else "ddpm", args.speedup), B, prec)
         result = {
             "metric": "audio-sec/wall-sec (RTF) end-to-end 44.1kHz %d-step %s + NSF-HiFiGAN" % (
                 args.ddpm_steps, "DDPM" if args.speedup <= 1 else "PLMS/%d" % args.speedup),
             "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "dtype_detail": "fp16 MFMA operands (%s), fp32 accumulate, fp32 residual/skip/state" % args.precision, "data": "synthetic",
+            "dtype": "f16", "dtype_detail": "fp16 MFMA operands (%s), fp32 accumulate, fp32 residual/skip/state" % prec, "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: single 10 s clip per GPU, 44.1 kHz, full %d-step DDPM + NSF-HiFiGAN" % args.ddpm_steps) if B == 1 else
                                    ("BASELINE configs[3] share: %d x 10 s clips per GPU in one batch (%d clips over %d GPU(s)), 44.1 kHz, full %d-step DDPM "
                                     "+ NSF-HiFiGAN, gather of the PCM; the same per-GPU workload on 1 GPU is `batched.value` of the --gpus 1 line"
                                     % (B, n_clips, world, args.ddpm_steps)),
                        "clips_per_gpu": B, "mel_frames": T_FRAMES, "content_frames": N_UNITS, "sampler_steps": args.ddpm_steps,
-                       "pndm_speedup": args.speedup, "precision": args.precision, "vocoder_precision": "f16_x3",
+                       "pndm_speedup": args.speedup, "precision": prec, "vocoder_precision": "f16_x3",
                        "weights": "random-init (synthetic checkpoint, seeds 0/1)", "parallelism": "utterance-sharded x%d, gather of PCM" % world},
             "finite_output": ok,
             "roofline": roof,
@@ -256,6 +258,7 @@ def main():
                 pipe.infer(hub, m2p, f0, speedup=20, seed=8 + i)
             torch.cuda.synchronize(); tpl = (time.perf_counter() - tp0) / 3
             result["plms_50"] = {"workload": "BASELINE configs[2]: single 10 s clip, 50-iteration PLMS (pndm_speedup=20) + NSF-HiFiGAN",
+                                 "precision": pipe.model.denoise_fn.precision_for("plms", 20),
                                  "value": CLIP_SECONDS / tpl, "unit": "audio-sec/wall-sec", "ms_per_clip": tpl * 1e3}
         if not args.no_batched and world == 1 and B == 1:
             # the throughput configuration (BASELINE configs[3] per-GPU share): 32 clips in one batch
@@ -267,11 +270,11 @@ def main():
             torch.cuda.synchronize(); tb = time.perf_counter()
             pipe.infer(hb, mb, fb, seed=2)
             torch.cuda.synchronize(); tb = time.perf_counter() - tb
-            broof = dominant_kernel_roofline(pipe.model._handle(), Bb, args.precision)
+            broof = dominant_kernel_roofline(pipe.model._handle("ddpm"), Bb, prec)
             result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
                                  "clips_per_gpu": Bb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
                                  "s_per_batch": tb, "roofline": broof}
-        if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched and args.precision != "f16_x3":
+        if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched and prec != "f16_x3":
             # like-for-like operand precision with the fp32 reference: the same clip at f16_x3 (split fp16 operands, 3 MFMAs per
             # product, 1e-5-class single evaluations) -- what the path costs when nothing is traded for the fp16 operand rounding
             del pipe

@@ -7,8 +7,12 @@ in libdsvc_hip.so.  Register it in the reference's seam with
     DIFF_DECODERS['wavenet'] = lambda hp: DiffNetHip(hp['audio_num_mel_bins'])
 
 (infer_tools/infer_tool.py:107-111).  ``precision`` selects the operand scheme of the two big per-layer contractions
-(include/dsvc.h): the default ``"f16_d64"`` is one fp16 MFMA per product with 64 time-dithered weight roundings (the
-configuration bench.py measures and the 1000-step parity test covers); ``"f16_w2"`` / ``"f16_x3"`` spend 2 / 3 MFMAs.
+(include/dsvc.h): ``"f16_d64"`` is one fp16 MFMA per product with 64 time-dithered weight roundings (what bench.py measures for
+the 1000-step DDPM and the 1000-step parity tests cover); ``"f16_w2"`` / ``"f16_x3"`` spend 2 / 3 MFMAs.  The default ``"auto"``
+picks per sampler: ``f16_d64`` for DDPM -- its per-step rounding noise averages out over the chain; for PLMS/PNDM, whose
+Adams-Bashforth extrapolation amplifies a single evaluation's rounding, ``f16_w2`` up to ``pndm_speedup`` 20 (measured on the
+50-iteration chain at T=861: 3.0e-3 mel error with f16_d64, 7.7e-4 with f16_w2; tests/test_gpu_headline.py) and the fp32-class
+``f16_x3`` for coarser schedules (20 iterations at pndm_speedup 50: 9e-3 with f16_w2, 1.2e-5 with f16_x3).
 Inference only: there is no autograd through the HIP kernels, so
 ``infer=False`` training keeps using the reference module.
 """
@@ -41,7 +45,9 @@ class _ResidualBlockParams(nn.Module):
 
 
 class DiffNetHip(nn.Module):
-    def __init__(self, in_dims=80, hparams=None, precision="f16_d64"):
+    AUTO = {"ddpm": "f16_d64", "plms": "f16_w2", "plms_coarse": "f16_x3", "forward": "f16_d64"}
+
+    def __init__(self, in_dims=80, hparams=None, precision="auto"):
         super().__init__()
         hp = hparams if hparams is not None else get_hparams()
         self.in_dims = in_dims
@@ -60,8 +66,7 @@ class DiffNetHip(nn.Module):
         nn.init.kaiming_normal_(self.skip_projection.weight)
         self.output_projection = nn.Conv1d(C, in_dims, 1)
         nn.init.zeros_(self.output_projection.weight)           # net.py:110
-        self._handle = None
-        self._handle_key = None
+        self._handles = {}             # precision -> (DenoiserHandle, params key): packed device weights are derived state
         self._cond_ref = None          # the cond tensor whose hoisted projections the C handle holds (a strong reference, so the
         self._cond_ver = -1            # caching allocator cannot hand its address to a different tensor: no ABA on data_ptr)
 
@@ -69,14 +74,27 @@ class DiffNetHip(nn.Module):
     def _params_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.precision,)
 
-    def handle(self):
+    def precision_for(self, use, speedup=1):
+        """The operand precision used for ``use`` in {'ddpm', 'plms', 'forward'} (PLMS: also by its step interval)."""
+        if self.precision != "auto":
+            return self.precision
+        if use == "plms" and speedup > 20:
+            use = "plms_coarse"
+        return self.AUTO[use]
+
+    def handle(self, use="forward", speedup=1):
+        """The C handle for a use; rebuilt whenever a parameter tensor changes (load_state_dict, .to(), in-place edits)."""
+        prec = self.precision_for(use, speedup)
         key = self._params_key()
-        if self._handle is None or key != self._handle_key:
-            self._handle = DenoiserHandle(self.state_dict(), self.in_dims, self.encoder_hidden, self.channels, self.n_layers,
-                                          self.dilation_cycle, self.max_steps, precision=self.precision)
-            self._handle_key = key
+        cur = self._handles.get(prec)
+        if cur is None or cur[1] != key:
+            # drop handles packed from older parameters first: a 64-variant handle is 3 GB of device memory
+            self._handles = {p: hk for p, hk in self._handles.items() if hk[1] == key}
+            cur = (DenoiserHandle(self.state_dict(), self.in_dims, self.encoder_hidden, self.channels, self.n_layers,
+                                  self.dilation_cycle, self.max_steps, precision=prec), key)
+            self._handles[prec] = cur
             self.invalidate_cond()
-        return self._handle
+        return cur[0]
 
     def invalidate_cond(self):
         """Forget which cond the C handle's hoisted conditioner projections belong to (the sampler path overwrites them)."""
@@ -84,7 +102,7 @@ class DiffNetHip(nn.Module):
 
     def forward(self, spec, diffusion_step, cond):
         """spec [B,1,M,T], diffusion_step [B] (long), cond [B,H,T] -> [B,1,M,T]   (net.py:112-135)"""
-        h = self.handle()
+        h = self.handle("forward")
         # a sampler loop calls with the SAME cond tensor 1000 times: the hoisted conditioner projections are recomputed only
         # when the tensor object or its version counter changes (identity, not address: see __init__)
         changed = not (cond is self._cond_ref and cond._version == self._cond_ver)

@@ -22,7 +22,7 @@ class SvcPipeline:
     """One process per GPU.  ``acoustic_state`` is a GaussianDiffusion state dict (no 'model.' prefix),
     ``vocoder_state``/``vocoder_cfg`` the NSF-HiFiGAN generator checkpoint and its config.json."""
 
-    def __init__(self, hp, acoustic_state, vocoder_state, vocoder_cfg, precision="f16_d64", vocoder_precision="f16_x3",
+    def __init__(self, hp, acoustic_state, vocoder_state, vocoder_cfg, precision="auto", vocoder_precision="f16_x3",
                  device="cuda"):
         if not torch.cuda.is_available():
             raise RuntimeError("SvcPipeline needs a HIP device (there is no CPU path)")

