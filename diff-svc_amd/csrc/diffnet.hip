@@ -124,11 +124,8 @@ template <class Epi, int NW>
 int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hipStream_t st) {
     constexpr int KG = NW == 2 ? 4 : 8;                  // two planes: half the ring depth, same bytes in flight
     if (rows_alloc / 128 >= 48) {
-        // experiment knob (A/B on the GPU): 64-frame tiles x 4 waves -- two workgroups share a CU (61 KB of LDS, 256 VGPRs each),
-        // so one workgroup's memory phases can sit under the other's MFMAs at the price of streaming every weight twice as often
-        static const int tile64 = getenv("DSVC_TG_TILE64") ? atoi(getenv("DSVC_TG_TILE64")) : 0;
-        if (tile64 && tgemm_smem<2>(a.taps, a.dil, a.cin) <= 80 * 1024)
-            return tgemm_launch<2, 4, 2, KG, NW, Epi>(a, e, rows_alloc, 1, st);
+        // (64-frame tiles x 4 waves, two workgroups per CU, measured 2.41 vs 2.22 ms per step: every weight is streamed twice as
+        //  often and the gate kernel slows from 60 to 71 us -- profiles/r2c_ab.txt; not kept)
         const int tiles = rows_alloc / 128, passes = ceil_div(a.m_tiles, 8);
         int ms = 256 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
         if (tgemm_smem<4>(a.taps, a.dil, a.cin) <= 160 * 1024) {

@@ -251,9 +251,21 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
                 for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
         }
         stamp(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Only the DMA'd tile has to have landed before the barrier; the weight rings issued behind it may stay in flight across
+        // it (vmcnt retires in order: allowing the 8 / 16 most recent loads to be outstanding still covers every DMA piece; the
+        // accumulator-init loads, issued last, only make the allowance more conservative).  __syncthreads() would drain
+        // everything (its fence waits vmcnt(0)), so the bare barrier is used: the tile was written by DMA, not by ds_write, and
+        // each wave's own vmcnt wait + the barrier is exactly what makes it visible (cdna_hip_programming.md 5.7 item 1).
+        {
+            const int later = (active && n > 0 ? 1 : 0) + (active && n > 1 ? 1 : 0);      // rings of KG*NW = 8 loads each
+            static_assert(KG * NW == 8, "the counted vmcnt immediates below assume 8 loads per ring");
+            if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         stamp(2);
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         stamp(3);
         if (active && !(a.dbg & 8)) {
             int i = 0;

@@ -243,13 +243,13 @@ int resblock_pair_launch(const float* x, float* out, const float* w1, const floa
 // ---- small kernels ----
 
 // mel [B][T][M] (log10) -> frame-major [B*stride][M] natural log (nsf_hifigan.py:63-65: c = 2.30259 * mel)
-__global__ void k_prep_mel(const float* __restrict__ mel, float* __restrict__ dst, int B, int T, int M, int stride) {
+__global__ void k_prep_mel(const float* __restrict__ mel, float* __restrict__ dst, int B, int T, int M, int stride, float scale) {
     const size_t n = (size_t)B * T * M;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(i % M);
         const size_t bt = i / M;
         const int t = (int)(bt % T), b = (int)(bt / T);
-        dst[((size_t)b * stride + t) * M + m] = 2.30259f * mel[i];
+        dst[((size_t)b * stride + t) * M + m] = scale * mel[i];
     }
 }
 
@@ -474,10 +474,12 @@ int dsvc_vocoder::finalize() {
         for (int q = i + 1; q < nu; ++q) s *= cfg.upsample_rates[q];
         const bool last = (i + 1 == nu);
         nc_s[i] = last ? 1 : s; nc_k[i] = last ? 1 : 2 * s; nc_pad[i] = last ? 0 : s / 2;
-        const std::vector<float>* nw = plain("noise_convs." + std::to_string(i) + ".weight", (size_t)cout * nc_k[i]);
-        const std::vector<float>* nb = plain("noise_convs." + std::to_string(i) + ".bias", cout);
-        if (!nw || !nb) return DSVC_ESTATE;
-        DSVC_TRY(upload(nc_w[i], nw->data(), nw->size() * 4)); DSVC_TRY(upload(nc_b[i], nb->data(), nb->size() * 4));
+        if (cfg.use_source) {
+            const std::vector<float>* nw = plain("noise_convs." + std::to_string(i) + ".weight", (size_t)cout * nc_k[i]);
+            const std::vector<float>* nb = plain("noise_convs." + std::to_string(i) + ".bias", cout);
+            if (!nw || !nb) return DSVC_ESTATE;
+            DSVC_TRY(upload(nc_w[i], nw->data(), nw->size() * 4)); DSVC_TRY(upload(nc_b[i], nb->data(), nb->size() * 4));
+        }
         // resblocks (ResBlock1, models.py:33-64)
         for (int j = 0; j < nk; ++j) {
             const int rk = cfg.resblock_kernel_sizes[j];
@@ -517,7 +519,7 @@ int dsvc_vocoder::finalize() {
         if (!b) return DSVC_ESTATE;
         DSVC_TRY(pack_conv(conv_post, 1, 7, cl, 1, [&](int, int tap, int ci) { return w[(size_t)ci * 7 + tap]; }, b->data(), 1));
     }
-    {
+    if (cfg.use_source) {
         const std::vector<float>* lw = plain("m_source.l_linear.weight", dim);
         const std::vector<float>* lb = plain("m_source.l_linear.bias", 1);
         if (!lw || !lb) return DSVC_ESTATE;
@@ -558,12 +560,13 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
     const int prec = cfg.precision;
     {
         const size_t n = (size_t)B * T * M;
-        hipLaunchKernelGGL(k_prep_mel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, mel, mel_in.as<float>(), B, T, M, Tp);
+        hipLaunchKernelGGL(k_prep_mel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, mel, mel_in.as<float>(), B, T, M, Tp, cfg.mel_scale);
     }
+    const bool src = cfg.use_source != 0;
     // excitation (models.py:363-366)
-    hipLaunchKernelGGL(k_source_frames, dim3(B), dim3(32), 0, st, f0, frames.as<SrcFrame>(), fl00.as<float>(), T, hop, dim,
+    if (src) hipLaunchKernelGGL(k_source_frames, dim3(B), dim3(32), 0, st, f0, frames.as<SrcFrame>(), fl00.as<float>(), T, hop, dim,
                        (float)cfg.sampling_rate, seed, clip0, clip_ids);
-    hipLaunchKernelGGL(k_source_samples, dim3(ceil_div(T * hop, 256), B), dim3(256), 0, st, f0, frames.as<SrcFrame>(), fl00.as<float>(),
+    if (src) hipLaunchKernelGGL(k_source_samples, dim3(ceil_div(T * hop, 256), B), dim3(256), 0, st, f0, frames.as<SrcFrame>(), fl00.as<float>(),
                        lin_w.as<float>(), lin_b.as<float>(), har.as<float>(), T, hop, dim, (float)cfg.sampling_rate, Tp * hop, seed, clip0, clip_ids,
                        0.1f, 0.003f);
     auto conv = [&](const PackedConv& pc, const float* x, int rows, int stride, int len, float slope) {
@@ -591,7 +594,7 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
         const int rows = B * Tp * rate, stride = Tp * rate, len = T * rate;
         float* S = buf[(i & 1) ? 4 : 3].as<float>();
         // x_source = noise_convs[i](har)  (models.py:373) written into U ...
-        {
+        if (src) {
             const size_t sm = (size_t)(64 * nc_s[i] + nc_k[i]) * 4;
             hipLaunchKernelGGL(k_noise_conv, dim3(ceil_div(len, 64), B), dim3(256), sm, st, har.as<float>(), nc_w[i].as<float>(),
                                nc_b[i].as<float>(), U, cout, nc_k[i], nc_s[i], nc_pad[i], len, T * hop, stride, Tp * hop);
@@ -600,7 +603,7 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
         {
             ConvGemmArgs a = conv(ups[i], prev, rows_in, stride_in, len_in, 0.1f);
             (void)cin;
-            EpiAffine::Args e{U, u * cout, ups[i].bias.as<float>(), cout, u * cout, nullptr, 0, 1.0f, 1};
+            EpiAffine::Args e{U, u * cout, ups[i].bias.as<float>(), cout, u * cout, nullptr, 0, 1.0f, src ? 1 : 0};
             DSVC_TRY(voc_dispatch<EpiAffine>(a, e, prec, st));
         }
         // MRF: mean over the nk ResBlock1 (models.py:376-382)
@@ -658,6 +661,7 @@ int dsvc_vocoder_create(const dsvc_vocoder_cfg* cfg, dsvc_vocoder** out) {
     int ndev = 0;
     DSVC_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(DSVC_EHIP, "no HIP device visible");
+    if (!(cfg->mel_scale > 0.f)) return fail(DSVC_EINVAL, "vocoder: mel_scale must be positive (2.30259 for log10 mels, 1 for natural-log mels)");
     dsvc_vocoder* v = new dsvc_vocoder();
     v->cfg = *cfg;
     *out = v;
@@ -681,8 +685,9 @@ void dsvc_vocoder_destroy(dsvc_vocoder* v) { delete v; }
 
 int dsvc_vocode(dsvc_vocoder* v, const float* mel, const float* f0, float* wav, int32_t B, int32_t T, uint64_t seed,
                 int32_t first_clip, const int32_t* clip_ids, void* stream) {
-    if (!v || !mel || !f0 || !wav) return fail(DSVC_EINVAL, "null argument");
+    if (!v || !mel || !wav) return fail(DSVC_EINVAL, "null argument");
     if (!v->finalized) return fail(DSVC_ESTATE, "vocoder not finalized");
+    if (v->cfg.use_source && !f0) return fail(DSVC_EINVAL, "this generator has a harmonic source: f0 is required");
     return v->run(mel, f0, wav, B, T, seed, first_clip, clip_ids, (hipStream_t)stream);
 }
 

@@ -161,9 +161,11 @@ class SamplerHandle:
 
 class VocoderHandle:
     """dsvc_vocoder: NSF-HiFiGAN generator.  ``state`` is the checkpoint's 'generator' dict (weight-norm pairs
-    included), ``h`` its config.json (modules/nsf_hifigan/models.py:14-30)."""
+    included), ``h`` its config.json (modules/nsf_hifigan/models.py:14-30).  The 24 kHz HifiGanGenerator
+    (modules/hifigan/hifigan.py:104-178) is the same network: ``mel_scale=1.0`` (its wrapper feeds natural-log mels unscaled),
+    ``use_source`` = the config's ``use_pitch_embed``, ``sampling_rate`` from ``audio_sample_rate``."""
 
-    def __init__(self, state, h, precision="f16_x3"):
+    def __init__(self, state, h, precision="f16_x3", mel_scale=2.30259, use_source=True):
         self._h = ctypes.c_void_p(0)
         if str(h.get("resblock", "1")) != "1":
             raise NotImplementedError("only ResBlock1 generators are supported (resblock='1')")
@@ -172,7 +174,10 @@ class VocoderHandle:
         if len(rates) > 8 or len(rks) > 4 or any(len(d) != 3 for d in rds):
             raise ValueError("unsupported generator geometry")
         cfg = _lib.VocoderCfg()
-        cfg.num_mels, cfg.upsample_initial_channel, cfg.sampling_rate = h["num_mels"], h["upsample_initial_channel"], h["sampling_rate"]
+        sr = h["sampling_rate"] if "sampling_rate" in h else h["audio_sample_rate"]
+        cfg.num_mels, cfg.upsample_initial_channel, cfg.sampling_rate = h["num_mels"], h["upsample_initial_channel"], sr
+        cfg.mel_scale, cfg.use_source = float(mel_scale), 1 if use_source else 0
+        self.use_source = bool(use_source)
         cfg.n_ups = len(rates)
         for i, (u, k) in enumerate(zip(rates, ksz)):
             cfg.upsample_rates[i], cfg.upsample_kernel_sizes[i] = u, k
@@ -198,10 +203,14 @@ class VocoderHandle:
         """mel [B,T,M] log10, f0 [B,T] Hz (0 = unvoiced) -> wav [B, T*hop].  clip_ids [B]: explicit Philox clip ids."""
         _need_cuda(mel, f0, clip_ids)
         B, T, M = mel.shape
-        if M != self.num_mels or f0.shape != (B, T):
-            raise ValueError("shape mismatch: mel %s f0 %s" % (tuple(mel.shape), tuple(f0.shape)))
+        if self.use_source and f0 is None:
+            raise ValueError("this generator has a harmonic source: f0 is required")
+        if not self.use_source:
+            f0 = None
+        if M != self.num_mels or (f0 is not None and f0.shape != (B, T)):
+            raise ValueError("shape mismatch: mel %s f0 %s" % (tuple(mel.shape), None if f0 is None else tuple(f0.shape)))
         mel = mel.contiguous().float()
-        f0 = f0.contiguous().float()
+        f0 = f0.contiguous().float() if f0 is not None else None
         wav = torch.empty(B, T * self.hop, device=mel.device, dtype=torch.float32)
         ids = clip_ids.to(torch.int32).contiguous() if clip_ids is not None else None
         if ids is not None and ids.numel() != B:

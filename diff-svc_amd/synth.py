@@ -46,6 +46,16 @@ VOCODER_44K = dict(
 )
 
 
+# --- the 24 kHz HiFi-GAN(-NSF) generator of the demo config (training/config.yaml:342-343 points at an unshipped checkpoint
+#     directory; its config.yaml is NOT in the reference repo: hop 128 = 8*4*4 [assumed], modules/hifigan/hifigan.py:104-144 reads
+#     these keys)
+VOCODER_24K = dict(
+    resblock="1", upsample_rates=[8, 4, 4], upsample_kernel_sizes=[16, 8, 8], upsample_initial_channel=512,
+    resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+    audio_sample_rate=24000, sampling_rate=24000, num_mels=80, use_pitch_embed=True, hop_size=128,
+)
+
+
 def tiny_hparams(M=16, H=32, C=64, L=4, K=50, cycle=4):
     """A shrunk architecture with the same structure, for fast CPU/GPU unit tests."""
     return dict(HPARAMS_44K, audio_num_mel_bins=M, keep_bins=M, hidden_size=H, residual_channels=C,
@@ -259,6 +269,18 @@ def save_vocoder_ckpt(dirpath, h, seed=0, name="model"):
     torch.save({"generator": sd}, os.path.join(dirpath, name))
     with open(os.path.join(dirpath, "config.json"), "w") as f:
         json.dump(h, f, indent=1)
+    return sd
+
+
+def save_hifigan_ckpt(dirpath, h, seed=0, steps=1000):
+    """The 24 kHz HifiGAN checkpoint directory as network/vocoders/hifigan.py:46-56 reads it: ``config.yaml`` +
+    ``model_ckpt_steps_<N>.ckpt`` holding ``{'state_dict': {'model_gen': weight-normed generator state}}``."""
+    import yaml
+    os.makedirs(dirpath, exist_ok=True)
+    sd = vocoder_state(h, seed)
+    torch.save({"state_dict": {"model_gen": sd}}, os.path.join(dirpath, "model_ckpt_steps_%d.ckpt" % steps))
+    with open(os.path.join(dirpath, "config.yaml"), "w") as f:
+        yaml.safe_dump({k: v for k, v in h.items()}, f)
     return sd
 
 

@@ -126,3 +126,85 @@ class NsfHifiGANHip(BaseVocoder):
         wav = read_wav(inp_path, hp["audio_sample_rate"])
         mel = _melspec_cache[key].mel(torch.from_numpy(wav)[None].cuda())[0]
         return wav, mel.cpu().numpy()
+
+
+def _load_yaml_chain(path, _seen=None):
+    """A checkpoint directory's config.yaml with its ``base_config`` chain resolved the way utils/hparams.py:40-60 does."""
+    import yaml
+    _seen = _seen or set()
+    with open(path, encoding="utf-8") as f:
+        cfg = yaml.safe_load(f) or {}
+    out = {}
+    base = cfg.get("base_config")
+    if base:
+        for b in (base if isinstance(base, list) else [base]):
+            if b.startswith("."):
+                b = os.path.normpath(os.path.join(os.path.dirname(path), b))
+            if b not in _seen and os.path.exists(b):
+                _seen.add(b)
+                out.update(_load_yaml_chain(b, _seen))
+    out.update({k: v for k, v in cfg.items() if k != "base_config"})
+    return out
+
+
+@register_vocoder
+class HifiGANHip(BaseVocoder):
+    """Drop-in for ``network.vocoders.hifigan.HifiGAN`` (hifigan.py:46-76), the 24 kHz vocoder of the demo config
+    (training/config.yaml:342-343): ``vocoder: diffsvc_amd.vocoder.HifiGANHip``.  ``hparams['vocoder_ckpt']`` is a DIRECTORY holding
+    ``config.yaml`` + ``model_ckpt_steps_<N>.ckpt`` (``['state_dict']['model_gen']``, highest N wins) or ``config.json`` +
+    ``generator_v1`` (``['generator']``).  ``HifiGanGenerator`` (modules/hifigan/hifigan.py:104-178) is the NSF-HiFiGAN network with
+    80 mel bins, natural-log mels fed unscaled, and the harmonic source only when the config says ``use_pitch_embed`` AND the call
+    carries an f0 with ``hparams['use_nsf']`` (hifigan.py:66-71) -- it runs on the same kernels (dsvc_vocoder, mel_scale 1)."""
+
+    def __init__(self, device=None, precision="f16_x3"):
+        import glob
+        import re
+        if not torch.cuda.is_available():
+            raise RuntimeError("HifiGANHip needs a HIP device (there is no CPU path)")
+        self.device = device or "cuda"
+        self.precision = precision
+        base_dir = get_hparams()["vocoder_ckpt"]
+        yml, jsn = os.path.join(base_dir, "config.yaml"), os.path.join(base_dir, "config.json")
+        if os.path.exists(yml):
+            files = [f for f in glob.glob(os.path.join(base_dir, "model_ckpt_steps_*.*")) if re.search(r"model_ckpt_steps_(\d+)", f)]
+            if not files:
+                raise FileNotFoundError("no model_ckpt_steps_*.ckpt in %s" % base_dir)
+            file_path = sorted(files, key=lambda x: int(re.findall(r"model_ckpt_steps_(\d+)", x.replace("\\", "/"))[-1]))[-1]
+            print("| load HifiGAN (HIP): ", file_path)
+            if os.path.splitext(file_path)[-1] != ".ckpt":
+                raise NotImplementedError("only .ckpt state-dict checkpoints are supported (a pickled .pth module cannot be repacked)")
+            self.config = _load_yaml_chain(yml)
+            self.state = torch.load(file_path, map_location="cpu")["state_dict"]["model_gen"]
+        elif os.path.exists(jsn):
+            with open(jsn, encoding="utf-8") as f:
+                self.config = json.load(f)
+            self.state = torch.load(os.path.join(base_dir, "generator_v1"), map_location="cpu")["generator"]
+        else:
+            raise FileNotFoundError("HifiGAN config not found in %s (config.yaml or config.json)" % base_dir)
+        self.h = dict(self.config, num_mels=80)                                  # Conv1d(80, ...) is hard-coded (hifigan.py:117)
+        self.has_source = bool(self.config.get("use_pitch_embed"))
+        self._handles = {}
+        self.seed = 0
+
+    def _handle(self, with_source):
+        if with_source not in self._handles:
+            self._handles[with_source] = VocoderHandle(self.state, self.h, precision=self.precision, mel_scale=1.0, use_source=with_source)
+        return self._handles[with_source]
+
+    def spec2wav(self, mel, **kwargs):
+        hp = get_hparams()
+        if hp.get("vocoder_denoise_c", 0.0) > 0:
+            raise NotImplementedError("vocoder_denoise_c > 0 (spectral-subtraction denoiser, vocoder_utils.py:7-15) is not part of this path")
+        f0 = kwargs.get("f0")
+        with_source = f0 is not None and bool(hp.get("use_nsf")) and self.has_source
+        if f0 is not None and hp.get("use_nsf") and not self.has_source:
+            raise RuntimeError("use_nsf with an f0, but this generator was built without use_pitch_embed")
+        self.seed += 1
+        c = torch.FloatTensor(np.asarray(mel)).unsqueeze(0).to(self.device)      # natural-log mel, NOT rescaled (hifigan.py:64)
+        f = torch.FloatTensor(np.asarray(f0)[None, :]).to(self.device) if with_source else None
+        y = self._handle(with_source).vocode(c, f, seed=kwargs.get("seed", self.seed)).view(-1)
+        return y.cpu().numpy()
+
+    @staticmethod
+    def wav2spec(wav_fn, **kwargs):
+        raise NotImplementedError("the 24 kHz mel front-end (PWG.wav2spec -> process_utterance, librosa) is not part of this path")

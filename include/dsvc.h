@@ -125,7 +125,9 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
 
 /* ------------------------------------------------------------------------------------------------
  * Vocoder -- replaces modules/nsf_hifigan/models.py:325-387 (Generator.forward) + :14-30 (load_model),
- * called through network/vocoders/nsf_hifigan.py:47-73 (NsfHifiGAN.spec2wav).
+ * called through network/vocoders/nsf_hifigan.py:47-73 (NsfHifiGAN.spec2wav); the same kernels serve the 24 kHz
+ * generator modules/hifigan/hifigan.py:104-178 (HifiGanGenerator: identical structure, identical source module,
+ * mel_scale 1, optional source) behind network/vocoders/hifigan.py:46-76 (HifiGAN.spec2wav).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct dsvc_vocoder dsvc_vocoder;
 
@@ -139,6 +141,10 @@ typedef struct {
     int32_t resblock_dilations[4][3];
     int32_t harmonics;             /* harmonic_num = 8 (models.py:334) */
     int32_t precision;             /* DSVC_PREC_* (F16_X3 keeps the waveform within 1e-4 RMS) */
+    float mel_scale;               /* the generator input is mel_scale * mel: 2.30259 (log10 -> ln) for NsfHifiGAN.spec2wav
+                                    * (nsf_hifigan.py:63-65), 1 for the 24 kHz HifiGAN wrapper (network/vocoders/hifigan.py:64) */
+    int32_t use_source;            /* 1: harmonic source + noise convs (NSF: models.py:363-375; HifiGanGenerator with
+                                    * use_pitch_embed and an f0, modules/hifigan/hifigan.py:110-116,150-162); 0: plain HiFi-GAN */
 } dsvc_vocoder_cfg;
 
 int dsvc_vocoder_create(const dsvc_vocoder_cfg* cfg, dsvc_vocoder** out);
@@ -148,7 +154,7 @@ int dsvc_vocoder_load_tensor(dsvc_vocoder* v, const char* name, const float* hos
 int dsvc_vocoder_finalize(dsvc_vocoder* v);
 void dsvc_vocoder_destroy(dsvc_vocoder* v);
 
-/* Generator.forward(2.30259 * mel^T, f0)   mel [B,T,M] log10 device, f0 [B,T] Hz device -> wav [B, T*hop] device.
+/* Generator.forward(mel_scale * mel^T, f0)   mel [B,T,M] device, f0 [B,T] Hz device (NULL iff use_source == 0) -> wav [B, T*hop] device.
  * The source module's random draws (models.py:192,271) come from Philox(seed, clip id), clip id = clip_ids[b] (device [B]) or,
  * when clip_ids is NULL, first_clip + b. */
 int dsvc_vocode(dsvc_vocoder* v, const float* mel, const float* f0, float* wav, int32_t B, int32_t T,

@@ -407,29 +407,33 @@ def sine_source(f0_up, sr, rand_ini, noise, lin_w, lin_b, harmonics=8,
 
 
 def generator_forward(gw, h, mel, f0, rand_ini, noise, taps=None):
-    """Generator.forward (models.py:361-387) on folded weights ``gw`` (see fold_weight_norm).
-    mel [B,M,T] natural-log, f0 [B,T] Hz -> wav [B,1,T*prod(rates)]."""
+    """Generator.forward (models.py:361-387) on folded weights ``gw`` (see fold_weight_norm); also the 24 kHz
+    HifiGanGenerator.forward (modules/hifigan/hifigan.py:146-170: the same network, ``f0`` optional).
+    mel [B,M,T] natural-log, f0 [B,T] Hz or None -> wav [B,1,T*prod(rates)]."""
     rates = list(h["upsample_rates"])
     ksz = list(h["upsample_kernel_sizes"])
     rks = list(h["resblock_kernel_sizes"])
     rds = [list(d) for d in h["resblock_dilation_sizes"]]
     hop = int(np.prod(rates))
-    f0_up = f0[:, :, None].repeat(1, 1, hop).reshape(f0.shape[0], -1)      # nn.Upsample nearest (models.py:331,363)
-    har = sine_source(f0_up, h["sampling_rate"], rand_ini, noise,
-                      gw["m_source.l_linear.weight"], gw["m_source.l_linear.bias"])
-    if taps is not None:
-        taps["har"] = har.clone()
+    har = None                               # f0 None: the plain HiFi-GAN path of HifiGanGenerator.forward (hifigan.py:150-162)
+    if f0 is not None:
+        f0_up = f0[:, :, None].repeat(1, 1, hop).reshape(f0.shape[0], -1)      # nn.Upsample nearest (models.py:331,363)
+        har = sine_source(f0_up, h["sampling_rate"] if "sampling_rate" in h else h["audio_sample_rate"], rand_ini, noise,
+                          gw["m_source.l_linear.weight"], gw["m_source.l_linear.bias"])
+        if taps is not None:
+            taps["har"] = har.clone()
     x = F.conv1d(mel, gw["conv_pre.weight"], gw["conv_pre.bias"], padding=3)
     nk = len(rks)
     for i, (u, k) in enumerate(zip(rates, ksz)):
         x = F.leaky_relu(x, LRELU)
         x = F.conv_transpose1d(x, gw["ups.%d.weight" % i], gw["ups.%d.bias" % i], stride=u, padding=(k - u) // 2)
-        if i + 1 < len(rates):
-            s = int(np.prod(rates[i + 1:]))
-            xs = F.conv1d(har, gw["noise_convs.%d.weight" % i], gw["noise_convs.%d.bias" % i], stride=s, padding=s // 2)
-        else:
-            xs = F.conv1d(har, gw["noise_convs.%d.weight" % i], gw["noise_convs.%d.bias" % i])
-        x = x + xs
+        if har is not None:
+            if i + 1 < len(rates):
+                s = int(np.prod(rates[i + 1:]))
+                xs = F.conv1d(har, gw["noise_convs.%d.weight" % i], gw["noise_convs.%d.bias" % i], stride=s, padding=s // 2)
+            else:
+                xs = F.conv1d(har, gw["noise_convs.%d.weight" % i], gw["noise_convs.%d.bias" % i])
+            x = x + xs
         if taps is not None:
             taps["up%d" % i] = x.clone()
         acc = None

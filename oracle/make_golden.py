@@ -258,6 +258,8 @@ def main():
         return golden_headline()
     if "--plms-only" in sys.argv:
         return golden_plms_conditioned()
+    if "--hifigan-only" in sys.argv:
+        return golden_hifigan_24k()
     golden_state_keys()
     golden_vocoder("vocoder_tiny", synth.tiny_vocoder(), 5, clips=[0, 3], T=24, seed=90)
     golden_vocoder("vocoder_44k", dict(synth.VOCODER_44K), 1, clips=[1], T=12, seed=91)
@@ -273,6 +275,7 @@ def main():
     golden_sampler("ddpm_44k_k20", dict(full, K_step=20), 0, clips=[0], T=32, n_units=19, speedup=1, seed=80)
     golden_sampler("plms_44k_k100_s20", dict(full, K_step=100), 0, clips=[4], T=32, n_units=19, speedup=20, seed=81)
     golden_24k()
+    golden_hifigan_24k()
     golden_plms_conditioned()
     golden_slicer()
     golden_slicer_demo_input()
@@ -343,6 +346,50 @@ def golden_slicer_demo_input():
         print("slicer test_input.wav", args, [v["split_time"] for v in chunks.values()][:8])
     with open(os.path.join(OUT, "slicer_test_input.json"), "w") as f:
         json.dump({"sr": sr, "n_samples": n, "cases": cases}, f, indent=0, sort_keys=True)
+
+
+def golden_hifigan_24k(name="hifigan_24k", clips=(1, 2), T=10, seed=92, wseed=7):
+    """The 24 kHz generator of the demo config: the REAL modules/hifigan/hifigan.py HifiGanGenerator (weight-normed checkpoint ->
+    strict load -> remove_weight_norm, as network/vocoders/hifigan.py:30-37 does) with and without an f0, source-module random
+    draws replaced by the Philox streams.  Natural-log mel, fed unscaled (hifigan.py:64)."""
+    refshim.install()
+    import modules.hifigan.hifigan as HG
+    clips = list(clips)
+    h = dict(synth.VOCODER_24K)
+    sdw = synth.vocoder_state(h, wseed)
+    gen = HG.HifiGanGenerator(h)
+    gen.load_state_dict(sdw, strict=True)
+    gen.eval()
+    gen.remove_weight_norm()
+    mel, f0 = vocoder_inputs(h, clips, T)
+    hop = int(np.prod(h["upsample_rates"]))
+    ini, nz = O.vocoder_rng(seed, clips, T * hop)
+    orig_rand, orig_randn_like = torch.rand, torch.randn_like
+
+    def rand(*shape, **kw):
+        assert tuple(shape) == tuple(ini.shape), shape
+        return ini.clone()
+
+    def randn_like(x, **kw):
+        return nz.clone() if x.shape[-1] == nz.shape[-1] else torch.zeros_like(x)
+
+    torch.rand, torch.randn_like = rand, randn_like
+    try:
+        with torch.no_grad():
+            c = torch.from_numpy(mel).transpose(2, 1)
+            wav_src = gen(c, torch.from_numpy(f0)).numpy().reshape(len(clips), -1)
+            wav_plain = gen(c).numpy().reshape(len(clips), -1)
+    finally:
+        torch.rand, torch.randn_like = orig_rand, orig_randn_like
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), mel=mel, f0=f0, wav_src=wav_src, wav_plain=wav_plain, wseed=wseed,
+                        clips=np.array(clips), seed=seed)
+    print(name, "wav rms with source %.4f, plain %.4f" % (float(np.sqrt((wav_src ** 2).mean())), float(np.sqrt((wav_plain ** 2).mean()))))
+    import json as _json
+    with open(os.path.join(OUT, "state_keys.json")) as f:
+        keys = _json.load(f)
+    keys["vocoder_24k"] = {k: list(v.shape) for k, v in HG.HifiGanGenerator(h).state_dict().items()}
+    with open(os.path.join(OUT, "state_keys.json"), "w") as f:
+        _json.dump(keys, f, indent=0, sort_keys=True)
 
 
 def golden_24k():

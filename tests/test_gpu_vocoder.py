@@ -120,3 +120,54 @@ def test_melspec_full_clip_batch_and_silence():
     assert torch.equal(part[0, :30], mel[0, :30])
     ref = O.mel_spectrogram(wav[:1, :20000], 44100, 2048, 2048, 512, 128, 40, 16000)[0]
     assert (part[0] - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("with_source", [True, False])
+def test_hifigan_24k_generator_vs_reference_golden(with_source):
+    """The 24 kHz demo-config vocoder (modules/hifigan/hifigan.py:104-178, HifiGanGenerator) on the same kernels: 80 natural-log mel
+    bins fed unscaled (mel_scale 1), hop 128, the harmonic source only when an f0 is given -- against the REAL generator."""
+    from diffsvc_amd.engine import VocoderHandle
+    g = load_golden("hifigan_24k")
+    h = dict(synth.VOCODER_24K)
+    voc = VocoderHandle(synth.vocoder_state(h, int(g["wseed"])), h, precision="f16_x3", mel_scale=1.0, use_source=with_source)
+    clips = [int(c) for c in g["clips"]]
+    wavs = []
+    for i, c in enumerate(clips):
+        f0 = torch.from_numpy(g["f0"][i:i + 1]).cuda() if with_source else None
+        wavs.append(voc.vocode(torch.from_numpy(g["mel"][i:i + 1]).cuda(), f0, seed=int(g["seed"]), first_clip=c).cpu())
+    ref = torch.from_numpy(g["wav_src" if with_source else "wav_plain"])
+    rms = (torch.cat(wavs) - ref).pow(2).mean().sqrt().item()
+    print("hifigan 24k (source=%s): wav RMS err %.2e" % (with_source, rms))
+    assert rms < WAV_RMS_TOL, rms
+
+
+def test_hifigan_24k_plugin_contract(tmp_path):
+    """HifiGANHip through the reference's 24 kHz vocoder contract (network/vocoders/hifigan.py:46-76): hparams['vocoder_ckpt'] is a
+    directory with config.yaml + model_ckpt_steps_<N>.ckpt (['state_dict']['model_gen'], highest N wins); spec2wav(numpy mel[T,80]
+    natural log, f0=...) -> numpy; the source is used only with an f0 AND hparams['use_nsf']."""
+    from diffsvc_amd.hparams import set_hparams
+    from diffsvc_amd.vocoder import HifiGANHip
+    h = dict(synth.VOCODER_24K)
+    d = str(tmp_path / "hifigan")
+    synth.save_hifigan_ckpt(d, h, seed=3, steps=900)                 # an older step count: must lose against ...
+    vs = synth.save_hifigan_ckpt(d, h, seed=7, steps=12000)           # ... this one
+    set_hparams(dict(synth.HPARAMS_24K, vocoder_ckpt=d, use_nsf=True))
+    voc = HifiGANHip()
+    g = load_golden("hifigan_24k")
+    mel, f0 = g["mel"][0], g["f0"][0]
+    hop = int(np.prod(h["upsample_rates"]))
+    ini, nz = O.vocoder_rng(5, [0], mel.shape[0] * hop)
+    gw = O.fold_weight_norm(vs)
+    wav = voc.spec2wav(mel, f0=f0, seed=5)
+    assert isinstance(wav, np.ndarray) and wav.dtype == np.float32 and wav.shape == (mel.shape[0] * hop,)
+    with torch.no_grad():
+        c = torch.from_numpy(mel)[None].transpose(2, 1)
+        ref_src = O.generator_forward(gw, h, c, torch.from_numpy(f0)[None], ini, nz).reshape(-1).numpy()
+        ref_plain = O.generator_forward(gw, h, c, None, ini, nz).reshape(-1).numpy()
+    assert np.sqrt(np.mean((wav - ref_src) ** 2)) < WAV_RMS_TOL
+    assert np.sqrt(np.mean((voc.spec2wav(mel) - ref_plain) ** 2)) < WAV_RMS_TOL            # no f0: plain HiFi-GAN (hifigan.py:66-71)
+    set_hparams(dict(synth.HPARAMS_24K, vocoder_ckpt=d, use_nsf=False))
+    assert np.sqrt(np.mean((voc.spec2wav(mel, f0=f0) - ref_plain) ** 2)) < WAV_RMS_TOL     # f0 ignored without use_nsf
+    with pytest.raises(FileNotFoundError):
+        set_hparams(dict(synth.HPARAMS_24K, vocoder_ckpt=str(tmp_path / "nothing")))
+        HifiGANHip()

@@ -47,7 +47,7 @@ def test_acoustic_state_dict_contract(tag, hp):
     assert torch.equal(model.betas, sd2["betas"])
 
 
-@pytest.mark.parametrize("tag,h", [("tiny", synth.tiny_vocoder()), ("44k", dict(synth.VOCODER_44K))])
+@pytest.mark.parametrize("tag,h", [("tiny", synth.tiny_vocoder()), ("44k", dict(synth.VOCODER_44K)), ("24k", dict(synth.VOCODER_24K))])
 def test_vocoder_checkpoint_keys_match_reference(tag, h):
     ref = _keys()["vocoder_" + tag]
     sd = synth.vocoder_state(h, 1)

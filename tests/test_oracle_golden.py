@@ -123,3 +123,20 @@ def test_mel_filterbank_hash_and_product_copy():
     assert np.array_equal(O.mel_filterbank(24000, 512, 80, 30, 12000), melfb.mel_filterbank(24000, 512, 80, 30, 12000))
     # every filter is a non-negative triangle with at least one non-zero bin
     assert (fb >= 0).all() and (fb.sum(1) > 0).all()
+
+
+@pytest.mark.parametrize("with_source", [True, False])
+def test_hifigan_24k_generator_matches_reference(with_source):
+    """The 24 kHz HifiGanGenerator (modules/hifigan/hifigan.py:104-178: BASELINE configs[0]'s vocoder) is the NSF-HiFiGAN network fed a
+    natural-log mel unscaled; with an f0 it adds the (identical) harmonic source, without one it is a plain HiFi-GAN."""
+    g = load_golden("hifigan_24k")
+    h = dict(synth.VOCODER_24K)
+    gw = O.fold_weight_norm(synth.vocoder_state(h, int(g["wseed"])))
+    clips = [int(c) for c in g["clips"]]
+    hop = int(np.prod(h["upsample_rates"]))
+    ini, nz = O.vocoder_rng(int(g["seed"]), clips, g["mel"].shape[1] * hop)
+    with torch.no_grad():
+        c = torch.from_numpy(g["mel"]).transpose(2, 1)
+        wav = O.generator_forward(gw, h, c, torch.from_numpy(g["f0"]) if with_source else None, ini, nz).reshape(len(clips), -1)
+    ref = torch.from_numpy(g["wav_src" if with_source else "wav_plain"])
+    assert (wav - ref).pow(2).mean().sqrt().item() < 2e-6
