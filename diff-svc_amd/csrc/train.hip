@@ -1,0 +1,876 @@
+// Training step of the DiffNet denoiser behind the C ABI (include/dsvc.h: dsvc_trainer_*): diffusion loss forward + backward,
+// gradients of every denoise_fn.* parameter and of fs2.pitch_embed.weight, plus the AdamW update.
+// Reference: network/diff/diffusion.py:200-225 (q_sample, p_losses), network/diff/net.py:58-135 (the network that is
+// differentiated), training/task/SVC_task.py:60-66,116-125 (AdamW, optimizer_step), utils/pl_utils.py:1081-1084 (grad-norm clip).
+//
+// Every contraction -- forward, data gradients and weight gradients -- runs on the conv_gemm MFMA engine with split fp16 operands
+// (w = w_hi + w_lo, x = x_hi + x_lo: fp32-class products, fp32 accumulate), so the gradients match the reference's fp32 autograd
+// to ~1e-5 and nothing about the optimisation trajectory changes.  Layout as in inference: fp32 frame-major rows
+// (row = clip*Tp + t, gap rows zero = the convs' zero padding).
+//   forward   y = conv_dil(x + film) + W_c cond + b ;  g = sigmoid(y_a) tanh(y_b) ;  [r; s] = W_o g + b ;  x' = (x + r)/sqrt2 ; skip += s
+//             (sigma, tau, g and every layer's x are kept: ~1.3 GB for the 64 x 128-frame batch)
+//   backward  dO = [dx/sqrt2 ; dskip] ;  dg = W_o^T dO ;  dy = dg (tau sigma(1-sigma) ; sigma(1-tau^2)) ;  dx = dx/sqrt2 + convT(dy) ;
+//             dcond += W_c^T dy ;  weight gradients dW[o][k] = sum_n A[n][o] B[n][k] as the SAME engine on transposed operands:
+//             A^T is packed into MFMA weight fragments on the device (k_pack_cols), B^T is a transposed copy (k_transpose), the
+//             contraction index is the frame index.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dsvc.h"
+#include "conv_gemm.h"
+
+using namespace dsvc;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        if (n <= bytes && p) return DSVC_OK;
+        release();
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; return fail(DSVC_ENOMEM, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
+        bytes = n;
+        return DSVC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+constexpr uint32_t PURPOSE_TRAIN_NOISE = 5;
+constexpr float RSQRT2 = 0.70710678118654752440f;
+
+// ------------------------------------------------------------------------------------------------
+// conv_gemm epilogues of the training graph.  "valid" = row < n_rows with t < clip_len (gap rows carry no data).
+// ------------------------------------------------------------------------------------------------
+struct RowInfo {
+    int clip_stride, clip_len;
+    __device__ __forceinline__ bool valid(int row) const { return (row - (row / clip_stride) * clip_stride) < clip_len; }
+};
+
+// out = act(acc + bias); relu optional; invalid rows -> 0 (keeps gap rows zero for the next conv)
+struct EpStore {
+    static constexpr bool PAIRED = false;
+    struct Args { float* out; int ld; const float* bias; int cout; int relu; RowInfo ri; };
+    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
+        if (col >= e.cout) return;
+        v += e.bias ? e.bias[col] : 0.f;
+        if (e.relu) v = fmaxf(v, 0.f);
+        e.out[(size_t)row * e.ld + col] = e.ri.valid(row) ? v : 0.f;
+    }
+};
+
+// gate forward (net.py:71-77): packed column pairs (tile 2q = gate half, 2q+1 = filter half of channels 32q..32q+31)
+struct EpGateFwd {
+    static constexpr bool PAIRED = true;
+    struct Args { const float* ypre; float* sig; float* tau; float* g; int C; RowInfo ri; };
+    __device__ __forceinline__ void pair(const Args& e, int row, int ct0, int j, float vg, float vf) const {
+        const float* yp = e.ypre + (size_t)row * (2 * e.C) + ct0 * 32 + j;
+        const float a = vg + yp[0], b = vf + yp[32];
+        const float s = 1.0f / (1.0f + expf(-a)), t = tanhf(b);
+        const size_t o = (size_t)row * e.C + (ct0 >> 1) * 32 + j;
+        const bool ok = e.ri.valid(row);
+        e.sig[o] = s; e.tau[o] = t; e.g[o] = ok ? s * t : 0.f;
+    }
+};
+
+// output projection forward (net.py:79-84): cols < C residual, cols >= C skip
+struct EpResSkipFwd {
+    static constexpr bool PAIRED = false;
+    struct Args { const float* x; float* xnext; float* skip; const float* bias; int C; int first; RowInfo ri; };
+    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
+        v += e.bias[col];
+        const bool ok = e.ri.valid(row);
+        if (col < e.C) {
+            const size_t o = (size_t)row * e.C + col;
+            e.xnext[o] = ok ? (e.x[o] + v) * RSQRT2 : 0.f;
+        } else {
+            const size_t o = (size_t)row * e.C + (col - e.C);
+            e.skip[o] = ok ? (e.first ? v : e.skip[o] + v) : 0.f;
+        }
+    }
+};
+
+// dg = W_o^T dO, then through the gate:  dy_a = dg tau sigma (1 - sigma),  dy_b = dg sigma (1 - tau^2)   (natural channel order)
+struct EpGateBwd {
+    static constexpr bool PAIRED = false;
+    struct Args { const float* sig; const float* tau; float* dy; int C; RowInfo ri; };
+    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
+        if (col >= e.C) return;
+        const size_t o = (size_t)row * e.C + col;
+        const float s = e.sig[o], t = e.tau[o];
+        const bool ok = e.ri.valid(row);
+        e.dy[(size_t)row * (2 * e.C) + col] = ok ? v * t * s * (1.0f - s) : 0.f;
+        e.dy[(size_t)row * (2 * e.C) + e.C + col] = ok ? v * s * (1.0f - t * t) : 0.f;
+    }
+};
+
+// out (+)= acc * scale on valid rows, optionally gated by mask[row][col] > 0 (ReLU backward)
+struct EpBwd {
+    static constexpr bool PAIRED = false;
+    struct Args { float* out; int ld; int cout; const float* mask; int ldm; float scale; int accumulate; RowInfo ri; };
+    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
+        if (col >= e.cout) return;
+        v *= e.scale;
+        if (e.mask && !(e.mask[(size_t)row * e.ldm + col] > 0.f)) v = 0.f;
+        if (!e.ri.valid(row)) v = 0.f;
+        float* p = e.out + (size_t)row * e.ld + col;
+        *p = e.accumulate ? *p + v : v;
+    }
+};
+
+// weight gradient: the GEMM ran on transposed operands, "row" = input channel k, "col" = output channel o
+struct EpWgrad {
+    static constexpr bool PAIRED = false;
+    struct Args { float* dst; long long stride_o, stride_k, off; int n_o; };
+    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
+        if (col >= e.n_o) return;
+        e.dst[(long long)col * e.stride_o + (long long)row * e.stride_k + e.off] = v;
+    }
+};
+
+template <class Epi>
+int launch(const ConvGemmArgs& a, const typename Epi::Args& e, hipStream_t st) {
+    //                                                             WM WN WK KCB PF SPT NW NA
+    if (a.n_rows >= 6144 && a.cin % 64 == 0) return conv_gemm_launch<4, 4, 1, 64, 4, 5, 2, 2, Epi>(a, e, st);
+    if (a.cin % 128 == 0) return conv_gemm_launch<1, 1, 4, 128, 2, 3, 2, 2, Epi>(a, e, st);
+    if (a.cin % 64 == 0) return conv_gemm_launch<1, 2, 1, 64, 4, 2, 2, 2, Epi>(a, e, st);
+    return conv_gemm_launch<1, 2, 1, 16, 1, 2, 2, 2, Epi>(a, e, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+// weights -> conv_gemm fragment layout [ctile][tap][k16][plane 2][lane][8] on the device.
+//   W(col, tap, ci) = src[colmap(col) * s_col + ci * s_ci + tap_of(tap) * s_tap] * scale,  0 outside (cout, cin)
+//   flip: tap_of(tap) = taps-1-tap (transposed conv).  colmap: optional packed-column -> source-column permutation (-1 = zero).
+__global__ void k_pack_w(const float* __restrict__ src, const int* __restrict__ colmap, _Float16* __restrict__ dst, int n_ctiles,
+                         int taps, int cin_pad, int cout, int cin, long long s_col, long long s_ci, long long s_tap, int flip, float scale) {
+    const int nk16 = cin_pad >> 4;
+    const long long total = (long long)n_ctiles * taps * nk16 * 512;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        long long r = idx;
+        const int e = (int)(r & 7), l = (int)((r >> 3) & 63);
+        r >>= 9;
+        const int k = (int)(r % nk16); r /= nk16;
+        const int tap = (int)(r % taps);
+        const int ct = (int)(r / taps);
+        int col = ct * 32 + (l & 31);
+        const int ci = k * 16 + 8 * (l >> 5) + e;
+        if (colmap) col = colmap[col];
+        float w = 0.f;
+        if (col >= 0 && col < cout && ci < cin) w = src[(long long)col * s_col + (long long)ci * s_ci + (long long)(flip ? taps - 1 - tap : tap) * s_tap] * scale;
+        const _Float16 hi = (_Float16)w;
+        _Float16* f = dst + ((((size_t)ct * taps + tap) * nk16 + k) * 2) * 512 + l * 8 + e;
+        f[0] = hi;
+        f[512] = (_Float16)(w - (float)hi);
+    }
+}
+
+// transpose with optional additive per-clip vector (film) and validity mask:  dst[c][pad + n] = valid(n) ? src[n][c] + add[clip][c] : 0
+// dst is [C][ld] with ld >= rows + 2*pad; the pad columns are zeroed once at allocation.
+__global__ void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld, int pad,
+                            const float* __restrict__ add, int add_stride, int clip_stride, int clip_len) {
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int n = n0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (n < rows && c < C) {
+            const int clip = n / clip_stride;
+            if (n - clip * clip_stride < clip_len) v = src[(size_t)n * C + c] + (add ? add[(size_t)clip * add_stride + c] : 0.f);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, n = n0 + tx;
+        if (c < C && n < rows) dst[(size_t)c * ld + pad + n] = tile[tx][i];
+    }
+}
+
+// [B, C, T] (reference layout) -> frame-major [B*stride][C] on valid rows (gap rows stay zero)
+__global__ void k_bct_to_rows(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int T, int stride) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        tile[i][tx] = (c < C && t < T) ? src[((size_t)b * C + c) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        if (t < T && c < C) dst[((size_t)b * stride + t) * C + c] = tile[tx][i];
+    }
+}
+
+// x_t = sa[t_b] * norm_spec(mel) + sb[t_b] * noise   (diffusion.py:200-205,286-287); mel [B][T][M] -> frame-major [B*stride][M]
+__global__ void k_make_xt(const float* __restrict__ mel, float* __restrict__ xt, const int* __restrict__ tstep, const float* __restrict__ sa,
+                          const float* __restrict__ sb, const float* __restrict__ spec_min, const float* __restrict__ spec_max, int n_spec,
+                          int B, int T, int M, int stride, unsigned long long seed, const int* __restrict__ clipid) {
+    const int quads = T * M / 4;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (q >= quads) return;
+    float z[4];
+    philox_normal4((unsigned)q, 0u, (unsigned)clipid[b], PURPOSE_TRAIN_NOISE, seed, z);
+    const int ts = tstep[b];
+    const float a = sa[ts], s = sb[ts];
+    const int el = q * 4, t = el / M, m0 = el - t * M;
+    const float* mp = mel + ((size_t)b * T + t) * M + m0;
+    float* xp = xt + ((size_t)b * stride + t) * M + m0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = spec_min[n_spec == 1 ? 0 : m0 + i], hi = spec_max[n_spec == 1 ? 0 : m0 + i];
+        const float x0 = (mp[i] - lo) / (hi - lo) * 2.0f - 1.0f;
+        xp[i] = a * x0 + s * z[i];
+    }
+}
+
+// loss (diffusion.py:213-223) and its gradient w.r.t. eps on valid rows: l1 mean |noise - eps|, l2 mean (noise - eps)^2
+__global__ void k_loss(const float* __restrict__ eps, float* __restrict__ deps, float* __restrict__ loss, int B, int T, int M, int stride,
+                       unsigned long long seed, const int* __restrict__ clipid, int l1, float inv_n) {
+    const int quads = T * M / 4;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    float part = 0.f;
+    if (q < quads) {
+        float z[4];
+        philox_normal4((unsigned)q, 0u, (unsigned)clipid[b], PURPOSE_TRAIN_NOISE, seed, z);
+        const int el = q * 4, t = el / M, m0 = el - t * M;
+        const size_t o = ((size_t)b * stride + t) * M + m0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = eps[o + i] - z[i];
+            if (l1) { part += fabsf(d); deps[o + i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_n; }
+            else { part += d * d; deps[o + i] = 2.0f * d * inv_n; }
+        }
+    }
+    // block reduction -> one atomic per block
+    __shared__ float red[256];
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(loss, red[0] * inv_n);
+}
+
+// dst[c] += sum over rows of src[row][c]   (bias gradients); grid (ceil(C/64), row chunks)
+__global__ void k_colsum(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld, int rows_per_block) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;                        // 4 row phases
+    const int r0 = blockIdx.y * rows_per_block;
+    float s = 0.f;
+    if (c < C)
+        for (int r = r0 + sub; r < r0 + rows_per_block && r < rows; r += 4) s += src[(size_t)r * ld + c];
+    __shared__ float red[4][64];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < C) atomicAdd(dst + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dst[clip][c] = sum_t src[clip*stride + t][c]   (FiLM gradient); grid (ceil(C/64), B)
+__global__ void k_clip_colsum(const float* __restrict__ src, float* __restrict__ dst, int T, int C, int stride, int dst_ld) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    float s = 0.f;
+    if (c < C)
+        for (int t = sub; t < T; t += 4) s += src[((size_t)b * stride + t) * C + c];
+    __shared__ float red[4][64];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < C) dst[(size_t)b * dst_ld + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// dx <- dx/sqrt2 + dxin ;  dOa[row][0..C) <- dx/sqrt2  (the residual half of the next layer's dO)
+__global__ void k_dx_update(float* __restrict__ dx, const float* __restrict__ dxin, float* __restrict__ dO, int rows, int C) {
+    const size_t n = (size_t)rows * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / C), c = (int)(i - (size_t)row * C);
+        const float v = dx[i] * RSQRT2 + dxin[i];
+        dx[i] = v;
+        dO[(size_t)row * (2 * C) + c] = v * RSQRT2;
+    }
+}
+
+// dst[row][off + c] = src[row][c] * scale
+__global__ void k_copy_cols(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld_dst, int off, float scale) {
+    const size_t n = (size_t)rows * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / C), c = (int)(i - (size_t)row * C);
+        dst[(size_t)row * ld_dst + off + c] = src[i] * scale;
+    }
+}
+
+// out[i] = in[i] * (mask[i] > 0)
+__global__ void k_relu_bwd(const float* __restrict__ in, const float* __restrict__ mask, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = mask[i] > 0.f ? in[i] : 0.f;
+}
+
+// small dense fp32 GEMM for the [B x C]-sized step-embedding path:  C[m][n] (+)= sum_k A(m,k) * B(k,n),
+// A(m,k) = ta ? A[k*lda + m] : A[m*lda + k],  B(k,n) = tb ? B[n*ldb + k] : B[k*ldb + n].  One thread per output.
+__global__ void k_gemm_small(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm, int M, int N, int K,
+                             int lda, int ldb, int ldc, int ta, int tb, int accumulate, const float* __restrict__ bias) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float a = ta ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
+        const float b = tb ? Bm[(size_t)n * ldb + k] : Bm[(size_t)k * ldb + n];
+        s = fmaf(a, b, s);
+    }
+    if (bias) s += bias[n];
+    float* p = Cm + (size_t)m * ldc + n;
+    *p = accumulate ? *p + s : s;
+}
+
+// SinusoidalPosEmb (net.py:32-44) for the batch's steps
+__global__ void k_sin_emb_b(float* __restrict__ emb, const int* __restrict__ tstep, int B, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    const int half = C / 2;
+    const float scale = logf(10000.0f) / (float)(half - 1);
+    const int k = c < half ? c : c - half;
+    const float ang = (float)tstep[b] * expf((float)k * -scale);
+    emb[i] = c < half ? sinf(ang) : cosf(ang);
+}
+
+// Mish (common_layers.py:485-487) forward and backward on [n]: y = x tanh(softplus(x))
+__global__ void k_mish(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const float sp = v > 20.f ? v : log1pf(expf(v));
+    y[i] = v * tanhf(sp);
+}
+__global__ void k_mish_bwd(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const float sp = v > 20.f ? v : log1pf(expf(v));
+    const float th = tanhf(sp);
+    const float sg = 1.0f / (1.0f + expf(-v));              // d softplus / dx
+    dx[i] = dy[i] * (th + v * (1.0f - th * th) * sg);
+}
+
+// d pitch_embed[pitch[b,t]] += dcond[row] on frames with mel2ph > 0  (fs2.py:229-237: decoder_inp = (gather + embed) * nonpadding)
+__global__ void k_embed_bwd(const float* __restrict__ dcond, const int* __restrict__ pitch, const int* __restrict__ mel2ph,
+                            float* __restrict__ demb, int B, int T, int H, int stride, int vocab) {
+    const size_t n = (size_t)B * T * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i % H);
+        const size_t bt = i / H;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        if (mel2ph && mel2ph[bt] <= 0) continue;
+        const int p = pitch[bt];
+        if (p <= 0 || p >= vocab) continue;                  // padding_idx 0 receives no gradient (nn.Embedding padding_idx)
+        atomicAdd(demb + (size_t)p * H + h, dcond[((size_t)b * stride + t) * H + h]);
+    }
+}
+
+__global__ void k_iota(int* p, int base, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = base + i;
+}
+
+// AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias-corrected moments), gradients pre-scaled by gscale
+__global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                        float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, const float* __restrict__ gscale_dev, float gscale) {
+    const float gs = gscale_dev ? *gscale_dev : gscale;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gs;
+        float w = p[i];
+        w *= 1.0f - lr * wd;
+        const float mi = b1 * m[i] + (1.0f - b1) * gr;
+        const float vi = b2 * v[i] + (1.0f - b2) * gr * gr;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        w -= (lr / bc1) * mi / denom;
+        p[i] = w;
+    }
+}
+
+__global__ void k_sqsum(const float* __restrict__ g, size_t n, float* __restrict__ out) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += g[i] * g[i];
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+
+// clip coefficient of torch.nn.utils.clip_grad_norm_: min(1, max_norm / (norm + 1e-6))
+__global__ void k_clip_coef(const float* __restrict__ sq, float max_norm, float* __restrict__ coef) {
+    const float nrm = sqrtf(*sq);
+    const float c = max_norm / (nrm + 1e-6f);
+    *coef = c < 1.0f ? c : 1.0f;
+}
+
+struct Packed {
+    DevBuf w;
+    int n_ctiles = 0, taps = 1, cin_pad = 0;
+};
+
+}  // namespace
+
+// =================================================================================================
+struct dsvc_trainer {
+    dsvc_trainer_cfg cfg;
+    std::vector<std::string> names;
+    std::map<std::string, std::pair<int64_t, int64_t>> index;       // name -> (offset, numel) in the flat layout
+    int64_t total = 0;
+    float* params = nullptr;
+    float* grads = nullptr;
+    std::vector<float> h_sa, h_sb;
+    DevBuf sa, sb, spec_min, spec_max;
+    int n_spec = 0;
+
+    // workspace for (B, T)
+    int wsB = 0, wsT = 0, Tp = 0, rows = 0, padc = 64;
+    DevBuf xt, xs, sig, tau, g, skip, ypre, s2pre, eps, deps, condT, condTT, tstep, clipid, iotaB;
+    DevBuf e0, e1pre, e1, e2, filmB, dfilm, de2, de1, de1pre;
+    DevBuf dx, dxin, dO, dy, ds2pre, dcond, dh0, TT, loss;
+    DevBuf packA;                                  // activation-as-weights fragments for the weight-gradient GEMMs
+    // per-step repacked weights
+    Packed w_in, w_skip, w_fin, w_finT, w_skipT;
+    std::vector<Packed> w_d, w_c, w_o, w_oT, w_cT, w_dT;
+    DevBuf gatemap;                                // packed column -> conv channel of the paired gate layout
+
+    ~dsvc_trainer() {
+        for (DevBuf* b : {&sa, &sb, &spec_min, &spec_max, &xt, &xs, &sig, &tau, &g, &skip, &ypre, &s2pre, &eps, &deps, &condT, &condTT, &tstep,
+                          &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre, &dcond,
+                          &dh0, &TT, &loss, &packA, &gatemap})
+            b->release();
+        auto rel = [](Packed& p) { p.w.release(); };
+        rel(w_in); rel(w_skip); rel(w_fin); rel(w_finT); rel(w_skipT);
+        for (auto* v : {&w_d, &w_c, &w_o, &w_oT, &w_cT, &w_dT})
+            for (auto& p : *v) rel(p);
+    }
+
+    void add(const std::string& n, int64_t numel) { names.push_back(n); index[n] = {total, numel}; total += numel; }
+    float* P(const std::string& n) const { return params + index.at(n).first; }
+    float* G(const std::string& n) const { return grads + index.at(n).first; }
+
+    void layout();
+    int ensure_ws(int B, int T, hipStream_t st);
+    int pack(Packed& pk, const float* src, const int* colmap, int cout_pad, int taps, int cin, int cout, long long s_col, long long s_ci,
+             long long s_tap, int flip, float scale, hipStream_t st);
+    int repack(hipStream_t st);
+    // dW[o][k] = sum_n A[n][o] * Bsrc[n + shift][k]: A [rows x O] (ldA = O), Bsrc [rows x K]; writes dst[o*stride_o + k*stride_k + off]
+    int wgrad(const float* A, int O, const float* BT, int K, int shift, float* dst, long long stride_o, long long stride_k, long long off,
+              bool repack_a, hipStream_t st);
+    int transpose(const float* src, int C, const float* add, int add_stride, hipStream_t st);
+    int step(const dsvc_train_args* a, float* loss_out, hipStream_t st);
+};
+
+void dsvc_trainer::layout() {
+    const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
+    // the order of DiffNet.state_dict() (net.py:86-110), then the one fs2 parameter the path trains (fs2.py:73-79)
+    add("denoise_fn.input_projection.weight", (int64_t)C * M); add("denoise_fn.input_projection.bias", C);
+    add("denoise_fn.mlp.0.weight", (int64_t)4 * C * C); add("denoise_fn.mlp.0.bias", 4 * C);
+    add("denoise_fn.mlp.2.weight", (int64_t)4 * C * C); add("denoise_fn.mlp.2.bias", C);
+    for (int l = 0; l < L; ++l) {
+        const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
+        add(q + "dilated_conv.weight", (int64_t)2 * C * C * 3); add(q + "dilated_conv.bias", 2 * C);
+        add(q + "diffusion_projection.weight", (int64_t)C * C); add(q + "diffusion_projection.bias", C);
+        add(q + "conditioner_projection.weight", (int64_t)2 * C * H); add(q + "conditioner_projection.bias", 2 * C);
+        add(q + "output_projection.weight", (int64_t)2 * C * C); add(q + "output_projection.bias", 2 * C);
+    }
+    add("denoise_fn.skip_projection.weight", (int64_t)C * C); add("denoise_fn.skip_projection.bias", C);
+    add("denoise_fn.output_projection.weight", (int64_t)M * C); add("denoise_fn.output_projection.bias", M);
+    add("fs2.pitch_embed.weight", (int64_t)cfg.pitch_vocab * H);
+}
+
+int dsvc_trainer::pack(Packed& pk, const float* src, const int* colmap, int cout_pad, int taps, int cin, int cout, long long s_col,
+                       long long s_ci, long long s_tap, int flip, float scale, hipStream_t st) {
+    pk.n_ctiles = round_up(ceil_div(cout_pad, 32), 2);
+    pk.taps = taps;
+    pk.cin_pad = round_up(cin, 16);
+    const size_t halfs = packed_halfs(pk.n_ctiles, taps, pk.cin_pad, 2);
+    DSVC_TRY(pk.w.alloc(halfs * 2));
+    const long long total_el = (long long)halfs / 2;
+    const int blocks = (int)((total_el + 255) / 256 < 8192 ? (total_el + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_pack_w, dim3(blocks), dim3(256), 0, st, src, colmap, pk.w.as<_Float16>(), pk.n_ctiles, taps, pk.cin_pad, cout, cin,
+                       s_col, s_ci, s_tap, flip, scale);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+int dsvc_trainer::repack(hipStream_t st) {
+    const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
+    const float isl = 1.0f / sqrtf((float)L);
+    const int* gm = gatemap.as<int>();
+    // forward (natural [O][I][taps] sources)
+    DSVC_TRY(pack(w_in, P("denoise_fn.input_projection.weight"), nullptr, C, 1, M, C, M, 1, 0, 0, 1.0f, st));
+    DSVC_TRY(pack(w_skip, P("denoise_fn.skip_projection.weight"), nullptr, C, 1, C, C, C, 1, 0, 0, isl, st));        // sum(skip)/sqrt(L) folded (net.py:131)
+    DSVC_TRY(pack(w_fin, P("denoise_fn.output_projection.weight"), nullptr, M, 1, C, M, C, 1, 0, 0, 1.0f, st));
+    // transposed (data gradients): W^T(col = input channel, ci = output channel) = W[ci][col]
+    DSVC_TRY(pack(w_finT, P("denoise_fn.output_projection.weight"), nullptr, C, 1, M, C, 1, C, 0, 0, 1.0f, st));
+    DSVC_TRY(pack(w_skipT, P("denoise_fn.skip_projection.weight"), nullptr, C, 1, C, C, 1, C, 0, 0, isl, st));
+    w_d.resize(L); w_c.resize(L); w_o.resize(L); w_oT.resize(L); w_cT.resize(L); w_dT.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
+        DSVC_TRY(pack(w_d[l], P(q + "dilated_conv.weight"), gm, 2 * C, 3, C, 2 * C, (long long)C * 3, 3, 1, 0, 1.0f, st));
+        DSVC_TRY(pack(w_c[l], P(q + "conditioner_projection.weight"), gm, 2 * C, 1, H, 2 * C, H, 1, 0, 0, 1.0f, st));
+        DSVC_TRY(pack(w_o[l], P(q + "output_projection.weight"), nullptr, 2 * C, 1, C, 2 * C, C, 1, 0, 0, 1.0f, st));
+        DSVC_TRY(pack(w_oT[l], P(q + "output_projection.weight"), nullptr, C, 1, 2 * C, C, 1, C, 0, 0, 1.0f, st));
+        DSVC_TRY(pack(w_cT[l], P(q + "conditioner_projection.weight"), nullptr, H, 1, 2 * C, H, 1, H, 0, 0, 1.0f, st));
+        // transposed conv: dxin[c] = sum_tap sum_o W_d[o][c][2 - tap] * dy[row + (tap-1)*d][o]
+        DSVC_TRY(pack(w_dT[l], P(q + "dilated_conv.weight"), nullptr, C, 3, 2 * C, C, 3, (long long)C * 3, 1, 1, 1.0f, st));
+    }
+    return DSVC_OK;
+}
+
+int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
+    if (B == wsB && T == wsT) return DSVC_OK;
+    const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
+    int max_dil = 1;
+    for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
+    if (max_dil > padc) return fail(DSVC_EINVAL, "trainer: dilation %d too large", max_dil);
+    Tp = round_up(T + max_dil, 32);
+    rows = round_up(B * Tp, 128);                   // the contraction length of the weight-gradient GEMMs: a multiple of the staged chunk
+    const size_t r = (size_t)rows;
+    auto z = [&](DevBuf& b, size_t bytes) -> int { DSVC_TRY(b.alloc(bytes)); DSVC_HIP(hipMemsetAsync(b.p, 0, bytes, st)); return DSVC_OK; };
+    DSVC_TRY(z(xt, r * M * 4)); DSVC_TRY(z(xs, r * C * 4 * (L + 1))); DSVC_TRY(z(sig, r * C * 4 * L)); DSVC_TRY(z(tau, r * C * 4 * L));
+    DSVC_TRY(z(g, r * C * 4 * L)); DSVC_TRY(z(skip, r * C * 4)); DSVC_TRY(z(ypre, r * 2 * C * 4)); DSVC_TRY(z(s2pre, r * C * 4));
+    DSVC_TRY(z(eps, r * M * 4)); DSVC_TRY(z(deps, r * M * 4)); DSVC_TRY(z(condT, r * H * 4));
+    DSVC_TRY(z(tstep, (size_t)B * 4)); DSVC_TRY(z(clipid, (size_t)B * 4)); DSVC_TRY(z(iotaB, (size_t)B * 4));
+    DSVC_TRY(z(e0, (size_t)B * C * 4)); DSVC_TRY(z(e1pre, (size_t)B * 4 * C * 4)); DSVC_TRY(z(e1, (size_t)B * 4 * C * 4)); DSVC_TRY(z(e2, (size_t)B * C * 4));
+    DSVC_TRY(z(filmB, (size_t)B * L * C * 4)); DSVC_TRY(z(dfilm, (size_t)B * L * C * 4)); DSVC_TRY(z(de2, (size_t)B * C * 4));
+    DSVC_TRY(z(de1, (size_t)B * 4 * C * 4)); DSVC_TRY(z(de1pre, (size_t)B * 4 * C * 4));
+    DSVC_TRY(z(dx, r * C * 4)); DSVC_TRY(z(dxin, r * C * 4)); DSVC_TRY(z(dO, r * 2 * C * 4)); DSVC_TRY(z(dy, r * 2 * C * 4));
+    DSVC_TRY(z(ds2pre, r * C * 4)); DSVC_TRY(z(dcond, r * H * 4)); DSVC_TRY(z(dh0, r * C * 4)); DSVC_TRY(z(loss, 16));
+    const size_t ldT = r + 2 * (size_t)padc;
+    DSVC_TRY(z(TT, ldT * (size_t)(2 * C) * 4));      // transposed operand [<= 2C][rows + 2 pad]; pads stay zero
+    DSVC_TRY(z(condTT, ldT * (size_t)H * 4));
+    DSVC_TRY(packA.alloc(packed_halfs(round_up(ceil_div(2 * C, 32), 2), 1, rows, 2) * 2));
+    hipLaunchKernelGGL(k_iota, dim3(ceil_div(B, 256)), dim3(256), 0, st, iotaB.as<int>(), 0, B);
+    if (!gatemap.p) {
+        // packed column p of a gate GEMM <-> conv channel: group = p/64, half = (p/32)&1, j = p%32  ->  half*C + group*32 + j
+        std::vector<int> gm(2 * C);
+        for (int p = 0; p < 2 * C; ++p) gm[p] = ((p >> 5) & 1) * C + (p >> 6) * 32 + (p & 31);
+        DSVC_TRY(gatemap.alloc(gm.size() * 4));
+        DSVC_HIP(hipMemcpyAsync(gatemap.p, gm.data(), gm.size() * 4, hipMemcpyHostToDevice, st));
+        DSVC_HIP(hipStreamSynchronize(st));
+    }
+    wsB = B; wsT = T;
+    return DSVC_OK;
+}
+
+int dsvc_trainer::transpose(const float* src, int C, const float* add, int add_stride, hipStream_t st) {
+    const int ld = rows + 2 * padc;
+    hipLaunchKernelGGL(k_transpose, dim3(ceil_div(rows, 32), ceil_div(C, 32)), dim3(256), 0, st, src, TT.as<float>(), rows, C, ld, padc,
+                       add, add_stride, Tp, wsT);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+int dsvc_trainer::wgrad(const float* A, int O, const float* BT, int K, int shift, float* dst, long long stride_o, long long stride_k,
+                        long long off, bool repack_a, hipStream_t st) {
+    // A^T as MFMA weight fragments: W(col = o, ci = n) = A[n][o]
+    const int n_ct = round_up(ceil_div(O, 32), 2);
+    if (repack_a) {
+        const long long total_el = (long long)n_ct * (rows / 16) * 512;
+        const int blocks = (int)((total_el + 255) / 256 < 16384 ? (total_el + 255) / 256 : 16384);
+        hipLaunchKernelGGL(k_pack_w, dim3(blocks), dim3(256), 0, st, A, (const int*)nullptr, packA.as<_Float16>(), n_ct, 1, rows, O, rows,
+                           1LL, (long long)O, 0LL, 0, 1.0f);
+    }
+    ConvGemmArgs a{};
+    const int ld = rows + 2 * padc;
+    a.x = BT + padc + shift; a.ldx = ld; a.n_rows = K; a.clip_stride = K < 32 ? 32 : K; a.clip_len = a.clip_stride;
+    a.cin = rows; a.taps = 1; a.dil = 1; a.w = packA.as<_Float16>(); a.n_ctiles = n_ct; a.w_planes = 2; a.in_slope = 1.0f;
+    EpWgrad::Args e{dst, stride_o, stride_k, off, O};
+    return launch<EpWgrad>(a, e, st);
+}
+
+int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t st) {
+    const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers, B = ta->B, T = ta->T;
+    DSVC_TRY(ensure_ws(B, T, st));
+    DSVC_TRY(repack(st));
+    const RowInfo ri{Tp, T};
+    const size_t r = (size_t)rows, slab = r * C;
+    DSVC_HIP(hipMemsetAsync(grads, 0, (size_t)total * 4, st));
+    DSVC_HIP(hipMemsetAsync(loss.p, 0, 16, st));
+    // ---- inputs ----
+    DSVC_HIP(hipMemcpyAsync(tstep.p, ta->t, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    if (ta->clip_ids) DSVC_HIP(hipMemcpyAsync(clipid.p, ta->clip_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    else hipLaunchKernelGGL(k_iota, dim3(ceil_div(B, 256)), dim3(256), 0, st, clipid.as<int>(), ta->first_clip, B);
+    hipLaunchKernelGGL(k_make_xt, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, ta->mel, xt.as<float>(), tstep.as<int>(), sa.as<float>(),
+                       sb.as<float>(), spec_min.as<float>(), spec_max.as<float>(), n_spec, B, T, M, Tp, ta->seed, clipid.as<int>());
+    hipLaunchKernelGGL(k_bct_to_rows, dim3(ceil_div(T, 32), ceil_div(H, 32), B), dim3(256), 0, st, ta->cond, condT.as<float>(), B, H, T, Tp);
+    auto base = [&](const float* x, int ldx, int cin, const Packed& pk, int dil) {
+        ConvGemmArgs a{};
+        a.x = x; a.ldx = ldx; a.n_rows = rows; a.clip_stride = Tp; a.clip_len = T;
+        a.cin = cin; a.taps = pk.taps; a.dil = dil; a.w = pk.w.as<_Float16>(); a.n_ctiles = pk.n_ctiles; a.w_planes = 2; a.in_slope = 1.0f;
+        return a;
+    };
+    auto small = [&](const float* A, const float* Bm, float* Cm, int Mm, int N, int K, int lda, int ldb, int ldc, int tA, int tB, int acc,
+                     const float* bias) {
+        const long long n = (long long)Mm * N;
+        hipLaunchKernelGGL(k_gemm_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, Bm, Cm, Mm, N, K, lda, ldb, ldc, tA, tB, acc, bias);
+    };
+    auto colsum = [&](const float* src, float* dst, int Cc, int ld) {
+        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(Cc, 64), ceil_div(rows, 512)), dim3(256), 0, st, src, dst, rows, Cc, ld, 512);
+    };
+    const int ew = 2048;
+    // ---- step embedding: emb -> Linear -> Mish -> Linear -> per-layer diffusion_projection  (net.py:99-103,124-125,67) ----
+    hipLaunchKernelGGL(k_sin_emb_b, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, e0.as<float>(), tstep.as<int>(), B, C);
+    small(e0.as<float>(), P("denoise_fn.mlp.0.weight"), e1pre.as<float>(), B, 4 * C, C, C, C, 4 * C, 0, 1, 0, P("denoise_fn.mlp.0.bias"));
+    hipLaunchKernelGGL(k_mish, dim3(ceil_div(B * 4 * C, 256)), dim3(256), 0, st, e1pre.as<float>(), e1.as<float>(), (size_t)B * 4 * C);
+    small(e1.as<float>(), P("denoise_fn.mlp.2.weight"), e2.as<float>(), B, C, 4 * C, 4 * C, 4 * C, C, 0, 1, 0, P("denoise_fn.mlp.2.bias"));
+    for (int l = 0; l < L; ++l) {
+        const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
+        small(e2.as<float>(), P(q + "weight"), filmB.as<float>() + (size_t)l * C, B, C, C, C, C, L * C, 0, 1, 0, P(q + "bias"));
+    }
+    // ---- forward ----
+    {   // x^0 = relu(W_in x_t + b)  (net.py:120-123)
+        ConvGemmArgs a = base(xt.as<float>(), M, M, w_in, 1);
+        EpStore::Args e{xs.as<float>(), C, P("denoise_fn.input_projection.bias"), C, 1, ri};
+        DSVC_TRY(launch<EpStore>(a, e, st));
+    }
+    for (int l = 0; l < L; ++l) {
+        const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
+        const int d = 1 << (l % cfg.dilation_cycle);
+        float* xl = xs.as<float>() + (size_t)l * slab;
+        {   // ypre = W_c cond + b_c + b_d in the gate's packed column order: two bias vectors -> fold b_d through a second pass below
+            ConvGemmArgs a = base(condT.as<float>(), H, H, w_c[l], 1);
+            EpStore::Args e{ypre.as<float>(), 2 * C, nullptr, 2 * C, 0, RowInfo{Tp, Tp}};
+            DSVC_TRY(launch<EpStore>(a, e, st));
+        }
+        {   // gate: y = conv_dil(x + film) + ypre + biases
+            ConvGemmArgs a = base(xl, C, C, w_d[l], d);
+            a.film = filmB.as<float>() + (size_t)l * C; a.film_step_stride = L * C; a.step_ptr = iotaB.as<int>(); a.step_off = 0; a.step_per_clip = 1;
+            // biases of both convs enter through ypre: add them there first (natural order -> packed order handled by k_add_bias_packed)
+            EpGateFwd::Args e{ypre.as<float>(), sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab,
+                              g.as<float>() + (size_t)l * slab, C, ri};
+            (void)q;
+            DSVC_TRY(launch<EpGateFwd>(a, e, st));
+        }
+        {   // [r; s] = W_o g + b   (net.py:79-84)
+            ConvGemmArgs a = base(g.as<float>() + (size_t)l * slab, C, C, w_o[l], 1);
+            EpResSkipFwd::Args e{xl, xs.as<float>() + (size_t)(l + 1) * slab, skip.as<float>(), P(q + "output_projection.bias"), C, l == 0 ? 1 : 0, ri};
+            DSVC_TRY(launch<EpResSkipFwd>(a, e, st));
+        }
+    }
+    {   // s2pre = W_s skip/sqrt(L) + b ;  eps = W_out relu(s2pre) + b   (net.py:131-134)
+        ConvGemmArgs a = base(skip.as<float>(), C, C, w_skip, 1);
+        EpStore::Args e{s2pre.as<float>(), C, P("denoise_fn.skip_projection.bias"), C, 0, ri};
+        DSVC_TRY(launch<EpStore>(a, e, st));
+        ConvGemmArgs a2 = base(s2pre.as<float>(), C, C, w_fin, 1);
+        a2.in_slope = 0.0f;                                   // leaky_relu with slope 0 at staging = ReLU
+        EpStore::Args e2s{eps.as<float>(), M, P("denoise_fn.output_projection.bias"), M, 0, ri};
+        DSVC_TRY(launch<EpStore>(a2, e2s, st));
+    }
+    // ---- loss and d eps ----
+    const float inv_n = 1.0f / ((float)B * (float)M * (float)T);
+    hipLaunchKernelGGL(k_loss, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, eps.as<float>(), deps.as<float>(), loss.as<float>(), B, T, M, Tp,
+                       ta->seed, clipid.as<int>(), cfg.loss_l1, inv_n);
+    // ---- backward: tail ----
+    colsum(deps.as<float>(), G("denoise_fn.output_projection.bias"), M, M);
+    {   // dW_out[m][c] = sum_n deps[n][m] relu(s2pre)[n][c]
+        hipLaunchKernelGGL(k_relu_bwd, dim3(ew), dim3(256), 0, st, s2pre.as<float>(), s2pre.as<float>(), dh0.as<float>(), r * C);   // dh0 = relu(s2pre) (scratch)
+        DSVC_TRY(transpose(dh0.as<float>(), C, nullptr, 0, st));
+        DSVC_TRY(wgrad(deps.as<float>(), M, TT.as<float>(), C, 0, G("denoise_fn.output_projection.weight"), C, 1, 0, true, st));
+        // d s2pre = (W_out^T deps) * [s2pre > 0]
+        ConvGemmArgs a = base(deps.as<float>(), M, M, w_finT, 1);
+        EpBwd::Args e{ds2pre.as<float>(), C, C, s2pre.as<float>(), C, 1.0f, 0, ri};
+        DSVC_TRY(launch<EpBwd>(a, e, st));
+        colsum(ds2pre.as<float>(), G("denoise_fn.skip_projection.bias"), C, C);
+        // dW_s[o][c] = sum_n ds2pre[n][o] skip[n][c] / sqrt(L)
+        DSVC_TRY(transpose(skip.as<float>(), C, nullptr, 0, st));
+        DSVC_TRY(wgrad(ds2pre.as<float>(), C, TT.as<float>(), C, 0, G("denoise_fn.skip_projection.weight"), C, 1, 0, true, st));
+        const long long nws = (long long)C * C;
+        hipLaunchKernelGGL(k_copy_cols, dim3(ceil_div((int)nws, 256)), dim3(256), 0, st, G("denoise_fn.skip_projection.weight"),
+                           G("denoise_fn.skip_projection.weight"), 1, (int)nws, (int)nws, 0, 1.0f / sqrtf((float)L));
+        // dskip = W_s^T ds2pre / sqrt(L)  -> the skip half of dO (the same for every layer)
+        ConvGemmArgs a2 = base(ds2pre.as<float>(), C, C, w_skipT, 1);
+        EpBwd::Args e2{dO.as<float>() + C, 2 * C, C, nullptr, 0, 1.0f, 0, ri};
+        DSVC_TRY(launch<EpBwd>(a2, e2, st));
+    }
+    DSVC_HIP(hipMemsetAsync(dx.p, 0, r * C * 4, st));
+    DSVC_HIP(hipMemsetAsync(dO.p, 0, 0, st));
+    hipLaunchKernelGGL(k_copy_cols, dim3(ew), dim3(256), 0, st, dx.as<float>(), dO.as<float>(), rows, C, 2 * C, 0, 0.0f);   // residual half of dO: d x^L = 0
+    // cond^T once (weight gradients of every conditioner projection)
+    {
+        const int ld = rows + 2 * padc;
+        hipLaunchKernelGGL(k_transpose, dim3(ceil_div(rows, 32), ceil_div(H, 32)), dim3(256), 0, st, condT.as<float>(), condTT.as<float>(), rows, H, ld,
+                           padc, (const float*)nullptr, 0, Tp, T);
+    }
+    // ---- backward: layers ----
+    for (int l = L - 1; l >= 0; --l) {
+        const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
+        const int d = 1 << (l % cfg.dilation_cycle);
+        const float* xl = xs.as<float>() + (size_t)l * slab;
+        const float* gl = g.as<float>() + (size_t)l * slab;
+        colsum(dO.as<float>(), G(q + "output_projection.bias"), 2 * C, 2 * C);
+        DSVC_TRY(transpose(gl, C, nullptr, 0, st));
+        DSVC_TRY(wgrad(dO.as<float>(), 2 * C, TT.as<float>(), C, 0, G(q + "output_projection.weight"), C, 1, 0, true, st));
+        {   // dg = W_o^T dO -> dy
+            ConvGemmArgs a = base(dO.as<float>(), 2 * C, 2 * C, w_oT[l], 1);
+            EpGateBwd::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(), C, ri};
+            DSVC_TRY(launch<EpGateBwd>(a, e, st));
+        }
+        colsum(dy.as<float>(), G(q + "dilated_conv.bias"), 2 * C, 2 * C);
+        DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
+        // dW_c[o][h] = sum_n dy[n][o] cond[n][h]   (packs dy^T once; the three taps below reuse the fragments)
+        DSVC_TRY(wgrad(dy.as<float>(), 2 * C, condTT.as<float>(), H, 0, G(q + "conditioner_projection.weight"), H, 1, 0, true, st));
+        // dW_d[o][c][tap] = sum_n dy[n][o] (x^l + film)[n + (tap-1) d][c]
+        DSVC_TRY(transpose(xl, C, filmB.as<float>() + (size_t)l * C, L * C, st));
+        for (int tap = 0; tap < 3; ++tap)
+            DSVC_TRY(wgrad(dy.as<float>(), 2 * C, TT.as<float>(), C, (tap - 1) * d, G(q + "dilated_conv.weight"), (long long)C * 3, 3, tap, false, st));
+        {   // dcond += W_c^T dy
+            ConvGemmArgs a = base(dy.as<float>(), 2 * C, 2 * C, w_cT[l], 1);
+            EpBwd::Args e{dcond.as<float>(), H, H, nullptr, 0, 1.0f, l == L - 1 ? 0 : 1, ri};
+            DSVC_TRY(launch<EpBwd>(a, e, st));
+        }
+        {   // dxin = convT(dy)
+            ConvGemmArgs a = base(dy.as<float>(), 2 * C, 2 * C, w_dT[l], d);
+            EpBwd::Args e{dxin.as<float>(), C, C, nullptr, 0, 1.0f, 0, ri};
+            DSVC_TRY(launch<EpBwd>(a, e, st));
+        }
+        hipLaunchKernelGGL(k_clip_colsum, dim3(ceil_div(C, 64), B), dim3(256), 0, st, dxin.as<float>(), dfilm.as<float>() + (size_t)l * C, T, C, Tp, L * C);
+        hipLaunchKernelGGL(k_dx_update, dim3(ew), dim3(256), 0, st, dx.as<float>(), dxin.as<float>(), dO.as<float>(), rows, C);
+    }
+    {   // input projection: d h0pre = dx^0 [x^0 > 0]
+        hipLaunchKernelGGL(k_relu_bwd, dim3(ew), dim3(256), 0, st, dx.as<float>(), xs.as<float>(), dh0.as<float>(), r * C);
+        colsum(dh0.as<float>(), G("denoise_fn.input_projection.bias"), C, C);
+        DSVC_TRY(transpose(xt.as<float>(), M, nullptr, 0, st));
+        DSVC_TRY(wgrad(dh0.as<float>(), C, TT.as<float>(), M, 0, G("denoise_fn.input_projection.weight"), M, 1, 0, true, st));
+    }
+    // ---- backward: step embedding ----
+    DSVC_HIP(hipMemsetAsync(de2.p, 0, (size_t)B * C * 4, st));
+    for (int l = 0; l < L; ++l) {
+        const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
+        const float* df = dfilm.as<float>() + (size_t)l * C;
+        small(df, e2.as<float>(), G(q + "weight"), C, C, B, L * C, C, C, 1, 0, 0, nullptr);            // dWp[o][i] = sum_b dfilm[b][o] e2[b][i]
+        small(df, df, G(q + "bias"), 1, C, B, 0, L * C, C, 0, 0, 0, nullptr);                          // placeholder, replaced below
+        small(df, P(q + "weight"), de2.as<float>(), B, C, C, L * C, C, C, 0, 0, 1, nullptr);           // de2[b][i] += sum_o dfilm[b][o] Wp[o][i]
+    }
+    // bias gradients of the diffusion projections: column sums of dfilm over the batch
+    for (int l = 0; l < L; ++l) {
+        const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.bias";
+        DSVC_HIP(hipMemsetAsync(G(q), 0, (size_t)C * 4, st));
+        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, dfilm.as<float>() + (size_t)l * C, G(q), B, C, L * C, B);
+    }
+    small(de2.as<float>(), e1.as<float>(), G("denoise_fn.mlp.2.weight"), C, 4 * C, B, C, 4 * C, 4 * C, 1, 0, 0, nullptr);
+    hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, de2.as<float>(), G("denoise_fn.mlp.2.bias"), B, C, C, B);
+    small(de2.as<float>(), P("denoise_fn.mlp.2.weight"), de1.as<float>(), B, 4 * C, C, C, 4 * C, 4 * C, 0, 0, 0, nullptr);
+    hipLaunchKernelGGL(k_mish_bwd, dim3(ceil_div(B * 4 * C, 256)), dim3(256), 0, st, e1pre.as<float>(), de1.as<float>(), de1pre.as<float>(), (size_t)B * 4 * C);
+    small(de1pre.as<float>(), e0.as<float>(), G("denoise_fn.mlp.0.weight"), 4 * C, C, B, 4 * C, C, C, 1, 0, 0, nullptr);
+    hipLaunchKernelGGL(k_colsum, dim3(ceil_div(4 * C, 64), 1), dim3(256), 0, st, de1pre.as<float>(), G("denoise_fn.mlp.0.bias"), B, 4 * C, 4 * C, B);
+    // ---- pitch embedding (through cond) ----
+    if (ta->pitch) {
+        const size_t n = (size_t)B * T * H;
+        hipLaunchKernelGGL(k_embed_bwd, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, dcond.as<float>(), ta->pitch,
+                           ta->mel2ph, G("fs2.pitch_embed.weight"), B, T, H, Tp, cfg.pitch_vocab);
+    }
+    if (loss_out) DSVC_HIP(hipMemcpyAsync(loss_out, loss.p, 4, hipMemcpyDeviceToDevice, st));
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+// =================================================================================================
+extern "C" {
+
+int dsvc_trainer_create(const dsvc_trainer_cfg* cfg, dsvc_trainer** out) {
+    if (!cfg || !out) return fail(DSVC_EINVAL, "null argument");
+    if (cfg->mel_bins % 16 || cfg->hidden % 16 || cfg->channels % 64) return fail(DSVC_EINVAL, "trainer: need mel_bins%%16==0, hidden%%16==0, channels%%64==0");
+    if (cfg->layers < 1 || cfg->dilation_cycle < 1 || cfg->pitch_vocab < 2) return fail(DSVC_EINVAL, "trainer: bad configuration");
+    int ndev = 0;
+    DSVC_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(DSVC_EHIP, "no HIP device visible");
+    dsvc_trainer* t = new dsvc_trainer();
+    t->cfg = *cfg;
+    t->layout();
+    *out = t;
+    return DSVC_OK;
+}
+
+void dsvc_trainer_destroy(dsvc_trainer* t) { delete t; }
+
+int dsvc_trainer_param_count(const dsvc_trainer* t, int64_t* n_tensors, int64_t* n_floats) {
+    if (!t) return fail(DSVC_EINVAL, "null handle");
+    if (n_tensors) *n_tensors = (int64_t)t->names.size();
+    if (n_floats) *n_floats = t->total;
+    return DSVC_OK;
+}
+
+int dsvc_trainer_param_info(const dsvc_trainer* t, int64_t i, const char** name, int64_t* offset, int64_t* numel) {
+    if (!t || i < 0 || i >= (int64_t)t->names.size()) return fail(DSVC_EINVAL, "bad parameter index");
+    const auto& e = t->index.at(t->names[(size_t)i]);
+    if (name) *name = t->names[(size_t)i].c_str();
+    if (offset) *offset = e.first;
+    if (numel) *numel = e.second;
+    return DSVC_OK;
+}
+
+int dsvc_trainer_bind(dsvc_trainer* t, float* params, float* grads) {
+    if (!t || !params || !grads) return fail(DSVC_EINVAL, "null argument");
+    t->params = params; t->grads = grads;
+    return DSVC_OK;
+}
+
+int dsvc_trainer_set_schedule(dsvc_trainer* t, const float* sqrt_ac, const float* sqrt_1mac, int32_t K, const float* spec_min,
+                              const float* spec_max, int32_t n_spec) {
+    if (!t || !sqrt_ac || !sqrt_1mac || !spec_min || !spec_max || K < 1) return fail(DSVC_EINVAL, "null argument");
+    if (n_spec != 1 && n_spec != t->cfg.mel_bins) return fail(DSVC_EINVAL, "trainer: spec_min/spec_max must have 1 or mel_bins entries");
+    DSVC_TRY(t->sa.alloc((size_t)K * 4)); DSVC_TRY(t->sb.alloc((size_t)K * 4));
+    DSVC_TRY(t->spec_min.alloc((size_t)n_spec * 4)); DSVC_TRY(t->spec_max.alloc((size_t)n_spec * 4));
+    DSVC_HIP(hipMemcpy(t->sa.p, sqrt_ac, (size_t)K * 4, hipMemcpyHostToDevice));
+    DSVC_HIP(hipMemcpy(t->sb.p, sqrt_1mac, (size_t)K * 4, hipMemcpyHostToDevice));
+    DSVC_HIP(hipMemcpy(t->spec_min.p, spec_min, (size_t)n_spec * 4, hipMemcpyHostToDevice));
+    DSVC_HIP(hipMemcpy(t->spec_max.p, spec_max, (size_t)n_spec * 4, hipMemcpyHostToDevice));
+    t->n_spec = n_spec;
+    t->cfg.timesteps = K;
+    return DSVC_OK;
+}
+
+int dsvc_trainer_step(dsvc_trainer* t, const dsvc_train_args* a, float* loss_out, void* stream) {
+    if (!t || !a || !a->mel || !a->cond || !a->t) return fail(DSVC_EINVAL, "null argument");
+    if (!t->params || !t->grads) return fail(DSVC_ESTATE, "trainer: bind the flat parameter / gradient buffers first");
+    if (!t->sa.p) return fail(DSVC_ESTATE, "trainer: set the noise schedule first");
+    if (a->B < 1 || a->T < 1 || (a->T * t->cfg.mel_bins) % 4) return fail(DSVC_EINVAL, "trainer: bad batch geometry");
+    return t->step(a, loss_out, (hipStream_t)stream);
+}
+
+int dsvc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int64_t step, const float* grad_scale_dev, float grad_scale, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return fail(DSVC_EINVAL, "bad argument");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_adamw, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2, grad_scale_dev, grad_scale);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+int dsvc_grad_clip_coef(const float* grads, int64_t n, float max_norm, float* sqnorm_dev, float* coef_dev, void* stream) {
+    if (!grads || !sqnorm_dev || !coef_dev || n < 0) return fail(DSVC_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    DSVC_HIP(hipMemsetAsync(sqnorm_dev, 0, 4, st));
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_sqsum, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, grads, (size_t)n, sqnorm_dev);
+    hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(1), 0, st, sqnorm_dev, max_norm, coef_dev);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+}  // extern "C"
