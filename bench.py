@@ -146,6 +146,34 @@ def cpu_baseline(hp, sd, vs, h, budget_s=20.0):
                       % (n, per_step, t_voc)}
 
 
+def train_batch(hp, B, T, rank, device):
+    """Synthetic training batch of BASELINE configs[4]: B clips x T mel frames (content units, alignment, f0, target mels)."""
+    n_units = max(2, T * N_UNITS // T_FRAMES)
+    hub, m2p, f0 = [], [], []
+    for c in range(B):
+        a, b, c_, _ = synth.clip_inputs(rank * B + c, T=T, n_units=n_units, H=hp["hidden_size"])
+        hub.append(a); m2p.append(b); f0.append(c_)
+    g = np.random.Generator(np.random.PCG64(77 + rank))
+    mels = (g.standard_normal((B, T, hp["audio_num_mel_bins"])) * 0.7 - 2.5).astype(np.float32)
+    return tuple(torch.from_numpy(np.stack(v)).to(device) for v in (hub, m2p, f0)) + (torch.from_numpy(mels).to(device),)
+
+
+def time_train_steps(hp, sd, B, T, steps, warmup, rank, device, sync):
+    """ms per optimisation step of DiffusionTrainerHip (forward + backward + gradient all-reduce over the ranks + clip + AdamW)."""
+    from diffsvc_amd.train import DiffusionTrainerHip
+    tr = DiffusionTrainerHip(dict(hp, lr=1e-4), sd)
+    hub, m2p, f0, mels = train_batch(hp, B, T, rank, device)
+    loss = None
+    for i in range(warmup):
+        loss = tr.train_step(hub, m2p, f0, mels, seed=10 + i, first_clip=rank * B)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = tr.train_step(hub, m2p, f0, mels, seed=100 + i, first_clip=rank * B)
+    sync()
+    return (time.perf_counter() - t0) / steps * 1e3, float(loss.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +189,9 @@ def main():
                          "1e-3 mel bar at the benchmarked sizes), f16_dN (fp16 operands, N time-dithered weight roundings), f16_w2, f16_x3, f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the extra batched (32 clips/GPU) measurement")
+    ap.add_argument("--train", action="store_true",
+                    help="measure BASELINE configs[4] instead: the training step (diffusion loss fwd+bwd + AdamW) on a 64 x 128-frame mel "
+                         "batch per GPU, gradients all-reduced over the ranks (weak scaling)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the sampler steps eagerly (rocprofv3 --pmc segfaults on hipGraph replays on this stack)")
     args = ap.parse_args()
@@ -189,6 +220,31 @@ def main():
     h = dict(synth.VOCODER_44K)
     sd = synth.acoustic_state(hp, 0)
     vs = synth.vocoder_state(h, 1)
+    if args.train:
+        def sync_t():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+        Bt, Tt = 64, 128
+        ms, loss = time_train_steps(hp, sd, Bt, Tt, args.steps, args.warmup, rank, dev, sync_t)
+        if world > 1:
+            tmax = torch.tensor([ms], device="cpu" if SHARE_DEVICE else dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            ms = float(tmax.item())
+        if rank == 0:
+            print(json.dumps({"metric": "training mel frames per wall-second (diffusion loss fwd+bwd + AdamW, 44.1 kHz DiffNet)",
+                              "value": world * Bt * Tt / (ms * 1e-3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16x3",
+                              "dtype_detail": "split fp16 MFMA operands (hi+lo weights and activations: fp32-class), fp32 accumulate, fp32 master weights",
+                              "data": "synthetic",
+                              "config": {"workload": "BASELINE configs[4]: training step on a 64 x 128-frame mel batch per GPU, gradient all-reduce (mean) "
+                                                     "of 32 M fp32 over the ranks", "clips_per_gpu": Bt, "mel_frames": Tt, "loss": hp["diff_loss_type"],
+                                         "parallelism": "data-parallel x%d" % world},
+                              "final_loss": loss}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     pipe = SvcPipeline(hp, sd, vs, h, precision=args.precision, vocoder_precision="f16_x3")
 
     prec = pipe.model.denoise_fn.precision_for("plms" if args.speedup > 1 else "ddpm", args.speedup)      # what the timed chain runs at
@@ -287,6 +343,16 @@ def main():
             result["fp32_class"] = {"precision": "f16_x3", "value": CLIP_SECONDS / t3, "unit": "audio-sec/wall-sec", "ms_per_clip": t3 * 1e3,
                                     "workload": "BASELINE configs[1] at split-fp16 (fp32-class) operands"}
             del pipe3
+        if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched:
+            # BASELINE configs[4]: the training step (64 clips x 128 frames: diffusion loss forward + backward + clip + AdamW)
+            try:
+                torch.cuda.empty_cache()
+                ms_t, loss_t = time_train_steps(hp, sd, 64, 128, 5, 2, 0, dev, torch.cuda.synchronize)
+                result["train_step"] = {"workload": "BASELINE configs[4]: diffusion loss fwd+bwd + AdamW on a 64 x 128-frame mel batch, 1 GPU",
+                                        "ms_per_step": ms_t, "value": 64 * 128 / (ms_t * 1e-3), "unit": "frames/s", "final_loss": loss_t,
+                                        "precision": "split fp16 operands (fp32-class), fp32 master weights"}
+            except Exception as ex:                                           # never lose the inference line to the extra measurement
+                result["train_step"] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(hp, sd, vs, h)
         else:

@@ -57,6 +57,17 @@ class MelspecCfg(ctypes.Structure):
                 ("n_mels", ctypes.c_int32), ("clip_val", ctypes.c_float)]
 
 
+class TrainerCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("mel_bins", "hidden", "channels", "layers", "dilation_cycle", "timesteps", "loss_l1", "pitch_vocab")]
+
+
+class TrainArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("T", ctypes.c_int32), ("mel", ctypes.c_void_p), ("cond", ctypes.c_void_p), ("t", ctypes.c_void_p),
+                ("pitch", ctypes.c_void_p), ("mel2ph", ctypes.c_void_p), ("seed", ctypes.c_uint64), ("first_clip", ctypes.c_int32),
+                ("clip_ids", ctypes.c_void_p)]
+
+
 # every symbol include/dsvc.h declares: (name, restype, argtypes)
 _VP = ctypes.c_void_p
 SYMBOLS = [
@@ -84,6 +95,17 @@ SYMBOLS = [
     ("dsvc_melspec_destroy", None, [_VP]),
     ("dsvc_melspec_frames", ctypes.c_int, [_VP, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]),
     ("dsvc_melspec_run", ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int64, _VP]),
+    ("dsvc_trainer_create", ctypes.c_int, [ctypes.POINTER(TrainerCfg), ctypes.POINTER(_VP)]),
+    ("dsvc_trainer_destroy", None, [_VP]),
+    ("dsvc_trainer_param_count", ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    ("dsvc_trainer_param_info", ctypes.c_int, [_VP, ctypes.c_int64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int64),
+                                               ctypes.POINTER(ctypes.c_int64)]),
+    ("dsvc_trainer_bind", ctypes.c_int, [_VP, _VP, _VP]),
+    ("dsvc_trainer_set_schedule", ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int32, _VP, _VP, ctypes.c_int32]),
+    ("dsvc_trainer_step", ctypes.c_int, [_VP, ctypes.POINTER(TrainArgs), _VP, _VP]),
+    ("dsvc_adamw_step", ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_float, ctypes.c_int64, _VP, ctypes.c_float, _VP]),
+    ("dsvc_grad_clip_coef", ctypes.c_int, [_VP, ctypes.c_int64, ctypes.c_float, _VP, _VP, _VP]),
 ]
 
 _lib = None

@@ -49,8 +49,8 @@ constexpr float RSQRT2 = 0.70710678118654752440f;
 // conv_gemm epilogues of the training graph.  "valid" = row < n_rows with t < clip_len (gap rows carry no data).
 // ------------------------------------------------------------------------------------------------
 struct RowInfo {
-    int clip_stride, clip_len;
-    __device__ __forceinline__ bool valid(int row) const { return (row - (row / clip_stride) * clip_stride) < clip_len; }
+    int clip_stride, clip_len, n_valid;
+    __device__ __forceinline__ bool valid(int row) const { return row < n_valid && (row - (row / clip_stride) * clip_stride) < clip_len; }
 };
 
 // out = act(acc + bias); relu optional; invalid rows -> 0 (keeps gap rows zero for the next conv)
@@ -68,10 +68,11 @@ struct EpStore {
 // gate forward (net.py:71-77): packed column pairs (tile 2q = gate half, 2q+1 = filter half of channels 32q..32q+31)
 struct EpGateFwd {
     static constexpr bool PAIRED = true;
-    struct Args { const float* ypre; float* sig; float* tau; float* g; int C; RowInfo ri; };
+    struct Args { const float* ypre; const float* bd; const float* bc; float* sig; float* tau; float* g; int C; RowInfo ri; };
     __device__ __forceinline__ void pair(const Args& e, int row, int ct0, int j, float vg, float vf) const {
         const float* yp = e.ypre + (size_t)row * (2 * e.C) + ct0 * 32 + j;
-        const float a = vg + yp[0], b = vf + yp[32];
+        const int c = (ct0 >> 1) * 32 + j;                  // g-channel: conv channels c (gate -> sigmoid) and C + c (filter -> tanh)
+        const float a = vg + yp[0] + e.bd[c] + e.bc[c], b = vf + yp[32] + e.bd[e.C + c] + e.bc[e.C + c];
         const float s = 1.0f / (1.0f + expf(-a)), t = tanhf(b);
         const size_t o = (size_t)row * e.C + (ct0 >> 1) * 32 + j;
         const bool ok = e.ri.valid(row);
@@ -175,14 +176,14 @@ __global__ void k_pack_w(const float* __restrict__ src, const int* __restrict__ 
 // transpose with optional additive per-clip vector (film) and validity mask:  dst[c][pad + n] = valid(n) ? src[n][c] + add[clip][c] : 0
 // dst is [C][ld] with ld >= rows + 2*pad; the pad columns are zeroed once at allocation.
 __global__ void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld, int pad,
-                            const float* __restrict__ add, int add_stride, int clip_stride, int clip_len) {
+                            const float* __restrict__ add, int add_stride, int clip_stride, int clip_len, int n_valid, int shift) {
     __shared__ float tile[32][33];
     const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
-        const int n = n0 + i, c = c0 + tx;
+        const int n = n0 + i + shift, c = c0 + tx;          // column n0+i of the output holds source row n0+i+shift (a conv tap)
         float v = 0.f;
-        if (n < rows && c < C) {
+        if (n >= 0 && n < n_valid && c < C) {
             const int clip = n / clip_stride;
             if (n - clip * clip_stride < clip_len) v = src[(size_t)n * C + c] + (add ? add[(size_t)clip * add_stride + c] : 0.f);
         }
@@ -444,7 +445,7 @@ struct dsvc_trainer {
     int n_spec = 0;
 
     // workspace for (B, T)
-    int wsB = 0, wsT = 0, Tp = 0, rows = 0, padc = 64;
+    int wsB = 0, wsT = 0, Tp = 0, rows = 0, nr = 0, padc = 64;      // nr = B*Tp data rows; rows = nr rounded up to 128
     DevBuf xt, xs, sig, tau, g, skip, ypre, s2pre, eps, deps, condT, condTT, tstep, clipid, iotaB;
     DevBuf e0, e1pre, e1, e2, filmB, dfilm, de2, de1, de1pre;
     DevBuf dx, dxin, dO, dy, ds2pre, dcond, dh0, TT, loss;
@@ -477,7 +478,7 @@ struct dsvc_trainer {
     // dW[o][k] = sum_n A[n][o] * Bsrc[n + shift][k]: A [rows x O] (ldA = O), Bsrc [rows x K]; writes dst[o*stride_o + k*stride_k + off]
     int wgrad(const float* A, int O, const float* BT, int K, int shift, float* dst, long long stride_o, long long stride_k, long long off,
               bool repack_a, hipStream_t st);
-    int transpose(const float* src, int C, const float* add, int add_stride, hipStream_t st);
+    int transpose(const float* src, int C, const float* add, int add_stride, int shift, hipStream_t st);
     int step(const dsvc_train_args* a, float* loss_out, hipStream_t st);
 };
 
@@ -546,7 +547,8 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     if (max_dil > padc) return fail(DSVC_EINVAL, "trainer: dilation %d too large", max_dil);
     Tp = round_up(T + max_dil, 32);
-    rows = round_up(B * Tp, 128);                   // the contraction length of the weight-gradient GEMMs: a multiple of the staged chunk
+    nr = B * Tp;
+    rows = round_up(nr, 128);                   // the contraction length of the weight-gradient GEMMs: a multiple of the staged chunk
     const size_t r = (size_t)rows;
     auto z = [&](DevBuf& b, size_t bytes) -> int { DSVC_TRY(b.alloc(bytes)); DSVC_HIP(hipMemsetAsync(b.p, 0, bytes, st)); return DSVC_OK; };
     DSVC_TRY(z(xt, r * M * 4)); DSVC_TRY(z(xs, r * C * 4 * (L + 1))); DSVC_TRY(z(sig, r * C * 4 * L)); DSVC_TRY(z(tau, r * C * 4 * L));
@@ -575,10 +577,10 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     return DSVC_OK;
 }
 
-int dsvc_trainer::transpose(const float* src, int C, const float* add, int add_stride, hipStream_t st) {
+int dsvc_trainer::transpose(const float* src, int C, const float* add, int add_stride, int shift, hipStream_t st) {
     const int ld = rows + 2 * padc;
     hipLaunchKernelGGL(k_transpose, dim3(ceil_div(rows, 32), ceil_div(C, 32)), dim3(256), 0, st, src, TT.as<float>(), rows, C, ld, padc,
-                       add, add_stride, Tp, wsT);
+                       add, add_stride, Tp, wsT, nr, shift);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
@@ -595,7 +597,8 @@ int dsvc_trainer::wgrad(const float* A, int O, const float* BT, int K, int shift
     }
     ConvGemmArgs a{};
     const int ld = rows + 2 * padc;
-    a.x = BT + padc + shift; a.ldx = ld; a.n_rows = K; a.clip_stride = K < 32 ? 32 : K; a.clip_len = a.clip_stride;
+    (void)shift;                                          // taps are materialised by transpose(..., shift): every staged row stays 16-byte aligned
+    a.x = BT + padc; a.ldx = ld; a.n_rows = K; a.clip_stride = K < 32 ? 32 : K; a.clip_len = a.clip_stride;
     a.cin = rows; a.taps = 1; a.dil = 1; a.w = packA.as<_Float16>(); a.n_ctiles = n_ct; a.w_planes = 2; a.in_slope = 1.0f;
     EpWgrad::Args e{dst, stride_o, stride_k, off, O};
     return launch<EpWgrad>(a, e, st);
@@ -605,7 +608,7 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers, B = ta->B, T = ta->T;
     DSVC_TRY(ensure_ws(B, T, st));
     DSVC_TRY(repack(st));
-    const RowInfo ri{Tp, T};
+    const RowInfo ri{Tp, T, nr};
     const size_t r = (size_t)rows, slab = r * C;
     DSVC_HIP(hipMemsetAsync(grads, 0, (size_t)total * 4, st));
     DSVC_HIP(hipMemsetAsync(loss.p, 0, 16, st));
@@ -618,7 +621,7 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     hipLaunchKernelGGL(k_bct_to_rows, dim3(ceil_div(T, 32), ceil_div(H, 32), B), dim3(256), 0, st, ta->cond, condT.as<float>(), B, H, T, Tp);
     auto base = [&](const float* x, int ldx, int cin, const Packed& pk, int dil) {
         ConvGemmArgs a{};
-        a.x = x; a.ldx = ldx; a.n_rows = rows; a.clip_stride = Tp; a.clip_len = T;
+        a.x = x; a.ldx = ldx; a.n_rows = nr; a.clip_stride = Tp; a.clip_len = T;
         a.cin = cin; a.taps = pk.taps; a.dil = dil; a.w = pk.w.as<_Float16>(); a.n_ctiles = pk.n_ctiles; a.w_planes = 2; a.in_slope = 1.0f;
         return a;
     };
@@ -628,7 +631,7 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         hipLaunchKernelGGL(k_gemm_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, Bm, Cm, Mm, N, K, lda, ldb, ldc, tA, tB, acc, bias);
     };
     auto colsum = [&](const float* src, float* dst, int Cc, int ld) {
-        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(Cc, 64), ceil_div(rows, 512)), dim3(256), 0, st, src, dst, rows, Cc, ld, 512);
+        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(Cc, 64), ceil_div(nr, 512)), dim3(256), 0, st, src, dst, nr, Cc, ld, 512);
     };
     const int ew = 2048;
     // ---- step embedding: emb -> Linear -> Mish -> Linear -> per-layer diffusion_projection  (net.py:99-103,124-125,67) ----
@@ -650,18 +653,16 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
         const int d = 1 << (l % cfg.dilation_cycle);
         float* xl = xs.as<float>() + (size_t)l * slab;
-        {   // ypre = W_c cond + b_c + b_d in the gate's packed column order: two bias vectors -> fold b_d through a second pass below
+        {   // ypre = W_c cond in the gate's packed column order (both biases are added, in natural order, by the gate epilogue)
             ConvGemmArgs a = base(condT.as<float>(), H, H, w_c[l], 1);
-            EpStore::Args e{ypre.as<float>(), 2 * C, nullptr, 2 * C, 0, RowInfo{Tp, Tp}};
+            EpStore::Args e{ypre.as<float>(), 2 * C, nullptr, 2 * C, 0, RowInfo{Tp, Tp, nr}};
             DSVC_TRY(launch<EpStore>(a, e, st));
         }
         {   // gate: y = conv_dil(x + film) + ypre + biases
             ConvGemmArgs a = base(xl, C, C, w_d[l], d);
             a.film = filmB.as<float>() + (size_t)l * C; a.film_step_stride = L * C; a.step_ptr = iotaB.as<int>(); a.step_off = 0; a.step_per_clip = 1;
-            // biases of both convs enter through ypre: add them there first (natural order -> packed order handled by k_add_bias_packed)
-            EpGateFwd::Args e{ypre.as<float>(), sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab,
-                              g.as<float>() + (size_t)l * slab, C, ri};
-            (void)q;
+            EpGateFwd::Args e{ypre.as<float>(), P(q + "dilated_conv.bias"), P(q + "conditioner_projection.bias"), sig.as<float>() + (size_t)l * slab,
+                              tau.as<float>() + (size_t)l * slab, g.as<float>() + (size_t)l * slab, C, ri};
             DSVC_TRY(launch<EpGateFwd>(a, e, st));
         }
         {   // [r; s] = W_o g + b   (net.py:79-84)
@@ -687,7 +688,7 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     colsum(deps.as<float>(), G("denoise_fn.output_projection.bias"), M, M);
     {   // dW_out[m][c] = sum_n deps[n][m] relu(s2pre)[n][c]
         hipLaunchKernelGGL(k_relu_bwd, dim3(ew), dim3(256), 0, st, s2pre.as<float>(), s2pre.as<float>(), dh0.as<float>(), r * C);   // dh0 = relu(s2pre) (scratch)
-        DSVC_TRY(transpose(dh0.as<float>(), C, nullptr, 0, st));
+        DSVC_TRY(transpose(dh0.as<float>(), C, nullptr, 0, 0, st));
         DSVC_TRY(wgrad(deps.as<float>(), M, TT.as<float>(), C, 0, G("denoise_fn.output_projection.weight"), C, 1, 0, true, st));
         // d s2pre = (W_out^T deps) * [s2pre > 0]
         ConvGemmArgs a = base(deps.as<float>(), M, M, w_finT, 1);
@@ -695,7 +696,7 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         DSVC_TRY(launch<EpBwd>(a, e, st));
         colsum(ds2pre.as<float>(), G("denoise_fn.skip_projection.bias"), C, C);
         // dW_s[o][c] = sum_n ds2pre[n][o] skip[n][c] / sqrt(L)
-        DSVC_TRY(transpose(skip.as<float>(), C, nullptr, 0, st));
+        DSVC_TRY(transpose(skip.as<float>(), C, nullptr, 0, 0, st));
         DSVC_TRY(wgrad(ds2pre.as<float>(), C, TT.as<float>(), C, 0, G("denoise_fn.skip_projection.weight"), C, 1, 0, true, st));
         const long long nws = (long long)C * C;
         hipLaunchKernelGGL(k_copy_cols, dim3(ceil_div((int)nws, 256)), dim3(256), 0, st, G("denoise_fn.skip_projection.weight"),
@@ -705,14 +706,13 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         EpBwd::Args e2{dO.as<float>() + C, 2 * C, C, nullptr, 0, 1.0f, 0, ri};
         DSVC_TRY(launch<EpBwd>(a2, e2, st));
     }
-    DSVC_HIP(hipMemsetAsync(dx.p, 0, r * C * 4, st));
-    DSVC_HIP(hipMemsetAsync(dO.p, 0, 0, st));
-    hipLaunchKernelGGL(k_copy_cols, dim3(ew), dim3(256), 0, st, dx.as<float>(), dO.as<float>(), rows, C, 2 * C, 0, 0.0f);   // residual half of dO: d x^L = 0
+    DSVC_HIP(hipMemsetAsync(dx.p, 0, r * C * 4, st));                                                                 // d x^L = 0: the loss sees x only through skip
+    hipLaunchKernelGGL(k_copy_cols, dim3(ew), dim3(256), 0, st, dx.as<float>(), dO.as<float>(), nr, C, 2 * C, 0, 0.0f);   // ... so the residual half of dO starts at 0
     // cond^T once (weight gradients of every conditioner projection)
     {
         const int ld = rows + 2 * padc;
         hipLaunchKernelGGL(k_transpose, dim3(ceil_div(rows, 32), ceil_div(H, 32)), dim3(256), 0, st, condT.as<float>(), condTT.as<float>(), rows, H, ld,
-                           padc, (const float*)nullptr, 0, Tp, T);
+                           padc, (const float*)nullptr, 0, Tp, T, nr, 0);
     }
     // ---- backward: layers ----
     for (int l = L - 1; l >= 0; --l) {
@@ -721,7 +721,7 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         const float* xl = xs.as<float>() + (size_t)l * slab;
         const float* gl = g.as<float>() + (size_t)l * slab;
         colsum(dO.as<float>(), G(q + "output_projection.bias"), 2 * C, 2 * C);
-        DSVC_TRY(transpose(gl, C, nullptr, 0, st));
+        DSVC_TRY(transpose(gl, C, nullptr, 0, 0, st));
         DSVC_TRY(wgrad(dO.as<float>(), 2 * C, TT.as<float>(), C, 0, G(q + "output_projection.weight"), C, 1, 0, true, st));
         {   // dg = W_o^T dO -> dy
             ConvGemmArgs a = base(dO.as<float>(), 2 * C, 2 * C, w_oT[l], 1);
@@ -733,9 +733,10 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         // dW_c[o][h] = sum_n dy[n][o] cond[n][h]   (packs dy^T once; the three taps below reuse the fragments)
         DSVC_TRY(wgrad(dy.as<float>(), 2 * C, condTT.as<float>(), H, 0, G(q + "conditioner_projection.weight"), H, 1, 0, true, st));
         // dW_d[o][c][tap] = sum_n dy[n][o] (x^l + film)[n + (tap-1) d][c]
-        DSVC_TRY(transpose(xl, C, filmB.as<float>() + (size_t)l * C, L * C, st));
-        for (int tap = 0; tap < 3; ++tap)
-            DSVC_TRY(wgrad(dy.as<float>(), 2 * C, TT.as<float>(), C, (tap - 1) * d, G(q + "dilated_conv.weight"), (long long)C * 3, 3, tap, false, st));
+        for (int tap = 0; tap < 3; ++tap) {
+            DSVC_TRY(transpose(xl, C, filmB.as<float>() + (size_t)l * C, L * C, (tap - 1) * d, st));
+            DSVC_TRY(wgrad(dy.as<float>(), 2 * C, TT.as<float>(), C, 0, G(q + "dilated_conv.weight"), (long long)C * 3, 3, tap, false, st));
+        }
         {   // dcond += W_c^T dy
             ConvGemmArgs a = base(dy.as<float>(), 2 * C, 2 * C, w_cT[l], 1);
             EpBwd::Args e{dcond.as<float>(), H, H, nullptr, 0, 1.0f, l == L - 1 ? 0 : 1, ri};
@@ -747,12 +748,12 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
             DSVC_TRY(launch<EpBwd>(a, e, st));
         }
         hipLaunchKernelGGL(k_clip_colsum, dim3(ceil_div(C, 64), B), dim3(256), 0, st, dxin.as<float>(), dfilm.as<float>() + (size_t)l * C, T, C, Tp, L * C);
-        hipLaunchKernelGGL(k_dx_update, dim3(ew), dim3(256), 0, st, dx.as<float>(), dxin.as<float>(), dO.as<float>(), rows, C);
+        hipLaunchKernelGGL(k_dx_update, dim3(ew), dim3(256), 0, st, dx.as<float>(), dxin.as<float>(), dO.as<float>(), nr, C);
     }
     {   // input projection: d h0pre = dx^0 [x^0 > 0]
         hipLaunchKernelGGL(k_relu_bwd, dim3(ew), dim3(256), 0, st, dx.as<float>(), xs.as<float>(), dh0.as<float>(), r * C);
         colsum(dh0.as<float>(), G("denoise_fn.input_projection.bias"), C, C);
-        DSVC_TRY(transpose(xt.as<float>(), M, nullptr, 0, st));
+        DSVC_TRY(transpose(xt.as<float>(), M, nullptr, 0, 0, st));
         DSVC_TRY(wgrad(dh0.as<float>(), C, TT.as<float>(), M, 0, G("denoise_fn.input_projection.weight"), M, 1, 0, true, st));
     }
     // ---- backward: step embedding ----
@@ -761,14 +762,8 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
         const float* df = dfilm.as<float>() + (size_t)l * C;
         small(df, e2.as<float>(), G(q + "weight"), C, C, B, L * C, C, C, 1, 0, 0, nullptr);            // dWp[o][i] = sum_b dfilm[b][o] e2[b][i]
-        small(df, df, G(q + "bias"), 1, C, B, 0, L * C, C, 0, 0, 0, nullptr);                          // placeholder, replaced below
         small(df, P(q + "weight"), de2.as<float>(), B, C, C, L * C, C, C, 0, 0, 1, nullptr);           // de2[b][i] += sum_o dfilm[b][o] Wp[o][i]
-    }
-    // bias gradients of the diffusion projections: column sums of dfilm over the batch
-    for (int l = 0; l < L; ++l) {
-        const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.bias";
-        DSVC_HIP(hipMemsetAsync(G(q), 0, (size_t)C * 4, st));
-        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, dfilm.as<float>() + (size_t)l * C, G(q), B, C, L * C, B);
+        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);   // dbp = sum_b dfilm[b]
     }
     small(de2.as<float>(), e1.as<float>(), G("denoise_fn.mlp.2.weight"), C, 4 * C, B, C, 4 * C, 4 * C, 1, 0, 0, nullptr);
     hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, de2.as<float>(), G("denoise_fn.mlp.2.bias"), B, C, C, B);

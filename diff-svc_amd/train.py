@@ -1,0 +1,156 @@
+"""``DiffusionTrainerHip`` -- the training step of the reference (BASELINE configs[4]) on the HIP kernels:
+``GaussianDiffusion.forward(infer=False)`` -> ``p_losses`` (network/diff/diffusion.py:200-225,237-241) with the gradients of
+every ``denoise_fn.*`` parameter and of ``fs2.pitch_embed.weight``, gradient-norm clipping (utils/pl_utils.py:1081-1084),
+AdamW and the StepLR schedule (training/task/SVC_task.py:60-66,116-125), and data-parallel training as the reference does it
+(utils/pl_utils.py:179-221: one process per GPU, gradients averaged over ranks) -- here one all-reduce of the flat gradient
+buffer per step through ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI; ``gloo`` in the CPU tests).
+
+Parameters and gradients are two flat fp32 device tensors owned by this object; the C ABI (include/dsvc.h, dsvc_trainer_*)
+reads / writes them in place, ``state_dict()`` exposes the reference's key names and shapes, so a checkpoint written from it
+loads into the reference (and into the inference drop-ins) unchanged.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+from .cond import CondBuilder
+
+
+class TrainerHandle:
+    def __init__(self, hp, loss_type="l2", pitch_vocab=300):
+        self._h = ctypes.c_void_p(0)
+        self.cfg = _lib.TrainerCfg(hp["audio_num_mel_bins"], hp["hidden_size"], hp["residual_channels"], hp["residual_layers"],
+                                   hp["dilation_cycle_length"], int(hp.get("timesteps", 1000)), 1 if loss_type == "l1" else 0, pitch_vocab)
+        check(lib().dsvc_trainer_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
+        nt, nf = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib().dsvc_trainer_param_count(self._h, ctypes.byref(nt), ctypes.byref(nf)))
+        self.n_floats = nf.value
+        self.layout = []                                   # (name, offset, numel) in flat order
+        for i in range(nt.value):
+            name, off, n = ctypes.c_char_p(), ctypes.c_int64(0), ctypes.c_int64(0)
+            check(lib().dsvc_trainer_param_info(self._h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(n)))
+            self.layout.append((name.value.decode(), off.value, n.value))
+
+    def bind(self, params, grads):
+        assert params.is_cuda and grads.is_cuda and params.numel() == self.n_floats == grads.numel()
+        self._keep = (params, grads)
+        check(lib().dsvc_trainer_bind(self._h, ptr(params), ptr(grads)))
+
+    def set_schedule(self, sqrt_ac, sqrt_1mac, spec_min, spec_max):
+        a, b = sqrt_ac.detach().cpu().float().contiguous(), sqrt_1mac.detach().cpu().float().contiguous()
+        lo, hi = spec_min.detach().cpu().float().reshape(-1).contiguous(), spec_max.detach().cpu().float().reshape(-1).contiguous()
+        check(lib().dsvc_trainer_set_schedule(self._h, ptr(a), ptr(b), a.numel(), ptr(lo), ptr(hi), lo.numel()))
+
+    def step(self, mel, cond, t, pitch=None, mel2ph=None, seed=0, first_clip=0, clip_ids=None, loss_out=None):
+        B, T, M = mel.shape
+        i32 = lambda x: x.to(torch.int32).contiguous() if x is not None else None
+        mel, cond = mel.contiguous().float(), cond.contiguous().float()
+        t, pitch, mel2ph, clip_ids = i32(t), i32(pitch), i32(mel2ph), i32(clip_ids)
+        for x in (mel, cond, t, pitch, mel2ph, clip_ids):
+            if x is not None and not x.is_cuda:
+                raise RuntimeError("diffsvc_amd: training tensors must live on the HIP device; there is no CPU path")
+        if tuple(cond.shape) != (B, self.cfg.hidden, T) or t.numel() != B:
+            raise ValueError("shape mismatch: mel %s cond %s t %s" % (tuple(mel.shape), tuple(cond.shape), tuple(t.shape)))
+        a = _lib.TrainArgs(B, T, mel.data_ptr(), cond.data_ptr(), t.data_ptr(), pitch.data_ptr() if pitch is not None else None,
+                           mel2ph.data_ptr() if mel2ph is not None else None, seed, first_clip,
+                           clip_ids.data_ptr() if clip_ids is not None else None)
+        loss = loss_out if loss_out is not None else torch.empty(1, device=mel.device, dtype=torch.float32)
+        check(lib().dsvc_trainer_step(self._h, ctypes.byref(a), ptr(loss), stream_ptr()))
+        return loss
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().dsvc_trainer_destroy(self._h)
+                self._h = ctypes.c_void_p(0)
+        except Exception:
+            pass
+
+
+def allreduce_mean_(flat, group=None):
+    """The one collective of data-parallel training: average the flat gradient buffer over the ranks in place (what the
+    reference's DDP reducer does bucket by bucket, utils/pl_utils.py:187-221).  One fp32 all-reduce of 32 M floats = 128 MB."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / world)
+    return flat
+
+
+class DiffusionTrainerHip:
+    """state: a GaussianDiffusion state dict (no ``model.`` prefix).  hp keys read beyond the architecture: ``diff_loss_type``,
+    ``lr``, ``optimizer_adam_beta1/2``, ``weight_decay``, ``clip_grad_norm``, ``decay_steps`` (training/config_nsf.yaml)."""
+
+    def __init__(self, hp, state, device="cuda", group=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DiffusionTrainerHip needs a HIP device (there is no CPU path)")
+        self.hp, self.group, self.device = hp, group, device
+        self.h = TrainerHandle(hp, hp.get("diff_loss_type", "l2"), state["fs2.pitch_embed.weight"].shape[0])
+        n = self.h.n_floats
+        self.params = torch.zeros(n, device=device, dtype=torch.float32)
+        self.grads = torch.zeros(n, device=device, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=device, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=device, dtype=torch.float32)
+        self._aux = torch.zeros(4, device=device, dtype=torch.float32)          # [0] ||g||^2, [1] clip coefficient
+        self.shapes = {}
+        for name, off, numel in self.h.layout:
+            v = state[name]
+            assert v.numel() == numel, (name, tuple(v.shape), numel)
+            self.params[off:off + numel].copy_(v.reshape(-1).float())
+            self.shapes[name] = tuple(v.shape)
+        self.other = {k: v.clone() for k, v in state.items() if k not in self.shapes}     # buffers + the fs2.* tensors no gradient reaches
+        self.h.bind(self.params, self.grads)
+        self.h.set_schedule(state["sqrt_alphas_cumprod"], state["sqrt_one_minus_alphas_cumprod"], state["spec_min"], state["spec_max"])
+        self.fs2 = CondBuilder(hp).to(device)
+        off, numel = next((o, m) for nme, o, m in self.h.layout if nme == "fs2.pitch_embed.weight")
+        self.fs2.pitch_embed.weight.data = self.params[off:off + numel].view(self.shapes["fs2.pitch_embed.weight"])   # shares the flat storage
+        self.global_step = 0
+        self.lr0 = float(hp.get("lr", 0.0004))
+
+    def view(self, flat, name):
+        off, numel = next((o, m) for nme, o, m in self.h.layout if nme == name)
+        return flat[off:off + numel].view(self.shapes[name])
+
+    def state_dict(self):
+        sd = {k: v.clone() for k, v in self.other.items()}
+        for name, off, numel in self.h.layout:
+            sd[name] = self.params[off:off + numel].view(self.shapes[name]).detach().clone().cpu()
+        return sd
+
+    def lr(self):
+        return self.lr0 * 0.5 ** (self.global_step // int(self.hp.get("decay_steps", 40000)))          # StepLR(decay_steps, gamma=0.5)
+
+    @torch.no_grad()
+    def forward_backward(self, hubert, mel2ph, f0, mels, t, seed=0, first_clip=0, clip_ids=None):
+        """loss (device scalar) of one batch; the gradients land in ``self.grads`` (this rank's, before any all-reduce)."""
+        ret = self.fs2(hubert, mel2ph, None, None, f0.clone(), None, None, infer=False)
+        cond = ret["decoder_inp"].transpose(1, 2).contiguous()
+        return self.h.step(mels, cond, t, pitch=ret["pitch_pred"].squeeze(-1), mel2ph=mel2ph, seed=seed, first_clip=first_clip, clip_ids=clip_ids)
+
+    @torch.no_grad()
+    def train_step(self, hubert, mel2ph, f0, mels, t=None, seed=None, first_clip=0, clip_ids=None):
+        """One optimisation step: forward + backward, all-reduce (mean) of the gradients over the ranks, gradient-norm clip, AdamW."""
+        B = mels.shape[0]
+        if t is None:
+            t = torch.randint(0, int(self.hp.get("K_step", self.hp["timesteps"])), (B,), device=mels.device)       # train_pipeline.py:233
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        loss = self.forward_backward(hubert, mel2ph, f0, mels, t, seed=seed, first_clip=first_clip, clip_ids=clip_ids)
+        allreduce_mean_(self.grads, self.group)
+        self.global_step += 1
+        hp, n = self.hp, self.h.n_floats
+        clip = float(hp.get("clip_grad_norm", 1.0))
+        coef = None
+        if clip > 0:
+            check(lib().dsvc_grad_clip_coef(ptr(self.grads), n, clip, ptr(self._aux[0:1]), ptr(self._aux[1:2]), stream_ptr()))
+            coef = self._aux[1:2]
+        check(lib().dsvc_adamw_step(ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), n, self.lr(),
+                                    float(hp.get("optimizer_adam_beta1", 0.9)), float(hp.get("optimizer_adam_beta2", 0.98)), 1e-8,
+                                    float(hp.get("weight_decay", 0.0)), self.global_step, ptr(coef), 1.0, stream_ptr()))
+        return loss

@@ -178,6 +178,53 @@ void dsvc_melspec_destroy(dsvc_melspec* m);
 int dsvc_melspec_frames(const dsvc_melspec* m, int64_t n_samples, int32_t* frames);
 int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, int64_t n_samples, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training step -- replaces GaussianDiffusion.forward(infer=False) -> p_losses (network/diff/diffusion.py:200-225,237-241;
+ * training/train_pipeline.py:222-238) with autograd through DiffNet (network/diff/net.py:112-135), and the optimizer step of
+ * training/task/SVC_task.py:60-66,116-125 (AdamW) with utils/pl_utils.py:1081-1084 (clip_grad_norm_).
+ * Parameters and gradients live in two caller-owned flat fp32 device buffers (a torch tensor each: DDP all-reduces the gradient
+ * buffer with RCCL between dsvc_trainer_step and dsvc_adamw_step); dsvc_trainer_param_info gives each state-dict tensor's slice.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsvc_trainer dsvc_trainer;
+
+typedef struct {
+    int32_t mel_bins, hidden, channels, layers, dilation_cycle;   /* as dsvc_denoiser_cfg */
+    int32_t timesteps;        /* schedule length K (t ~ U{0..K-1}, train_pipeline.py:233) */
+    int32_t loss_l1;          /* hparams['diff_loss_type']: 1 = 'l1', 0 = 'l2' (diffusion.py:213-223) */
+    int32_t pitch_vocab;      /* rows of fs2.pitch_embed.weight (300, fs2.py:73) */
+} dsvc_trainer_cfg;
+
+typedef struct {
+    int32_t B, T;             /* clips, mel frames per clip */
+    const float* mel;         /* [B,T,M] device: target log-mel (ref_mels); normalised inside (norm_spec, diffusion.py:286-287) */
+    const float* cond;        /* [B,H,T] device: decoder_inp^T of this batch (fs2.py:94-154) */
+    const int32_t* t;         /* [B] device: the diffusion step of every clip (the reference draws torch.randint) */
+    const int32_t* pitch;     /* [B,T] device or NULL: coarse pitch bins -> gradient of fs2.pitch_embed.weight through cond */
+    const int32_t* mel2ph;    /* [B,T] device or NULL: frames with mel2ph == 0 carry no pitch-embedding gradient */
+    uint64_t seed;            /* Philox key of the noise eps ~ N(0,1) (stream 5: (element/4, 0, clip id)) */
+    int32_t first_clip;       /* Philox clip id of batch element 0 ... */
+    const int32_t* clip_ids;  /* ... or explicit ids [B] device */
+} dsvc_train_args;
+
+int dsvc_trainer_create(const dsvc_trainer_cfg* cfg, dsvc_trainer** out);
+void dsvc_trainer_destroy(dsvc_trainer* t);
+/* the flat layout: number of tensors / of floats; tensor i's state-dict name ("denoise_fn.*" in DiffNet.state_dict() order, then
+ * "fs2.pitch_embed.weight"), offset and size in floats.  Tensors keep the checkpoint's own layouts (Conv1d [out,in,k], Linear [out,in]). */
+int dsvc_trainer_param_count(const dsvc_trainer* t, int64_t* n_tensors, int64_t* n_floats);
+int dsvc_trainer_param_info(const dsvc_trainer* t, int64_t i, const char** name, int64_t* offset, int64_t* numel);
+int dsvc_trainer_bind(dsvc_trainer* t, float* params, float* grads);          /* device, n_floats each; retained until destroy */
+/* registered buffers of GaussianDiffusion the loss needs (diffusion.py:107-108,122-123), host pointers */
+int dsvc_trainer_set_schedule(dsvc_trainer* t, const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod, int32_t K,
+                              const float* spec_min, const float* spec_max, int32_t n_spec);
+/* forward + backward of one batch: grads <- d loss / d params (overwritten), *loss_out (device float, may be NULL) <- the loss */
+int dsvc_trainer_step(dsvc_trainer* t, const dsvc_train_args* a, float* loss_out, void* stream);
+/* torch.optim.AdamW update of a flat buffer.  The gradient is multiplied by *grad_scale_dev (device, e.g. the clip coefficient)
+ * when that pointer is not NULL, else by grad_scale. */
+int dsvc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int64_t step, const float* grad_scale_dev, float grad_scale, void* stream);
+/* clip_grad_norm_: *sqnorm_dev <- ||g||^2, *coef_dev <- min(1, max_norm / (||g|| + 1e-6)) */
+int dsvc_grad_clip_coef(const float* grads, int64_t n, float max_norm, float* sqnorm_dev, float* coef_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -300,6 +300,33 @@ def q_sample(sd, x0, t, noise):
     return _at(sd["sqrt_alphas_cumprod"], t) * x0 + _at(sd["sqrt_one_minus_alphas_cumprod"], t) * noise
 
 
+PURPOSE_TRAIN_NOISE = 5
+
+
+def p_losses(sd, x_start, t, cond, noise, dilation_cycle, loss_type="l2"):
+    """diffusion.py:207-225 (the nonpadding-weighted l1 variant is commented out in the reference's call site,
+    train_pipeline.py:236-238).  x_start [B,1,M,T] normalised, t [B] long, cond [B,H,T], noise like x_start."""
+    x_noisy = q_sample(sd, x_start, t, noise)
+    x_recon = diffnet_forward(sd, x_noisy, t, cond, dilation_cycle)
+    if loss_type == "l1":
+        return (noise - x_recon).abs().mean()
+    return F.mse_loss(noise, x_recon)
+
+
+def train_loss_and_grads(sd, hubert, mel2ph, f0, mels, t, noise, hp):
+    """GaussianDiffusion.forward(infer=False) (diffusion.py:227-241 -> train_pipeline.py:222-238) with torch autograd: the loss and
+    the gradient of every ``denoise_fn.*`` parameter and of ``fs2.pitch_embed.weight``.  mels [B,T,M] (log-mel targets)."""
+    names = [k for k in sd if k.startswith("denoise_fn.")] + ["fs2.pitch_embed.weight"]
+    p = dict(sd)
+    for k in names:
+        p[k] = sd[k].detach().clone().requires_grad_(True)
+    cond, _, _ = build_cond(p, hubert, mel2ph, f0.clone(), hp)
+    x0 = norm_spec(sd, mels).transpose(1, 2)[:, None, :, :]
+    loss = p_losses(p, x0, t, cond.transpose(1, 2), noise, hp["dilation_cycle_length"], hp.get("diff_loss_type", "l2"))
+    grads = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
+    return loss.detach(), {k: (g if g is not None else torch.zeros_like(sd[k])) for k, g in zip(names, grads)}
+
+
 def norm_spec(sd, mel):
     """diffusion.py:286-287.  mel [B,T,M]."""
     return (mel - sd["spec_min"]) / (sd["spec_max"] - sd["spec_min"]) * 2 - 1

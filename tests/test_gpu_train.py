@@ -1,0 +1,94 @@
+"""GPU parity of the training step (BASELINE configs[4]): loss, every parameter gradient, the gradient-norm
+clip and the AdamW update of the HIP path (dsvc_trainer_*) against torch autograd / torch.optim on the oracle's restatement of
+GaussianDiffusion.forward(infer=False) -> p_losses (diffusion.py:200-225), same inputs, same Philox noise."""
+import numpy as np
+import pytest
+import torch
+
+from diffsvc_amd import synth
+import dsvc_oracle as O
+from util import clip_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(hp, clips, T, n_units, seed):
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    g = np.random.Generator(np.random.PCG64(seed))
+    M = hp["audio_num_mel_bins"]
+    mels = torch.from_numpy((g.standard_normal((len(clips), T, M)) * 0.7 - 2.5).astype(np.float32))
+    t = torch.from_numpy(g.integers(0, hp["timesteps"], size=(len(clips),)))
+    return hub, m2p, f0, mels, t
+
+
+@pytest.mark.parametrize("arch,loss_type", [("tiny", "l2"), ("tiny", "l1"), ("44k", "l2")])
+def test_train_step_loss_and_gradients_vs_autograd(arch, loss_type):
+    """Forward + backward: the loss and EVERY gradient tensor (43 for the tiny architecture, 171 for the 44.1 kHz one, plus the
+    pitch embedding reached through cond).  All contractions run at split-fp16 (fp32-class) precision: per-tensor relative L2
+    error <= 1e-3 of autograd's, worst printed."""
+    from diffsvc_amd.train import DiffusionTrainerHip
+    hp = dict(synth.tiny_hparams(K=50) if arch == "tiny" else synth.HPARAMS_44K, diff_loss_type=loss_type)
+    sd = synth.acoustic_state(hp, 3)
+    clips, T, n_units, seed = ([0, 1, 2], 40, 23, 5) if arch == "tiny" else ([4, 9], 64, 37, 6)
+    hub, m2p, f0, mels, t = _batch(hp, clips, T, n_units, seed)
+    m2p[0, T - 5:] = 0                                        # a clip with padded frames: no pitch-embedding gradient there
+    noise = O.ddpm_noise_ref_layout(seed, clips, 0, T, hp["audio_num_mel_bins"], O.PURPOSE_TRAIN_NOISE)
+    ref_loss, ref = O.train_loss_and_grads(sd, hub, m2p, f0, mels, t, noise, hp)
+    tr = DiffusionTrainerHip(hp, sd)
+    ids = torch.tensor(clips, dtype=torch.int32, device="cuda")
+    loss = tr.forward_backward(hub.cuda(), m2p.cuda(), f0.cuda(), mels.cuda(), t.cuda(), seed=seed, clip_ids=ids)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * max(1.0, abs(ref_loss.item())), (loss.item(), ref_loss.item())
+    worst, worst_name = 0.0, None
+    for name, off, numel in tr.h.layout:
+        got = tr.view(tr.grads, name).cpu()
+        r = ref[name]
+        assert got.shape == r.shape, name
+        den = r.norm().item()
+        err = (got - r).norm().item() / (den if den > 0 else 1.0)
+        if den == 0:
+            assert got.abs().max().item() == 0.0, name
+        if err > worst:
+            worst, worst_name = err, name
+    print("train step %s %s: loss %.6f (ref %.6f), worst gradient rel-L2 err %.2e (%s)" % (arch, loss_type, loss.item(), ref_loss.item(), worst, worst_name))
+    assert worst < 1e-3, (worst, worst_name)
+
+
+def test_optimizer_step_matches_torch_adamw_with_grad_clip():
+    """clip_grad_norm_(1) + torch.optim.AdamW + StepLR of the reference task (SVC_task.py:60-66,116-125; pl_utils.py:1081-1084) over
+    three steps on the tiny architecture: parameters within 1e-5 of torch's own optimizer driven by autograd gradients."""
+    from diffsvc_amd.train import DiffusionTrainerHip
+    hp = dict(synth.tiny_hparams(K=50), diff_loss_type="l2", lr=2e-3, optimizer_adam_beta1=0.9, optimizer_adam_beta2=0.98, weight_decay=0.01,
+              clip_grad_norm=1.0, decay_steps=2)
+    sd = synth.acoustic_state(hp, 3)
+    tr = DiffusionTrainerHip(hp, sd)
+    names = [n for n, _, _ in tr.h.layout]
+    ref_p = {k: sd[k].clone().requires_grad_(True) for k in names}
+    opt = torch.optim.AdamW([ref_p[k] for k in names], lr=hp["lr"], betas=(0.9, 0.98), weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.StepLR(opt, hp["decay_steps"], gamma=0.5)
+    clips, T, n_units = [0, 1, 2], 40, 23
+    for it in range(3):
+        hub, m2p, f0, mels, t = _batch(hp, clips, T, n_units, 20 + it)
+        noise = O.ddpm_noise_ref_layout(30 + it, clips, 0, T, hp["audio_num_mel_bins"], O.PURPOSE_TRAIN_NOISE)
+        cur = dict(sd, **{k: v.detach() for k, v in ref_p.items()})
+        _, gr = O.train_loss_and_grads(cur, hub, m2p, f0, mels, t, noise, hp)
+        for k in names:
+            ref_p[k].grad = gr[k].clone()
+        torch.nn.utils.clip_grad_norm_([ref_p[k] for k in names], 1.0)
+        opt.step(); opt.zero_grad(); sched.step()
+        tr.train_step(hub.cuda(), m2p.cuda(), f0.cuda(), mels.cuda(), t=t.cuda(), seed=30 + it, first_clip=0)
+    got = tr.state_dict()
+    worst = max((got[k] - ref_p[k].detach()).abs().max().item() for k in names)
+    print("optimizer: worst |param diff| after 3 steps %.2e" % worst)
+    assert worst < 1e-5, worst
+    assert set(got) == set(sd) and all(tuple(got[k].shape) == tuple(sd[k].shape) for k in sd)      # a loadable checkpoint comes back
+
+
+def test_train_step_rejects_bad_arguments():
+    from diffsvc_amd.train import DiffusionTrainerHip
+    hp = synth.tiny_hparams(K=50)
+    tr = DiffusionTrainerHip(hp, synth.acoustic_state(hp, 3))
+    hub, m2p, f0, mels, t = _batch(hp, [0], 40, 23, 1)
+    with pytest.raises(RuntimeError):
+        tr.h.step(mels, torch.zeros(1, 32, 40), t)                                   # host tensors
+    with pytest.raises(ValueError):
+        tr.h.step(mels.cuda(), torch.zeros(1, 31, 40, device="cuda"), t.cuda())     # wrong hidden size

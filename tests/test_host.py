@@ -220,3 +220,34 @@ def test_drop_in_constructor_buffers_match_the_reference_constructor(tag, extra)
     assert len(keys) == 12
     for k in keys:
         assert np.array_equal(getattr(model, k).numpy(), g[tag + "_" + k]), k
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from diffsvc_amd.train import allreduce_mean_
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)            # this rank's "gradients"
+    allreduce_mean_(flat)
+    dist.barrier()
+    if rank == 0:
+        q.put(flat.numpy())
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_mean_world2_gloo():
+    """Data-parallel training's one collective (BASELINE configs[4]): the flat gradient buffer averaged over the ranks in place
+    (what the reference's DDP reducer does, utils/pl_utils.py:187-221).  gloo on CPU stands in for RCCL."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(got, np.arange(1000, dtype=np.float32) * 1.5)
