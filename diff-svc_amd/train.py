@@ -143,6 +143,7 @@ class DiffusionTrainerHip:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         loss = self.forward_backward(hubert, mel2ph, f0, mels, t, seed=seed, first_clip=first_clip, clip_ids=clip_ids)
         allreduce_mean_(self.grads, self.group)
+        lr = self.lr()                                       # StepLR: the k-th step (0-based) runs at lr0 * 0.5 ** (k // decay_steps)
         self.global_step += 1
         hp, n = self.hp, self.h.n_floats
         clip = float(hp.get("clip_grad_norm", 1.0))
@@ -150,7 +151,7 @@ class DiffusionTrainerHip:
         if clip > 0:
             check(lib().dsvc_grad_clip_coef(ptr(self.grads), n, clip, ptr(self._aux[0:1]), ptr(self._aux[1:2]), stream_ptr()))
             coef = self._aux[1:2]
-        check(lib().dsvc_adamw_step(ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), n, self.lr(),
+        check(lib().dsvc_adamw_step(ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), n, lr,
                                     float(hp.get("optimizer_adam_beta1", 0.9)), float(hp.get("optimizer_adam_beta2", 0.98)), 1e-8,
                                     float(hp.get("weight_decay", 0.0)), self.global_step, ptr(coef), 1.0, stream_ptr()))
         return loss
