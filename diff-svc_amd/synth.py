@@ -284,6 +284,58 @@ def save_hifigan_ckpt(dirpath, h, seed=0, steps=1000):
     return sd
 
 
+def hubert_state(seed=0):
+    """HubertSoft state dict (network/hubert/hubert_model.py:16-33,82-137: HuBERT-base with a 256-dim soft-unit head, 94.7 M parameters)
+    with random weights scaled so that every activation stays O(1) and the attention scores have unit variance -- the reference's real
+    checkpoint (checkpoints/hubert/hubert_soft.pt) is not shipped.  Includes the two tensors inference never touches
+    (masked_spec_embed, label_embedding.weight): the reference loads strictly."""
+    n = lambda k, shape, std: _normal("hubert." + k, seed, shape, std)
+    sd = {}
+    sd["masked_spec_embed"] = torch.from_numpy(_rng("hubert.mse", seed).random(768).astype(np.float32))
+    sd["feature_extractor.conv0.weight"] = n("fe0", (512, 1, 10), 10 ** -0.5)
+    sd["feature_extractor.norm0.weight"] = 1.0 + n("gn.w", (512,), 0.1)
+    sd["feature_extractor.norm0.bias"] = n("gn.b", (512,), 0.1)
+    for i, k in ((1, 3), (2, 3), (3, 3), (4, 3), (5, 2), (6, 2)):
+        sd["feature_extractor.conv%d.weight" % i] = n("fe%d" % i, (512, 512, k), 1.6 * (512 * k) ** -0.5)
+    sd["feature_projection.norm.weight"] = 1.0 + n("fp.ln.w", (512,), 0.1)
+    sd["feature_projection.norm.bias"] = n("fp.ln.b", (512,), 0.1)
+    sd["feature_projection.projection.weight"] = n("fp.w", (768, 512), 512 ** -0.5)
+    sd["feature_projection.projection.bias"] = n("fp.b", (768,), 0.1)
+    sd["positional_embedding.conv.bias"] = n("pos.b", (768,), 0.1)
+    sd["positional_embedding.conv.weight_g"] = 2.0 + n("pos.g", (1, 1, 128), 0.2)
+    sd["positional_embedding.conv.weight_v"] = n("pos.v", (768, 48, 128), 1.0)
+    sd["norm.weight"] = 1.0 + n("ln.w", (768,), 0.1)
+    sd["norm.bias"] = n("ln.b", (768,), 0.1)
+    for l in range(12):
+        q = "encoder.layers.%d." % l
+        sd[q + "self_attn.in_proj_weight"] = n(q + "in.w", (2304, 768), 768 ** -0.5)
+        sd[q + "self_attn.in_proj_bias"] = n(q + "in.b", (2304,), 0.1)
+        sd[q + "self_attn.out_proj.weight"] = n(q + "out.w", (768, 768), 768 ** -0.5)
+        sd[q + "self_attn.out_proj.bias"] = n(q + "out.b", (768,), 0.1)
+        sd[q + "linear1.weight"] = n(q + "l1.w", (3072, 768), 768 ** -0.5)
+        sd[q + "linear1.bias"] = n(q + "l1.b", (3072,), 0.1)
+        sd[q + "linear2.weight"] = n(q + "l2.w", (768, 3072), 1.5 * 3072 ** -0.5)
+        sd[q + "linear2.bias"] = n(q + "l2.b", (768,), 0.1)
+        for nm in ("norm1", "norm2"):
+            sd[q + nm + ".weight"] = 1.0 + n(q + nm + ".w", (768,), 0.1)
+            sd[q + nm + ".bias"] = n(q + nm + ".b", (768,), 0.1)
+    sd["proj.weight"] = n("proj.w", (256, 768), 768 ** -0.5)
+    sd["proj.bias"] = n("proj.b", (256,), 0.1)
+    sd["label_embedding.weight"] = n("label", (100, 256), 1.0)
+    return sd
+
+
+def speech_like_wav(seed, n, sr=16000):
+    """A deterministic voiced-ish test signal in [-1, 1]: gliding harmonics with an amplitude envelope plus a little noise."""
+    g = _rng("wav", seed)
+    t = np.arange(n) / sr
+    f0 = 140.0 * 2.0 ** (0.3 * np.sin(2 * np.pi * 1.7 * t + seed))
+    ph = 2 * np.pi * np.cumsum(f0) / sr
+    x = sum(a * np.sin(k * ph + 0.3 * k) for k, a in ((1, 0.5), (2, 0.3), (3, 0.2), (5, 0.1)))
+    env = 0.5 + 0.5 * np.sin(2 * np.pi * 3.1 * t) ** 2
+    return (0.6 * env * x + 0.02 * g.standard_normal(n)).astype(np.float32)
+
+
 def align_units(n_mel, n_units):
     """mel2ph for a uniform stretch of n_units content frames over n_mel mel frames -- the integer
     recurrence of infer_tools/infer_tool.py:231-242 (bit-exact index work, kept on the host)."""

@@ -179,6 +179,26 @@ int dsvc_melspec_frames(const dsvc_melspec* m, int64_t n_samples, int32_t* frame
 int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, int64_t n_samples, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Content encoder -- replaces network/hubert/hubert_model.py:67-77 (HubertSoft.units: pad 40|40 -> FeatureExtractor ->
+ * FeatureProjection -> + PositionalConvEmbedding -> LayerNorm -> 12 post-LN transformer layers -> proj), loaded by
+ * hubert_soft() (:218-231) and called through preprocessing/hubertinfer.py:30-42 (Hubertencoder.encode -> get_units).
+ * The architecture is fixed (HuBERT-base, 768/12/3072, 256-dim soft units at 50 Hz from 16 kHz audio).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsvc_hubert dsvc_hubert;
+
+int dsvc_hubert_create(dsvc_hubert** out);
+/* name = key of HubertSoft.state_dict() ("feature_extractor.conv0.weight", "positional_embedding.conv.weight_g",
+ * "encoder.layers.3.self_attn.in_proj_weight", ...); host fp32 in the checkpoint's layout.  Keys the inference path does not use
+ * (masked_spec_embed, label_embedding.weight) are accepted and ignored. */
+int dsvc_hubert_load_tensor(dsvc_hubert* h, const char* name, const float* host, int64_t numel);
+int dsvc_hubert_finalize(dsvc_hubert* h);
+void dsvc_hubert_destroy(dsvc_hubert* h);
+/* frames produced for n_samples of 16 kHz audio: seven valid convolutions of total stride 320 over n_samples + 80 */
+int dsvc_hubert_frames(int64_t n_samples, int32_t* frames);
+/* wav [n_samples] device fp32 in [-1, 1] at 16 kHz (one utterance) -> units [frames][256] device */
+int dsvc_hubert_units(dsvc_hubert* h, const float* wav, int64_t n_samples, float* units, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Training step -- replaces GaussianDiffusion.forward(infer=False) -> p_losses (network/diff/diffusion.py:200-225,237-241;
  * training/train_pipeline.py:222-238) with autograd through DiffNet (network/diff/net.py:112-135), and the optimizer step of
  * training/task/SVC_task.py:60-66,116-125 (AdamW) with utils/pl_utils.py:1081-1084 (clip_grad_norm_).

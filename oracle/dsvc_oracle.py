@@ -565,6 +565,40 @@ def mel_spectrogram(wav, sr, n_fft, win_size, hop, n_mels, fmin, fmax, clip_val=
 
 
 # ----------------------------------------------------------------------------------------------
+# Content encoder  (network/hubert/hubert_model.py)
+# ----------------------------------------------------------------------------------------------
+def hubert_units(sd, wav):
+    """HubertSoft.units (hubert_model.py:67-77) in functional form: wav [1,1,N] at 16 kHz -> units [1,T,256].
+    FeatureExtractor :82-102, FeatureProjection :105-116, PositionalConvEmbedding :119-137 (weight_norm over dim 2),
+    nn.TransformerEncoderLayer(768, 12, 3072, gelu, batch_first) x 12 (post-LN), proj."""
+    x = F.pad(wav, (40, 40))
+    x = F.conv1d(x, sd["feature_extractor.conv0.weight"], stride=5)
+    x = F.gelu(F.group_norm(x, 512, sd["feature_extractor.norm0.weight"], sd["feature_extractor.norm0.bias"]))
+    for i in range(1, 7):
+        x = F.gelu(F.conv1d(x, sd["feature_extractor.conv%d.weight" % i], stride=2))
+    x = x.transpose(1, 2)
+    x = F.layer_norm(x, (512,), sd["feature_projection.norm.weight"], sd["feature_projection.norm.bias"])
+    x = F.linear(x, sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"])
+    g, v = sd["positional_embedding.conv.weight_g"], sd["positional_embedding.conv.weight_v"]
+    w = g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()                       # torch._weight_norm(v, g, dim=2)
+    p = F.conv1d(x.transpose(1, 2), w, sd["positional_embedding.conv.bias"], padding=64, groups=16)
+    x = x + F.gelu(p[:, :, :-1]).transpose(1, 2)
+    x = F.layer_norm(x, (768,), sd["norm.weight"], sd["norm.bias"])
+    B, T, _ = x.shape
+    for l in range(12):
+        q = "encoder.layers.%d." % l
+        qkv = F.linear(x, sd[q + "self_attn.in_proj_weight"], sd[q + "self_attn.in_proj_bias"])
+        qh, kh, vh = (t.reshape(B, T, 12, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+        att = torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, dim=-1) @ vh
+        att = att.transpose(1, 2).reshape(B, T, 768)
+        x = F.layer_norm(x + F.linear(att, sd[q + "self_attn.out_proj.weight"], sd[q + "self_attn.out_proj.bias"]), (768,),
+                         sd[q + "norm1.weight"], sd[q + "norm1.bias"])
+        ff = F.linear(F.gelu(F.linear(x, sd[q + "linear1.weight"], sd[q + "linear1.bias"])), sd[q + "linear2.weight"], sd[q + "linear2.bias"])
+        x = F.layer_norm(x + ff, (768,), sd[q + "norm2.weight"], sd[q + "norm2.bias"])
+    return F.linear(x, sd["proj.weight"], sd["proj.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
 # Host glue between the sampler and the vocoder  (infer_tools/infer_tool.py:171-200)
 # ----------------------------------------------------------------------------------------------
 def after_infer_mel(mel_pred, f0_pred, hp):

@@ -260,6 +260,8 @@ def main():
         return golden_plms_conditioned()
     if "--hifigan-only" in sys.argv:
         return golden_hifigan_24k()
+    if "--hubert-only" in sys.argv:
+        return golden_hubert()
     golden_state_keys()
     golden_vocoder("vocoder_tiny", synth.tiny_vocoder(), 5, clips=[0, 3], T=24, seed=90)
     golden_vocoder("vocoder_44k", dict(synth.VOCODER_44K), 1, clips=[1], T=12, seed=91)
@@ -276,6 +278,7 @@ def main():
     golden_sampler("plms_44k_k100_s20", dict(full, K_step=100), 0, clips=[4], T=32, n_units=19, speedup=20, seed=81)
     golden_24k()
     golden_hifigan_24k()
+    golden_hubert()
     golden_plms_conditioned()
     golden_slicer()
     golden_slicer_demo_input()
@@ -388,6 +391,31 @@ def golden_hifigan_24k(name="hifigan_24k", clips=(1, 2), T=10, seed=92, wseed=7)
     with open(os.path.join(OUT, "state_keys.json")) as f:
         keys = _json.load(f)
     keys["vocoder_24k"] = {k: list(v.shape) for k, v in HG.HifiGanGenerator(h).state_dict().items()}
+    with open(os.path.join(OUT, "state_keys.json"), "w") as f:
+        _json.dump(keys, f, indent=0, sort_keys=True)
+
+
+def golden_hubert(name="hubert_units", lengths=(16000, 33333), wseed=11):
+    """HubertSoft.units of the REAL reference (network/hubert/hubert_model.py) on a synthetic checkpoint (strict load, eval) for two
+    utterance lengths (an even and an odd frame-count chain through the seven strided convs)."""
+    refshim.set_hparams(dict(synth.HPARAMS_44K))
+    from network.hubert.hubert_model import HubertSoft
+    sd = synth.hubert_state(wseed)
+    m = HubertSoft()
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    out = {"wseed": wseed, "lengths": np.array(lengths)}
+    for i, n in enumerate(lengths):
+        wav = synth.speech_like_wav(100 + i, n)
+        with torch.no_grad():
+            u = m.units(torch.from_numpy(wav)[None, None])
+        out["units%d" % i] = u[0].numpy()
+        print(name, n, "samples ->", tuple(u.shape), "units std %.3f max %.3f" % (u.std().item(), u.abs().max().item()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    import json as _json
+    with open(os.path.join(OUT, "state_keys.json")) as f:
+        keys = _json.load(f)
+    keys["hubert_soft"] = {k: list(v.shape) for k, v in HubertSoft().state_dict().items()}
     with open(os.path.join(OUT, "state_keys.json"), "w") as f:
         _json.dump(keys, f, indent=0, sort_keys=True)
 

@@ -191,7 +191,7 @@ def test_committed_bench_line_follows_the_driver_contract():
     driver and the judge read: the metric contract, `roofline` and `cpu_baseline`."""
     import glob
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r*_bench.json")) if "prof" not in os.path.basename(f))   # (*prof*_bench = lines printed under rocprofv3)
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r*_bench.json")) if "prof" not in os.path.basename(f) and "train" not in os.path.basename(f))   # (*prof*_bench = lines printed under rocprofv3, *train* = bench.py --train)
     assert files, "no bench line committed under profiles/"
     with open(files[-1]) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
@@ -251,3 +251,9 @@ def test_gradient_allreduce_mean_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.array_equal(got, np.arange(1000, dtype=np.float32) * 1.5)
+
+
+def test_hubert_checkpoint_keys_match_reference():
+    """The synthetic HuBERT-soft checkpoint carries exactly the keys / shapes of the real HubertSoft.state_dict() (strict load)."""
+    ref = _keys()["hubert_soft"]
+    assert {k: list(v.shape) for k, v in synth.hubert_state(0).items()} == ref

@@ -140,3 +140,16 @@ def test_hifigan_24k_generator_matches_reference(with_source):
         wav = O.generator_forward(gw, h, c, torch.from_numpy(g["f0"]) if with_source else None, ini, nz).reshape(len(clips), -1)
     ref = torch.from_numpy(g["wav_src" if with_source else "wav_plain"])
     assert (wav - ref).pow(2).mean().sqrt().item() < 2e-6
+
+
+def test_hubert_soft_units_match_reference():
+    """The oracle's functional restatement of HubertSoft.units (hubert_model.py:67-137 + nn.TransformerEncoderLayer) against the REAL
+    module on a synthetic 94.7 M-parameter checkpoint, two utterance lengths."""
+    g = load_golden("hubert_units")
+    sd = synth.hubert_state(int(g["wseed"]))
+    for i, n in enumerate(g["lengths"]):
+        wav = torch.from_numpy(synth.speech_like_wav(100 + i, int(n)))[None, None]
+        with torch.no_grad():
+            u = O.hubert_units(sd, wav)[0]
+        assert u.shape == g["units%d" % i].shape
+        assert (u - torch.from_numpy(g["units%d" % i])).abs().max().item() < 2e-4
