@@ -142,6 +142,12 @@ class DiffusionTrainerHip:
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         loss = self.forward_backward(hubert, mel2ph, f0, mels, t, seed=seed, first_clip=first_clip, clip_ids=clip_ids)
+        self.optimizer_step()
+        return loss
+
+    @torch.no_grad()
+    def optimizer_step(self):
+        """What follows the backward pass: all-reduce (mean) of ``self.grads`` over the ranks, clip_grad_norm_, AdamW at the StepLR rate."""
         allreduce_mean_(self.grads, self.group)
         lr = self.lr()                                       # StepLR: the k-th step (0-based) runs at lr0 * 0.5 ** (k // decay_steps)
         self.global_step += 1
@@ -154,4 +160,3 @@ class DiffusionTrainerHip:
         check(lib().dsvc_adamw_step(ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), n, lr,
                                     float(hp.get("optimizer_adam_beta1", 0.9)), float(hp.get("optimizer_adam_beta2", 0.98)), 1e-8,
                                     float(hp.get("weight_decay", 0.0)), self.global_step, ptr(coef), 1.0, stream_ptr()))
-        return loss
