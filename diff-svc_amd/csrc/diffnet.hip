@@ -177,7 +177,6 @@ struct dsvc_denoiser {
     DevBuf lens, clipid;  // int [B]: valid frames per clip (zero padding beyond), Philox clip id per batch element
     DevBuf rowclip;       // int [rows_alloc]: clip of a row, -1 on gap / padded rows (RowMap)
     bool cond_ready = false;
-    int sub_begin = 0, sub_count = 0;   // eval() covers only these rows when sub_count > 0 (the sampler runs a batch as two independent halves)
     unsigned ws_gen = 0;  // bumped whenever the workspace is (re)built: captured graphs bake its pointers and are keyed on this
 
     ~dsvc_denoiser() {
@@ -518,7 +517,6 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         a.x = x; a.cin = cin_pad; a.taps = taps; a.dil = dil; a.w = tp.w.as<_Float16>(); a.m_tiles = tp.m_tiles;
         a.w_planes = tp.planes; a.variant_halfs = (long long)tp.variant_halfs; a.n_variants = tp.n_variants;
         a.step_ptr = step.ptr; a.step_off = step.off; a.clip_rows = Tp;
-        a.row_begin = sub_begin; a.row_count = sub_count;
         if (host_step >= 0 && tp.n_variants > 1 && step.per_clip == 0) {      // variant known at launch: pass it by value
             a.w += (size_t)(host_step % tp.n_variants) * tp.variant_halfs;
             a.n_variants = 1;
@@ -590,7 +588,6 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
         a.x = xh_buf(l); a.cin = Cp; a.taps = taps; a.dil = dil; a.w = tp.w.as<_Float16>(); a.m_tiles = tp.m_tiles;
         a.w_planes = tp.planes; a.variant_halfs = (long long)tp.variant_halfs; a.n_variants = tp.n_variants;
         a.step_ptr = step.ptr; a.step_off = step.off; a.clip_rows = Tp;
-        a.row_begin = sub_begin; a.row_count = sub_count;
         if (host_step >= 0 && tp.n_variants > 1 && step.per_clip == 0) {
             a.w += (size_t)(host_step % tp.n_variants) * tp.variant_halfs;
             a.n_variants = 1;
@@ -625,18 +622,14 @@ struct dsvc_sampler {
     unsigned p_gen = 0;
     // captured DDPM graph
     hipGraphExec_t gexec = nullptr;
-    hipStream_t cap_stream = nullptr, cap_stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int g_unroll = 0, gB = 0, gT = 0, g_prec = -1, g_split = -1;
+    hipStream_t cap_stream = nullptr;
+    int g_unroll = 0, gB = 0, gT = 0, g_prec = -1;
     unsigned g_gen = 0;
 
     ~dsvc_sampler() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
         if (gexec_plms) (void)hipGraphExecDestroy(gexec_plms);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
-        if (cap_stream2) (void)hipStreamDestroy(cap_stream2);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
         for (DevBuf* b : {&alphas_cumprod, &sqrt_recip, &sqrt_recipm1, &coef1, &coef2, &sigma, &spec_min, &spec_max,
                           &xstate, &hist, &xpred, &step_dev})
             b->release();
@@ -726,58 +719,29 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
     const int nvar = (den->tpath && den->cfg.precision == DSVC_PREC_F16 && den->cfg.weight_variants > 1) ? den->cfg.weight_variants : 1;
     const int UNROLL = (nvar > 1 && nvar <= 64) ? nvar : 10;
     const bool aligned = UNROLL == nvar && nvar > 1;
-    // Throughput batches run as TWO independent halves on two branches of the graph (clips never interact): each kernel then has
-    // half the workgroups, kernels of the two branches share the chip, and whenever they are in different phases one branch's
-    // HBM-bound output phase runs beside the other's MFMA-bound gate phase instead of the whole chip alternating between the two
-    // (DESIGN.md 4.1b).  Tile indices stay absolute, so the result is bit-identical to the unsplit launch.
-    const int half_rows = (a->B / 2) * den->Tp;
-    static const int split_env = getenv("DSVC_SPLIT2") ? atoi(getenv("DSVC_SPLIT2")) : 1;
-    const bool split2 = split_env && den->fused_layer_ok() && a->B % 2 == 0 && half_rows % 128 == 0 && den->rows_alloc / 128 >= 96 &&
-                        den->rows_alloc == a->B * den->Tp;
     if (a->use_graph && n >= 2 * UNROLL) {
-        const bool stale = !gexec || g_unroll != UNROLL || gB != a->B || gT != a->T || g_prec != den->cfg.precision || g_gen != den->ws_gen ||
-                           g_split != (split2 ? 1 : 0);
+        const bool stale = !gexec || g_unroll != UNROLL || gB != a->B || gT != a->T || g_prec != den->cfg.precision || g_gen != den->ws_gen;
         if (stale) {
             if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
             DSVC_TRY(eager_step());                       // one eager step first: sets every function attribute outside the capture
             if (!cap_stream) DSVC_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
-            if (split2 && !cap_stream2) {
-                DSVC_HIP(hipStreamCreateWithFlags(&cap_stream2, hipStreamNonBlocking));
-                DSVC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-                DSVC_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-            }
             DSVC_HIP(hipStreamSynchronize(st));
             DSVC_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
             int rc = DSVC_OK;
-            hipError_t fe = hipSuccess;
-            if (split2) {
-                fe = hipEventRecord(ev_fork, cap_stream);
-                if (fe == hipSuccess) fe = hipStreamWaitEvent(cap_stream2, ev_fork, 0);
+            for (int u = 0; u < UNROLL && rc == DSVC_OK; ++u) {
+                dsvc_denoiser::DdpmCtx e = ddpm_ctx();
+                rc = den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), u, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, cap_stream,
+                               aligned ? UNROLL - 1 - u : -1);
             }
-            for (int br = 0; br < (split2 ? 2 : 1) && rc == DSVC_OK && fe == hipSuccess; ++br) {
-                hipStream_t cs = br == 0 ? cap_stream : cap_stream2;
-                if (split2) { den->sub_begin = br * half_rows; den->sub_count = half_rows; }
-                for (int u = 0; u < UNROLL && rc == DSVC_OK; ++u) {
-                    dsvc_denoiser::DdpmCtx e = ddpm_ctx();
-                    rc = den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), u, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, cs,
-                                   aligned ? UNROLL - 1 - u : -1);
-                }
-            }
-            den->sub_begin = 0; den->sub_count = 0;
-            if (split2 && fe == hipSuccess) {
-                fe = hipEventRecord(ev_join, cap_stream2);
-                if (fe == hipSuccess) fe = hipStreamWaitEvent(cap_stream, ev_join, 0);
-            }
-            if (rc == DSVC_OK && fe == hipSuccess) hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, cap_stream, step_dev.as<int>(), -UNROLL);
+            if (rc == DSVC_OK) hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, cap_stream, step_dev.as<int>(), -UNROLL);
             hipGraph_t graph = nullptr;
             hipError_t ce = hipStreamEndCapture(cap_stream, &graph);
             if (rc != DSVC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            if (fe != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return fail(DSVC_EHIP, "graph fork/join: %s", hipGetErrorString(fe)); }
             if (ce != hipSuccess) return fail(DSVC_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
             ce = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             if (ce != hipSuccess) { gexec = nullptr; return fail(DSVC_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ce)); }
-            g_unroll = UNROLL; gB = a->B; gT = a->T; g_prec = den->cfg.precision; g_split = split2 ? 1 : 0;
+            g_unroll = UNROLL; gB = a->B; gT = a->T; g_prec = den->cfg.precision;
             g_gen = den->ws_gen;
         }
         if (aligned)

@@ -60,8 +60,6 @@ struct TGemmArgs {
                             //  dependent scalar load, ~0.4 us per kernel in the single-clip regime, out of the front of the weight stream)
     int clip_rows;          // rows per clip (clip stride) or 0: the K-loop stagger is keyed on a tile's position inside its clip, so a
                             // clip computes bit-identically alone and inside a batch
-    int row_begin, row_count;     // launch only the rows [row_begin, row_begin + row_count) (multiples of the frame tile; row_count 0 = all): a
-                                  // batch can run as independent halves on two streams; tile indices stay absolute, so results do not change
     unsigned long long* stamps;   // profiling: per-wave phase time stamps (s_memrealtime, 100 MHz), 16 per wave; null in production
     int dbg;                // ablation knobs for profiling (env DSVC_TG_DEBUG): 1 = no acc-init loads, 2 = no epilogue,
                             // 4 = no tile DMA, 8 = no MFMA main loop, 16 = no wave priority split, 32 = all tiles stream
@@ -90,8 +88,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = KS > 1 ? wave_all % WAVES : wave_all;      // which output tile of the pass
     const int ks = KS > 1 ? wave_all / WAVES : 0;               // which slice of the K loop
-    const int tile = (int)blockIdx.x + a.row_begin / TN;   // absolute frame tile (a launch may cover a sub-range of the rows)
-    const int row0 = tile * TN;
+    const int row0 = blockIdx.x * TN;
     constexpr bool STAMPS = NT_N == 1;                    // the phase stamps exist only in the small-batch kernels: in the 128-frame
                                                           // tiling their few SGPRs/VGPRs tip the register allocation into spills
     auto stamp = [&](int i) {
@@ -231,7 +228,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     //  extra index arithmetic tips its 256-register allocation into spills)
     constexpr bool STAGGER = NT_N < 4;
     const unsigned tiles_pc = (a.clip_rows > 0 && a.clip_rows % TN == 0) ? (unsigned)(a.clip_rows / TN) : 0u;
-    const int rk = (!STAGGER || (a.dbg & 1024)) ? 0 : (int)((tiles_pc ? (unsigned)tile % tiles_pc : (unsigned)tile) % (unsigned)G);
+    const int rk = (!STAGGER || (a.dbg & 1024)) ? 0 : (int)((tiles_pc ? blockIdx.x % tiles_pc : blockIdx.x) % (unsigned)G);
     auto gmap = [&](int g) { if constexpr (!STAGGER) return g; const int x = g + rk; return x >= G ? x - G : x; };
     auto wgrp = [&](int g) { return (a.dbg & 4096) ? 0 : gmap(g); };    // dbg 4096: the ring re-reads group 0 (L1-hot weight stream)
     if constexpr (KS > 1) {
@@ -432,13 +429,6 @@ template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 
 inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, int m_split, hipStream_t stream) {
     if (a.cin % (16 * KG) != 0) return fail(DSVC_EINVAL, "tgemm: cin %d not a multiple of %d", a.cin, 16 * KG);
     if (n_rows % (32 * NT_N) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N);
-    if (a.row_count > 0) {
-        if (a.row_begin % (32 * NT_N) || a.row_count % (32 * NT_N) || a.row_begin + a.row_count > n_rows)
-            return fail(DSVC_EINVAL, "tgemm: row range %d+%d does not fit the %d-frame tiling of %d rows", a.row_begin, a.row_count, 32 * NT_N, n_rows);
-        n_rows = a.row_count;
-    } else {
-        a.row_begin = 0;
-    }
     if (a.w_planes != NW) return fail(DSVC_EINVAL, "tgemm: weights packed with %d plane(s), kernel streams %d", a.w_planes, NW);
     a.swz = tgemm_swizzle_mask(a.cin);
     const char* dbg_s = getenv("DSVC_TG_DEBUG");           // profiling ablations only; results are WRONG when set

@@ -35,7 +35,6 @@ struct TLayerArgs {
     const _Float16* gw;         // gate weights  [variant][C/16 m_tiles][3 taps][C/16][planes][lane][8]
     const _Float16* ow;         // output 1x1    [variant][2C/32 m_tiles][C/16][planes][lane][8]
     long long gvar, ovar;       // halfs between dither variants
-    int row_begin;              // first row of this launch (a multiple of 128): a batch can run as independent halves on two streams
     int n_variants;             // > 1: variant = (*step_ptr - step_off) mod n_variants is resolved in the kernel; the sampler passes
     const int* step_ptr;        //      the variant by value (gw / ow already offset, n_variants = 1)
     int step_off;
@@ -100,7 +99,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = ga.row_begin + blockIdx.x * TL_TN;
+    const int row0 = blockIdx.x * TL_TN;
     const int halo = ga.dil;                              // taps == 3
     const int rows_lds = TL_TN + 2 * halo;
     const int chunks = ga.cin >> 3;
@@ -314,11 +313,6 @@ inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs
     TLayerArgs a{};
     a.x = g.x; a.cin = g.cin; a.swz = tgemm_swizzle_mask(g.cin); a.dil = g.dil; a.gw = g.w; a.ow = o.w;
     a.gvar = g.variant_halfs; a.ovar = o.variant_halfs; a.n_variants = g.n_variants; a.step_ptr = g.step_ptr; a.step_off = g.step_off;
-    if (g.row_count > 0) {
-        if (g.row_begin % TL_TN || g.row_count % TL_TN || g.row_begin + g.row_count > n_rows) return fail(DSVC_EINVAL, "tlayer: bad row range");
-        a.row_begin = g.row_begin;
-        n_rows = g.row_count;
-    }
     if (C == 384) return prefetch ? tlayer_launch_t<3, KG, NW, 1>(a, cproj, oe, n_rows, stream) : tlayer_launch_t<3, KG, NW, 0>(a, cproj, oe, n_rows, stream);
     return prefetch ? tlayer_launch_t<2, KG, NW, 1>(a, cproj, oe, n_rows, stream) : tlayer_launch_t<2, KG, NW, 0>(a, cproj, oe, n_rows, stream);
 }
