@@ -301,6 +301,15 @@ def main():
             "finite_output": ok,
             "roofline": roof,
         }
+        if world == 1 and not args.no_batched:
+            # what the chip sustains on dense fp16 MFMA with real (random) operands: the clock drops under that load, the datasheet
+            # peak assumes it does not -- the context a roofline fraction needs (csrc/probe.hip)
+            import ctypes
+            from diffsvc_amd import _lib
+            tf, ghz = ctypes.c_float(0), ctypes.c_float(0)
+            _lib.check(_lib.lib().dsvc_probe_mfma(1, ctypes.byref(tf), ctypes.byref(ghz), _lib.stream_ptr()))
+            result["mfma_sustained"] = {"tflops": tf.value, "clock_ghz": ghz.value, "operands": "random fp16, register-resident 32x32x16 loop, 2 waves/SIMD",
+                                        "datasheet_tflops": PEAK_TFLOPS_F16}
         if os.environ.get("DSVC_BENCH_PCM_STATS") == "1":       # test hook: per-clip moments of the gathered PCM of the last step
             w64 = wav.double()
             result["pcm_stats"] = [[int(i), float(w64[i].sum()), float((w64[i] ** 2).sum())] for i in range(w64.shape[0])]

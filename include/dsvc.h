@@ -37,6 +37,9 @@ enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2 };
 
 int dsvc_abi_version(void);
 const char* dsvc_last_error(void);
+/* measurement aid for bench.py: the dense fp16 MFMA rate (TFLOP/s) and shader clock (GHz) this chip sustains right now on a
+ * register-resident loop with random (1) or zero (0) operands -- the rate a roofline fraction can actually approach. */
+int dsvc_probe_mfma(int32_t random_data, float* tflops, float* clock_ghz, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Denoiser -- replaces network/diff/net.py:86-135 (class DiffNet), selected through the DIFF_DECODERS

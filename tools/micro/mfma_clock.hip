@@ -22,9 +22,11 @@ __global__ void k_mfma(const _Float16* __restrict__ src, float* __restrict__ sin
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     __syncthreads();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < iters; it += 4) {               // 16 MFMAs per trip, every register index static (a dynamic one would go through scratch)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[(i + it) & 3], acc[i], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[(i + j) & 3], acc[i], 0, 0, 0);
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
