@@ -62,6 +62,12 @@ class TrainerCfg(ctypes.Structure):
                 ("mel_bins", "hidden", "channels", "layers", "dilation_cycle", "timesteps", "loss_l1", "pitch_vocab")]
 
 
+class PeCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("n_mel", "hidden", "predictor_hidden", "prenet_layers", "conv_layers", "predictor_layers", "kernel",
+                 "predictor_kernel", "pitch_norm", "use_uv")] + [("f0_mean", ctypes.c_float), ("f0_std", ctypes.c_float)]
+
+
 class TrainArgs(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("T", ctypes.c_int32), ("mel", ctypes.c_void_p), ("cond", ctypes.c_void_p), ("t", ctypes.c_void_p),
                 ("pitch", ctypes.c_void_p), ("mel2ph", ctypes.c_void_p), ("seed", ctypes.c_uint64), ("first_clip", ctypes.c_int32),
@@ -102,6 +108,12 @@ SYMBOLS = [
     ("dsvc_hubert_destroy", None, [_VP]),
     ("dsvc_hubert_frames", ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]),
     ("dsvc_hubert_units", ctypes.c_int, [_VP, _VP, ctypes.c_int64, _VP, _VP]),
+    ("dsvc_pe_create", ctypes.c_int, [ctypes.POINTER(PeCfg), ctypes.POINTER(_VP)]),
+    ("dsvc_pe_load_tensor", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64]),
+    ("dsvc_pe_finalize", ctypes.c_int, [_VP]),
+    ("dsvc_pe_set_positions", ctypes.c_int, [_VP, _VP, ctypes.c_int32]),
+    ("dsvc_pe_destroy", None, [_VP]),
+    ("dsvc_pe_run", ctypes.c_int, [_VP, _VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP, _VP]),
     ("dsvc_trainer_create", ctypes.c_int, [ctypes.POINTER(TrainerCfg), ctypes.POINTER(_VP)]),
     ("dsvc_trainer_destroy", None, [_VP]),
     ("dsvc_trainer_param_count", ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),

@@ -20,6 +20,7 @@
 
 #include "../../include/dsvc.h"
 #include "cg_util.h"
+#include "rowops.h"
 
 using namespace dsvc;
 
@@ -92,25 +93,6 @@ __global__ void k_gn_apply_gelu(float* __restrict__ x, const double* __restrict_
         const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-5));
         x[i] = gelu_exact((x[i] - (float)mean) * rstd * gamma[c] + beta[c]);
     }
-}
-
-// LayerNorm over the channel axis, one wave per row (eps 1e-5); out may alias in
-__global__ void k_layernorm(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ gamma, const float* __restrict__ beta,
-                            int rows, int C) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* p = in + (size_t)row * C;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += p[c];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)C;
-    float q = 0.f;
-    for (int c = lane; c < C; c += 64) { const float d = p[c] - mean; q += d * d; }
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
-    float* o_ = out + (size_t)row * C;
-    for (int c = lane; c < C; c += 64) o_[c] = (p[c] - mean) * rstd * gamma[c] + beta[c];
 }
 
 // row softmax over the first n columns of [rows][ld]; columns n..ld-1 are zeroed (they are K padding of the next GEMM)
@@ -322,7 +304,7 @@ int dsvc_hubert::units(const float* wav, long long n, float* out, hipStream_t st
     }
     const float* feat = c[cur].as<float>();                       // [T][512]
     // ---- feature projection: LayerNorm(512) -> Linear(512, 768)  (hubert_model.py:105-116) ----
-    hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(T, 4)), dim3(256), 0, st, feat, c[cur ^ 1].as<float>(), fp_ln_g.as<float>(), fp_ln_b.as<float>(), T, HB_C0);
+    hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(T, 4)), dim3(256), 0, st, feat, c[cur ^ 1].as<float>(), fp_ln_g.as<float>(), fp_ln_b.as<float>(), T, HB_C0, 1e-5f);
     {
         EpLin::Args e{h.as<float>(), HB_D, fp_b.as<float>(), HB_D, 0, nullptr, 0, 0, T, 1.0f};
         DSVC_TRY(gemm(c[cur ^ 1].as<float>(), HB_C0, T, HB_C0, fp_w, 1, e));
@@ -333,7 +315,7 @@ int dsvc_hubert::units(const float* wav, long long n, float* out, hipStream_t st
         EpLin::Args e{posb.as<float>(), HB_D, pos_b.as<float>() + gi * gc, gc, 1, h.as<float>(), HB_D, gi * gc, T, 1.0f};
         DSVC_TRY(gemm(h.as<float>() + gi * gc, HB_D, T, gc, pos[gi], HB_PK, e));
     }
-    hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(T, 4)), dim3(256), 0, st, posb.as<float>(), h.as<float>(), ln_g.as<float>(), ln_b.as<float>(), T, HB_D);
+    hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(T, 4)), dim3(256), 0, st, posb.as<float>(), h.as<float>(), ln_g.as<float>(), ln_b.as<float>(), T, HB_D, 1e-5f);
     // ---- 12 post-LN transformer encoder layers (nn.TransformerEncoderLayer(768, 12, 3072, gelu, batch_first)) ----
     const int Tp = round_up(T, 32), Tk = round_up(T, 16);
     const int nctK = round_up(ceil_div(T, 32), 2);
@@ -373,14 +355,14 @@ int dsvc_hubert::units(const float* wav, long long n, float* out, hipStream_t st
         {   // x = LayerNorm1(x + out_proj(attn))
             EpLin::Args e{h2.as<float>(), HB_D, y.out_b.as<float>(), HB_D, 0, h.as<float>(), HB_D, 0, T, 1.0f};
             DSVC_TRY(gemm(attn.as<float>(), HB_D, T, HB_D, y.out_w, 1, e));
-            hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(T, 4)), dim3(256), 0, st, h2.as<float>(), h.as<float>(), y.n1g.as<float>(), y.n1b.as<float>(), T, HB_D);
+            hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(T, 4)), dim3(256), 0, st, h2.as<float>(), h.as<float>(), y.n1g.as<float>(), y.n1b.as<float>(), T, HB_D, 1e-5f);
         }
         {   // x = LayerNorm2(x + linear2(gelu(linear1(x))))
             EpLin::Args e1{ffb.as<float>(), HB_FF, y.b1.as<float>(), HB_FF, 1, nullptr, 0, 0, T, 1.0f};
             DSVC_TRY(gemm(h.as<float>(), HB_D, T, HB_D, y.ff1, 1, e1));
             EpLin::Args e2{h2.as<float>(), HB_D, y.b2.as<float>(), HB_D, 0, h.as<float>(), HB_D, 0, T, 1.0f};
             DSVC_TRY(gemm(ffb.as<float>(), HB_FF, T, HB_FF, y.ff2, 1, e2));
-            hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(T, 4)), dim3(256), 0, st, h2.as<float>(), h.as<float>(), y.n2g.as<float>(), y.n2b.as<float>(), T, HB_D);
+            hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(T, 4)), dim3(256), 0, st, h2.as<float>(), h.as<float>(), y.n2g.as<float>(), y.n2b.as<float>(), T, HB_D, 1e-5f);
         }
     }
     {   // units = proj(x)  (hubert_model.py:74-77)

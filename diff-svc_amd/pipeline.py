@@ -23,7 +23,7 @@ class SvcPipeline:
     ``vocoder_state``/``vocoder_cfg`` the NSF-HiFiGAN generator checkpoint and its config.json."""
 
     def __init__(self, hp, acoustic_state, vocoder_state, vocoder_cfg, precision="auto", vocoder_precision="f16_x3",
-                 device="cuda"):
+                 device="cuda", pe_state=None):
         if not torch.cuda.is_available():
             raise RuntimeError("SvcPipeline needs a HIP device (there is no CPU path)")
         self.hp = hp
@@ -35,10 +35,16 @@ class SvcPipeline:
         self.model.load_state_dict(acoustic_state, strict=True)
         self.model.to(device)
         self.vocoder = VocoderHandle(vocoder_state, vocoder_cfg, precision=vocoder_precision)
+        self.pe = None
+        if pe_state is not None:                                    # Svc.__init__: PitchExtractor().cuda() + strict load (infer_tool.py:134-136)
+            from .pe import PitchExtractorHip
+            self.pe = PitchExtractorHip(n_mel_bins=hp["audio_num_mel_bins"], hparams=hp).cuda()
+            self.pe.load_state_dict(pe_state, strict=True)
+            self.pe.eval()
 
     @torch.no_grad()
     def infer(self, hubert, mel2ph, f0, speedup=1, seed=0, first_clip=0, clip_ids=None, use_graph=True, return_mel=False,
-              return_lens=False):
+              return_lens=False, use_pe=False):
         """hubert [B,N,H], mel2ph [B,T] long, f0 [B,T] log2 (interpolated) -- all device tensors.
         Returns PCM [B, T*hop] on the device (and mel [B,T,M] / the per-clip sample counts if asked).
 
@@ -48,7 +54,12 @@ class SvcPipeline:
         (infer_tool.py:177-191) is reproduced per clip -- frames whose predicted mel row is all-zero are dropped (``mel_out``
         is masked by ``mel2ph > 0``, diffusion.py:280-281, so those are exactly the ``mel2ph == 0`` frames), the mel is clipped to
         [mel_vmin, mel_vmax], f0 is cut with the same mask -- before the vocoder sees it.  PCM rows are zero beyond a clip's own
-        ``kept_frames * hop`` samples."""
+        ``kept_frames * hop`` samples.
+
+        ``use_pe``: drive the vocoder with the pitch extractor's f0 read off the sampled mel instead of the input f0
+        (Svc.infer's ``use_pe``, infer_tool.py:165-168; needs ``pe_state`` at construction)."""
+        if use_pe and self.pe is None:
+            raise RuntimeError("use_pe=True needs a pitch-extractor checkpoint (SvcPipeline(..., pe_state=...))")
         hp = dict(self.hp, pndm_speedup=speedup)
         self.model.hp = hp
         self.model.fs2.hp = hp
@@ -65,17 +76,35 @@ class SvcPipeline:
         mel = ret["mel_out"]
         mel_c = torch.clamp(mel, hp["mel_vmin"], hp["mel_vmax"])
         hop = self.vocoder.hop
+        if use_pe:
+            self.pe.hp = hp
+            f0_hz = self._pe_f0(mel, clip_lens)
+        else:
+            f0_hz = ret["f0_denorm"]
         if not ragged:
-            wav = self.vocoder.vocode(mel_c, ret["f0_denorm"], seed=seed, first_clip=first_clip, clip_ids=clip_ids)
+            wav = self.vocoder.vocode(mel_c, f0_hz, seed=seed, first_clip=first_clip, clip_ids=clip_ids)
             lens = torch.full((B,), T * hop, dtype=torch.int64, device=wav.device)
         else:
-            wav, lens = self._vocode_ragged(mel_c, ret["f0_denorm"], valid, seed, first_clip, clip_ids)
+            wav, lens = self._vocode_ragged(mel_c, f0_hz, valid, seed, first_clip, clip_ids)
         out = (wav,)
         if return_mel:
             out += (mel,)
         if return_lens:
             out += (lens,)
         return out if len(out) > 1 else wav
+
+    def _pe_f0(self, mel, clip_lens):
+        """``self.pe(outputs['mel_out'])['f0_denorm_pred']`` per clip as the reference's B=1 loop sees it: a clip padded to the batch's T
+        must not let the padding frames into its GroupNorm statistics, so clips run at their own length (grouped by length)."""
+        if clip_lens is None:
+            return self.pe(mel)["f0_denorm_pred"]
+        B, T, _ = mel.shape
+        f0 = torch.zeros(B, T, device=mel.device, dtype=torch.float32)
+        lens = clip_lens.tolist()
+        for n in sorted(set(lens)):
+            members = torch.tensor([b for b in range(B) if lens[b] == n], device=mel.device)
+            f0[members, :n] = self.pe(mel[members, :n].contiguous())["f0_denorm_pred"]
+        return f0
 
     def _vocode_ragged(self, mel_c, f0_hz, valid, seed, first_clip, clip_ids):
         """after_infer's frame drop per clip, then one vocoder call per group of equal kept length."""

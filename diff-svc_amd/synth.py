@@ -325,6 +325,71 @@ def hubert_state(seed=0):
     return sd
 
 
+def pe_state(hp, seed=0, n_mel=80, conv_layers=2):
+    """PitchExtractor state dict (modules/fastspeech/pe.py:120-135) with random weights: He-scaled convs so activations stay O(1),
+    non-trivial BatchNorm running statistics / affine norms / biases so every term of the forward is exercised, and a final linear
+    whose first output sits around log2(200 Hz).  Includes the buffers a strict load needs (num_batches_tracked,
+    embed_positions._float_tensor)."""
+    H = hp["hidden_size"]
+    P = hp["predictor_hidden"] if hp["predictor_hidden"] > 0 else H
+    K, PK = 5, hp["predictor_kernel"]
+    n = lambda k, shape, std: _normal("pe." + k, seed, shape, std)
+    u = lambda k, shape, lo, hi: torch.from_numpy(_rng("pe." + k, seed).uniform(lo, hi, shape).astype(np.float32))
+    sd = {}
+    for l in range(3):
+        q = "mel_prenet.layers.%d." % l
+        cin = n_mel if l == 0 else H
+        sd[q + "0.weight"] = n(q + "w", (H, cin, K), (1.0 if l == 0 else 2.0) ** 0.5 * (cin * K) ** -0.5 * (0.6 if l == 0 else 1.0))
+        sd[q + "0.bias"] = n(q + "b", (H,), 0.2)
+        sd[q + "2.weight"] = 1.0 + n(q + "bn.w", (H,), 0.1)
+        sd[q + "2.bias"] = n(q + "bn.b", (H,), 0.2)
+        sd[q + "2.running_mean"] = u(q + "bn.m", (H,), 0.1, 0.7)
+        sd[q + "2.running_var"] = u(q + "bn.v", (H,), 0.4, 1.4)
+        sd[q + "2.num_batches_tracked"] = torch.tensor(1000 + l, dtype=torch.long)
+    sd["mel_prenet.out_proj.weight"] = n("pre.out.w", (H, H), H ** -0.5)
+    sd["mel_prenet.out_proj.bias"] = n("pre.out.b", (H,), 0.1)
+    if conv_layers > 0:
+        sd["mel_encoder.in_proj.weight"] = n("enc.in.w", (H, H), H ** -0.5)
+        sd["mel_encoder.in_proj.bias"] = n("enc.in.b", (H,), 0.1)
+        for l in range(conv_layers):
+            q = "mel_encoder.conv.%d." % l
+            sd[q + "conv.conv.weight"] = n(q + "w", (H, H, K), (H * K) ** -0.5)
+            sd[q + "conv.conv.bias"] = n(q + "b", (H,), 0.1)
+            sd[q + "norm.weight"] = 1.0 + n(q + "gn.w", (H,), 0.1)
+            sd[q + "norm.bias"] = n(q + "gn.b", (H,), 0.2)
+        sd["mel_encoder.out_proj.weight"] = n("enc.out.w", (H, H), H ** -0.5)
+        sd["mel_encoder.out_proj.bias"] = n("enc.out.b", (H,), 0.1)
+    for l in range(5):
+        q = "pitch_predictor.conv.%d." % l
+        cin = H if l == 0 else P
+        sd[q + "1.weight"] = n(q + "w", (P, cin, PK), 2.0 ** 0.5 * (cin * PK) ** -0.5)
+        sd[q + "1.bias"] = n(q + "b", (P,), 0.2)
+        sd[q + "3.weight"] = 1.0 + n(q + "ln.w", (P,), 0.1)
+        sd[q + "3.bias"] = n(q + "ln.b", (P,), 0.2)
+    sd["pitch_predictor.linear.weight"] = n("lin.w", (2, P), 0.35 * P ** -0.5)
+    sd["pitch_predictor.linear.bias"] = torch.tensor([7.6, -0.1], dtype=torch.float32)
+    sd["pitch_predictor.embed_positions._float_tensor"] = torch.zeros(1)
+    sd["pitch_predictor.pos_embed_alpha"] = torch.tensor([0.8], dtype=torch.float32)
+    return sd
+
+
+def mel_like(seed, B, T, M, pad_tail=(0,)):
+    """A log-mel-like batch [B, T, M] in about [-5, 0] with smooth time structure; clip b has its last pad_tail[b % len] frames exactly
+    zero (padding rows, as the sampler's ``mel_out * mask`` leaves them)."""
+    g = _rng("mel_like", seed)
+    base = g.standard_normal((B, T, M)).astype(np.float32)
+    k = np.array([0.25, 0.5, 0.25], np.float32)
+    for _ in range(2):
+        base = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 1, base)
+    mel = -2.6 + 1.8 * base + 0.6 * np.sin(np.arange(M, dtype=np.float32) / 9.0)[None, None, :]
+    mel = np.clip(mel, -5.0, 0.0).astype(np.float32)
+    for b in range(B):
+        n = pad_tail[b % len(pad_tail)]
+        if n:
+            mel[b, T - n:] = 0.0
+    return mel
+
+
 def speech_like_wav(seed, n, sr=16000):
     """A deterministic voiced-ish test signal in [-1, 1]: gliding harmonics with an amplitude envelope plus a little noise."""
     g = _rng("wav", seed)

@@ -202,6 +202,41 @@ int dsvc_hubert_frames(int64_t n_samples, int32_t* frames);
 int dsvc_hubert_units(dsvc_hubert* h, const float* wav, int64_t n_samples, float* units, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Pitch extractor (mel -> f0) -- replaces modules/fastspeech/pe.py:120-148 (PitchExtractor.forward: Prenet :7-42 -> ConvStacks
+ * :81-117 -> PitchPredictor modules/fastspeech/tts_modules.py:192-235 -> denorm_f0 utils/pitch_utils.py:63-76), which the 24 kHz
+ * path runs on the sampled mel to drive the vocoder (infer_tools/infer_tool.py:134-136,165-166).  Eval mode (BatchNorm running
+ * statistics, no dropout), 'SAME' padding.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsvc_pe dsvc_pe;
+
+typedef struct {
+    int32_t n_mel;              /* PitchExtractor(n_mel_bins), 80 */
+    int32_t hidden;             /* hparams['hidden_size'], multiple of 16 */
+    int32_t predictor_hidden;   /* hparams['predictor_hidden'] if > 0 else hidden */
+    int32_t prenet_layers;      /* Prenet n_layers, 3 */
+    int32_t conv_layers;        /* PitchExtractor(conv_layers), 2; 0 = no mel_encoder */
+    int32_t predictor_layers;   /* 5 */
+    int32_t kernel;             /* Prenet / ConvStacks kernel, 5 */
+    int32_t predictor_kernel;   /* hparams['predictor_kernel'], 5 */
+    int32_t pitch_norm;         /* hparams['pitch_norm']: 0 = 'log' (f0 = 2**x), 1 = 'standard' (x*f0_std + f0_mean), 2 = neither */
+    int32_t use_uv;             /* pitch_type == 'frame' and hparams['use_uv']: f0 = 0 where pitch_pred[..., 1] > 0 */
+    float f0_mean, f0_std;
+} dsvc_pe_cfg;
+
+int dsvc_pe_create(const dsvc_pe_cfg* cfg, dsvc_pe** out);
+/* name = key of PitchExtractor.state_dict() ("mel_prenet.layers.0.0.weight", "mel_prenet.layers.0.2.running_var",
+ * "mel_encoder.conv.1.norm.weight", "pitch_predictor.conv.4.3.bias", "pitch_predictor.pos_embed_alpha", ...); host fp32 in the
+ * checkpoint's layout.  Keys the forward does not read (num_batches_tracked, embed_positions._float_tensor) are accepted and ignored. */
+int dsvc_pe_load_tensor(dsvc_pe* p, const char* name, const float* host, int64_t numel);
+int dsvc_pe_finalize(dsvc_pe* p);
+/* the sinusoidal table SinusoidalPositionalEmbedding.weights [n_rows][hidden] (common_layers.py:105-122; a constructor constant, not
+ * in the state dict); a run over T frames needs n_rows >= T + 1 */
+int dsvc_pe_set_positions(dsvc_pe* p, const float* host_table, int32_t n_rows);
+void dsvc_pe_destroy(dsvc_pe* p);
+/* mel [B][T][n_mel] device fp32 (all-zero rows are padding) -> pitch_pred [B][T][2] (may be NULL), f0 [B][T] (Hz) device */
+int dsvc_pe_run(dsvc_pe* p, const float* mel, int32_t B, int32_t T, float* pitch_pred, float* f0, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Training step -- replaces GaussianDiffusion.forward(infer=False) -> p_losses (network/diff/diffusion.py:200-225,237-241;
  * training/train_pipeline.py:222-238) with autograd through DiffNet (network/diff/net.py:112-135), and the optimizer step of
  * training/task/SVC_task.py:60-66,116-125 (AdamW) with utils/pl_utils.py:1081-1084 (clip_grad_norm_).

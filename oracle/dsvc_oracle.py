@@ -616,3 +616,68 @@ def spec2wav(gw, h, mel_log10, f0, rand_ini, noise):
     f = torch.as_tensor(f0, dtype=torch.float32)[None, :]
     with torch.no_grad():
         return generator_forward(gw, h, c, f, rand_ini, noise).view(-1)
+
+
+# ----------------------------------------------------------------------------------------------
+# Pitch extractor  (modules/fastspeech/pe.py)
+# ----------------------------------------------------------------------------------------------
+def sinusoid_table(n_rows, dim):
+    """SinusoidalPositionalEmbedding.get_embedding(n_rows, dim, padding_idx=0)  (modules/commons/common_layers.py:105-122)."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float) * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(n_rows, dtype=torch.float).unsqueeze(1) * freq.unsqueeze(0)
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1).view(n_rows, -1)
+    if dim % 2 == 1:
+        tab = torch.cat([tab, torch.zeros(n_rows, 1)], dim=1)
+    tab[0, :] = 0
+    return tab
+
+
+def pitch_extractor(sd, mel, hp, conv_layers=2):
+    """PitchExtractor.forward in eval mode (pe.py:136-148), functional: mel [B,T,M] -> (pitch_pred [B,T,2], f0_denorm_pred [B,T]).
+    Prenet :23-42 (Conv1d k5 -> ReLU -> BatchNorm1d running stats, masked), ConvStacks :98-117 (residual GroupNorm(C/16) blocks),
+    PitchPredictor tts_modules.py:222-235 (positions from make_positions(xs[..., 0], 0), LayerNorm over channels eps 1e-12),
+    denorm_f0 pitch_utils.py:63-76."""
+    pad = mel.abs().sum(-1).eq(0)
+    keep = 1 - pad.float()[:, None, :]
+    x = mel.transpose(1, 2)
+    for l in range(3):
+        q = "mel_prenet.layers.%d." % l
+        k = sd[q + "0.weight"].shape[-1]
+        x = F.relu(F.conv1d(x, sd[q + "0.weight"], sd[q + "0.bias"], padding=k // 2))
+        x = F.batch_norm(x, sd[q + "2.running_mean"], sd[q + "2.running_var"], sd[q + "2.weight"], sd[q + "2.bias"], False, 0.1, 1e-5)
+        x = x * keep
+    x = F.linear(x.transpose(1, 2), sd["mel_prenet.out_proj.weight"], sd["mel_prenet.out_proj.bias"]) * keep.transpose(1, 2)
+    if conv_layers > 0:
+        x = F.linear(x, sd["mel_encoder.in_proj.weight"], sd["mel_encoder.in_proj.bias"]).transpose(1, 2)
+        for l in range(conv_layers):
+            q = "mel_encoder.conv.%d." % l
+            w = sd[q + "conv.conv.weight"]
+            y = F.conv1d(x, w, sd[q + "conv.conv.bias"], padding=w.shape[-1] // 2)
+            y = F.group_norm(y, w.shape[0] // 16, sd[q + "norm.weight"], sd[q + "norm.bias"], 1e-5)
+            x = x + F.relu(y)
+        x = F.linear(x.transpose(1, 2), sd["mel_encoder.out_proj.weight"], sd["mel_encoder.out_proj.bias"])
+    B, T, H = x.shape
+    m = x[..., 0].ne(0).int()
+    positions = (torch.cumsum(m, dim=1).type_as(m) * m).long()
+    tab = sinusoid_table(max(4096, T + 1), H)
+    x = x + sd["pitch_predictor.pos_embed_alpha"] * tab.index_select(0, positions.view(-1)).view(B, T, -1)
+    x = x.transpose(1, 2)
+    for l in range(5):
+        q = "pitch_predictor.conv.%d." % l
+        w = sd[q + "1.weight"]
+        k = w.shape[-1]
+        x = F.relu(F.conv1d(F.pad(x, ((k - 1) // 2, (k - 1) // 2)), w, sd[q + "1.bias"]))
+        x = F.layer_norm(x.transpose(1, 2), (w.shape[0],), sd[q + "3.weight"], sd[q + "3.bias"], 1e-12).transpose(1, 2)
+    pred = F.linear(x.transpose(1, 2), sd["pitch_predictor.linear.weight"], sd["pitch_predictor.linear.bias"])
+    f0 = pred[:, :, 0]
+    if hp["pitch_norm"] == "standard":
+        f0 = f0 * hp["f0_std"] + hp["f0_mean"]
+    if hp["pitch_norm"] == "log":
+        f0 = 2 ** f0
+    else:
+        f0 = f0.clone()
+    if hp["pitch_type"] == "frame" and hp["use_uv"]:
+        f0[pred[:, :, 1] > 0] = 0
+    f0[pad] = 0
+    return pred, f0

@@ -262,6 +262,8 @@ def main():
         return golden_hifigan_24k()
     if "--hubert-only" in sys.argv:
         return golden_hubert()
+    if "--pe-only" in sys.argv:
+        return golden_pe()
     golden_state_keys()
     golden_vocoder("vocoder_tiny", synth.tiny_vocoder(), 5, clips=[0, 3], T=24, seed=90)
     golden_vocoder("vocoder_44k", dict(synth.VOCODER_44K), 1, clips=[1], T=12, seed=91)
@@ -279,6 +281,7 @@ def main():
     golden_24k()
     golden_hifigan_24k()
     golden_hubert()
+    golden_pe()
     golden_plms_conditioned()
     golden_slicer()
     golden_slicer_demo_input()
@@ -416,6 +419,41 @@ def golden_hubert(name="hubert_units", lengths=(16000, 33333), wseed=11):
     with open(os.path.join(OUT, "state_keys.json")) as f:
         keys = _json.load(f)
     keys["hubert_soft"] = {k: list(v.shape) for k, v in HubertSoft().state_dict().items()}
+    with open(os.path.join(OUT, "state_keys.json"), "w") as f:
+        _json.dump(keys, f, indent=0, sort_keys=True)
+
+
+PE_CASES = (  # (B, T, zero tail frames per clip, use_uv)
+    (2, 50, (0, 7), False), (1, 300, (0,), False), (2, 20, (3, 0), False), (3, 33, (0, 5, 33), True))
+
+
+def golden_pe(name="pe_24k", wseed=5):
+    """PitchExtractor of the REAL reference (modules/fastspeech/pe.py) on a synthetic checkpoint (strict load, eval) at the 24 kHz
+    demo shapes (80 mel bins, hidden 256): ragged padding tails, a clip shorter than 32 frames, an all-padding clip, and use_uv."""
+    hp = dict(synth.HPARAMS_24K)
+    refshim.set_hparams(hp)
+    from modules.fastspeech.pe import PitchExtractor
+    from utils.hparams import hparams as ref_hp
+    sd = synth.pe_state(hp, wseed)
+    m = PitchExtractor()
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    out = {"wseed": wseed}
+    for i, (B, T, tails, use_uv) in enumerate(PE_CASES):
+        ref_hp["use_uv"] = use_uv
+        mel = torch.from_numpy(synth.mel_like(40 + i, B, T, 80, tails))
+        with torch.no_grad():
+            r = m(mel)
+        out["pitch_pred%d" % i] = r["pitch_pred"].numpy()
+        out["f0_%d" % i] = r["f0_denorm_pred"].numpy()
+        f = r["f0_denorm_pred"]
+        print(name, (B, T, tails, use_uv), "f0 range %.1f..%.1f Hz, zeros %d" % (f[f > 0].min().item(), f.max().item(), int((f == 0).sum())))
+    ref_hp["use_uv"] = hp["use_uv"]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    import json as _json
+    with open(os.path.join(OUT, "state_keys.json")) as f:
+        keys = _json.load(f)
+    keys["pitch_extractor"] = {k: list(v.shape) for k, v in PitchExtractor().state_dict().items()}
     with open(os.path.join(OUT, "state_keys.json"), "w") as f:
         _json.dump(keys, f, indent=0, sort_keys=True)
 

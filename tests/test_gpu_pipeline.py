@@ -302,3 +302,40 @@ def test_denoiser_seam_recomputes_cond_projections_for_a_new_tensor_at_a_recycle
         den(spec.cuda(), torch.tensor([hp["timesteps"]]).cuda(), cond=c1)
     with pytest.raises(ValueError):
         den(spec.cuda(), torch.tensor([-1]).cuda(), cond=c1)
+
+
+def test_use_pe_drives_the_vocoder_with_the_extracted_f0():
+    """Svc.infer(use_pe=True) (infer_tool.py:165-166): the vocoder's f0 is PitchExtractor(mel_out)['f0_denorm_pred'], not the input f0.
+    A full batch and a ragged one (each clip's extractor run sees only its own frames, as the reference's B=1 loop does): the f0 the
+    oracle extracts from the SAME sampled mel, through the oracle vocoder, must give the pipeline's PCM."""
+    from diffsvc_amd.pipeline import SvcPipeline
+    hp = synth.tiny_hparams(K=20)
+    h = synth.tiny_vocoder(num_mels=hp["audio_num_mel_bins"])
+    sd, vs = synth.acoustic_state(hp, 3), synth.vocoder_state(h, 5)
+    M = hp["audio_num_mel_bins"]
+    ps = synth.pe_state(hp, 4, n_mel=M)
+    pipe = SvcPipeline(hp, sd, vs, h, precision="f16_x3", vocoder_precision="f16_x3", pe_state=ps)
+    hop = int(np.prod(h["upsample_rates"]))
+    gw = O.fold_weight_norm(vs)
+    clips, lens, T, seed = [3, 8, 5], [40, 40, 40], 40, 23
+    for lens in ([40, 40, 40], [40, 26, 33]):
+        n_units_of = lambda l: max(2, (l * 23) // 40)
+        hub, m2p, f0, _ = _ragged_inputs(hp, clips, lens, n_units_of, T)
+        ids = torch.tensor(clips, dtype=torch.int32, device="cuda")
+        wav, mel = pipe.infer(hub.cuda(), m2p.cuda(), f0.cuda(), seed=seed, clip_ids=ids, return_mel=True, use_pe=True)
+        plain = pipe.infer(hub.cuda(), m2p.cuda(), f0.cuda(), seed=seed, clip_ids=ids)
+        assert not torch.allclose(wav, plain, atol=1e-3)              # the extracted f0 really is what drives the source
+        for i, (c, l) in enumerate(zip(clips, lens)):
+            m_i = mel[i, :l].cpu()
+            with torch.no_grad():
+                _, f0_ref = O.pitch_extractor(ps, m_i[None], hp)
+            mel_k, f0_k = O.after_infer_mel(m_i.numpy(), f0_ref[0].numpy(), hp)
+            ini, nz = O.vocoder_rng(seed, [c], l * hop)
+            ref = O.spec2wav(gw, h, mel_k, f0_k, ini, nz)
+            rms = (wav[i, :l * hop].cpu() - ref).pow(2).mean().sqrt().item()
+            print("use_pe lens=%s clip %d: wav RMS err %.2e" % (lens, c, rms))
+            assert rms < 1e-4, (lens, i, rms)
+            assert (wav[i, l * hop:] == 0).all()
+    bare = SvcPipeline(hp, sd, vs, h, precision="f16_x3")
+    with pytest.raises(RuntimeError, match="pe_state"):
+        bare.infer(hub.cuda(), m2p.cuda(), f0.cuda(), use_pe=True)

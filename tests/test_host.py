@@ -257,3 +257,22 @@ def test_hubert_checkpoint_keys_match_reference():
     """The synthetic HuBERT-soft checkpoint carries exactly the keys / shapes of the real HubertSoft.state_dict() (strict load)."""
     ref = _keys()["hubert_soft"]
     assert {k: list(v.shape) for k, v in synth.hubert_state(0).items()} == ref
+
+
+def test_pe_checkpoint_keys_match_reference():
+    """synth.pe_state mints exactly PitchExtractor().state_dict()'s keys and shapes (the reference loads it strictly, tts.py:113)."""
+    ref = _keys()["pitch_extractor"]
+    assert {k: list(v.shape) for k, v in synth.pe_state(dict(synth.HPARAMS_24K), 0).items()} == ref
+
+
+def test_pe_expected_keys_and_position_table():
+    """PitchExtractorHip's strict-load key table equals the real module's state_dict (names, shapes, order), and its sinusoid table is
+    bit-identical to the oracle's restatement of SinusoidalPositionalEmbedding.get_embedding."""
+    from diffsvc_amd.pe import expected_keys, position_table
+    import dsvc_oracle as O
+    ref = _keys()["pitch_extractor"]
+    got = expected_keys(80, 256, 256, 2)
+    assert {k: list(v) for k, v in got.items()} == ref
+    assert list(got.keys()) == list(synth.pe_state(dict(synth.HPARAMS_24K), 0).keys())
+    for rows, dim in ((4096, 256), (37, 32), (5000, 384)):
+        assert torch.equal(position_table(rows, dim), O.sinusoid_table(rows, dim))

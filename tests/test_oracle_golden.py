@@ -153,3 +153,23 @@ def test_hubert_soft_units_match_reference():
             u = O.hubert_units(sd, wav)[0]
         assert u.shape == g["units%d" % i].shape
         assert (u - torch.from_numpy(g["units%d" % i])).abs().max().item() < 2e-4
+
+
+PE_CASES = ((2, 50, (0, 7), False), (1, 300, (0,), False), (2, 20, (3, 0), False), (3, 33, (0, 5, 33), True))   # as oracle/make_golden.py
+
+
+def test_pitch_extractor_matches_reference():
+    """The oracle's functional restatement of PitchExtractor.forward (pe.py:136-148) against the REAL module (strict load, eval) on a
+    synthetic checkpoint: ragged zero tails, a clip under 32 frames, an all-padding clip, and the use_uv branch of denorm_f0."""
+    g = load_golden("pe_24k")
+    hp = dict(synth.HPARAMS_24K)
+    sd = synth.pe_state(hp, int(g["wseed"]))
+    for i, (B, T, tails, use_uv) in enumerate(PE_CASES):
+        mel = torch.from_numpy(synth.mel_like(40 + i, B, T, 80, tails))
+        with torch.no_grad():
+            pred, f0 = O.pitch_extractor(sd, mel, dict(hp, use_uv=use_uv))
+        assert (pred - torch.from_numpy(g["pitch_pred%d" % i])).abs().max().item() < 1e-5
+        ref = torch.from_numpy(g["f0_%d" % i])
+        assert torch.equal(f0 == 0, ref == 0)
+        assert ((f0 - ref).abs() / ref.clamp(min=1)).max().item() < 1e-5
+
