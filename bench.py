@@ -73,12 +73,15 @@ def dominant_kernel_roofline(handle, B, precision):
     return roof
 
 
+SAMPLER_SOURCES = ("common.h", "common.hip", "tgemm.h", "tlayer.h", "diffnet_t.h", "diffnet_kernels.h", "diffnet.hip")
+
+
 def kernel_sources_sha():
-    """sha256 of the HIP sources the kernels are built from: a PMC traffic file measured on other sources is stale."""
+    """sha256 of the HIP sources the DiffNet / sampler kernels are built from: a PMC traffic file measured on other sources is stale."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "diff-svc_amd", "csrc", "*"))):
-        with open(f, "rb") as fh:
-            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    for name in SAMPLER_SOURCES:
+        with open(os.path.join(ROOT, "diff-svc_amd", "csrc", name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 
