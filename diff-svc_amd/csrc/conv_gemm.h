@@ -63,11 +63,14 @@ constexpr int min_waves_per_simd(int wm_tiles, int waves) { return wm_tiles <= 2
 
 // latency tilings (one 32-frame tile) cap their registers at 256 so two workgroups share a CU; the
 // 128-frame throughput tiling needs 128 accumulators + staging and runs one wave per SIMD.
-template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int PF, int SPT, int NW, int NA, class Epi>
-__global__ void __launch_bounds__(64 * WAVES_N * WAVES_K, min_waves_per_simd(WM_TILES, WAVES_N * WAVES_K))
+// WAVES_M > 1: several waves take consecutive 32*WM_TILES-row slabs of ONE staged time tile (more waves per CU for the same halo and LDS
+// planes: the vocoder's narrow stages, where a one-wave workgroup leaves the CU with under one wave per SIMD).
+template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int PF, int SPT, int NW, int NA, class Epi, int WAVES_M = 1>
+__global__ void __launch_bounds__(64 * WAVES_N * WAVES_K * WAVES_M, min_waves_per_simd(WM_TILES, WAVES_N * WAVES_K * WAVES_M))
 conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
-    constexpr int NT = 64 * WAVES_N * WAVES_K;
-    constexpr int TM = 32 * WM_TILES;
+    constexpr int NT = 64 * WAVES_N * WAVES_K * WAVES_M;
+    constexpr int TM = 32 * WM_TILES * WAVES_M;
+    static_assert(WAVES_M == 1 || WAVES_K == 1, "row-split and k-split waves are not combined");
     constexpr int TN = 64 * WAVES_N;
     constexpr int KCW = KCB / WAVES_K;   // channels of a staged chunk owned by one k-slice wave
     constexpr int KS = KCW / 16;         // k16 steps per tap per chunk per wave
@@ -92,7 +95,8 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WAVES_N;
-    const int kz = wave / WAVES_N;
+    const int kz = (wave / WAVES_N) % WAVES_K;
+    const int wm = wave / (WAVES_N * WAVES_K);          // row slab of this wave inside the staged tile
     const int ct0 = (cg * WAVES_N + wn) * 2;          // first of this wave's two column tiles
     const bool active = ct0 < a.n_ctiles;
 
@@ -230,7 +234,7 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
         if (active) {
             for (int tap = 0; tap < a.taps; ++tap) {
                 const int roff = halo + (tap - a.taps / 2) * a.dil;
-                const _Float16* xrow = xs + (roff + arow) * XS + kz * KCW + acol;
+                const _Float16* xrow = xs + (roff + wm * (32 * WM_TILES) + arow) * XS + kz * KCW + acol;
 #pragma unroll
                 for (int ksg = 0; ksg < KS; ksg += PF) {
 #pragma unroll
@@ -280,7 +284,7 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
         for (int m = 0; m < WM_TILES; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = row0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = row0 + (wm * WM_TILES + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < a.n_rows) {
                     if constexpr (Epi::PAIRED) {
                         epi.pair(ea, row, ct0, lane & 31, acc[m][0][r], acc[m][1][r]);
@@ -339,24 +343,24 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
 }
 
 // LDS bytes a launch needs (x tile planes, or the split-K partial tiles, whichever is larger)
-template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int NA>
+template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int NA, int WAVES_M = 1>
 inline size_t conv_gemm_smem(int taps, int dil, int cin) {
     const int halo = (taps / 2) * dil;
-    size_t x = (size_t)NA * (32 * WM_TILES + 2 * halo) * (KCB + 8) * sizeof(_Float16);
+    size_t x = (size_t)NA * (32 * WM_TILES * WAVES_M + 2 * halo) * (KCB + 8) * sizeof(_Float16);
     x = ((x + 15) & ~(size_t)15) + (size_t)cin * sizeof(float);          // + the FiLM vector
     size_t p = WAVES_K > 1 ? (size_t)WAVES_K * 32 * WM_TILES * 64 * WAVES_N * sizeof(float) : 0;
     return x > p ? x : p;
 }
 
-template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int PF, int SPT, int NW, int NA, class Epi>
+template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int PF, int SPT, int NW, int NA, class Epi, int WAVES_M = 1>
 inline int conv_gemm_launch(const ConvGemmArgs& a, const typename Epi::Args& ea, hipStream_t stream) {
     if (a.cin % KCB != 0) return fail(DSVC_EINVAL, "conv_gemm: cin %d not a multiple of the staged chunk %d", a.cin, KCB);
     if (a.w_planes < NW) return fail(DSVC_EINVAL, "conv_gemm: weights packed with %d plane(s), kernel needs %d", a.w_planes, NW);
     if (a.ldx % 4 != 0) return fail(DSVC_EINVAL, "conv_gemm: ldx %d not a multiple of 4", a.ldx);
     if (a.n_ctiles & 1) return fail(DSVC_EINVAL, "conv_gemm: odd column-tile count %d", a.n_ctiles);
     if (a.clip_stride < 32) return fail(DSVC_EINVAL, "conv_gemm: clip_stride %d < 32", a.clip_stride);
-    auto kern = conv_gemm_kernel<WM_TILES, WAVES_N, WAVES_K, KCB, PF, SPT, NW, NA, Epi>;
-    const size_t smem = conv_gemm_smem<WM_TILES, WAVES_N, WAVES_K, KCB, NA>(a.taps, a.dil, a.cin);
+    auto kern = conv_gemm_kernel<WM_TILES, WAVES_N, WAVES_K, KCB, PF, SPT, NW, NA, Epi, WAVES_M>;
+    const size_t smem = conv_gemm_smem<WM_TILES, WAVES_N, WAVES_K, KCB, NA, WAVES_M>(a.taps, a.dil, a.cin);
     if (smem > 160 * 1024) return fail(DSVC_EINVAL, "conv_gemm: %zu B of LDS requested", smem);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {
@@ -364,9 +368,9 @@ inline int conv_gemm_launch(const ConvGemmArgs& a, const typename Epi::Args& ea,
         smem_set = smem;
     }
     const int ncg = ceil_div(a.n_ctiles, 2 * WAVES_N);
-    const int nrt = ceil_div(a.n_rows, 32 * WM_TILES);
+    const int nrt = ceil_div(a.n_rows, 32 * WM_TILES * WAVES_M);
     const int grid = round_up(nrt, 8) * ncg;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES_N * WAVES_K), smem, stream, a, ea);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES_N * WAVES_K * WAVES_M), smem, stream, a, ea);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }

@@ -14,6 +14,7 @@
 
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "conv_gemm.h"
@@ -82,6 +83,17 @@ struct EpiTanhWav {
 template <class Epi, int NW, int NA>
 int voc_tiling(const ConvGemmArgs& a, const typename Epi::Args& e, hipStream_t st) {
     if (a.cin % 64 == 0) {
+        if constexpr (NW == 2 && NA == 2 && std::is_same<Epi, EpiAffine>::value) {
+            // The shipped (fp32-class) MRF convs: two waves per SIMD (<= 256 VGPRs: 2 x 2 accumulator tiles per wave) and several
+            // row slabs per staged tile beat the one-wave-per-SIMD 128-row tiles above by 10-40 % per stage (profiles/r2k_ab.txt,
+            // r2l_ab.txt: 221 -> 175 ms per 32 clips, 9.1 -> 7.7 ms per clip).            WM WN WK KCB PF SPT        row slabs
+            if (a.n_ctiles >= 8) {
+                if (a.n_rows < 65536) return conv_gemm_launch<1, 4, 1, 64, 4, 2, NW, NA, Epi, 1>(a, e, st);   // few rows: 32-row tiles fill the chip
+                return conv_gemm_launch<2, 4, 1, 32, 2, 3, NW, NA, Epi, 2>(a, e, st);
+            }
+            if (a.n_ctiles >= 4) return conv_gemm_launch<2, 2, 1, 32, 2, 3, NW, NA, Epi, 4>(a, e, st);
+            return conv_gemm_launch<2, 1, 1, 32, 2, 3, NW, NA, Epi, 8>(a, e, st);
+        }
         //                                                 WM WN WK KCB PF SPT
         if (a.n_ctiles >= 8) return conv_gemm_launch<4, 4, 1, 64, 4, 6, NW, NA, Epi>(a, e, st);
         if (a.n_ctiles >= 4) return conv_gemm_launch<4, 2, 1, 64, 4, 6, NW, NA, Epi>(a, e, st);
