@@ -252,6 +252,210 @@ int resblock_pair_launch(const float* x, float* out, const float* w1, const floa
     return DSVC_OK;
 }
 
+// ---- the same fused pair on the matrix cores (C = 16 / 32 / 64) ----
+// One workgroup of W waves owns 32*(2W-1) output rows.  lrelu(x) for those rows plus both convs' halos is staged ONCE as split fp16
+// (hi + lo planes, row stride C+8 halfs: conflict-free ds_read_b128); conv1 runs as the TRANSPOSED product (weights as the A operand),
+// so a lane ends up holding 4 consecutive channels of ONE row of the intermediate activation and parks lrelu(b1 + .) back into LDS
+// with 8-byte writes -- over the x tile, which is dead by then; conv2 reads it from there and its epilogue (bias + residual + MRF
+// scale / accumulate) writes 128-byte row segments.  Products are the three-MFMA split (x_hi w_hi + x_hi w_lo + x_lo w_hi: fp32-class,
+// as the rest of the shipped vocoder); each wave keeps 2 row tiles so a 1 KiB weight fragment (streamed from L2 in conv_gemm's
+// fragment order through a 4-deep register ring) feeds 6 MFMAs.
+template <int C, int W>
+__global__ void __launch_bounds__(64 * W, 2)
+k_pair_mfma(const float* __restrict__ x, float* __restrict__ out, const _Float16* __restrict__ w1, const float* __restrict__ b1,
+            const _Float16* __restrict__ w2, const float* __restrict__ b2, int k, int d, int n_rows, int stride, int len, float alpha, int accumulate) {
+    constexpr int MT = 2;                      // row tiles per wave
+    constexpr int MM = W * MT;                 // intermediate row tiles (32 rows each)
+    constexpr int MO = MM - 1;                 // output row tiles
+    constexpr int NT = (C + 31) / 32;          // 32-column tiles
+    constexpr int KS = C / 16;                 // k16 steps per tap
+    constexpr int XS = C + 8;                  // LDS row stride in halfs
+    constexpr int RD = 4;                      // weight ring depth (steps)
+    constexpr int NTH = 64 * W;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);
+    const int h2 = k >> 1, h1 = h2 * d;
+    const int XR = 32 * MM + 2 * h1;           // staged x rows: row r <-> global row tile0 - h2 - h1 + r
+    const int xplane = XR * XS;                // halfs per x plane (hi, then lo)
+    constexpr int mplane = 32 * MM * XS;       // halfs per plane of the intermediate (aliases the x planes)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long tile0 = (long long)blockIdx.x * (32 * MO);
+    auto valid = [&](long long g) { return g >= 0 && g < n_rows && (int)(g % stride) < len; };
+    const int nk16 = KS;
+    const size_t tile_halfs = (size_t)k * nk16 * 2 * 512;      // one 32-column tile of a packed conv: [tap][k16][plane 2][lane][8]
+    // step s = tap * KS + ks; fragment (n, plane) of step s
+    auto wload = [&](const _Float16* w, half8 (&dst)[NT][2], int s) {
+        const _Float16* p = w + (size_t)s * (2 * 512) + lane * 8;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            dst[n][0] = *reinterpret_cast<const half8*>(p + n * tile_halfs);
+            dst[n][1] = *reinterpret_cast<const half8*>(p + n * tile_halfs + 512);
+        }
+    };
+    const int S = k * KS;
+    half8 ring[RD][NT][2];
+#pragma unroll
+    for (int u = 0; u < RD; ++u)
+        if (u < S) wload(w1, ring[u], u);
+    // ---- stage lrelu(x) as fp16 hi | lo ----
+    {
+        constexpr int IPR = C / 8;
+        const int items = XR * IPR;
+        for (int i = tid; i < items; i += NTH) {
+            const int r = i / IPR, c8 = (i - r * IPR) * 8;
+            const long long g = tile0 - h2 - h1 + r;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (valid(g)) {
+                const f32x4v a = *reinterpret_cast<const f32x4v*>(x + (size_t)g * C + c8);
+                const f32x4v b = *reinterpret_cast<const f32x4v*>(x + (size_t)g * C + c8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = a[e] > 0.f ? a[e] : 0.1f * a[e]; v[4 + e] = b[e] > 0.f ? b[e] : 0.1f * b[e]; }
+            }
+            half8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+            *reinterpret_cast<half8*>(lds + r * XS + c8) = hi;
+            *reinterpret_cast<half8*>(lds + xplane + r * XS + c8) = lo;
+        }
+    }
+    __syncthreads();
+    const int arow = lane & 31, acol = 8 * (lane >> 5);
+    // ---- conv1 (dilation d), transposed: acc1[m][n][r] = mid[row 32*(wave*MT+m) + (lane&31)][channel 32n + (r&3) + 8(r>>2) + 4(lane>>5)] ----
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    for (int s0 = 0; s0 < S; s0 += RD) {
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+            const int s = s0 + u;
+            if (s < S) {
+                const int tap = s / KS, ks = s - tap * KS;
+                half8 wf[NT][2];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) { wf[n][0] = ring[u][n][0]; wf[n][1] = ring[u][n][1]; }
+                if (s + RD < S) wload(w1, ring[u], s + RD);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const _Float16* xr = lds + (32 * (wave * MT + m) + arow + tap * d) * XS + ks * 16 + acol;
+                    const half8 xh = *reinterpret_cast<const half8*>(xr);
+                    const half8 xl = *reinterpret_cast<const half8*>(xr + xplane);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n][0], xh, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n][1], xh, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n][0], xl, acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // conv2's first weight fragments fly while the intermediate is parked
+#pragma unroll
+    for (int u = 0; u < RD; ++u)
+        if (u < S) wload(w2, ring[u], u);
+    __syncthreads();                                   // every wave is done reading the x tile
+    // ---- lrelu(b1 + conv1) -> LDS (hi | lo), zero on rows outside the clip (conv2's zero padding) ----
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int j = 32 * (wave * MT + m) + arow;
+        const bool ok = valid(tile0 - h2 + j);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = 32 * n + 8 * q + 4 * (lane >> 5);
+                if (ch < C) {
+                    const f32x4v bb = *reinterpret_cast<const f32x4v*>(b1 + ch);
+                    half4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[m][n][4 * q + e] + bb[e];
+                        v = v > 0.f ? v : 0.1f * v;
+                        if (!ok) v = 0.f;
+                        hi[e] = (_Float16)v;
+                        lo[e] = (_Float16)(v - (float)hi[e]);
+                    }
+                    *reinterpret_cast<half4*>(lds + j * XS + ch) = hi;
+                    *reinterpret_cast<half4*>(lds + mplane + j * XS + ch) = lo;
+                }
+            }
+    }
+    __syncthreads();
+    // ---- conv2 (dilation 1): acc[m][n][r] = out[row 32*(wave*MT+m) + (r&3) + 8(r>>2) + 4(lane>>5)][column 32n + (lane&31)] ----
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    for (int s0 = 0; s0 < S; s0 += RD) {
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+            const int s = s0 + u;
+            if (s < S) {
+                const int tap = s / KS, ks = s - tap * KS;
+                half8 wf[NT][2];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) { wf[n][0] = ring[u][n][0]; wf[n][1] = ring[u][n][1]; }
+                if (s + RD < S) wload(w2, ring[u], s + RD);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    if (wave * MT + m < MO) {
+                        const _Float16* tr = lds + (32 * (wave * MT + m) + arow + tap) * XS + ks * 16 + acol;
+                        const half8 th = *reinterpret_cast<const half8*>(tr);
+                        const half8 tl = *reinterpret_cast<const half8*>(tr + mplane);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, wf[n][0], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, wf[n][1], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, wf[n][0], acc[m][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- out = alpha * (x + b2 + conv2) [+ out], zero on gap rows ----
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (wave * MT + m >= MO) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = 32 * n + (lane & 31);
+            if (col >= C) continue;
+            const float bias = b2[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long g = tile0 + 32 * (wave * MT + m) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (g >= n_rows) continue;
+                float o = 0.f;
+                if ((int)(g % stride) < len) {
+                    o = alpha * (acc[m][n][r] + bias + x[(size_t)g * C + col]);
+                    if (accumulate) o += out[(size_t)g * C + col];
+                }
+                out[(size_t)g * C + col] = o;
+            }
+        }
+    }
+}
+
+template <int C, int W>
+int pair_mfma_launch(const float* x, float* out, const _Float16* w1, const float* b1, const _Float16* w2, const float* b2, int k, int d,
+                     int n_rows, int stride, int len, float alpha, int accumulate, hipStream_t st) {
+    const int h1 = (k / 2) * d;
+    const size_t smem = (size_t)2 * (32 * 2 * W + 2 * h1) * (C + 8) * sizeof(_Float16);
+    if (smem > 64 * 1024) return fail(DSVC_EINVAL, "resblock pair (mfma): %zu B of LDS", smem);
+    hipLaunchKernelGGL((k_pair_mfma<C, W>), dim3(ceil_div(n_rows, 32 * (2 * W - 1))), dim3(64 * W), smem, st, x, out, w1, b1, w2, b2, k, d, n_rows,
+                       stride, len, alpha, accumulate);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
 // ---- small kernels ----
 
 // mel [B][T][M] (log10) -> frame-major [B*stride][M] natural log (nsf_hifigan.py:63-65: c = 2.30259 * mel)
@@ -622,7 +826,28 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
         for (int j = 0; j < nk; ++j) {
             for (int m = 0; m < 3; ++m) {
                 const size_t idx = ((size_t)i * nk + j) * 3 + m;
-                static const bool no_fused = getenv("DSVC_VOC_NO_FUSED") && atoi(getenv("DSVC_VOC_NO_FUSED"));   // A/B knob
+                static const bool no_fused = getenv("DSVC_VOC_NO_FUSED") && atoi(getenv("DSVC_VOC_NO_FUSED"));   // A/B knobs
+                static const bool pair_f32 = getenv("DSVC_VOC_PAIR_F32") && atoi(getenv("DSVC_VOC_PAIR_F32"));
+                const int pk = rb1[idx].taps, pd = rb1[idx].dil;
+                const bool mfma_pair = prec == DSVC_PREC_F16_X3 && !no_fused && !pair_f32 && (cout == 16 || cout == 32 || cout == 64) &&
+                                       rb2[idx].taps == pk && rb2[idx].dil == 1 &&
+                                       (size_t)2 * (32 * 2 * (cout == 64 ? 2 : 4) + 2 * (pk / 2) * pd) * (cout + 8) * 2 <= 64 * 1024;
+                if (mfma_pair) {
+                    // one LDS-fused MFMA kernel per conv pair; ping-pong U -> A -> Tm -> S (the kernel reads its input with halos, so it
+                    // cannot run in place)
+                    const float* fin = (m == 0) ? U : (m == 1 ? A : Tm);
+                    float* fout = (m == 0) ? A : (m == 1 ? Tm : S);
+                    const float al = (m == 2) ? 1.0f / (float)nk : 1.0f;
+                    const int accu = (m == 2 && j > 0) ? 1 : 0;
+                    const _Float16* pw1 = rb1[idx].w.as<_Float16>();
+                    const _Float16* pw2 = rb2[idx].w.as<_Float16>();
+                    const float* pb1 = rb1[idx].bias.as<float>();
+                    const float* pb2 = rb2[idx].bias.as<float>();
+                    if (cout == 16) DSVC_TRY((pair_mfma_launch<16, 4>(fin, fout, pw1, pb1, pw2, pb2, pk, pd, rows, stride, len, al, accu, st)));
+                    else if (cout == 32) DSVC_TRY((pair_mfma_launch<32, 4>(fin, fout, pw1, pb1, pw2, pb2, pk, pd, rows, stride, len, al, accu, st)));
+                    else DSVC_TRY((pair_mfma_launch<64, 2>(fin, fout, pw1, pb1, pw2, pb2, pk, pd, rows, stride, len, al, accu, st)));
+                    continue;
+                }
                 if (rb1_f32[idx].p && !no_fused) {
                     // narrow stage: one LDS-fused kernel per conv pair; ping-pong U -> A -> Tm -> S (the pair kernel reads its
                     // input with halos, so it cannot run in place)
