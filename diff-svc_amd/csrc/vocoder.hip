@@ -254,16 +254,19 @@ int resblock_pair_launch(const float* x, float* out, const float* w1, const floa
 
 // ---- the same fused pair on the matrix cores (C = 16 / 32 / 64) ----
 // One workgroup of W waves owns 32*(2W-1) output rows.  lrelu(x) for those rows plus both convs' halos is staged ONCE as split fp16
-// (hi + lo planes, row stride C+8 halfs: conflict-free ds_read_b128); conv1 runs as the TRANSPOSED product (weights as the A operand),
-// so a lane ends up holding 4 consecutive channels of ONE row of the intermediate activation and parks lrelu(b1 + .) back into LDS
-// with 8-byte writes -- over the x tile, which is dead by then; conv2 reads it from there and its epilogue (bias + residual + MRF
-// scale / accumulate) writes 128-byte row segments.  Products are the three-MFMA split (x_hi w_hi + x_hi w_lo + x_lo w_hi: fp32-class,
-// as the rest of the shipped vocoder); each wave keeps 2 row tiles so a 1 KiB weight fragment (streamed from L2 in conv_gemm's
-// fragment order through a 4-deep register ring) feeds 6 MFMAs.
+// (hi + lo planes, row stride C+8 halfs: conflict-free ds_read_b128).  Both convs run as the TRANSPOSED product (weights as the A
+// operand), so a lane ends up holding 4 consecutive channels of ONE row: conv1 parks lrelu(b1 + .) back into LDS with 8-byte writes
+// -- over the x tile, which is dead by then -- and conv2's epilogue (bias + residual + MRF scale / accumulate) moves 16 bytes per
+// access.  Products are the three-MFMA split (x_hi w_hi + x_hi w_lo + x_lo w_hi: fp32-class, as the rest of the shipped vocoder);
+// each wave keeps 2 row tiles, so a 1 KiB weight fragment (streamed from L2 in conv_gemm's fragment order through a 4-deep register
+// ring) feeds 6 MFMAs.
+// Measured at 32 clips (profiles/r2o_pair_ablate.txt, DSVC_PAIR_DBG): C = 64 / 32 / 16: 1.99 / 1.12 / 1.01 ms per pair, of which the
+// two MFMA loops are 1.1 / 0.44 / 0.42 ms = 78-90 % of the matrix rate the chip sustains on real data, staging + LDS park
+// 0.49 / 0.30 / 0.32 and the epilogue 0.3-0.4: the phases of a workgroup do not overlap, the rest is occupancy (LDS: 3-5 per CU).
 template <int C, int W>
 __global__ void __launch_bounds__(64 * W, 2)
 k_pair_mfma(const float* __restrict__ x, float* __restrict__ out, const _Float16* __restrict__ w1, const float* __restrict__ b1,
-            const _Float16* __restrict__ w2, const float* __restrict__ b2, int k, int d, int n_rows, int stride, int len, float alpha, int accumulate) {
+            const _Float16* __restrict__ w2, const float* __restrict__ b2, int k, int d, int n_rows, int stride, int len, float alpha, int accumulate, int dbg) {
     constexpr int MT = 2;                      // row tiles per wave
     constexpr int MM = W * MT;                 // intermediate row tiles (32 rows each)
     constexpr int MO = MM - 1;                 // output row tiles
@@ -280,8 +283,12 @@ k_pair_mfma(const float* __restrict__ x, float* __restrict__ out, const _Float16
     constexpr int mplane = 32 * MM * XS;       // halfs per plane of the intermediate (aliases the x planes)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long tile0 = (long long)blockIdx.x * (32 * MO);
-    auto valid = [&](long long g) { return g >= 0 && g < n_rows && (int)(g % stride) < len; };
+    const int tile0 = blockIdx.x * (32 * MO);            // (n_rows < 2^31 - a tile: checked by the launcher)
+    // rows of a tile are consecutive: one division per tile, then offsets with a wrap
+    auto valid = [&](int g) {
+        if (g < 0 || g >= n_rows) return false;
+        return (g - (g / stride) * stride) < len;
+    };
     const int nk16 = KS;
     const size_t tile_halfs = (size_t)k * nk16 * 2 * 512;      // one 32-column tile of a packed conv: [tap][k16][plane 2][lane][8]
     // step s = tap * KS + ks; fragment (n, plane) of step s
@@ -304,7 +311,7 @@ k_pair_mfma(const float* __restrict__ x, float* __restrict__ out, const _Float16
         const int items = XR * IPR;
         for (int i = tid; i < items; i += NTH) {
             const int r = i / IPR, c8 = (i - r * IPR) * 8;
-            const long long g = tile0 - h2 - h1 + r;
+            const int g = tile0 - h2 - h1 + r;
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (valid(g)) {
                 const f32x4v a = *reinterpret_cast<const f32x4v*>(x + (size_t)g * C + c8);
@@ -329,7 +336,7 @@ k_pair_mfma(const float* __restrict__ x, float* __restrict__ out, const _Float16
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    for (int s0 = 0; s0 < S; s0 += RD) {
+    for (int s0 = 0; s0 < ((dbg & 1) ? 0 : S); s0 += RD) {
 #pragma unroll
         for (int u = 0; u < RD; ++u) {
             const int s = s0 + u;
@@ -386,14 +393,14 @@ k_pair_mfma(const float* __restrict__ x, float* __restrict__ out, const _Float16
             }
     }
     __syncthreads();
-    // ---- conv2 (dilation 1): acc[m][n][r] = out[row 32*(wave*MT+m) + (r&3) + 8(r>>2) + 4(lane>>5)][column 32n + (lane&31)] ----
+    // ---- conv2 (dilation 1), transposed as well: acc[m][n][r] = out[row 32*(wave*MT+m) + (lane&31)][channel 32n + (r&3) + 8(r>>2) + 4(lane>>5)] ----
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    for (int s0 = 0; s0 < S; s0 += RD) {
+    for (int s0 = 0; s0 < ((dbg & 1) ? 0 : S); s0 += RD) {
 #pragma unroll
         for (int u = 0; u < RD; ++u) {
             const int s = s0 + u;
@@ -411,36 +418,45 @@ k_pair_mfma(const float* __restrict__ x, float* __restrict__ out, const _Float16
                         const half8 tl = *reinterpret_cast<const half8*>(tr + mplane);
 #pragma unroll
                         for (int n = 0; n < NT; ++n) {
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, wf[n][0], acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, wf[n][1], acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, wf[n][0], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n][0], th, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n][1], th, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n][0], tl, acc[m][n], 0, 0, 0);
                         }
                     }
                 }
             }
         }
     }
-    // ---- out = alpha * (x + b2 + conv2) [+ out], zero on gap rows ----
+    // ---- out = alpha * (x + b2 + conv2) [+ out], zero on gap rows: a lane owns 4 consecutive channels of its row (16-byte accesses) ----
+    if (dbg & 2) return;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if (wave * MT + m >= MO) continue;
+        const int g = tile0 + 32 * (wave * MT + m) + arow;
+        if (g >= n_rows) continue;
+        const bool ok = (g - (g / stride) * stride) < len;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int col = 32 * n + (lane & 31);
-            if (col >= C) continue;
-            const float bias = b2[col];
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long g = tile0 + 32 * (wave * MT + m) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (g >= n_rows) continue;
-                float o = 0.f;
-                if ((int)(g % stride) < len) {
-                    o = alpha * (acc[m][n][r] + bias + x[(size_t)g * C + col]);
-                    if (accumulate) o += out[(size_t)g * C + col];
+            for (int q = 0; q < 4; ++q) {
+                const int ch = 32 * n + 8 * q + 4 * (lane >> 5);
+                if (ch < C) {
+                    f32x4v o = {0.f, 0.f, 0.f, 0.f};
+                    float* po = out + (size_t)g * C + ch;
+                    if (ok) {
+                        const f32x4v bb = *reinterpret_cast<const f32x4v*>(b2 + ch);
+                        const f32x4v xv = *reinterpret_cast<const f32x4v*>(x + (size_t)g * C + ch);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = alpha * (acc[m][n][4 * q + e] + bb[e] + xv[e]);
+                        if (accumulate) {
+                            const f32x4v pv = *reinterpret_cast<const f32x4v*>(po);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += pv[e];
+                        }
+                    }
+                    *reinterpret_cast<f32x4v*>(po) = o;
                 }
-                out[(size_t)g * C + col] = o;
             }
-        }
     }
 }
 
@@ -450,8 +466,10 @@ int pair_mfma_launch(const float* x, float* out, const _Float16* w1, const float
     const int h1 = (k / 2) * d;
     const size_t smem = (size_t)2 * (32 * 2 * W + 2 * h1) * (C + 8) * sizeof(_Float16);
     if (smem > 64 * 1024) return fail(DSVC_EINVAL, "resblock pair (mfma): %zu B of LDS", smem);
+    if (n_rows > 0x7fffff00 - 64 * W) return fail(DSVC_EINVAL, "resblock pair (mfma): %d rows", n_rows);
+    static const int dbg = getenv("DSVC_PAIR_DBG") ? atoi(getenv("DSVC_PAIR_DBG")) : 0;       // phase ablation (timing only): 1 = no MFMA loops, 2 = no epilogue
     hipLaunchKernelGGL((k_pair_mfma<C, W>), dim3(ceil_div(n_rows, 32 * (2 * W - 1))), dim3(64 * W), smem, st, x, out, w1, b1, w2, b2, k, d, n_rows,
-                       stride, len, alpha, accumulate);
+                       stride, len, alpha, accumulate, dbg);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
