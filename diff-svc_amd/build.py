@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdsvc_hip.so")
-SOURCES = ["common.hip", "diffnet.hip", "vocoder.hip", "melspec.hip", "train.hip", "hubert.hip", "pe.hip", "probe.hip"]
+SOURCES = ["common.hip", "diffnet.hip", "vocoder.hip", "melspec.hip", "train.hip", "hubert.hip", "pe.hip", "cond.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]       # the per-kernel register / scratch report is kept next to the object
 

@@ -1,8 +1,10 @@
 """Condition builder -- the ``no_fs2: true`` branch of ``FastSpeech2.forward`` (modules/fastspeech/fs2.py:94-154)
 with ``add_pitch`` (fs2.py:185-238): cond = (gather(pad(hubert), mel2ph) + pitch_embed[coarse(2**f0)]) * (mel2ph>0).
 
-Index work (f0 -> coarse pitch bin) is kept bit-exact by doing it with the same fp32 torch-CPU
-ops the reference CPU path uses; the gather / embedding / mask are exact data movement on the device.
+Index work (f0 -> coarse pitch bin) is kept exact: for host tensors with the same fp32 torch-CPU ops the
+reference CPU path uses; for device tensors by ``dsvc_pitch_coarse`` (csrc/cond.hip), a binary search over the fp32 thresholds
+at which that very expression steps to the next bin (``coarse_thresholds``: bisection with the reference expression, once per
+hparams) -- no device log/pow decides a bin and nothing leaves the device.  The gather / embedding / mask are exact data movement.
 Registered under the attribute name ``fs2`` so a reference checkpoint's ``fs2.*`` keys load strictly; the
 parameters the disabled FastSpeech2 branches own (mel_out, pitch_predictor) are accepted and kept as buffers."""
 import numpy as np
@@ -25,6 +27,48 @@ def f0_to_coarse(f0, hp):
     return coarse
 
 
+_THRESHOLDS = {}
+
+
+def _coarse_of(x, hp):
+    """The reference expression on ONE normalised pitch value: f0_to_coarse(2 ** x) as a [1, 1] fp32 tensor (scalar code path)."""
+    return int(f0_to_coarse(2 ** torch.tensor([[x]], dtype=torch.float32), hp)[0, 0])
+
+
+def coarse_thresholds(hp):
+    """fp32 thresholds thr[0..f0_bin-3] of the normalised pitch x = log2(f0): f0_to_coarse(2**x) == 1 + #{k: x >= thr[k]}.
+    thr[k] is the smallest fp32 x whose bin is >= k + 2, found by bisection over the (ordered) bit patterns of positive floats with
+    the reference expression itself; the result is checked for a clean step at every threshold and on a random sample."""
+    key = (hp["f0_bin"], float(hp["f0_min"]), float(hp["f0_max"]))
+    if key in _THRESHOLDS:
+        return _THRESHOLDS[key]
+    as_bits = lambda v: int(np.float32(v).view(np.uint32))
+    as_float = lambda b: float(np.uint32(b).view(np.float32))
+    top = f0_to_coarse(torch.tensor([[float("inf")]]), hp).item()          # f0_bin - 1
+    lo_b, hi_b = as_bits(0.0), as_bits(64.0)
+    assert _coarse_of(as_float(lo_b), hp) == 1 and _coarse_of(as_float(hi_b), hp) == top
+    thr, start = [], lo_b
+    for k in range(2, top + 1):
+        a, b = start, hi_b                                                 # coarse(a) < k <= coarse(b)
+        while b - a > 1:
+            m = (a + b) // 2
+            if _coarse_of(as_float(m), hp) >= k:
+                b = m
+            else:
+                a = m
+        if not (_coarse_of(as_float(b), hp) >= k > _coarse_of(as_float(b - 1), hp)):
+            raise RuntimeError("f0_to_coarse is not a clean step function around bin %d on this host" % k)
+        thr.append(as_float(b))
+        start = b - 1 if b > lo_b else b
+    t = np.asarray(thr, dtype=np.float32)
+    assert np.all(np.diff(t) >= 0)
+    g = np.random.Generator(np.random.PCG64(7))
+    for x in np.concatenate([g.uniform(4.0, 11.0, 192).astype(np.float32), t[::16], np.nextafter(t[::16], np.float32(-1))]):
+        assert _coarse_of(float(x), hp) == 1 + int(np.searchsorted(t, x, side="right")), float(x)
+    _THRESHOLDS[key] = torch.from_numpy(t)
+    return _THRESHOLDS[key]
+
+
 class CondBuilder(nn.Module):
     def __init__(self, hparams, out_dims=None):
         super().__init__()
@@ -35,6 +79,7 @@ class CondBuilder(nn.Module):
         nn.init.normal_(self.pitch_embed.weight, mean=0, std=self.hidden_size ** -0.5)
         nn.init.constant_(self.pitch_embed.weight[self.padding_idx], 0)
         self._extras = {}          # checkpointed-but-unused fs2.* tensors (mel_out, pitch_predictor, ...)
+        self._thr_dev = None       # (device, thresholds) of the device pitch path
 
     # accept (and round-trip) the fs2.* tensors of the branches that are disabled by no_fs2 / use_pe=False
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
@@ -51,17 +96,25 @@ class CondBuilder(nn.Module):
         for k, v in self._extras.items():
             destination[prefix + k] = v
 
-    def forward(self, hubert, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
-                skip_decoder=True, spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, **kwargs):
+    def _pitch_device(self, f0, mel2ph, uv):
+        """f0_denorm and the coarse bin on the device (csrc/cond.hip): no host round trip, no synchronisation."""
+        import ctypes
+        from ._lib import check, lib, ptr, stream_ptr
+        hp, dev = self.hp, f0.device
+        if self._thr_dev is None or self._thr_dev[0] != dev:
+            self._thr_dev = (dev, coarse_thresholds(hp).to(dev))
+        thr = self._thr_dev[1]
+        x = f0.detach().to(torch.float32).contiguous()
+        m2p = mel2ph.to(torch.int64).contiguous()
+        uv_t = uv.to(dev, torch.float32).contiguous() if (uv is not None and hp.get("use_uv")) else None
+        f0_denorm = torch.empty(x.shape, device=dev, dtype=torch.float32)
+        coarse = torch.empty(x.shape, device=dev, dtype=torch.int64)
+        check(lib().dsvc_pitch_coarse(ptr(x), ptr(m2p), ptr(uv_t) if uv_t is not None else ctypes.c_void_p(0), ptr(thr), thr.numel(),
+                                      x.numel(), ptr(f0_denorm), ptr(coarse), stream_ptr()))
+        return f0_denorm, coarse
+
+    def _pitch_host(self, f0, mel2ph, uv):
         hp = self.hp
-        if hp.get("use_spk_embed") or hp.get("use_spk_id") or hp.get("use_energy_embed") or not hp.get("no_fs2", False):
-            raise NotImplementedError("only the no_fs2 / pitch-embed configuration of the reference is supported")
-        ret = {"mel2ph": mel2ph}
-        dev = hubert.device
-        padded = F.pad(hubert, [0, 0, 1, 0])
-        idx = mel2ph[..., None].repeat([1, 1, hubert.shape[-1]])
-        gathered = torch.gather(padded, 1, idx)                               # [B, T, H]
-        nonpad = (mel2ph > 0).float()[:, :, None]
         # ---- index work on the host, bit-exact with the reference CPU path (fs2.py:229-233, pitch_utils.py) ----
         # The reference runs every clip ALONE as a [1, T_clip] tensor (infer_tool.py:277), and torch's CPU kernels are not
         # position-independent in the last bit: a vectorised loop handles the last (numel mod 16) elements with the scalar libm
@@ -71,8 +124,6 @@ class CondBuilder(nn.Module):
         f0_cpu = f0.detach().to("cpu", torch.float32)
         m2p_cpu = mel2ph.cpu()
         pad_cpu = m2p_cpu == 0
-        if hp.get("pitch_norm", "log") != "log":
-            raise NotImplementedError("pitch_norm must be 'log'")
         B, T = m2p_cpu.shape
         uv_cpu = uv.cpu() if (uv is not None and hp.get("use_uv")) else None
         f0_denorm = torch.zeros(B, T, dtype=torch.float32)
@@ -86,6 +137,25 @@ class CondBuilder(nn.Module):
             d[pad_cpu[b:b + 1, :n]] = 0
             f0_denorm[b, :n] = d[0]
             coarse[b, :n] = f0_to_coarse(d.clone(), hp)[0]
+        return f0_denorm, coarse
+
+    def forward(self, hubert, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
+                skip_decoder=True, spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, **kwargs):
+        hp = self.hp
+        if hp.get("use_spk_embed") or hp.get("use_spk_id") or hp.get("use_energy_embed") or not hp.get("no_fs2", False):
+            raise NotImplementedError("only the no_fs2 / pitch-embed configuration of the reference is supported")
+        ret = {"mel2ph": mel2ph}
+        dev = hubert.device
+        padded = F.pad(hubert, [0, 0, 1, 0])
+        idx = mel2ph[..., None].repeat([1, 1, hubert.shape[-1]])
+        gathered = torch.gather(padded, 1, idx)                               # [B, T, H]
+        nonpad = (mel2ph > 0).float()[:, :, None]
+        if hp.get("pitch_norm", "log") != "log":
+            raise NotImplementedError("pitch_norm must be 'log'")
+        if hubert.is_cuda:
+            f0_denorm, coarse = self._pitch_device(f0, mel2ph, uv)
+        else:
+            f0_denorm, coarse = self._pitch_host(f0, mel2ph, uv)
         f0[(mel2ph == 0)] = 0                                                  # the reference mutates its argument (fs2.py:231)
         ret["f0_denorm"] = f0_denorm.to(dev)
         ret["pitch_pred"] = coarse.unsqueeze(-1).to(dev)

@@ -182,6 +182,16 @@ int dsvc_melspec_frames(const dsvc_melspec* m, int64_t n_samples, int32_t* frame
 int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, int64_t n_samples, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Pitch index work of the condition builder -- replaces the host arithmetic of add_pitch (modules/fastspeech/fs2.py:229-237):
+ *   f0_denorm = denorm_f0(f0, uv, pitch_padding = mel2ph == 0)   (utils/pitch_utils.py:63-76, pitch_norm 'log': 2**f0, 0 where off)
+ *   coarse    = f0_to_coarse(f0_denorm)                          (utils/pitch_utils.py:17-31) = 1 + #{k: f0 >= thresholds[k]}
+ * thresholds: the ascending fp32 values of the NORMALISED pitch at which the reference's own expression steps to the next bin
+ * (found by bisection with that expression, diff-svc_amd/cond.py), n = B*T elements, all pointers device; uv may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int dsvc_pitch_coarse(const float* f0_log2, const int64_t* mel2ph, const float* uv, const float* thresholds, int32_t n_thresholds,
+                      int64_t n, float* f0_denorm, int64_t* coarse, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Content encoder -- replaces network/hubert/hubert_model.py:67-77 (HubertSoft.units: pad 40|40 -> FeatureExtractor ->
  * FeatureProjection -> + PositionalConvEmbedding -> LayerNorm -> 12 post-LN transformer layers -> proj), loaded by
  * hubert_soft() (:218-231) and called through preprocessing/hubertinfer.py:30-42 (Hubertencoder.encode -> get_units).

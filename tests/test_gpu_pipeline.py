@@ -339,3 +339,41 @@ def test_use_pe_drives_the_vocoder_with_the_extracted_f0():
     bare = SvcPipeline(hp, sd, vs, h, precision="f16_x3")
     with pytest.raises(RuntimeError, match="pe_state"):
         bare.infer(hub.cuda(), m2p.cuda(), f0.cuda(), use_pe=True)
+
+
+def test_cond_builder_device_pitch_path_equals_host_path():
+    """CondBuilder on device tensors (dsvc_pitch_coarse: threshold search, no host round trip) against the host path (the reference's
+    torch-CPU expression per clip): identical pitch bins and decoder_inp, f0_denorm to the last ulp of exp2 -- on the benchmark inputs,
+    a ragged batch with an interior mel2ph == 0 gap and the use_uv branch.  Pitch values sitting exactly on a bin threshold (and one
+    ulp below) are checked against the reference expression evaluated one value at a time: there torch's vectorised CPU loop and its
+    scalar tail may themselves disagree in the last bit (profiles/r2b_diag_position.txt), the device follows the scalar one."""
+    from diffsvc_amd.cond import CondBuilder, coarse_thresholds
+    hp = dict(synth.HPARAMS_44K)
+    sd = synth.acoustic_state(hp, 0)
+    cb = CondBuilder(hp)
+    cb.load_state_dict({k[len("fs2."):]: v for k, v in sd.items() if k.startswith("fs2.")}, strict=True)
+    cbd = CondBuilder(hp).cuda()
+    cbd.load_state_dict(cb.state_dict(), strict=True)
+    hub, m2p, f0 = clip_batch(hp, [0, 3, 7], 861, 500)
+    m2p = m2p.clone(); f0 = f0.clone()
+    m2p[1, 700:] = 0; f0[1, 700:] = 0                        # trailing padding
+    m2p[2, 100:110] = 0                                     # an interior gap
+    uv = (torch.arange(861)[None].repeat(3, 1) % 97 == 0).float()
+    for use_uv in (False, True):
+        cb.hp = dict(hp, use_uv=use_uv); cbd.hp = cb.hp
+        a = cb(hub, mel2ph=m2p, f0=f0.clone(), uv=uv)
+        b = cbd(hub.cuda(), mel2ph=m2p.cuda(), f0=f0.clone().cuda(), uv=uv.cuda())
+        assert torch.equal(a["pitch_pred"], b["pitch_pred"].cpu())
+        assert torch.equal(a["decoder_inp"], b["decoder_inp"].cpu())
+        fa, fb = a["f0_denorm"], b["f0_denorm"].cpu()
+        assert torch.equal(fa == 0, fb == 0)
+        assert ((fa - fb).abs() <= 2.4e-7 * fa.abs()).all()
+        if use_uv:
+            assert (b["pitch_pred"][:, ::97, 0] == 1).all() and (fb[:, ::97] == 0).all()
+    thr = coarse_thresholds(hp)
+    n = thr.numel()
+    probe = torch.cat([thr, torch.from_numpy(np.nextafter(thr.numpy(), np.float32(0)))])[None]           # on / one ulp below every step
+    cbd.hp = hp
+    r = cbd(hub[:1, :, :].cuda(), mel2ph=torch.ones(1, 2 * n, dtype=torch.long).cuda(), f0=probe.cuda())
+    assert (r["pitch_pred"][0, :n, 0].cpu() == torch.arange(2, n + 2)).all()
+    assert (r["pitch_pred"][0, n:, 0].cpu() == torch.arange(1, n + 1)).all()

@@ -276,3 +276,21 @@ def test_pe_expected_keys_and_position_table():
     assert list(got.keys()) == list(synth.pe_state(dict(synth.HPARAMS_24K), 0).keys())
     for rows, dim in ((4096, 256), (37, 32), (5000, 384)):
         assert torch.equal(position_table(rows, dim), O.sinusoid_table(rows, dim))
+
+
+def test_coarse_pitch_thresholds_reproduce_f0_to_coarse():
+    """cond.coarse_thresholds (what the device pitch kernel searches): 1 + #{k: x >= thr[k]} equals the reference expression
+    f0_to_coarse(2**x) (utils/pitch_utils.py:17-31) at the thresholds themselves, one ulp below them, and on a dense random sample
+    evaluated through torch's vectorised CPU path."""
+    from diffsvc_amd.cond import coarse_thresholds, f0_to_coarse
+    hp = dict(synth.HPARAMS_44K)
+    thr = coarse_thresholds(hp).numpy()
+    assert thr.shape == (hp["f0_bin"] - 2,) and np.all(np.diff(thr) > 0)
+    for k in (0, 1, 100, 253):
+        at = f0_to_coarse(2 ** torch.tensor([[float(thr[k])]]), hp).item()
+        below = f0_to_coarse(2 ** torch.tensor([[float(np.nextafter(thr[k], np.float32(0)))]]), hp).item()
+        assert (at, below) == (k + 2, k + 1)
+    g = np.random.Generator(np.random.PCG64(3))
+    x = torch.from_numpy(g.uniform(3.0, 11.0, 100003).astype(np.float32))[None]
+    ref = f0_to_coarse(2 ** x, hp)[0].numpy()
+    assert np.array_equal(ref, 1 + np.searchsorted(thr, x[0].numpy(), side="right"))
