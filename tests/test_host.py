@@ -294,3 +294,41 @@ def test_coarse_pitch_thresholds_reproduce_f0_to_coarse():
     x = torch.from_numpy(g.uniform(3.0, 11.0, 100003).astype(np.float32))[None]
     ref = f0_to_coarse(2 ** x, hp)[0].numpy()
     assert np.array_equal(ref, 1 + np.searchsorted(thr, x[0].numpy(), side="right"))
+
+
+def test_formats_indexed_dataset_singer_features_and_wire_payload(tmp_path):
+    """diffsvc_amd.formats: the binarised-dataset container round-trips (with its read cache), the singer-mode _mel.npy/_f0.npy pair
+    lands where Svc.after_infer puts it, and the VST-bridge payload decodes / encodes (PCM-16 wav at the DAW's rate)."""
+    import io
+    import wave
+    from diffsvc_amd import formats
+    from diffsvc_amd.vocoder import read_wav
+    path = str(tmp_path / "train")
+    b = formats.IndexedDatasetBuilder(path)
+    items = [{"i": i, "x": np.full((i + 1, 3), i, np.float32)} for i in range(5)]
+    for it in items:
+        b.add_item(it)
+    b.finalize()
+    ds = formats.IndexedDataset(path, num_cache=2)
+    assert len(ds) == 5
+    for i in (4, 4, 0, 2, 4, 1):
+        assert ds[i]["i"] == i and np.array_equal(ds[i]["x"], items[i]["x"])
+    assert len(ds._recent) == 2
+    with pytest.raises(IndexError):
+        ds[5]
+    (tmp_path / "batch").mkdir()
+    mel, f0 = np.ones((7, 4), np.float32), np.arange(7, dtype=np.float32)
+    mp, fp = formats.save_singer_features(str(tmp_path / "batch" / "a.wav"), mel, f0)
+    assert mp.endswith(os.path.join("singer_data", "a_mel.npy")) and np.array_equal(np.load(mp), mel) and np.array_equal(np.load(fp), f0)
+    sr = 44100
+    tone = (0.5 * np.sin(2 * np.pi * 440 * np.arange(sr // 10) / sr)).astype(np.float32)
+    body = formats.encode_voice_change_response(tone, sr, sr)
+    with wave.open(io.BytesIO(body.getvalue()), "rb") as w:
+        assert (w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()) == (sr, 1, 2, tone.size)
+    wav_io, key, daw_sr, spk = formats.decode_voice_change_request({"fPitchChange": "-3.0", "sampleRate": "48000.0", "sSpeakId": "0"}, body.getvalue())
+    assert (key, daw_sr, spk) == (-3.0, 48000, 0)
+    back = read_wav(wav_io, sr)
+    assert back.shape == tone.shape and np.abs(back - tone).max() < 1.0 / 16384
+    half = formats.encode_voice_change_response(tone, sr, 22050)
+    with wave.open(io.BytesIO(half.getvalue()), "rb") as w:
+        assert w.getframerate() == 22050 and abs(w.getnframes() - tone.size // 2) <= 1

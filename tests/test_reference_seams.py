@@ -44,3 +44,35 @@ def test_slicer_on_the_reference_demo_input_matches_the_real_slicer():
     for case in kat["cases"]:
         got = Slicer(sr=sr, **case["args"]).slice(audio)
         assert got == case["chunks"], case["args"]
+
+
+@needs_ref
+def test_indexed_dataset_is_byte_compatible_with_the_reference(tmp_path):
+    """utils/indexed_datasets.py: files written by our builder are read by the REAL IndexedDataset, files written by the real builder
+    are read by ours, and the two builders produce identical bytes for the same items."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_indexed_datasets", os.path.join(REF, "utils", "indexed_datasets.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    from diffsvc_amd.formats import IndexedDataset, IndexedDatasetBuilder
+    g = np.random.default_rng(0)
+    items = [{"item_name": "clip%d" % i, "mel": g.standard_normal((5 + i, 8)).astype(np.float32), "f0": g.random(5 + i).astype(np.float32),
+              "hubert": g.standard_normal((3 + i, 4)).astype(np.float32), "mel2ph": np.arange(5 + i) // 2 + 1} for i in range(7)]
+    ours, theirs = str(tmp_path / "ours"), str(tmp_path / "theirs")
+    b = IndexedDatasetBuilder(ours)
+    rb = ref.IndexedDatasetBuilder(theirs)
+    for it in items:
+        b.add_item(it); rb.add_item(it)
+    b.finalize(); rb.finalize()
+    assert open(ours + ".data", "rb").read() == open(theirs + ".data", "rb").read()
+    assert open(ours + ".idx", "rb").read() == open(theirs + ".idx", "rb").read()
+    for reader, path in ((ref.IndexedDataset, ours), (IndexedDataset, theirs)):
+        ds = reader(path)
+        assert len(ds) == len(items)
+        for i in (3, 0, 6, 3, 1):
+            for k, v in items[i].items():
+                assert np.array_equal(ds[i][k], v) if isinstance(v, np.ndarray) else ds[i][k] == v
+        with pytest.raises(IndexError):
+            ds[len(items)]
+        with pytest.raises(IndexError):
+            ds[-1]
