@@ -51,6 +51,8 @@ struct ConvGemmArgs {
     int step_per_clip;     // 0: one shared scalar, 1: one entry per clip (DiffNet.forward's t[B])
     int film_step_stride;
     float in_slope;        // leaky-relu slope applied to the staged input (1 = identity)
+    int k_slices;          // > 1: the reduction (cin) is cut into k_slices ranges of k_slice_len channels over blockIdx.y; every slice
+    int k_slice_len;       //      runs its own epilogue (which tells slices apart by blockIdx.y): weight-gradient GEMMs (train.hip)
 };
 
 // number of halfs of one packed [lane 64][8] fragment
@@ -85,7 +87,9 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
     // ---- block -> (time tile, column group), XCD-aware: block b is dispatched to XCD b % 8 ----
     const int ncg = (a.n_ctiles + 2 * WAVES_N - 1) / (2 * WAVES_N);
     const int nrt = (a.n_rows + TM - 1) / TM;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    // (k-sliced launches rotate the XCD of a row tile with the slice: a GEMM with fewer than 8 row tiles would otherwise keep every
+    //  slice of a row tile -- all of its workgroups -- on the same few XCDs; gridDim.x is a multiple of 8, so block (x, y) runs on XCD x % 8)
+    const int xcd = ((int)(blockIdx.x & 7) + (a.k_slices > 1 ? (int)blockIdx.y : 0)) & 7, slot = blockIdx.x >> 3;
     const int rt = xcd + 8 * (slot / ncg);
     const int cg = slot % ncg;
     if (rt >= nrt) return;
@@ -100,6 +104,8 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
     const int ct0 = (cg * WAVES_N + wn) * 2;          // first of this wave's two column tiles
     const bool active = ct0 < a.n_ctiles;
 
+    const int c_begin = a.k_slices > 1 ? (int)blockIdx.y * a.k_slice_len : 0;
+    const int c_end = a.k_slices > 1 ? (c_begin + a.k_slice_len < a.cin ? c_begin + a.k_slice_len : a.cin) : a.cin;
     const int halo = (a.taps / 2) * a.dil;
     const int rows_lds = TM + 2 * halo;
     const int plane_halfs = rows_lds * XS;
@@ -135,7 +141,7 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
     };
     if (active) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) wload(bring[u], 0, 0, u);     // PF <= KS, so these are tap 0 of chunk 0
+        for (int u = 0; u < PF; ++u) wload(bring[u], c_begin, 0, u);     // PF <= KS, so these are tap 0 of the first chunk
     }
 
     const int arow = (lane & 31);
@@ -218,18 +224,18 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
 
     float4 sreg[SPT][2];
     unsigned vmask = 0;
-    stage_load(0, 0, sreg, vmask);                   // first batch of chunk 0 in flight beside the weight ring
+    stage_load(c_begin, 0, sreg, vmask);             // first batch of the first chunk in flight beside the weight ring
     if (film) __syncthreads();                       // film_lds visible before the first store phase
 
-    for (int c0 = 0; c0 < a.cin; c0 += KCB) {
-        if (c0 > 0) __syncthreads();                 // previous chunk fully consumed
+    for (int c0 = c_begin; c0 < c_end; c0 += KCB) {
+        if (c0 > c_begin) __syncthreads();           // previous chunk fully consumed
         stage_store(c0, 0, sreg, vmask);
         for (int b0 = NT * SPT; b0 < items; b0 += NT * SPT) {     // tile larger than the register batch (big halo)
             stage_load(c0, b0, sreg, vmask);
             stage_store(c0, b0, sreg, vmask);
         }
         __syncthreads();
-        if (c0 + KCB < a.cin) stage_load(c0 + KCB, 0, sreg, vmask);   // next chunk's loads fly under this chunk's MFMAs
+        if (c0 + KCB < c_end) stage_load(c0 + KCB, 0, sreg, vmask);   // next chunk's loads fly under this chunk's MFMAs
 
         if (active) {
             for (int tap = 0; tap < a.taps; ++tap) {
@@ -258,7 +264,7 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
                             int nks = ks + PF, ntap = tap, nc0 = c0;
                             if (nks >= KS) { nks -= KS; ntap += 1; }
                             if (ntap >= a.taps) { ntap = 0; nc0 += KCB; }
-                            if (nc0 < a.cin) wload(bring[u], nc0, ntap, nks);
+                            if (nc0 < c_end) wload(bring[u], nc0, ntap, nks);
                         }
 #pragma unroll
                         for (int m = 0; m < WM_TILES; ++m)
@@ -355,6 +361,8 @@ inline size_t conv_gemm_smem(int taps, int dil, int cin) {
 template <int WM_TILES, int WAVES_N, int WAVES_K, int KCB, int PF, int SPT, int NW, int NA, class Epi, int WAVES_M = 1>
 inline int conv_gemm_launch(const ConvGemmArgs& a, const typename Epi::Args& ea, hipStream_t stream) {
     if (a.cin % KCB != 0) return fail(DSVC_EINVAL, "conv_gemm: cin %d not a multiple of the staged chunk %d", a.cin, KCB);
+    if (a.k_slices > 1 && (a.k_slice_len % KCB != 0 || (long long)a.k_slices * a.k_slice_len < a.cin || a.film))
+        return fail(DSVC_EINVAL, "conv_gemm: %d k-slices of %d channels do not tile cin %d in chunks of %d", a.k_slices, a.k_slice_len, a.cin, KCB);
     if (a.w_planes < NW) return fail(DSVC_EINVAL, "conv_gemm: weights packed with %d plane(s), kernel needs %d", a.w_planes, NW);
     if (a.ldx % 4 != 0) return fail(DSVC_EINVAL, "conv_gemm: ldx %d not a multiple of 4", a.ldx);
     if (a.n_ctiles & 1) return fail(DSVC_EINVAL, "conv_gemm: odd column-tile count %d", a.n_ctiles);
@@ -370,7 +378,7 @@ inline int conv_gemm_launch(const ConvGemmArgs& a, const typename Epi::Args& ea,
     const int ncg = ceil_div(a.n_ctiles, 2 * WAVES_N);
     const int nrt = ceil_div(a.n_rows, 32 * WM_TILES * WAVES_M);
     const int grid = round_up(nrt, 8) * ncg;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES_N * WAVES_K * WAVES_M), smem, stream, a, ea);
+    hipLaunchKernelGGL(kern, dim3(grid, a.k_slices > 1 ? a.k_slices : 1), dim3(64 * WAVES_N * WAVES_K * WAVES_M), smem, stream, a, ea);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }

@@ -14,6 +14,7 @@
 //             A^T is packed into MFMA weight fragments on the device (k_pack_cols), B^T is a transposed copy (k_transpose), the
 //             contraction index is the frame index.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -120,9 +121,31 @@ struct EpWgrad {
     }
 };
 
+// the same GEMM cut into k-slices over blockIdx.y (conv_gemm's k_slices): slice s parks its partial tile in part[s][row][col]
+constexpr int WGRAD_MAX_TILES = 448;     // k-slices x output tiles of a sliced weight-gradient GEMM (workgroups per launch)
+
+struct EpWgradPart {
+    static constexpr bool PAIRED = false;
+    struct Args { float* part; int n_k, ld; };
+    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
+        e.part[((size_t)blockIdx.y * e.n_k + row) * e.ld + col] = v;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
+// dW[o][k] = sum over the k-slices of a weight-gradient GEMM (deterministic: fixed order)
+__global__ void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dst, int n_slices, int n_k, int ld, int n_o, long long stride_o,
+                               long long stride_k, long long off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_k * n_o) return;
+    const int row = i / n_o, col = i - row * n_o;
+    float s = 0.f;
+    for (int z = 0; z < n_slices; ++z) s += part[((size_t)z * n_k + row) * ld + col];
+    dst[(long long)col * stride_o + (long long)row * stride_k + off] = s;
+}
+
 // transpose with optional additive per-clip vector (film) and validity mask:  dst[c][pad + n] = valid(n) ? src[n][c] + add[clip][c] : 0
 // dst is [C][ld] with ld >= rows + 2*pad; the pad columns are zeroed once at allocation.
 __global__ void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld, int pad,
@@ -288,6 +311,28 @@ __global__ void k_gemm_small(const float* __restrict__ A, const float* __restric
     *p = accumulate ? *p + s : s;
 }
 
+// the per-layer [B x C] GEMMs of the step-embedding path (20 diffusion_projection layers: forward, weight gradient, input gradient)
+// as ONE launch: entry z = blockIdx.y has its own operand pointers (sum_batch: one entry that adds all of them up instead)
+struct SmallBatch { const float* A[32]; const float* B[32]; float* C[32]; const float* bias[32]; int n; };
+__global__ void k_gemm_small_b(const SmallBatch t, int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int sum_batch) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
+    const int z0 = sum_batch ? 0 : blockIdx.y, z1 = sum_batch ? t.n : z0 + 1;
+    float s = 0.f;
+    for (int z = z0; z < z1; ++z) {
+        const float* A = t.A[z];
+        const float* Bm = t.B[z];
+        for (int k = 0; k < K; ++k) {
+            const float a = ta ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
+            const float b = tb ? Bm[(size_t)n * ldb + k] : Bm[(size_t)k * ldb + n];
+            s = fmaf(a, b, s);
+        }
+    }
+    if (t.bias[z0]) s += t.bias[z0][n];
+    t.C[z0][(size_t)m * ldc + n] = s;
+}
+
 // SinusoidalPosEmb (net.py:32-44) for the batch's steps
 __global__ void k_sin_emb_b(float* __restrict__ emb, const int* __restrict__ tstep, int B, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -400,6 +445,7 @@ struct dsvc_trainer {
     DevBuf e0, e1pre, e1, e2, filmB, dfilm, de2, de1, de1pre;
     DevBuf dx, dxin, dO, dy, ds2pre, dcond, dh0, TT, loss;
     DevBuf packA;                                  // activation-as-weights fragments for the weight-gradient GEMMs
+    DevBuf wpart;                                  // k-slice partial tiles of one weight-gradient GEMM
     // per-step repacked weights
     Packed w_in, w_skip, w_fin, w_finT, w_skipT;
     std::vector<Packed> w_d, w_c, w_o, w_oT, w_cT, w_dT;
@@ -408,7 +454,7 @@ struct dsvc_trainer {
     ~dsvc_trainer() {
         for (DevBuf* b : {&sa, &sb, &spec_min, &spec_max, &xt, &xs, &sig, &tau, &g, &skip, &ypre, &s2pre, &eps, &deps, &condT, &condTT, &tstep,
                           &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre, &dcond,
-                          &dh0, &TT, &loss, &packA, &gatemap})
+                          &dh0, &TT, &loss, &packA, &wpart, &gatemap})
             b->release();
         auto rel = [](Packed& p) { p.w.release(); };
         rel(w_in); rel(w_skip); rel(w_fin); rel(w_finT); rel(w_skipT);
@@ -514,6 +560,7 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     DSVC_TRY(z(TT, ldT * (size_t)(2 * C) * 4));      // transposed operand [<= 2C][rows + 2 pad]; pads stay zero
     DSVC_TRY(z(condTT, ldT * (size_t)H * 4));
     DSVC_TRY(packA.alloc(packed_halfs(round_up(ceil_div(2 * C, 32), 2), 1, rows, 2) * 2));
+    DSVC_TRY(wpart.alloc((size_t)WGRAD_MAX_TILES * 128 * 128 * 4));
     hipLaunchKernelGGL(k_iota, dim3(ceil_div(B, 256)), dim3(256), 0, st, iotaB.as<int>(), 0, B);
     if (!gatemap.p) {
         // packed column p of a gate GEMM <-> conv channel: group = p/64, half = (p/32)&1, j = p%32  ->  half*C + group*32 + j
@@ -550,6 +597,29 @@ int dsvc_trainer::wgrad(const float* A, int O, const float* BT, int K, int shift
     (void)shift;                                          // taps are materialised by transpose(..., shift): every staged row stays 16-byte aligned
     a.x = BT + padc; a.ldx = ld; a.n_rows = K; a.clip_stride = K < 32 ? 32 : K; a.clip_len = a.clip_stride;
     a.cin = rows; a.taps = 1; a.dil = 1; a.w = packA.as<_Float16>(); a.n_ctiles = n_ct; a.w_planes = 2; a.in_slope = 1.0f;
+    // A [K x O] result reduced over ~10^4 frames: as 32 x 64 output tiles every workgroup re-reads both operands over the whole frame
+    // range (144 workgroups, 450 MB of operand traffic for the 384 x 768 gradients: 151 us each, 41 % of the step).  Instead: 128 x 128
+    // tiles and the frame range cut into slices over blockIdx.y so that ~400 workgroups exist; partial tiles go to a scratch buffer and a
+    // second kernel adds the slices in a fixed order (deterministic, unlike atomics).
+    static const bool sliced = !(getenv("DSVC_TRAIN_WGRAD_FLAT") && atoi(getenv("DSVC_TRAIN_WGRAD_FLAT")));     // A/B knob
+    const int tiles = ceil_div(K, 128) * ceil_div(n_ct, 4);
+    if (sliced && rows % 64 == 0 && tiles <= WGRAD_MAX_TILES) {
+        int S = WGRAD_MAX_TILES / tiles;
+        if (S > rows / 64) S = rows / 64;
+        const int slice_len = round_up(ceil_div(rows, S), 64);
+        S = ceil_div(rows, slice_len);
+        a.k_slices = S; a.k_slice_len = slice_len;
+        if (S > 1) {
+            const int ldp = n_ct * 32;
+            if ((size_t)S * K * ldp * 4 > wpart.bytes) return fail(DSVC_EINVAL, "wgrad: partial-tile scratch too small (%d slices of %d x %d)", S, K, ldp);
+            EpWgradPart::Args e{wpart.as<float>(), K, ldp};
+            DSVC_TRY((conv_gemm_launch<4, 2, 1, 64, 4, 5, 2, 2, EpWgradPart>(a, e, st)));
+            hipLaunchKernelGGL(k_wgrad_reduce, dim3(ceil_div(K * O, 256)), dim3(256), 0, st, wpart.as<float>(), dst, S, K, ldp, O, stride_o, stride_k, off);
+            DSVC_HIP(hipGetLastError());
+            return DSVC_OK;
+        }
+        a.k_slices = 0; a.k_slice_len = 0;
+    }
     EpWgrad::Args e{dst, stride_o, stride_k, off, O};
     return launch<EpWgrad>(a, e, st);
 }
@@ -589,7 +659,16 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     small(e0.as<float>(), P("denoise_fn.mlp.0.weight"), e1pre.as<float>(), B, 4 * C, C, C, C, 4 * C, 0, 1, 0, P("denoise_fn.mlp.0.bias"));
     hipLaunchKernelGGL(k_mish, dim3(ceil_div(B * 4 * C, 256)), dim3(256), 0, st, e1pre.as<float>(), e1.as<float>(), (size_t)B * 4 * C);
     small(e1.as<float>(), P("denoise_fn.mlp.2.weight"), e2.as<float>(), B, C, 4 * C, 4 * C, 4 * C, C, 0, 1, 0, P("denoise_fn.mlp.2.bias"));
-    for (int l = 0; l < L; ++l) {
+    const bool batched_small = L <= 32 && (size_t)L * B * C * 4 <= wpart.bytes;
+    if (batched_small) {   // film_l = e2 W_l^T + b_l for all layers in one launch
+        SmallBatch sb{};
+        sb.n = L;
+        for (int l = 0; l < L; ++l) {
+            const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
+            sb.A[l] = e2.as<float>(); sb.B[l] = P(q + "weight"); sb.C[l] = filmB.as<float>() + (size_t)l * C; sb.bias[l] = P(q + "bias");
+        }
+        hipLaunchKernelGGL(k_gemm_small_b, dim3(ceil_div(B * C, 256), L), dim3(256), 0, st, sb, B, C, C, C, C, L * C, 0, 1, 0);
+    } else for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
         small(e2.as<float>(), P(q + "weight"), filmB.as<float>() + (size_t)l * C, B, C, C, C, C, L * C, 0, 1, 0, P(q + "bias"));
     }
@@ -708,7 +787,22 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     }
     // ---- backward: step embedding ----
     DSVC_HIP(hipMemsetAsync(de2.p, 0, (size_t)B * C * 4, st));
-    for (int l = 0; l < L; ++l) {
+    if (batched_small) {
+        SmallBatch dw{}, dx2{};
+        dw.n = dx2.n = L;
+        for (int l = 0; l < L; ++l) {
+            const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
+            const float* df = dfilm.as<float>() + (size_t)l * C;
+            dw.A[l] = df; dw.B[l] = e2.as<float>(); dw.C[l] = G(q + "weight");                          // dWp[o][i] = sum_b dfilm[b][o] e2[b][i]
+            dx2.A[l] = df; dx2.B[l] = P(q + "weight"); dx2.C[l] = de2.as<float>();                      // de2[b][i] = sum_l sum_o dfilm[b][o] Wp[o][i]
+            hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);   // dbp = sum_b dfilm[b]
+        }
+        hipLaunchKernelGGL(k_gemm_small_b, dim3(ceil_div(C * C, 256), L), dim3(256), 0, st, dw, C, C, B, L * C, C, C, 1, 0, 0);
+        // de2 = sum over the layers: per-layer partials into the (idle) weight-gradient scratch, then a fixed-order sum
+        for (int l = 0; l < L; ++l) dx2.C[l] = wpart.as<float>() + (size_t)l * B * C;
+        hipLaunchKernelGGL(k_gemm_small_b, dim3(ceil_div(B * C, 256), L), dim3(256), 0, st, dx2, B, C, C, L * C, C, C, 0, 0, 0);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, wpart.as<float>(), de2.as<float>(), L, B, C, C, 1LL, (long long)C, 0LL);
+    } else for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
         const float* df = dfilm.as<float>() + (size_t)l * C;
         small(df, e2.as<float>(), G(q + "weight"), C, C, B, L * C, C, C, 1, 0, 0, nullptr);            // dWp[o][i] = sum_b dfilm[b][o] e2[b][i]
