@@ -332,3 +332,30 @@ def test_formats_indexed_dataset_singer_features_and_wire_payload(tmp_path):
     half = formats.encode_voice_change_response(tone, sr, 22050)
     with wave.open(io.BytesIO(half.getvalue()), "rb") as w:
         assert w.getframerate() == 22050 and abs(w.getnframes() - tone.size // 2) <= 1
+
+
+def test_infer_driver_host_logic(tmp_path):
+    """diffsvc_amd.infer: norm_interp_f0 (utils/pitch_utils.py:45-60) reproduces the interpolated log2-f0 the goldens were minted with;
+    load_ckpt (utils/__init__.py:178-209) takes a file or the highest model_ckpt_steps_<N>.ckpt of a directory, strips the prefix, loads
+    strictly and asserts on a missing checkpoint."""
+    from diffsvc_amd.infer import load_ckpt, norm_interp_f0
+    hp = dict(synth.HPARAMS_44K)
+    _, _, f0_log, f0_hz = synth.clip_inputs(3, T=200, n_units=100)
+    f0, uv = norm_interp_f0(f0_hz, hp)
+    assert torch.equal(f0, torch.from_numpy(f0_log)) and torch.equal(uv, torch.from_numpy((f0_hz == 0).astype(np.float32)))
+    f0, uv = norm_interp_f0(np.zeros(7, np.float32), hp)
+    assert (f0 == 0).all() and (uv == 1).all()
+    lin = torch.nn.Linear(3, 2)
+    d = tmp_path / "ck"
+    d.mkdir()
+    for n, scale in ((5, 0.0), (120, 1.0), (37, 2.0)):
+        torch.save({"state_dict": {"model.weight": torch.full((2, 3), scale), "model.bias": torch.zeros(2), "other.x": torch.ones(1)}},
+                   str(d / ("model_ckpt_steps_%d.ckpt" % n)))
+    assert load_ckpt(lin, str(d)).endswith("model_ckpt_steps_120.ckpt") and (lin.weight == 1.0).all()
+    assert load_ckpt(lin, str(d / "model_ckpt_steps_37.ckpt")).endswith("37.ckpt") and (lin.weight == 2.0).all()
+    torch.save({"state_dict": {"model.weight": torch.zeros(2, 3)}}, str(d / "model_ckpt_steps_999.ckpt"))
+    with pytest.raises(RuntimeError):
+        load_ckpt(lin, str(d))                                 # strict: bias missing
+    with pytest.raises(AssertionError):
+        load_ckpt(lin, str(tmp_path / "nowhere"))
+    assert load_ckpt(lin, str(tmp_path / "nowhere"), force=False) is None
