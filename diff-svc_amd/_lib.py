@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(HERE, "libdsvc_hip.so")
 
 PREC_F16, PREC_F16_W2, PREC_F16_X3 = 0, 1, 2
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def parse_precision(p):
@@ -54,7 +54,7 @@ class VocoderCfg(ctypes.Structure):
 
 class MelspecCfg(ctypes.Structure):
     _fields_ = [("n_fft", ctypes.c_int32), ("win_size", ctypes.c_int32), ("hop", ctypes.c_int32),
-                ("n_mels", ctypes.c_int32), ("clip_val", ctypes.c_float)]
+                ("n_mels", ctypes.c_int32), ("clip_val", ctypes.c_float), ("mode", ctypes.c_int32)]
 
 
 class TrainerCfg(ctypes.Structure):

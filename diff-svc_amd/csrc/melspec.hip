@@ -26,14 +26,16 @@ namespace {
 
 __global__ void k_melspec(const float* __restrict__ wav, float* __restrict__ mel, const float* __restrict__ basis,
                           const int* __restrict__ range, int n_samples, int n_frames, int n_fft, int log2n, int win,
-                          int hop, int n_mels, float clip_val) {
+                          int hop, int n_mels, float clip_val, int mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* buf = reinterpret_cast<float2*>(smem);                 // [n_fft] complex
     float2* tw = buf + n_fft;                                      // [n_fft/2] twiddles e^{-2 pi i k / n_fft}
     const int t = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int pad = (n_fft - hop) / 2;
-    const int woff = (n_fft - win) / 2;                            // torch.stft centres a short window in the frame
+    // mode 0: nvSTFT (reflect pad (n_fft - hop)/2, sqrt(. + 1e-9), natural log of the clamped mel scaled to log10)
+    // mode 1: process_utterance (preprocessing/data_gen_utils.py:124-136: librosa.stft centred with ZERO padding n_fft/2, |X|, log10(max(eps, mel)))
+    const int pad = mode == 1 ? n_fft / 2 : (n_fft - hop) / 2;
+    const int woff = (n_fft - win) / 2;                            // torch.stft / librosa centre a short window in the frame
     const float* x = wav + (size_t)b * n_samples;
     for (int k = tid; k < n_fft / 2; k += nt) {
         float s, c;
@@ -42,13 +44,19 @@ __global__ void k_melspec(const float* __restrict__ wav, float* __restrict__ mel
     }
     for (int n = tid; n < n_fft; n += nt) {
         int i = t * hop + n - pad;
-        if (i < 0) i = -i;                                         // F.pad(mode='reflect')
-        if (i >= n_samples) i = 2 * (n_samples - 1) - i;
+        bool inside = true;
+        if (mode == 1) {
+            inside = i >= 0 && i < n_samples;                      // pad_mode='constant'
+            if (!inside) i = 0;
+        } else {
+            if (i < 0) i = -i;                                     // F.pad(mode='reflect')
+            if (i >= n_samples) i = 2 * (n_samples - 1) - i;
+        }
         float w = 0.f;
         const int wn = n - woff;
         if (wn >= 0 && wn < win) w = 0.5f - 0.5f * cospif(2.0f * (float)wn / (float)win);   // periodic hann
         const int r = (int)(__brev((unsigned)n) >> (32 - log2n));  // bit-reversed order for the DIT butterflies
-        buf[r] = make_float2(x[i] * w, 0.f);
+        buf[r] = make_float2(inside ? x[i] * w : 0.f, 0.f);
     }
     __syncthreads();
     for (int s = 1; s <= log2n; ++s) {
@@ -69,7 +77,7 @@ __global__ void k_melspec(const float* __restrict__ wav, float* __restrict__ mel
     float* mag = reinterpret_cast<float*>(tw);                     // twiddles are dead now; n_bins <= n_fft floats
     for (int k = tid; k < n_bins; k += nt) {
         const float2 v = buf[k];
-        mag[k] = sqrtf(v.x * v.x + v.y * v.y + 1e-9f);
+        mag[k] = sqrtf(v.x * v.x + v.y * v.y + (mode == 1 ? 0.f : 1e-9f));
     }
     __syncthreads();
     for (int m = tid; m < n_mels; m += nt) {
@@ -77,7 +85,7 @@ __global__ void k_melspec(const float* __restrict__ wav, float* __restrict__ mel
         const float* bw = basis + (size_t)m * n_bins;
         float acc = 0.f;
         for (int k = lo; k < hi; ++k) acc = fmaf(bw[k], mag[k], acc);
-        mel[((size_t)b * n_frames + t) * n_mels + m] = 0.434294f * logf(fmaxf(acc, clip_val));
+        mel[((size_t)b * n_frames + t) * n_mels + m] = mode == 1 ? log10f(fmaxf(acc, clip_val)) : 0.434294f * logf(fmaxf(acc, clip_val));
     }
 }
 
@@ -92,6 +100,7 @@ int dsvc_melspec_create(const dsvc_melspec_cfg* cfg, const float* mel_basis, dsv
     if ((1 << l2) != cfg->n_fft || cfg->n_fft < 64 || cfg->n_fft > 4096) return fail(DSVC_EINVAL, "melspec: n_fft must be a power of two in [64, 4096], got %d", cfg->n_fft);
     if (cfg->win_size > cfg->n_fft || cfg->win_size < 2 || cfg->hop < 1 || cfg->hop > cfg->n_fft || cfg->n_mels < 1)
         return fail(DSVC_EINVAL, "melspec: bad win/hop/n_mels");
+    if (cfg->mode != 0 && cfg->mode != 1) return fail(DSVC_EINVAL, "melspec: mode must be 0 (nvSTFT) or 1 (centred, zero-padded)");
     int ndev = 0;
     DSVC_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(DSVC_EHIP, "no HIP device visible");
@@ -125,6 +134,11 @@ void dsvc_melspec_destroy(dsvc_melspec* m) {
 
 int dsvc_melspec_frames(const dsvc_melspec* m, int64_t n_samples, int32_t* frames) {
     if (!m || !frames) return fail(DSVC_EINVAL, "null argument");
+    if (m->cfg.mode == 1) {                                                  // librosa.stft(center=True): 1 + N // hop
+        if (n_samples < 1) return fail(DSVC_EINVAL, "melspec: empty input");
+        *frames = (int32_t)(1 + n_samples / m->cfg.hop);
+        return DSVC_OK;
+    }
     const int64_t pad = (m->cfg.n_fft - m->cfg.hop) / 2;
     if (n_samples <= pad) return fail(DSVC_EINVAL, "melspec: %lld samples is not enough for a reflect pad of %lld", (long long)n_samples, (long long)pad);
     const int64_t padded = n_samples + 2 * pad;
@@ -140,7 +154,7 @@ int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, i
     const size_t smem = (size_t)m->cfg.n_fft * 8 + (size_t)m->cfg.n_fft * 4;
     hipLaunchKernelGGL(k_melspec, dim3(T, B), dim3(256), smem, (hipStream_t)stream, wav, mel, (const float*)m->basis,
                        (const int*)m->range, (int)n_samples, T, m->cfg.n_fft, m->log2n, m->cfg.win_size, m->cfg.hop,
-                       m->cfg.n_mels, m->cfg.clip_val);
+                       m->cfg.n_mels, m->cfg.clip_val, m->cfg.mode);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }

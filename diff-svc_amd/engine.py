@@ -228,14 +228,15 @@ class VocoderHandle:
 
 
 class MelspecHandle:
-    """dsvc_melspec: STFT -> mel -> log10 (modules/nsf_hifigan/nvSTFT.py:72-104 + nsf_hifigan.py:86-91)."""
+    """dsvc_melspec: STFT -> mel -> log10.  mode 0: modules/nsf_hifigan/nvSTFT.py:72-104 + nsf_hifigan.py:86-91; mode 1: the centred,
+    zero-padded front-end of process_utterance (preprocessing/data_gen_utils.py:124-136) with ``clip_val`` = its eps."""
 
-    def __init__(self, sr, n_fft, win_size, hop, n_mels, fmin, fmax, clip_val=1e-5):
+    def __init__(self, sr, n_fft, win_size, hop, n_mels, fmin, fmax, clip_val=1e-5, mode=0):
         from .melfb import mel_filterbank
         self._h = ctypes.c_void_p(0)
         self.n_mels = n_mels
         basis = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax)).contiguous()
-        cfg = _lib.MelspecCfg(n_fft, win_size, hop, n_mels, clip_val)
+        cfg = _lib.MelspecCfg(n_fft, win_size, hop, n_mels, clip_val, mode)
         check(lib().dsvc_melspec_create(ctypes.byref(cfg), ctypes.c_void_p(basis.data_ptr()), ctypes.byref(self._h)))
 
     def frames(self, n_samples):

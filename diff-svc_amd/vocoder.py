@@ -206,5 +206,24 @@ class HifiGANHip(BaseVocoder):
         return y.cpu().numpy()
 
     @staticmethod
-    def wav2spec(wav_fn, **kwargs):
-        raise NotImplementedError("the 24 kHz mel front-end (PWG.wav2spec -> process_utterance, librosa) is not part of this path")
+    def wav2spec(wav_fn, return_linear=False):
+        """PWG.wav2spec (network/vocoders/pwg.py:106-122) -> process_utterance (preprocessing/data_gen_utils.py:96-145): the file at the
+        model's rate, a centred zero-padded STFT, |X| through the mel filterbank, log10(max(eps, .)); the waveform comes back
+        zero-padded to frames * hop.  Returns (wav [T*hop], mel [T, num_mels])."""
+        hp = get_hparams()
+        if return_linear:
+            raise NotImplementedError("return_linear (the normalised linear spectrogram) is not part of this path")
+        if hp.get("loud_norm"):
+            raise NotImplementedError("loud_norm (pyloudnorm BS.1770 normalisation) is not part of this path")
+        sr, hop = hp["audio_sample_rate"], hp["hop_size"]
+        fmin = 0 if hp["fmin"] == -1 else hp["fmin"]
+        fmax = sr / 2 if hp["fmax"] == -1 else hp["fmax"]
+        eps = float(hp.get("wav2spec_eps", 1e-10))
+        key = ("pwg", sr, hp["fft_size"], hp["win_size"], hop, hp["audio_num_mel_bins"], fmin, fmax, eps)
+        if key not in _melspec_cache:
+            _melspec_cache[key] = MelspecHandle(sr, hp["fft_size"], hp["win_size"], hop, hp["audio_num_mel_bins"], fmin, fmax, clip_val=eps, mode=1)
+        wav = read_wav(wav_fn, sr)
+        mel = _melspec_cache[key].mel(torch.from_numpy(wav)[None].cuda())[0].cpu().numpy()
+        n = mel.shape[0] * hop                                                   # librosa_pad_lr(..., 1) then wav[:T * hop]
+        wav = np.pad(wav, (0, max(0, n - len(wav))))[:n]
+        return wav, mel

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DSVC_ABI_VERSION 3
+#define DSVC_ABI_VERSION 4
 
 enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM = 4 };
 
@@ -171,7 +171,10 @@ typedef struct dsvc_melspec dsvc_melspec;
 
 typedef struct {
     int32_t n_fft, win_size, hop, n_mels;
-    float clip_val;                /* 1e-5 */
+    float clip_val;                /* mode 0: 1e-5 (nvSTFT's clamp); mode 1: hparams['wav2spec_eps'] */
+    int32_t mode;                  /* 0: nvSTFT.py:72-104 (reflect pad (n_fft-hop)/2, sqrt(|X|^2 + 1e-9), ln -> log10);
+                                      1: process_utterance, preprocessing/data_gen_utils.py:124-136, the 24 kHz PWG / HifiGAN front-end
+                                         (librosa.stft centred with zero padding, |X|, log10(max(eps, mel)), T = 1 + N // hop) */
 } dsvc_melspec_cfg;
 
 /* mel_basis: host [n_mels][n_fft/2+1] fp32 (librosa.filters.mel, built by the Python host) */

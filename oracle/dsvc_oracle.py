@@ -564,6 +564,19 @@ def mel_spectrogram(wav, sr, n_fft, win_size, hop, n_mels, fmin, fmax, clip_val=
     return (0.434294 * mel).transpose(1, 2)
 
 
+def process_utterance_mel(wav, sr, n_fft, win_size, hop, n_mels, fmin, fmax, eps=1e-10, basis=None):
+    """The mel of process_utterance (preprocessing/data_gen_utils.py:124-136), the 24 kHz front-end behind PWG.wav2spec / HifiGAN:
+    librosa.stft(n_fft, hop, win_length, 'hann', pad_mode='constant') = a centred STFT over a zero-padded signal with a periodic hann
+    window, |X|, librosa mel filterbank, log10(max(eps, .)).  wav [B,N] -> mel [B, 1 + N // hop, n_mels].
+    PARITY UNPINNED at librosa (not installable here, like the filterbank): restated from librosa 0.9.1's published definition."""
+    if basis is None:
+        basis = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax))
+    spec = torch.stft(wav, n_fft, hop_length=hop, win_length=win_size, window=torch.hann_window(win_size), center=True,
+                      pad_mode="constant", normalized=False, onesided=True, return_complex=True)
+    mel = torch.matmul(basis, spec.abs())
+    return torch.log10(torch.clamp(mel, min=eps)).transpose(1, 2)
+
+
 # ----------------------------------------------------------------------------------------------
 # Content encoder  (network/hubert/hubert_model.py)
 # ----------------------------------------------------------------------------------------------

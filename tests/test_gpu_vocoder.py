@@ -171,3 +171,32 @@ def test_hifigan_24k_plugin_contract(tmp_path):
     with pytest.raises(FileNotFoundError):
         set_hparams(dict(synth.HPARAMS_24K, vocoder_ckpt=str(tmp_path / "nothing")))
         HifiGANHip()
+
+
+def test_pwg_front_end_wav2spec_24k(tmp_path):
+    """HifiGANHip.wav2spec = PWG.wav2spec -> process_utterance (preprocessing/data_gen_utils.py:124-145), the 24 kHz demo config's mel
+    front-end (fft 512, hop 128, 80 bins, fmin 30, fmax 12000, eps 1e-6): centred zero-padded STFT, |X|, mel, log10(max(eps, .)) -- against
+    the oracle restatement (unpinned at librosa, like the filterbank), incl. a 22.05 kHz file that is resampled first, lengths that are
+    and are not multiples of the hop, and the waveform zero-padded to frames * hop."""
+    import wave
+    from diffsvc_amd.hparams import set_hparams
+    from diffsvc_amd.vocoder import HifiGANHip, read_wav
+    hp = set_hparams(dict(synth.HPARAMS_24K, wav2spec_eps=1e-6, loud_norm=False))
+    for sr, n in ((24000, 24000), (24000, 12345), (22050, 30000)):
+        pcm = (synth.speech_like_wav(n, n, sr) * 32767).astype("<i2")
+        path = str(tmp_path / ("a%d_%d.wav" % (sr, n)))
+        with wave.open(path, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr)
+            w.writeframes(pcm.tobytes())
+        wav, mel = HifiGANHip.wav2spec(path)
+        src = read_wav(path, 24000)
+        T = 1 + len(src) // 128
+        assert mel.shape == (T, 80) and wav.shape == (T * 128,)
+        assert np.array_equal(wav[:len(src)], src[:len(wav)]) and (wav[len(src):] == 0).all()
+        ref = O.process_utterance_mel(torch.from_numpy(src)[None], 24000, 512, 512, 128, 80, 30, 12000, eps=1e-6)[0].numpy()
+        err = np.abs(mel - ref).max()
+        print("pwg wav2spec %d Hz, %d samples -> %d frames: max-abs err %.2e (mel range %.2f..%.2f)" % (sr, n, T, err, ref.min(), ref.max()))
+        assert err < 2e-4, err
+    with pytest.raises(NotImplementedError):
+        set_hparams(dict(hp, loud_norm=True), clear=False)
+        HifiGANHip.wav2spec(path)
