@@ -132,3 +132,35 @@ def test_use_gt_mel_starts_from_the_noised_input_mel(svc):
         s.vocoder.spec2wav = orig
     ref = np.clip(mel_in[:len(shallow)], hp["mel_vmin"], hp["mel_vmax"])
     assert np.abs(shallow - ref).mean() < 0.5 * np.abs(full[:len(ref)] - ref).mean()
+
+
+def test_config_b_demo_chain_24k_with_pitch_extractor(tmp_path):
+    """BASELINE configs[0] shapes end to end without the reference tree: 22.05 kHz input -> slicer -> [PWG wav2spec (24 kHz, 80 bins),
+    HuBERT-soft, f0 read off the input mel by the pitch extractor (no crepe / parselmouth here), get_align] -> 20-iteration PLMS
+    (acc 50 over a 1000-step schedule) -> PitchExtractor(mel_out) drives the 24 kHz HiFi-GAN (use_pe) -> stitched PCM."""
+    from diffsvc_amd.denoiser import DiffNetHip
+    from diffsvc_amd.hparams import set_hparams
+    from diffsvc_amd.hubert import HubertSoftHip
+    from diffsvc_amd.infer import SvcHip, run_clip
+    from diffsvc_amd.pe import PitchExtractorHip
+    from diffsvc_amd.sampler import GaussianDiffusionHip
+    from diffsvc_amd.vocoder import HifiGANHip
+    hp = set_hparams(dict(synth.HPARAMS_24K, residual_layers=4, wav2spec_eps=1e-6, loud_norm=False, use_nsf=True,
+                          vocoder_ckpt=str(tmp_path / "hifigan"), max_frames=42000, max_input_tokens=60000))
+    synth.save_hifigan_ckpt(str(tmp_path / "hifigan"), dict(synth.VOCODER_24K), 4)
+    sd = synth.acoustic_state_conditioned(hp, 2, 1.35, 0.05)
+    model = GaussianDiffusionHip(None, 80, DiffNetHip(80, hparams=hp), timesteps=1000, K_step=1000, loss_type="l2",
+                                 spec_min=hp["spec_min"], spec_max=hp["spec_max"], hparams=hp)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    pe = PitchExtractorHip(hparams=hp).cuda()
+    pe.load_state_dict(synth.pe_state(hp, 5), strict=True)
+    s = SvcHip("demo", model, HifiGANHip(), _Units(HubertSoftHip(synth.hubert_state(11))), pe=pe.eval(), hparams=hp)
+    sr = 22050
+    audio = np.concatenate([_speech(5, 2.5, sr), np.zeros(int(1.2 * sr), np.float32), _speech(6, 3.5, sr)]).astype(np.float32)
+    f0_t, f0_p, out = run_clip(s, key=2, acc=50, use_pe=True, use_crepe=False, thre=0.05, use_gt_mel=False, add_noise_step=500,
+                               audio=audio, sr=sr, out_path=str(tmp_path / "o.wav"), seed=3)
+    out = np.asarray(out)
+    assert abs(len(out) - len(audio) / sr * 24000) <= 4 and np.isfinite(out).all() and np.abs(out).max() <= 1.0
+    assert len(f0_t) == len(f0_p) and (np.asarray(f0_p) > 0).any()
+    assert not np.allclose(np.asarray(f0_p)[:50], np.asarray(f0_t)[:50])        # the vocoder's f0 came from the extractor, not the input track
