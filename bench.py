@@ -342,6 +342,38 @@ def main():
             result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
                                  "clips_per_gpu": Bb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
                                  "s_per_batch": tb, "roofline": broof}
+        if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched:
+            # the stages either side of the sampler, one 10 s clip each (informational; `value` above is cond -> PCM on the device)
+            try:
+                def timed(fn, n=5):
+                    fn(); torch.cuda.synchronize(); t = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t) / n * 1e3
+                stages = {}
+                mel1 = (torch.randn(1, T_FRAMES, hp["audio_num_mel_bins"], device=dev) * 0.5 - 2.5).clamp(hp["mel_vmin"], hp["mel_vmax"])
+                f01 = torch.full((1, T_FRAMES), 220.0, device=dev)
+                stages["vocoder_ms"] = timed(lambda: pipe.vocoder.vocode(mel1, f01, seed=1))
+                # what the reference's host glue adds around the device path (infer_tool.py:174,200: mel / f0 to numpy, PCM to numpy)
+                stages["host_round_trip_ms"] = timed(lambda: (mel1.cpu().numpy(), f01.cpu().numpy(), wav[:1].cpu().numpy()))
+                from diffsvc_amd.hubert import HubertSoftHip
+                from diffsvc_amd.pe import PitchExtractorHip
+                hb = HubertSoftHip(synth.hubert_state(11))
+                w16 = torch.from_numpy(synth.speech_like_wav(1, 160000)).to(dev)
+                stages["hubert_soft_ms"] = timed(lambda: hb.units(w16))
+                del hb
+                hp24 = dict(synth.HPARAMS_24K)
+                pe = PitchExtractorHip(hparams=hp24).cuda()
+                pe.load_state_dict(synth.pe_state(hp24, 5))
+                mel24 = torch.from_numpy(synth.mel_like(1, 1, 1875, 80)).to(dev)
+                stages["pitch_extractor_ms"] = timed(lambda: pe(mel24))
+                del pe
+                stages["note"] = ("one 10 s clip: NSF-HiFiGAN alone (inside `value`), HuBERT-soft on 160 000 samples at 16 kHz and the 24 kHz pitch "
+                                  "extractor on 1875 frames (outside `value`: upstream / config B), D2H of mel + f0 + PCM")
+                result["stages"] = stages
+            except Exception as ex:
+                result["stages"] = {"error": repr(ex)[:300]}
         if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched and prec != "f16_x3":
             # like-for-like operand precision with the fp32 reference: the same clip at f16_x3 (split fp16 operands, 3 MFMAs per
             # product, 1e-5-class single evaluations) -- what the path costs when nothing is traded for the fp16 operand rounding
