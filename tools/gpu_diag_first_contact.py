@@ -1,7 +1,7 @@
 """First-contact diagnostics for the GPU box: prints per-stage errors instead of asserting.
-Usage on the box: python tools_gpu_diag.py > gpurun_out/diag.txt"""
+Usage on the box: python tools/gpu_diag_first_contact.py > gpurun_out/diag.txt"""
 import sys, os, time, traceback
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np, torch
