@@ -37,7 +37,10 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "dsvc.h"))
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    missing = [s for s in SOURCES if not os.path.exists(os.path.join(CSRC, s))]
+    if missing:
+        raise RuntimeError("HIP sources missing from %s: %s" % (CSRC, ", ".join(missing)))
+    srcs = list(SOURCES)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
 
     def compile_one(pair):
