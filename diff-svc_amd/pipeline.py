@@ -18,6 +18,20 @@ def shard_clips(n_clips, rank, world):
     return list(range(rank, n_clips, world))
 
 
+def shard_clips_by_length(lengths, world):
+    """Variable-length clips: longest-processing-time-first -- clips sorted by frame count, each handed to the rank with
+    the least frames so far (ties: lowest rank).  Returns one list of clip ids per rank, each sorted by length so that a rank can cut its
+    share into padded batches of similar clips; deterministic, so every rank computes the same partition without talking."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world
+    parts = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        parts[r].append(i)
+        load[r] += int(lengths[i])
+    return parts
+
+
 class SvcPipeline:
     """One process per GPU.  ``acoustic_state`` is a GaussianDiffusion state dict (no 'model.' prefix),
     ``vocoder_state``/``vocoder_cfg`` the NSF-HiFiGAN generator checkpoint and its config.json."""

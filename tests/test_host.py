@@ -359,3 +359,21 @@ def test_infer_driver_host_logic(tmp_path):
     with pytest.raises(AssertionError):
         load_ckpt(lin, str(tmp_path / "nowhere"))
     assert load_ckpt(lin, str(tmp_path / "nowhere"), force=False) is None
+
+
+def test_shard_clips_by_length_balances_and_is_deterministic():
+    """Variable-length partitioning: every clip lands on exactly one rank, the heaviest rank is within one clip of the
+    mean (LPT bound), equal-length clips reduce to an even split, and the result does not depend on who computes it."""
+    from diffsvc_amd.pipeline import shard_clips, shard_clips_by_length
+    g = np.random.Generator(np.random.PCG64(5))
+    lens = g.integers(50, 2000, 257).tolist()
+    for world in (1, 2, 8):
+        parts = shard_clips_by_length(lens, world)
+        assert sorted(i for p in parts for i in p) == list(range(len(lens)))
+        loads = [sum(lens[i] for i in p) for p in parts]
+        assert max(loads) - sum(lens) / world <= max(lens)
+        assert parts == shard_clips_by_length(list(lens), world)
+        for p in parts:
+            assert [lens[i] for i in p] == sorted((lens[i] for i in p), reverse=True)
+    even = shard_clips_by_length([861] * 256, 8)
+    assert all(len(p) == 32 for p in even) and sorted(even[3]) == shard_clips(256, 3, 8)
