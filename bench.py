@@ -41,7 +41,7 @@ PEAK_HBM_GBS = 8000.0                              # HBM3E peak (MI355X_MICROARC
 BYTES_PER_FRAME_GATE = 814 + 3072 + 768
 BYTES_PER_FRAME_LAYER = 814 + 3072 + 3072 + 3072 + 768
 WEIGHT_BYTES_GATE = 768 * 1152 * 2
-WEIGHT_BYTES_LAYER = WEIGHT_BYTES_GATE + 768 * 384 * 2
+WEIGHT_BYTES_OUT = 768 * 384 * 2                   # one fp16 plane of the output 1x1 (f16_mN / f16_w2 stream hi + lo: twice that)
 
 
 def dominant_kernel_roofline(handle, B, precision):
@@ -59,7 +59,9 @@ def dominant_kernel_roofline(handle, B, precision):
                 "algorithmic_bytes": BYTES_PER_FRAME_GATE * frames + WEIGHT_BYTES_GATE}
         tfile = {1: "gate_traffic.json", 32: "gate_traffic_b32.json"}.get(B)
     else:
-        nbytes = BYTES_PER_FRAME_LAYER * frames + WEIGHT_BYTES_LAYER
+        out_planes = 2 if (precision.startswith("f16_m") or precision == "f16_w2") else 1
+        gate_planes = 2 if precision == "f16_w2" else 1
+        nbytes = BYTES_PER_FRAME_LAYER * frames + gate_planes * WEIGHT_BYTES_GATE + out_planes * WEIGHT_BYTES_OUT
         ach = nbytes / (us * 1e-6) / 1e9
         tf = (FLOP_PER_FRAME_DILATED + FLOP_PER_FRAME_OUTPROJ) * frames / (us * 1e-6) / 1e12
         roof = {"bound": "hbm", "kernel": "tlayer_kernel (one residual layer in one launch: dilated conv + cond projection + gate -> g in LDS -> "
@@ -68,7 +70,7 @@ def dominant_kernel_roofline(handle, B, precision):
                 "avg_launch_us": us, "frames_per_launch": frames, "traffic": None, "algorithmic_bytes": nbytes,
                 "mfma_tflops": tf, "mfma_frac": tf / PEAK_TFLOPS_F16}
         tfile = {32: "layer_traffic_b32.json"}.get(B)
-    if precision == "f16_d64" and tfile:
+    if precision == "f16_m64" and tfile:
         roof["traffic"], roof["traffic_source"] = load_traffic(tfile)
     return roof
 
@@ -188,8 +190,9 @@ def main():
     ap.add_argument("--ddpm-steps", type=int, default=1000)
     ap.add_argument("--speedup", type=int, default=1, help="pndm_speedup (>1 = PLMS); the headline config is 1")
     ap.add_argument("--precision", default="auto",
-                    help="auto (default: f16_d64 for the DDPM chain, f16_w2 for PLMS -- the precisions the parity tests hold to the "
-                         "1e-3 mel bar at the benchmarked sizes), f16_dN (fp16 operands, N time-dithered weight roundings), f16_w2, f16_x3, f16")
+                    help="auto (default: f16_m64 for the DDPM chain, f16_w2 for PLMS -- the precisions the parity tests hold to the "
+                         "1e-3 mel bar at the benchmarked sizes), f16_mN / f16_dN (fp16 operands, N time-dithered weight roundings; m: exact "
+                         "output 1x1), f16_w2, f16_x3, f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the extra batched (32 clips/GPU) measurement")
     ap.add_argument("--train", action="store_true",

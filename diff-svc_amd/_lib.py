@@ -9,12 +9,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdsvc_hip.so")
 
 PREC_F16, PREC_F16_W2, PREC_F16_X3 = 0, 1, 2
+PREC_F16_MIX = 3
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3}
 ABI_VERSION = 4
 
 
 def parse_precision(p):
-    """'f16' | 'f16_w2' | 'f16_x3' | 'f16_dN' (fp16 operands, N time-dithered weight roundings) -> (enum, variants)."""
+    """'f16' | 'f16_w2' | 'f16_x3' | 'f16_dN' (fp16 operands, N time-dithered weight roundings) | 'f16_mN' (the same for the dilated
+    conv, exact hi+lo weights for the output 1x1) -> (enum, variants)."""
     if isinstance(p, (tuple, list)):
         return int(p[0]), int(p[1])
     if isinstance(p, int):
@@ -23,7 +25,9 @@ def parse_precision(p):
         return PRECISIONS[p], 1
     if p.startswith("f16_d") and p[5:].isdigit() and int(p[5:]) >= 1:
         return PREC_F16, int(p[5:])
-    raise ValueError("precision must be one of %s or 'f16_dN'" % sorted(PRECISIONS))
+    if p.startswith("f16_m") and p[5:].isdigit() and int(p[5:]) >= 1:
+        return PREC_F16_MIX, int(p[5:])
+    raise ValueError("precision must be one of %s, 'f16_dN' or 'f16_mN'" % sorted(PRECISIONS))
 
 c_f32p = ctypes.POINTER(ctypes.c_float)
 c_i32p = ctypes.POINTER(ctypes.c_int32)

@@ -342,7 +342,7 @@ int dsvc_denoiser::finalize_t() {
     for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     guard = round_up(max_dil, 8);
     const int planes = cfg.precision == DSVC_PREC_F16_W2 ? 2 : 1;
-    const int nvar = (planes == 1 && cfg.weight_variants > 1) ? cfg.weight_variants : 1;
+    const int nvar = (planes == 1 && cfg.weight_variants > 1) ? cfg.weight_variants : 1;       // (F16 and F16_MIX)
 #define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
     {
         GET(w, "input_projection.weight", C * M);
@@ -350,6 +350,10 @@ int dsvc_denoiser::finalize_t() {
         DSVC_TRY(tpack(in_t, *w, C, M, 1, C / 32, 2, 1, 1.0f, 11u, true,
                        [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, b->data(), C));
     }
+    // F16_MIX: the output 1x1 with exact (hi + lo) weights while the dilated conv keeps its dithered single plane -- the output
+    // projection's rounding error goes straight into the residual stream and the skip sum, and removing it is what brings the
+    // 1000-step chain robustly under the 1e-3 bar (profiles/r2w_precision_spread.txt)
+    const bool out_w2 = cfg.precision == DSVC_PREC_F16_MIX;
     dil_t.resize(L); out_t.resize(L);
     for (int l = 0; l < L; ++l) {
         const std::string q = "residual_layers." + std::to_string(l) + ".";
@@ -363,7 +367,7 @@ int dsvc_denoiser::finalize_t() {
                        [&](int r) { const int mt = r >> 5, i = r & 31; return (i >> 4) * C + mt * 16 + trow_to_ch8(i & 15); },
                        bo->data(), 1, &gsc));
         // output 1x1: tiles 0..C/32-1 residual half (conv channels 0..C-1), then the skip half (C..2C-1)
-        DSVC_TRY(tpack(out_t[l], *wo, 2 * C, C, 1, 2 * C / 32, planes, nvar, 1.0f, 1001u + 2 * l, false,
+        DSVC_TRY(tpack(out_t[l], *wo, 2 * C, C, 1, 2 * C / 32, out_w2 ? 2 : planes, out_w2 ? 1 : nvar, 1.0f, 1001u + 2 * l, false,
                        [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, bo->data(), 2 * C));
     }
     {
@@ -574,7 +578,8 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
 }
 
 bool dsvc_denoiser::fused_layer_ok() const {
-    if (getenv("DSVC_NO_FUSED_LAYER") || !tpath || rows_alloc / 128 < 48) return false;      // (the env knob is read per call: A/B tests toggle it)
+    if (getenv("DSVC_NO_FUSED_LAYER") || !tpath || rows_alloc / 128 < 48) return false;
+    if (!dil_t.empty() && dil_t[0].planes != out_t[0].planes) return false;      // (the env knob is read per call: A/B tests toggle it)
     int max_dil = 1;
     for (int l = 0; l < cfg.layers; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     return tlayer_supported(cfg.channels, Cp, max_dil, rows_alloc);
@@ -602,6 +607,7 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
                          out_t[l].bias.as<float>(), last ? nullptr : film.as<float>() + (size_t)(l + 1) * C, L * C, step, C, Cp,
                          l == 0 ? 1 : 0, rowmap(), 1};
     static const int pf = getenv("DSVC_FUSED_PF") ? atoi(getenv("DSVC_FUSED_PF")) : 0;
+    if (dil_t[l].planes == 1 && out_t[l].planes == 2) return tlayer_launch<1, 2>(ga, cp, oa, oe, C, rows_alloc, pf, st);      // F16_MIX
     return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st);
 }
 
@@ -716,7 +722,8 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
     // The captured segment is one period of the dither schedule (64 steps for f16_d64) replayed from a period-aligned step, so
     // every kernel node knows its weight variant at capture time and passes it by value: the alternative -- a scalar load of the
     // step in front of every kernel's weight stream -- costs ~0.4 us x 43 kernels per step in the single-clip regime.
-    const int nvar = (den->tpath && den->cfg.precision == DSVC_PREC_F16 && den->cfg.weight_variants > 1) ? den->cfg.weight_variants : 1;
+    const int nvar = (den->tpath && (den->cfg.precision == DSVC_PREC_F16 || den->cfg.precision == DSVC_PREC_F16_MIX) && den->cfg.weight_variants > 1)
+                         ? den->cfg.weight_variants : 1;
     const int UNROLL = (nvar > 1 && nvar <= 64) ? nvar : 10;
     const bool aligned = UNROLL == nvar && nvar > 1;
     if (a->use_graph && n >= 2 * UNROLL) {
@@ -831,7 +838,7 @@ int dsvc_abi_version(void) { return DSVC_ABI_VERSION; }
 
 int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out) {
     if (!cfg || !out) return fail(DSVC_EINVAL, "null argument");
-    if (cfg->precision < DSVC_PREC_F16 || cfg->precision > DSVC_PREC_F16_X3) return fail(DSVC_EINVAL, "unknown precision %d", cfg->precision);
+    if (cfg->precision < DSVC_PREC_F16 || cfg->precision > DSVC_PREC_F16_MIX) return fail(DSVC_EINVAL, "unknown precision %d", cfg->precision);
     int ndev = 0;
     DSVC_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(DSVC_EHIP, "no HIP device visible");

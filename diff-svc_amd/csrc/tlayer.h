@@ -44,8 +44,10 @@ struct TLayerArgs {
 //   base0     LDS byte address of this lane's row of N-tile 0
 //   nt_stride bytes between N-tiles (32 rows)
 //   xs        (((row & swz) ^ (lane >> 5)) << 4) ^ (first k16 step of the group << 5)
+// (rings are flat arrays of KG * NW fragments -- [k-step][plane] -- so that the two phases of a layer can use different (KG, NW) splits of
+//  the same eight registers: F16_MIX streams one dithered plane for the gate and hi + lo planes for the output projection)
 template <int KG, int NW>
-__device__ __forceinline__ void tl_compute_group(const half8 (&ring)[KG][NW], f32x16 (&acc)[4], unsigned base0, unsigned nt_stride, unsigned xs) {
+__device__ __forceinline__ void tl_compute_group(const half8 (&ring)[KG * NW], f32x16 (&acc)[4], unsigned base0, unsigned nt_stride, unsigned xs) {
     typedef const half8 __attribute__((address_space(3))) * lds_frag_ptr;
     unsigned base[4];
     base[0] = base0;
@@ -65,8 +67,8 @@ __device__ __forceinline__ void tl_compute_group(const half8 (&ring)[KG][NW], f3
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][0], bq[kk & 1][nt], acc[nt], 0, 0, 0);
-            if constexpr (NW == 2) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][1], bq[kk & 1][nt], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk * NW], bq[kk & 1][nt], acc[nt], 0, 0, 0);
+            if constexpr (NW == 2) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk * NW + 1], bq[kk & 1][nt], acc[nt], 0, 0, 0);
         }
     }
     // pin the software pipeline: one B-fragment read of step kk+1 behind each MFMA (pair) of step kk
@@ -82,19 +84,20 @@ __device__ __forceinline__ void tl_compute_group(const half8 (&ring)[KG][NW], f3
 }
 
 template <int KG, int NW>
-__device__ __forceinline__ void tl_load_group(half8 (&ring)[KG][NW], const _Float16* p) {
+__device__ __forceinline__ void tl_load_group(half8 (&ring)[KG * NW], const _Float16* p) {
 #pragma unroll
-    for (int u = 0; u < KG; ++u)
-#pragma unroll
-        for (int q = 0; q < NW; ++q) ring[u][q] = *reinterpret_cast<const half8*>(p + (u * NW + q) * TFRAG_HALFS);
+    for (int u = 0; u < KG * NW; ++u) ring[u] = *reinterpret_cast<const half8*>(p + u * TFRAG_HALFS);
 }
 
 // NB = C / 128 = gate passes = output passes (8 waves x 16 g-channels, 8 waves x 32 output rows of 2C): 2 (C = 256) or 3 (C = 384).
 // PF: prefetch the output projection's first accumulator init (residual stream) already under the LAST gate pass's main loop
 // (64 more live VGPRs there) instead of right after it.
-template <int NB, int KG, int NW, int PF>
+// NW2: weight planes of the output projection (= NW, or 2 with NW = 1 for F16_MIX); its groups are KG2 = KG * NW / NW2 k-steps deep.
+template <int NB, int KG, int NW, int PF, int NW2 = NW>
 __global__ void __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
 tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiResSkip::Args oe) {
+    constexpr int KG2 = KG * NW / NW2;
+    static_assert(KG2 * NW2 == KG * NW && KG2 >= 1, "both phases use the same eight ring registers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -138,7 +141,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const int lane8 = lane * 8;
     const int gpt = (ga.cin >> 4) / KG;                   // gate: groups per tap
     const int G1 = 3 * gpt;                               // gate: groups per output tile
-    const int G2 = gpt;                                   // output projection: groups per tile (K = C)
+    const int G2 = (ga.cin >> 4) / KG2;                   // output projection: groups per tile (K = C)
     const long long tile1 = (long long)G1 * GROUP_HALFS, tile2 = (long long)G2 * GROUP_HALFS;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);         // waves w and w+4 share a SIMD: let the pair drift apart (tgemm.h)
     const int rot = (int)(blockIdx.x % (unsigned)NB);     // per-workgroup rotated pass order (tgemm.h)
@@ -149,7 +152,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     TEpiResSkip oepi;
     const TEpiGate::Args ge{cproj, nullptr, ga.cin, ga.cin};
     f32x16 acc[4], nxt[4];
-    half8 ringA[KG][NW], ringB[KG][NW];
+    half8 ringA[KG * NW], ringB[KG * NW];
     half8 gmid[4];                                        // the middle gate pass's g block share (NB == 3)
 
     // first operands in flight before the barrier
@@ -200,7 +203,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
         }
         // the next tile's weight stream starts before this tile's epilogue
         if (!last) tl_load_group<KG, NW>(ringA, gw + (long long)mt_n * tile1 + lane8);
-        else tl_load_group<KG, NW>(ringA, ow + (long long)mt_n * tile2 + lane8);
+        else tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
         if (!nxt_issued && (!last || PF)) issue_next_init();
         // ---- gate epilogue: g = sigmoid * tanh -> fp16 (TEpiGate::finish, kept on chip) ----
         half8 gq[4];
@@ -246,25 +249,25 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
         const int mt_n = last ? 0 : tile_of(po + 1);
         bool nxt_issued = false;
         auto group_b = [&](int g, unsigned& base0, unsigned& xs) {
-            const int kb = g * KG;                          // first k16 step of the group; 8 steps per 128-channel block
+            const int kb = g * KG2;                          // first k16 step of the group; 8 steps per 128-channel block
             int pos = (kb >> 3) - rot; if (pos < 0) pos += NB;
             base0 = block_base(pos) + (unsigned)(lane & 31) * 256u;
             xs = xs_g ^ ((unsigned)(kb & 7) << 5);
         };
         int g = 0;
         for (; g + 1 < G2; g += 2) {
-            tl_load_group<KG, NW>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
+            tl_load_group<KG2, NW2>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
             if (g == g_issue2 && !last) { oepi.init(oe, mt_n, row0, lane, nxt); nxt_issued = true; }
             __builtin_amdgcn_sched_barrier(0);
-            { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG, NW>(ringA, acc, b0, 32u * 256u, xs); }
+            { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG2, NW2>(ringA, acc, b0, 32u * 256u, xs); }
             const int gn = g + 2 < G2 ? g + 2 : G2 - 1;
-            tl_load_group<KG, NW>(ringA, wp + (long long)gn * GROUP_HALFS + lane8);
+            tl_load_group<KG2, NW2>(ringA, wp + (long long)gn * GROUP_HALFS + lane8);
             __builtin_amdgcn_sched_barrier(0);
-            { unsigned b0, xs; group_b(g + 1, b0, xs); tl_compute_group<KG, NW>(ringB, acc, b0, 32u * 256u, xs); }
+            { unsigned b0, xs; group_b(g + 1, b0, xs); tl_compute_group<KG2, NW2>(ringB, acc, b0, 32u * 256u, xs); }
         }
-        if (g < G2) { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG, NW>(ringA, acc, b0, 32u * 256u, xs); }
+        if (g < G2) { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG2, NW2>(ringA, acc, b0, 32u * 256u, xs); }
         if (!last) {
-            tl_load_group<KG, NW>(ringA, ow + (long long)mt_n * tile2 + lane8);
+            tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
             if (!nxt_issued) oepi.init(oe, mt_n, row0, lane, nxt);
         }
         oepi.finish(oe, mt, row0, lane, acc);
@@ -286,9 +289,9 @@ inline bool tlayer_supported(int C, int cin_pad, int dil, int n_rows) {
     return C == cin_pad && (C == 256 || C == 384) && n_rows % TL_TN == 0 && tlayer_smem(dil, cin_pad) <= 160 * 1024;
 }
 
-template <int NB, int KG, int NW, int PF>
+template <int NB, int KG, int NW, int PF, int NW2 = NW>
 inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiResSkip::Args& oe, int n_rows, hipStream_t stream) {
-    auto kern = tlayer_kernel<NB, KG, NW, PF>;
+    auto kern = tlayer_kernel<NB, KG, NW, PF, NW2>;
     const size_t smem = tlayer_smem(ga.dil, ga.cin);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {
@@ -301,18 +304,24 @@ inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiR
 }
 
 // gate weights `g` (taps 3, m_tiles C/16) + output-projection weights `o` (taps 1, m_tiles 2C/32) of ONE layer, as tgemm would get them
-template <int NW>
+template <int NW, int NW2 = NW>
 inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs& o, const TEpiResSkip::Args& oe, int C, int n_rows,
                          int prefetch, hipStream_t stream) {
     constexpr int KG = NW == 2 ? 4 : 8;
     if (g.taps != 3 || o.taps != 1 || g.m_tiles != C / 16 || o.m_tiles != 2 * C / 32 || g.cin != C || o.cin != C)
         return fail(DSVC_EINVAL, "tlayer: unexpected layer geometry");
-    if (g.w_planes != NW || o.w_planes != NW) return fail(DSVC_EINVAL, "tlayer: weight planes");
-    if (g.n_variants != o.n_variants) return fail(DSVC_EINVAL, "tlayer: the two contractions must carry the same number of dither variants");
+    if (g.w_planes != NW || o.w_planes != NW2) return fail(DSVC_EINVAL, "tlayer: weight planes");
+    if (g.n_variants != o.n_variants && o.n_variants != 1)
+        return fail(DSVC_EINVAL, "tlayer: the output projection carries %d dither variants, the gate %d", o.n_variants, g.n_variants);
     if (!tlayer_supported(C, g.cin, g.dil, n_rows)) return fail(DSVC_EINVAL, "tlayer: shape not supported by the fused layer kernel");
     TLayerArgs a{};
     a.x = g.x; a.cin = g.cin; a.swz = tgemm_swizzle_mask(g.cin); a.dil = g.dil; a.gw = g.w; a.ow = o.w;
-    a.gvar = g.variant_halfs; a.ovar = o.variant_halfs; a.n_variants = g.n_variants; a.step_ptr = g.step_ptr; a.step_off = g.step_off;
+    a.gvar = g.variant_halfs; a.ovar = o.n_variants == g.n_variants ? o.variant_halfs : 0; a.n_variants = g.n_variants;
+    a.step_ptr = g.step_ptr; a.step_off = g.step_off;
+    if constexpr (NW2 != NW) {                            // (the prefetch variant is not instantiated for the mixed kernel)
+        if (C == 384) return tlayer_launch_t<3, KG, NW, 0, NW2>(a, cproj, oe, n_rows, stream);
+        return tlayer_launch_t<2, KG, NW, 0, NW2>(a, cproj, oe, n_rows, stream);
+    }
     if (C == 384) return prefetch ? tlayer_launch_t<3, KG, NW, 1>(a, cproj, oe, n_rows, stream) : tlayer_launch_t<3, KG, NW, 0>(a, cproj, oe, n_rows, stream);
     return prefetch ? tlayer_launch_t<2, KG, NW, 1>(a, cproj, oe, n_rows, stream) : tlayer_launch_t<2, KG, NW, 0>(a, cproj, oe, n_rows, stream);
 }

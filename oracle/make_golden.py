@@ -169,7 +169,7 @@ def golden_vocoder(name, h, wseed, clips, T, seed):
     print(name, "wav rms %.4f max %.3f" % (float(np.sqrt((wav ** 2).mean())), float(np.abs(wav).max())))
 
 
-def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500, seed=2026, wseed=0, vseed=1, K=1000, speedup=1):
+def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500, seed=2026, wseed=0, vseed=1, K=1000, speedup=1, with_wav=True):
     """The BENCHMARKED configuration (BASELINE configs[1]: 10 s clip, T=861, 44.1 kHz architecture, full 1000-step DDPM) through
     the REAL reference end to end: GaussianDiffusion.forward(infer=True) (diffusion.py:227-284) -> the host glue of
     Svc.after_infer (clip to [mel_vmin, mel_vmax], infer_tool.py:177-183) -> Generator.forward (models.py:361-387) for the first
@@ -185,14 +185,24 @@ def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500,
     ret = run_reference_sampler(model, hp, hub, m2p, f0, clips, speedup, seed)
     mel = ret["mel_out"].numpy()
     print(name, "sampler %.0f s, mel range %.3f..%.3f" % (time.time() - t0, mel.min(), mel.max()))
-    h = dict(synth.VOCODER_44K)
-    mel_c = np.clip(mel[:1], hp["mel_vmin"], hp["mel_vmax"])
-    f0_hz = ret["f0_denorm"].numpy()[:1]
-    wav = run_reference_vocoder(h, vseed, mel_c, f0_hz, clips[:1], seed)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), mel_out=mel, wav0=wav[0], f0_denorm=ret["f0_denorm"].numpy(),
+    extra = {}
+    if with_wav:
+        h = dict(synth.VOCODER_44K)
+        mel_c = np.clip(mel[:1], hp["mel_vmin"], hp["mel_vmax"])
+        f0_hz = ret["f0_denorm"].numpy()[:1]
+        wav = run_reference_vocoder(h, vseed, mel_c, f0_hz, clips[:1], seed)
+        extra["wav0"] = wav[0]
+        print(name, "wav rms %.4f max %.3f" % (float(np.sqrt((wav ** 2).mean())), float(np.abs(wav).max())))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), mel_out=mel, f0_denorm=ret["f0_denorm"].numpy(),
                         pitch=ret["pitch_pred"].numpy().astype(np.int16), wseed=wseed, vseed=vseed, clips=np.array(clips), T=T,
-                        n_units=n_units, speedup=speedup, seed=seed, K_step=K)
-    print(name, "wav rms %.4f max %.3f" % (float(np.sqrt((wav ** 2).mean())), float(np.abs(wav).max())))
+                        n_units=n_units, speedup=speedup, seed=seed, K_step=K, **extra)
+
+
+def golden_headline_extra():
+    """Two more single-clip runs of the benchmarked configuration through the real reference: the (clip, seed) pairs on which a spread
+    study of the HIP path's 1000-step error (tools/study_headline_spread.py, profiles/r2w_*) found its largest values."""
+    golden_headline(name="e2e_44k_T861_k1000_c4", clips=(4,), seed=1004, with_wav=False)
+    golden_headline(name="e2e_44k_T861_k1000_c6", clips=(6,), seed=1006, with_wav=False)
 
 
 def golden_melspec(name, sr, n_fft, win, hop, n_mels, fmin, fmax, n_samples):
@@ -256,6 +266,8 @@ def main():
         return golden_schedule()
     if "--headline-only" in sys.argv:
         return golden_headline()
+    if "--headline-extra" in sys.argv:
+        return golden_headline_extra()
     if "--plms-only" in sys.argv:
         return golden_plms_conditioned()
     if "--hifigan-only" in sys.argv:
@@ -283,6 +295,7 @@ def main():
     golden_hubert()
     golden_pe()
     golden_plms_conditioned()
+    golden_headline_extra()
     golden_slicer()
     golden_slicer_demo_input()
     golden_schedule()

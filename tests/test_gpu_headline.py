@@ -23,7 +23,7 @@ MEL_BAR = 1e-3          # north_star: mel within 1e-3 max-abs
 WAV_BAR = 1e-4          # north_star: waveform within 1e-4 RMS
 # max-abs tolerance on ONE denoiser evaluation (O(1) outputs) per operand precision: a single evaluation carries the whole
 # fp16 operand rounding; the chain tests above are the ones held to the mel bar
-FWD_TOL = {"f16": 2e-2, "f16_d64": 2e-2, "f16_w2": 6e-3}
+FWD_TOL = {"f16": 2e-2, "f16_d64": 2e-2, "f16_m64": 2e-2, "f16_w2": 6e-3}
 
 
 def make_handles(hp, wseed, precision):
@@ -52,10 +52,10 @@ def headline():
     return _HEAD
 
 
-@pytest.mark.parametrize("precision", ["f16_d64", "f16_w2"])
+@pytest.mark.parametrize("precision", ["f16_m64", "f16_d64", "f16_w2"])
 def test_headline_single_clip_T861_1000_steps_vs_reference(precision):
-    """BENCH config: B=1, T=861, 1000 steps, graph replay, shipped precision -- mel within 1e-3 of the REAL reference, two clips /
-    noise streams."""
+    """BENCH config: B=1, T=861, 1000 steps, graph replay, shipped precision (f16_m64) -- mel within 1e-3 of the REAL reference, two
+    clips / noise streams.  (f16_d64 -- every weight dithered -- passes on these two but not robustly: see the next test.)"""
     H = headline()
     g = H["g"]
     sd, den, smp = make_handles(H["hp"], int(g["wseed"]), precision)
@@ -65,6 +65,29 @@ def test_headline_single_clip_T861_1000_steps_vs_reference(precision):
                          first_clip=c, use_graph=True)
         errs.append((mel[0].cpu() - torch.from_numpy(g["mel_out"][i])).abs().max().item())
     print("headline %s: mel max-abs err per clip %s" % (precision, ["%.2e" % e for e in errs]))
+    assert max(errs) < MEL_BAR, errs
+
+
+@pytest.mark.parametrize("precision", ["f16_m64", "f16_w2"])
+def test_headline_worst_found_realisations_vs_reference(precision):
+    """Two more single-clip runs of the REAL reference at the benchmarked configuration (e2e_44k_T861_k1000_c4 / _c6): the (clip,
+    noise) pairs on which a spread study over eight realisations found the all-dithered f16_d64 at 1.02e-3 and 1.27e-3 -- over the
+    bar (profiles/r2w_precision_spread.txt).  The shipped f16_m64 (dithered dilated conv, exact output 1x1) and f16_w2 stay inside."""
+    from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
+    hp = dict(synth.HPARAMS_44K)
+    sd = synth.acoustic_state(hp, 0)
+    den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=precision, prefix="denoise_fn.")
+    smp = SamplerHandle(den, sd)
+    errs = []
+    for name in ("e2e_44k_T861_k1000_c4", "e2e_44k_T861_k1000_c6"):
+        g = load_golden(name)
+        clips = [int(c) for c in g["clips"]]
+        hub, m2p, f0 = clip_batch(hp, clips, int(g["T"]), int(g["n_units"]))
+        cond, f0_denorm, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+        assert np.array_equal(f0_denorm.numpy(), g["f0_denorm"])
+        mel = smp.sample(cond.transpose(1, 2).contiguous().cuda(), 1000, mel2ph=m2p.cuda(), seed=int(g["seed"]), first_clip=clips[0])
+        errs.append((mel.cpu() - torch.from_numpy(g["mel_out"])).abs().max().item())
+    print("headline extra %s: mel max-abs err (clip 4, clip 6) %s" % (precision, ["%.2e" % e for e in errs]))
     assert max(errs) < MEL_BAR, errs
 
 
@@ -99,7 +122,7 @@ def test_plms_50_iterations_T861_vs_reference(precision):
         assert max(errs) < MEL_BAR, errs
 
 
-@pytest.mark.parametrize("precision", ["f16_d64"])
+@pytest.mark.parametrize("precision", ["f16_m64", "f16_d64"])
 def test_throughput_tiling_full_chain_vs_reference(precision):
     """The batched number's kernels over the FULL chain: 8 clips x T=861 (7168 rows -> the 128-frame tgemm tiling with the
     non-temporal residual/skip stream), 1000 steps; clips 0 and 1 of the batch are the reference golden's clips."""
@@ -119,7 +142,7 @@ def test_throughput_tiling_full_chain_vs_reference(precision):
     assert max(errs) < MEL_BAR, errs
 
 
-@pytest.mark.parametrize("precision", ["f16", "f16_w2", "f16_d64"])
+@pytest.mark.parametrize("precision", ["f16", "f16_w2", "f16_d64", "f16_m64"])
 def test_throughput_tiling_forward_vs_oracle(precision):
     """dsvc_denoiser_forward at B=8 x T=861 on the tgemm engine (tgemm_kernel<4,8,...>), per-clip steps differ."""
     hp = dict(synth.HPARAMS_44K)
@@ -139,7 +162,7 @@ def test_throughput_tiling_forward_vs_oracle(precision):
     assert max(errs) < FWD_TOL[precision], errs
 
 
-@pytest.mark.parametrize("precision", ["f16_w2", "f16_d64"])
+@pytest.mark.parametrize("precision", ["f16_w2", "f16_d64", "f16_m64"])
 def test_throughput_tiling_ddpm_20_steps_vs_oracle(precision):
     """20-step DDPM at B=8 x T=861 on the throughput tiling; two clips of the batch against B=1 oracle chains."""
     hp = dict(synth.HPARAMS_44K, K_step=20)
@@ -181,7 +204,8 @@ def _tap_errors(den, sd, spec, t, cond, rows_of):
 
 
 @pytest.mark.parametrize("precision,B,T,fused", [("f16_w2", 1, 45, True), ("f16_d64", 1, 45, True), ("f16_d64", 2, 861, True),
-                                                 ("f16_w2", 8, 861, True), ("f16_d64", 8, 861, True), ("f16_d64", 8, 861, False)])
+                                                 ("f16_w2", 8, 861, True), ("f16_d64", 8, 861, True), ("f16_d64", 8, 861, False),
+                                                 ("f16_m64", 1, 45, True), ("f16_m64", 8, 861, True)])
 def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused):
     """Per-layer localisation on the PRODUCT engine (tgemm): after every residual block the residual stream x_l, the gate
     output g_l and the running skip sum are compared with the oracle -- for the split-K single-clip tiling (T=45 and T=861), the
@@ -210,7 +234,7 @@ def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused):
     assert worst["x"][0] < tol and (worst["g"][0] < tol or not g_live) and worst["s"][0] < 4 * tol, worst
 
 
-@pytest.mark.parametrize("precision", ["f16_d64", "f16_w2", "f16_x3"])
+@pytest.mark.parametrize("precision", ["f16_m64", "f16_d64", "f16_w2", "f16_x3"])
 def test_end_to_end_waveform_vs_reference(precision):
     """cond -> 1000-step DDPM -> clip -> NSF-HiFiGAN through the HIP path against the REAL reference's PCM for the same inputs and
     noise streams (golden wav0: reference sampler -> after_infer clip -> reference generator).  The mel the vocoder sees is the
@@ -232,7 +256,7 @@ def test_end_to_end_waveform_vs_reference(precision):
     assert rms < WAV_BAR, rms
 
 
-@pytest.mark.parametrize("precision", ["f16_d64", "f16_w2"])
+@pytest.mark.parametrize("precision", ["f16_m64", "f16_d64", "f16_w2"])
 def test_fused_layer_kernel_equals_the_two_launch_layer_bit_for_bit(precision):
     """The throughput tiling runs a residual layer as ONE kernel (tlayer.h: gate GEMM -> g in LDS -> output projection).  It issues
     the same MFMAs on the same operands in the same order as the two tgemm launches it replaces (DSVC_NO_FUSED_LAYER=1), so a
