@@ -578,8 +578,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
 }
 
 bool dsvc_denoiser::fused_layer_ok() const {
-    if (getenv("DSVC_NO_FUSED_LAYER") || !tpath || rows_alloc / 128 < 48) return false;
-    if (!dil_t.empty() && dil_t[0].planes != out_t[0].planes) return false;      // (the env knob is read per call: A/B tests toggle it)
+    if (getenv("DSVC_NO_FUSED_LAYER") || !tpath || rows_alloc / 128 < 48) return false;      // (the env knob is read per call: A/B tests toggle it)
     int max_dil = 1;
     for (int l = 0; l < cfg.layers; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     return tlayer_supported(cfg.channels, Cp, max_dil, rows_alloc);

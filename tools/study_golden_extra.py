@@ -26,6 +26,8 @@ for prec in precs:
         cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
         ids = torch.tensor(clips, dtype=torch.int32, device="cuda")
         mel = smp.sample(cond.transpose(1, 2).contiguous().cuda(), 1000, seed=int(g["seed"]), clip_ids=ids, mel2ph=m2p.cuda())
-        err = (mel.cpu() - torch.from_numpy(g["mel_out"])).abs().amax(dim=(1, 2))
-        line += "  clips %s: %s" % (clips, ["%.2e" % e for e in err.tolist()])
+        d = mel.cpu() - torch.from_numpy(g["mel_out"])
+        err = d.abs().amax(dim=(1, 2))
+        rms = d.pow(2).mean(dim=(1, 2)).sqrt()
+        line += "  clips %s: max %s rms %s" % (clips, ["%.2e" % e for e in err.tolist()], ["%.2e" % e for e in rms.tolist()])
     print(line, flush=True)
