@@ -11,7 +11,7 @@ in libdsvc_hip.so.  Register it in the reference's seam with
 the dilated conv with exact (hi + lo) weights for the output 1x1 (what bench.py measures for the 1000-step DDPM and the 1000-step
 parity tests hold to the bar); ``"f16_w2"`` / ``"f16_x3"`` spend 2 / 3 MFMAs everywhere.  The default ``"auto"`` picks per sampler:
 ``f16_m64`` for DDPM -- the dither's rounding noise averages out over the chain, and the output projection, whose error goes
-straight into the residual stream and the skip sum, is exact (eight (clip, noise) pairs against the real reference: 6.7e-4 ... 9.2e-4;
+straight into the residual stream and the skip sum, is exact (fourteen (clip, noise) pairs against the reference: 6.7e-4 ... 9.7e-4;
 all-dithered f16_d64 7.8e-4 ... 1.27e-3, over the bar on two of them); for PLMS/PNDM, whose Adams-Bashforth extrapolation amplifies a
 single evaluation's rounding, ``f16_w2`` up to ``pndm_speedup`` 20 (measured on the 50-iteration chain at T=861: 3.0e-3 mel error
 with f16_d64, 7.7e-4 with f16_w2; tests/test_gpu_headline.py) and the fp32-class

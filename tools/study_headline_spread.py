@@ -18,7 +18,7 @@ hp = dict(synth.HPARAMS_44K)
 sd = synth.acoustic_state(hp, 0)
 torch.set_num_threads(min(32, os.cpu_count() or 1))
 handles = {}
-for prec in ("f16_d64", "f16_w2"):
+for prec in ("f16_m64", "f16_d64", "f16_w2"):
     den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=prec, prefix="denoise_fn.")
     handles[prec] = SamplerHandle(den, sd)
 for c in clips:
