@@ -13,9 +13,10 @@ parity tests hold to the bar); ``"f16_w2"`` / ``"f16_x3"`` spend 2 / 3 MFMAs eve
 ``f16_m64`` for DDPM -- the dither's rounding noise averages out over the chain, and the output projection, whose error goes
 straight into the residual stream and the skip sum, is exact (fourteen (clip, noise) pairs against the reference: 6.7e-4 ... 9.7e-4;
 all-dithered f16_d64 7.8e-4 ... 1.27e-3, over the bar on two of them); for PLMS/PNDM, whose Adams-Bashforth extrapolation amplifies a
-single evaluation's rounding, ``f16_w2`` up to ``pndm_speedup`` 20 (measured on the 50-iteration chain at T=861: 3.0e-3 mel error
-with f16_d64, 7.7e-4 with f16_w2; tests/test_gpu_headline.py) and the fp32-class
-``f16_x3`` for coarser schedules (20 iterations at pndm_speedup 50: 9e-3 with f16_w2, 1.2e-5 with f16_x3).
+single evaluation's rounding, the fp32-class ``f16_x3`` (split activations as well: 1e-5): with fp16 activations even exact weights
+(``f16_w2``) leave the 50-iteration chain at T=861 at (8.2 +- 1.2)e-4 -- ten (clip, noise) pairs, one of them at 1.08e-3, over the bar
+(profiles/r2w_precision_spread.txt) -- and ``f16_d64`` at 3e-3; coarser schedules (20 iterations at pndm_speedup 50) need it anyway
+(9e-3 with f16_w2, 1.2e-5 with f16_x3).
 Inference only: there is no autograd through the HIP kernels, so
 ``infer=False`` training keeps using the reference module.
 """
@@ -48,7 +49,7 @@ class _ResidualBlockParams(nn.Module):
 
 
 class DiffNetHip(nn.Module):
-    AUTO = {"ddpm": "f16_m64", "plms": "f16_w2", "plms_coarse": "f16_x3", "forward": "f16_m64"}
+    AUTO = {"ddpm": "f16_m64", "plms": "f16_x3", "plms_coarse": "f16_x3", "forward": "f16_m64"}
 
     def __init__(self, in_dims=80, hparams=None, precision="auto"):
         super().__init__()

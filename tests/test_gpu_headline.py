@@ -91,7 +91,7 @@ def test_headline_worst_found_realisations_vs_reference(precision):
     assert max(errs) < MEL_BAR, errs
 
 
-@pytest.mark.parametrize("precision", ["f16_d64", "f16_w2"])
+@pytest.mark.parametrize("precision", ["f16_x3", "f16_d64", "f16_w2"])
 def test_plms_50_iterations_T861_vs_reference(precision):
     """BASELINE configs[2] at the benchmarked size: one 10 s clip (T=861), 44.1 kHz architecture, the full 1000-step schedule at
     pndm_speedup=20 (50 PLMS iterations, 51 denoiser evaluations), the captured-graph path bench.py times -- mel within 1e-3 of the
@@ -115,11 +115,14 @@ def test_plms_50_iterations_T861_vs_reference(precision):
     print("PLMS-50 T=861 %s: mel max-abs err eager/graph/replay %s" % (precision, ["%.2e" % e for e in errs]))
     assert errs[0] == errs[1] == errs[2]                    # the captured graph is the eager loop
     if precision == "f16_d64":
-        # documents WHY the drop-in runs PLMS at f16_w2 (DiffNetHip.precision_for): one dithered fp16 MFMA per product, fine over
-        # a 1000-step DDPM chain, misses the bar when 51 evaluations are extrapolated
+        # documents WHY the drop-in does not run PLMS on dithered single-plane weights (DiffNetHip.precision_for): fine over a
+        # 1000-step DDPM chain, well over the bar when 51 evaluations are extrapolated
         assert MEL_BAR < max(errs) < 1e-2, errs
+    elif precision == "f16_x3":
+        assert max(errs) < 5e-5, errs                       # the shipped PLMS precision: fp32-class
     else:
-        assert max(errs) < MEL_BAR, errs
+        assert max(errs) < MEL_BAR, errs                    # f16_w2 passes on THIS pair (7.7e-4); over ten pairs it is (8.2 +- 1.2)e-4
+                                                            # with one at 1.08e-3 (profiles/r2w_precision_spread.txt): not shipped
 
 
 @pytest.mark.parametrize("precision", ["f16_m64", "f16_d64"])
