@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libdsvc_hip.so")
 PREC_F16, PREC_F16_W2, PREC_F16_X3 = 0, 1, 2
 PREC_F16_MIX = 3
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def parse_precision(p):
@@ -90,6 +90,8 @@ SYMBOLS = [
     ("dsvc_denoiser_destroy", None, [_VP]),
     ("dsvc_denoiser_forward", ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     ("dsvc_denoiser_debug_buffer", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64, c_i32p, c_i32p]),
+    ("dsvc_denoiser_check", ctypes.c_int, [_VP, _VP]),
+    ("dsvc_denoiser_debug_set", ctypes.c_int, [_VP, ctypes.c_char_p, ctypes.c_int32]),
     ("dsvc_sampler_create", ctypes.c_int, [_VP, ctypes.POINTER(_VP)]),
     ("dsvc_sampler_load_tensor", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64]),
     ("dsvc_sampler_finalize", ctypes.c_int, [_VP]),
@@ -133,6 +135,15 @@ SYMBOLS = [
 ]
 
 _lib = None
+
+
+def use_profiling_build():
+    """Profiling tools only (tools/): bind to libdsvc_hip_prof.so, the -DDSVC_PROFILING build whose kernels carry the ablation knobs
+    (``python -m diffsvc_amd.build --profiling``).  Must be called before the first ``lib()``."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("the library is already loaded")
+    LIB_PATH = os.path.join(HERE, "libdsvc_hip_prof.so")
 
 
 def lib():

@@ -12,6 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdsvc_hip.so")
+OUT_PROF = os.path.join(HERE, "libdsvc_hip_prof.so")
 SOURCES = ["common.hip", "diffnet.hip", "vocoder.hip", "melspec.hip", "train.hip", "hubert.hip", "pe.hip", "cond.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]       # the per-kernel register / scratch report is kept next to the object
@@ -31,9 +32,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, profiling=False):
+    """profiling=True compiles a SEPARATE library, libdsvc_hip_prof.so, with -DDSVC_PROFILING: the ablation / A-B knobs of the kernels
+    (environment variables DSVC_TG_DEBUG, DSVC_TG_STAMPS, DSVC_PROFILE_KERNEL, ... -- several of them give WRONG results by design) exist
+    only there.  The product library reads no environment variable; tools load the other one with _lib.use_profiling_build()."""
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_prof" if profiling else "build")
+    out = OUT_PROF if profiling else OUT
+    flags = FLAGS + (["-DDSVC_PROFILING"] if profiling else [])
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "dsvc.h"))
@@ -47,7 +53,7 @@ def build(force=False, verbose=True):
         src, obj = pair
         if not force and not _stale(obj, [os.path.join(CSRC, src)] + headers):
             return None
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-8000:]))
@@ -57,20 +63,20 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         built = [b for b in ex.map(compile_one, zip(srcs, objs)) if b]
-    if built or force or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if built or force or _stale(out, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-8000:])
         if verbose:
-            print("built %s (%s)" % (OUT, ", ".join(built) if built else "relink"))
+            print("built %s (%s)" % (out, ", ".join(built) if built else "relink"))
     elif verbose:
-        print("up to date: %s" % OUT)
-    return OUT
+        print("up to date: %s" % out)
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, profiling="--profiling" in sys.argv)
 
 
 def kernel_resources(source="diffnet.hip"):

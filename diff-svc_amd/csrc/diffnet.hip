@@ -139,7 +139,11 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
     // path (every wave streams its own weights: ~40 B/clk measured against 64 peak) and by in-order issue of a lone wave per
     // SIMD (~85 cycles per k-step).  So the work is cut finer: 3 output tiles per workgroup (224 workgroups for the layer
     // kernels instead of 168) and each tile's K loop split over 3 waves that reduce through LDS (9 waves per workgroup).
+#ifdef DSVC_PROFILING
     static const int ksplit = getenv("DSVC_TG_KS") ? atoi(getenv("DSVC_TG_KS")) : 3;       // tuning knob (1 = off)
+#else
+    constexpr int ksplit = 3;
+#endif
     if (ksplit == 3 && tiles * ceil_div(a.m_tiles, 3) <= 256)
         return tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 3>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st);
     return tgemm_launch<1, 4, 2, KG, NW, Epi>(a, e, rows_alloc, ms, st);
@@ -177,9 +181,14 @@ struct dsvc_denoiser {
     DevBuf lens, clipid;  // int [B]: valid frames per clip (zero padding beyond), Philox clip id per batch element
     DevBuf rowclip;       // int [rows_alloc]: clip of a row, -1 on gap / padded rows (RowMap)
     bool cond_ready = false;
+    // test support, set through dsvc_denoiser_debug_set (explicit handle state -- the product library reads no environment variable):
+    int dbg_stop_after = -1;     // >= 0: an evaluation returns after this many residual layers (per-layer taps, tests/test_gpu_headline.py)
+    bool dbg_two_launch = false; // run a residual layer as its two tgemm launches even where the fused kernel applies (bit-equality test)
+    int* step_err = nullptr;     // host-mapped sticky flag: a dsvc_denoiser_forward call saw a diffusion step outside [0, max_steps)
     unsigned ws_gen = 0;  // bumped whenever the workspace is (re)built: captured graphs bake its pointers and are keyed on this
 
     ~dsvc_denoiser() {
+        if (step_err) (void)hipHostFree(step_err);
         for (DevBuf* b : {&film, &xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps, &lens, &clipid, &rowclip, &xh, &xh2, &gh, &skiph, &s2h, &xsh}) b->release();
         auto rel = [](PackedConv& p) { p.w.release(); p.bias.release(); };
         rel(in_proj); rel(skip_proj); rel(fin_proj);
@@ -238,7 +247,7 @@ int dsvc_denoiser::finalize() {
         if (max_dil > 64) return fail(DSVC_EINVAL, "denoiser: dilation %d > 64 is not supported (dilation_cycle_length %d over %d layers)", max_dil, cfg.dilation_cycle, L);
     }
     // F16 (optionally time-dithered) and F16_W2 run on the tgemm engine; F16_X3 (split activations) on conv_gemm
-    tpath = cfg.precision != DSVC_PREC_F16_X3 && !getenv("DSVC_FORCE_CONV_GEMM");
+    tpath = cfg.precision != DSVC_PREC_F16_X3;
 #define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
     if (!tpath) {
         {
@@ -536,8 +545,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         TEpiInProj::Args e{xres.as<float>(), xh_row0(), in_t.bias.as<float>(), film.as<float>(), L * C, step, C, Cp, rm};
         DSVC_TRY(tlaunch_prec<TEpiInProj>(a, e, 2, rows_alloc, st));
     }
-    const char* stop_env = getenv("DSVC_DEBUG_STOP_AFTER_LAYERS");      // parity-debugging aid: run only the first n layers
-    const int stop_after = stop_env ? atoi(stop_env) : -1;
+    const int stop_after = dbg_stop_after;
     const bool fused = fused_layer_ok();
     for (int l = 0; l < L; ++l) {
         if (stop_after >= 0 && l >= stop_after) return DSVC_OK;
@@ -578,7 +586,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
 }
 
 bool dsvc_denoiser::fused_layer_ok() const {
-    if (getenv("DSVC_NO_FUSED_LAYER") || !tpath || rows_alloc / 128 < 48) return false;      // (the env knob is read per call: A/B tests toggle it)
+    if (dbg_two_launch || !tpath || rows_alloc / 128 < 48) return false;
     int max_dil = 1;
     for (int l = 0; l < cfg.layers; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     return tlayer_supported(cfg.channels, Cp, max_dil, rows_alloc);
@@ -605,7 +613,11 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
     TEpiResSkip::Args oe{xres.as<float>(), last ? nullptr : xh_buf(l + 1), skip.as<float>(), last ? skiph.as<_Float16>() : nullptr,
                          out_t[l].bias.as<float>(), last ? nullptr : film.as<float>() + (size_t)(l + 1) * C, L * C, step, C, Cp,
                          l == 0 ? 1 : 0, rowmap(), 1};
+#ifdef DSVC_PROFILING
     static const int pf = getenv("DSVC_FUSED_PF") ? atoi(getenv("DSVC_FUSED_PF")) : 0;
+#else
+    constexpr int pf = 0;
+#endif
     if (dil_t[l].planes == 1 && out_t[l].planes == 2) return tlayer_launch<1, 2>(ga, cp, oa, oe, C, rows_alloc, pf, st);      // F16_MIX
     return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st);
 }
@@ -872,10 +884,21 @@ int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t,
     const bool fresh = !(B == d->wsB && T == d->wsT);
     DSVC_TRY(d->ensure_ws(B, T, st));
     DSVC_TRY(d->set_clip_meta(nullptr, 0, nullptr, st));
+    // steps: clamped on the device (no synchronising range check per call); a step outside the table raises the sticky flag, which
+    // the NEXT call -- or dsvc_denoiser_check -- reports
+    if (!d->step_err) {
+        DSVC_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->step_err), sizeof(int), hipHostMallocMapped));
+        *d->step_err = 0;
+    }
+    if (*d->step_err) {
+        *d->step_err = 0;
+        return fail(DSVC_EINVAL, "an earlier dsvc_denoiser_forward call passed a diffusion step outside [0, %d): its output used the clamped step", d->cfg.max_steps);
+    }
+    hipLaunchKernelGGL(k_clamp_steps, dim3(ceil_div(B, 256)), dim3(256), 0, st, d->tsteps.as<int>(), t, d->cfg.max_steps, B, d->step_err);
     if (fresh || cond_changed || !d->cond_ready) DSVC_TRY(d->prepare_cond(cond, B, T, st));
     hipLaunchKernelGGL(k_to_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st, spec,
                        d->xin.as<float>(), B, M, T, d->Tp, 1.0f);
-    DSVC_TRY(d->eval(d->xin.as<float>(), StepRef{t, 0, 1}, dsvc_denoiser::TAIL_EPS, nullptr, false, st));
+    DSVC_TRY(d->eval(d->xin.as<float>(), StepRef{d->tsteps.as<int>(), 0, 1}, dsvc_denoiser::TAIL_EPS, nullptr, false, st));
     hipLaunchKernelGGL(k_from_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st,
                        d->eps.as<float>(), out, B, M, T, d->Tp);
     DSVC_HIP(hipGetLastError());
@@ -923,6 +946,26 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
             DSVC_HIP(hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToDevice));
         }
     }
+    return DSVC_OK;
+}
+
+int dsvc_denoiser_check(dsvc_denoiser* d, void* stream) {
+    if (!d) return fail(DSVC_EINVAL, "null handle");
+    DSVC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (d->step_err && *d->step_err) {
+        *d->step_err = 0;
+        return fail(DSVC_EINVAL, "a dsvc_denoiser_forward call passed a diffusion step outside [0, %d): its output used the clamped step", d->cfg.max_steps);
+    }
+    return DSVC_OK;
+}
+
+int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
+    if (!d || !key) return fail(DSVC_EINVAL, "null argument");
+    const std::string k(key);
+    if (k == "stop_after_layers") d->dbg_stop_after = value;
+    else if (k == "two_launch_layer") d->dbg_two_launch = value != 0;
+    else return fail(DSVC_EINVAL, "unknown debug setting '%s'", key);
+    ++d->ws_gen;                 // captured graphs bake the launch sequence: force a re-capture
     return DSVC_OK;
 }
 
@@ -1012,7 +1055,11 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
         hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, s->step_dev.as<int>(), ((it + 2) * 37) % s->K);
         DSVC_HIP(hipEventRecord(e0, st));
         for (int l = 0; l < L; ++l) {
+#ifdef DSVC_PROFILING
             const char* which = getenv("DSVC_PROFILE_KERNEL");          // "out": time the output projection instead (profiling aid)
+#else
+            const char* which = nullptr;
+#endif
             if (d->fused_layer_ok() && !which) {                        // the product path at this size is the fused layer kernel
                 DSVC_TRY(d->launch_fused_layer(l, StepRef{s->step_dev.as<int>(), 0, 0}, st, -1));
             } else if (d->tpath && which && which[0] == 'o') {
@@ -1053,7 +1100,11 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_us = (float)(total * 1000.0 / count);
     *rows = d->rows;
+#ifdef DSVC_PROFILING
     if (kind) *kind = (d->fused_layer_ok() && !getenv("DSVC_PROFILE_KERNEL")) ? 1 : 0;
+#else
+    if (kind) *kind = d->fused_layer_ok() ? 1 : 0;
+#endif
     return DSVC_OK;
 }
 

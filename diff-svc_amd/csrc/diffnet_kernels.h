@@ -208,6 +208,16 @@ __global__ void k_iota_int(int* p, int base, int stride, int n) {
     if (i < n) p[i] = base + i * stride;
 }
 // p[i] = min(max(src[i], lo), hi)  (caller-supplied per-clip lengths, clamped to the workspace)
+// dsvc_denoiser_forward's diffusion steps: a clamped copy (the FiLM table is tabulated for 0 .. K-1: nothing may index outside it) and a
+// sticky error flag in host-mapped memory instead of a device-to-host check per call (the denoiser seam is called 1000 times per clip)
+__global__ void k_clamp_steps(int* __restrict__ dst, const int* __restrict__ src, int K, int n, int* err_flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = src[i];
+    if (t < 0 || t >= K) *err_flag = 1;
+    dst[i] = t < 0 ? 0 : (t >= K ? K - 1 : t);
+}
+
 __global__ void k_clamp_copy_int(int* p, const int* __restrict__ src, int lo, int hi, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const int v = src[i]; p[i] = v < lo ? lo : (v > hi ? hi : v); }

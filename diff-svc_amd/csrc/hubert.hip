@@ -411,7 +411,7 @@ int dsvc_hubert_frames(int64_t n_samples, int32_t* frames) {
 int dsvc_hubert_units(dsvc_hubert* h, const float* wav, int64_t n_samples, float* units, void* stream) {
     if (!h || !wav || !units) return fail(DSVC_EINVAL, "null argument");
     if (!h->finalized) return fail(DSVC_ESTATE, "hubert not finalized");
-    if (n_samples < 400) return fail(DSVC_EINVAL, "hubert: at least 400 samples (25 ms at 16 kHz) are needed");
+    // (320 samples already give one frame after the 40 + 40 sample padding of HubertSoft.units; units() rejects anything shorter)
     return h->units(wav, n_samples, units, (hipStream_t)stream);
 }
 

@@ -73,7 +73,8 @@ extern "C" int dsvc_probe_mfma(int32_t random_data, float* tflops, float* clock_
     DSVC_HIP(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long hs[2];
     DSVC_HIP(hipMemcpy(hs, stamps, 16, hipMemcpyDeviceToHost));
-    *tflops = (float)(2.0 * 32 * 32 * 16 * (double)iters * 8 * blocks / (ms * 1e-3) / 1e12);
+    // the loop runs iters / 4 trips of 16 MFMAs: 4 * iters MFMAs per wave, 8 waves per workgroup
+    *tflops = (float)(2.0 * 32 * 32 * 16 * 4.0 * (double)iters * 8 * blocks / (ms * 1e-3) / 1e12);
     *clock_ghz = hs[1] ? (float)((double)hs[0] / ((double)hs[1] * 10.0)) : 0.f;            // shader cycles / (100 MHz ticks * 10 ns)
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(src); (void)hipFree(sink); (void)hipFree(stamps);

@@ -60,12 +60,22 @@ struct TGemmArgs {
                             //  dependent scalar load, ~0.4 us per kernel in the single-clip regime, out of the front of the weight stream)
     int clip_rows;          // rows per clip (clip stride) or 0: the K-loop stagger is keyed on a tile's position inside its clip, so a
                             // clip computes bit-identically alone and inside a batch
-    unsigned long long* stamps;   // profiling: per-wave phase time stamps (s_memrealtime, 100 MHz), 16 per wave; null in production
-    int dbg;                // ablation knobs for profiling (env DSVC_TG_DEBUG): 1 = no acc-init loads, 2 = no epilogue,
+#ifdef DSVC_PROFILING       // profiling builds only (python -m diffsvc_amd.build --profiling): the product library has neither field nor branch
+    unsigned long long* stamps;   // per-wave phase time stamps (s_memrealtime, 100 MHz), 16 per wave (env DSVC_TG_STAMPS)
+    int dbg;                // ablation knobs (env DSVC_TG_DEBUG; results are WRONG when set): 1 = no acc-init loads, 2 = no epilogue,
                             // 4 = no tile DMA, 8 = no MFMA main loop, 16 = no wave priority split, 32 = all tiles stream
                             // tile 0's weights (L2-hot), 64 = no pass rotation, 128 = next-tile init loads issued at the
-                            // end of the pass (both waves of a SIMD together) instead of staggered inside it, 1024 = no K-loop stagger.  0 in production.
+                            // end of the pass (both waves of a SIMD together) instead of staggered inside it, 1024 = no K-loop stagger
+#endif
 };
+
+#ifdef DSVC_PROFILING
+#define TG_DBG(a, bit) ((a).dbg & (bit))
+#define TG_STAMPS(a) ((a).stamps)
+#else
+#define TG_DBG(a, bit) (0)
+#define TG_STAMPS(a) ((unsigned long long*)nullptr)
+#endif
 
 // the row <-> channel permutation inside a 32-row output tile that makes a lane's 16 accumulator registers hold 16
 // consecutive channels:  tile row i = 4h + 8j + e  (h = lane>>5, j = reg>>2, e = reg&3)  <->  channel 16h + 4j + e
@@ -92,8 +102,12 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     constexpr bool STAMPS = NT_N == 1;                    // the phase stamps exist only in the small-batch kernels: in the 128-frame
                                                           // tiling their few SGPRs/VGPRs tip the register allocation into spills
     auto stamp = [&](int i) {
+#ifdef DSVC_PROFILING
         if constexpr (STAMPS) if (a.stamps && lane == 0)
             a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (WAVES * KS) + wave_all) * 16 + i] = __builtin_amdgcn_s_memrealtime();
+#else
+        (void)i;
+#endif
     };
     stamp(0);
     const int halo = (a.taps >> 1) * a.dil;
@@ -108,7 +122,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         int slot = wave_all * 64 + lane;
         int r = slot / chunks, c = slot - r * chunks;
         const _Float16* xrow0 = a.x + (long long)(row0 - halo) * a.cin;
-        for (int it = wave_all; it * 64 < total && !(a.dbg & 4); it += WAVES * KS) {
+        for (int it = wave_all; it * 64 < total && !TG_DBG(a, 4); it += WAVES * KS) {
             const int rc = r < rows_lds ? r : rows_lds - 1;            // lanes past the tile re-read its last row
             const _Float16* src = xrow0 + (long long)rc * a.cin + ((c ^ (rc & a.swz)) << 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -125,7 +139,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         variant = st % a.n_variants;
         if (variant < 0) variant += a.n_variants;
     }
-    if constexpr (STAMPS) if (a.stamps) { asm volatile("" :: "s"(variant)); stamp(13); }
+    if constexpr (STAMPS) if (TG_STAMPS(a)) { asm volatile("" :: "s"(variant)); stamp(13); }
     constexpr int GROUP_HALFS = KG * NW * TFRAG_HALFS;   // one ring refill = KG k16-steps of one output tile
     const _Float16* wbase = a.w + (long long)variant * a.variant_halfs + lane * 8;
     const int gpt = (a.cin >> 4) / KG;                   // groups per tap
@@ -135,7 +149,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
 
     // two waves share a SIMD (waves w and w + 4): give one of them priority so the pair drifts apart and one wave's
     // epilogue / memory waits sit under the other's MFMAs instead of both stalling together
-    if (WAVES > 4 && wave >= 4 && !(a.dbg & 16)) __builtin_amdgcn_s_setprio(1);     // waves w and w+4 share SIMD (w & 3)
+    if (WAVES > 4 && wave >= 4 && !TG_DBG(a, 16)) __builtin_amdgcn_s_setprio(1);     // waves w and w+4 share SIMD (w & 3)
 
     auto load_group = [&](half8 (&ring)[KG][NW], const _Float16* p) {
 #pragma unroll
@@ -213,7 +227,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     // output-channel passes are visited in a per-workgroup rotated order: all workgroups stream the SAME weights, and
     // without the rotation they all miss L2 on the same fragment at the same moment (the whole chip then advances at
     // first-touch latency); rotated, a tile's first toucher warms it for the other two thirds
-    const int rot = gridDim.y == 1 && !(a.dbg & 64) ? (int)(blockIdx.x % (unsigned)passes) : 0;
+    const int rot = gridDim.y == 1 && !TG_DBG(a, 64) ? (int)(blockIdx.x % (unsigned)passes) : 0;
     auto tile_of = [&](int pi) { const int p = pi + rot; return (p < passes ? p : p - passes) * WAVES + wave; };
     auto next_active = [&](int pi) {                      // next position of this workgroup's sequence where this wave has a tile
         for (; pi < passes; pi += gridDim.y)
@@ -228,9 +242,9 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     //  extra index arithmetic tips its 256-register allocation into spills)
     constexpr bool STAGGER = NT_N < 4;
     const unsigned tiles_pc = (a.clip_rows > 0 && a.clip_rows % TN == 0) ? (unsigned)(a.clip_rows / TN) : 0u;
-    const int rk = (!STAGGER || (a.dbg & 1024)) ? 0 : (int)((tiles_pc ? blockIdx.x % tiles_pc : blockIdx.x) % (unsigned)G);
+    const int rk = (!STAGGER || TG_DBG(a, 1024)) ? 0 : (int)((tiles_pc ? blockIdx.x % tiles_pc : blockIdx.x) % (unsigned)G);
     auto gmap = [&](int g) { if constexpr (!STAGGER) return g; const int x = g + rk; return x >= G ? x - G : x; };
-    auto wgrp = [&](int g) { return (a.dbg & 4096) ? 0 : gmap(g); };    // dbg 4096: the ring re-reads group 0 (L1-hot weight stream)
+    auto wgrp = [&](int g) { return TG_DBG(a, 4096) ? 0 : gmap(g); };    // dbg 4096: the ring re-reads group 0 (L1-hot weight stream)
     if constexpr (KS > 1) {
         // ---- split-K flow: one tile per wave triple, gridDim.y == passes (host-checked), reduction through LDS ----
         const int mt = blockIdx.y * WAVES + wave;
@@ -242,7 +256,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         // L2/HBM latency, there is no other work in a 3-group slice to hide it behind
         if (active && n > 1) load_group(ringB, wp + (long long)gmap(g0 + 1) * GROUP_HALFS);
         stamp(14);
-        if (active && ks == 0 && !(a.dbg & 1)) {
+        if (active && ks == 0 && !TG_DBG(a, 1)) {
             epi.init(ea, mt, row0, lane, acc);
         } else {
 #pragma unroll
@@ -267,7 +281,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         stamp(3);
-        if (active && !(a.dbg & 8)) {
+        if (active && !TG_DBG(a, 8)) {
             int i = 0;
             for (; i + 1 < n; i += 2) {
                 if (i > 0) load_group(ringB, wp + (long long)gmap(g0 + i + 1) * GROUP_HALFS);
@@ -302,17 +316,17 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) acc[nt][4 * q + i] += v[i];
                     }
-            if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
-            if constexpr (STAMPS) if (a.stamps) { stamp(10); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(11); }
-        } else if constexpr (STAMPS) { if (a.stamps) { stamp(10); stamp(11); } }
+            if (!TG_DBG(a, 2)) epi.finish(ea, mt, row0, lane, acc);
+            if constexpr (STAMPS) if (TG_STAMPS(a)) { stamp(10); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(11); }
+        } else if constexpr (STAMPS) { if (TG_STAMPS(a)) { stamp(10); stamp(11); } }
         return;
     }
     int pi = next_active(blockIdx.y);
     int mt = pi >= 0 ? tile_of(pi) : 0;
     if (pi >= 0) {
-        load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt) * tile_halfs + (long long)gmap(0) * GROUP_HALFS);
+        load_group(ringA, wbase + (long long)(TG_DBG(a, 32) ? 0 : mt) * tile_halfs + (long long)gmap(0) * GROUP_HALFS);
         stamp(14);
-        if (a.dbg & 1) {
+        if TG_DBG(a, 1) {
 #pragma unroll
             for (int nt = 0; nt < NT_N; ++nt)
 #pragma unroll
@@ -334,13 +348,13 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     // sits behind its burst, and the chip-wide HBM demand is spread instead of arriving from every workgroup at once.
     const int g_issue = (WAVES > 4 && wave >= WAVES / 2) ? ((G / 2) & ~1) : 0;
     while (pi >= 0) {
-        const _Float16* wp = wbase + (long long)((a.dbg & 32) ? 0 : mt) * tile_halfs;      // dbg 32: every tile streams tile 0 (L2-hot)
+        const _Float16* wp = wbase + (long long)(TG_DBG(a, 32) ? 0 : mt) * tile_halfs;      // dbg 32: every tile streams tile 0 (L2-hot)
         const int pn = next_active(pi + gridDim.y);
         const int mt_n = pn >= 0 ? tile_of(pn) : 0;
         f32x16 nxt[NT_N];
         bool nxt_issued = false;
         auto issue_next_init = [&]() {
-            if (a.dbg & 1) {
+            if TG_DBG(a, 1) {
 #pragma unroll
                 for (int nt = 0; nt < NT_N; ++nt)
 #pragma unroll
@@ -349,34 +363,34 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
                 epi.init(ea, mt_n, row0, lane, nxt);
             }
         };
-        int g = ((a.dbg & 8) || ((a.dbg & 256) && wave >= WAVES / 2)) ? G : 0;      // dbg 256: half the waves skip their MFMAs
+        int g = (TG_DBG(a, 8) || (TG_DBG(a, 256) && wave >= WAVES / 2)) ? G : 0;      // dbg 256: half the waves skip their MFMAs
         for (; g + 1 < G; g += 2) {     // straight-line body (no branch around the prefetches): IR-level sinking cannot move one below its group
-            if constexpr (STAMPS) if (a.dbg & 2048) {                         // profiling: no weight stream inside the loop
+            if constexpr (STAMPS) if TG_DBG(a, 2048) {                         // profiling: no weight stream inside the loop
                 compute_group(ringA, acc, gmap(g));
                 compute_group(ringA, acc, gmap(g + 1));
-                if constexpr (STAMPS) if (a.stamps && g < 8) stamp(4 + (g >> 1));
+                if constexpr (STAMPS) if (TG_STAMPS(a) && g < 8) stamp(4 + (g >> 1));
                 continue;
             }
             load_group(ringB, wp + (long long)wgrp(g + 1) * GROUP_HALFS);      // ringB <- group g+1, under group g's MFMAs
-            if (g == g_issue && pn >= 0 && !(a.dbg & 128)) { issue_next_init(); nxt_issued = true; }
+            if (g == g_issue && pn >= 0 && !TG_DBG(a, 128)) { issue_next_init(); nxt_issued = true; }
             __builtin_amdgcn_sched_barrier(0);
             compute_group(ringA, acc, gmap(g));
             const int gn = g + 2 < G ? g + 2 : G - 1;
             load_group(ringA, wp + (long long)wgrp(gn) * GROUP_HALFS);         // ringA <- group g+2, under group g+1's MFMAs
             __builtin_amdgcn_sched_barrier(0);
             compute_group(ringB, acc, gmap(g + 1));
-            if constexpr (STAMPS) if (a.stamps && g < 8) stamp(4 + (g >> 1));
+            if constexpr (STAMPS) if (TG_STAMPS(a) && g < 8) stamp(4 + (g >> 1));
         }
         if (g < G) compute_group(ringA, acc, gmap(g));                         // odd group count: the tail group
         stamp(9);
         // the next tile's weight stream starts before this tile's epilogue, so its latency sits under the epilogue
         if (pn >= 0) {
-            load_group(ringA, wbase + (long long)((a.dbg & 32) ? 0 : mt_n) * tile_halfs + (long long)gmap(0) * GROUP_HALFS);
+            load_group(ringA, wbase + (long long)(TG_DBG(a, 32) ? 0 : mt_n) * tile_halfs + (long long)gmap(0) * GROUP_HALFS);
             if (!nxt_issued) issue_next_init();                                // short K loops (or dbg 128): issue here instead
         }
-        if (!(a.dbg & 2)) epi.finish(ea, mt, row0, lane, acc);
+        if (!TG_DBG(a, 2)) epi.finish(ea, mt, row0, lane, acc);
         else asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT_N - 1][15]));
-        if constexpr (STAMPS) if (a.stamps) {
+        if constexpr (STAMPS) if (TG_STAMPS(a)) {
             stamp(10);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(11);
@@ -431,8 +445,10 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
     if (n_rows % (32 * NT_N) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N);
     if (a.w_planes != NW) return fail(DSVC_EINVAL, "tgemm: weights packed with %d plane(s), kernel streams %d", a.w_planes, NW);
     a.swz = tgemm_swizzle_mask(a.cin);
+#ifdef DSVC_PROFILING
     const char* dbg_s = getenv("DSVC_TG_DEBUG");           // profiling ablations only; results are WRONG when set
     a.dbg = dbg_s ? atoi(dbg_s) : 0;
+#endif
     auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS>;
     const size_t smem = tgemm_smem<NT_N>(a.taps, a.dil, a.cin) + (size_t)(KS - 1) * WAVES * NT_N * 4096;
     if (smem > 160 * 1024) return fail(DSVC_EINVAL, "tgemm: %zu B of LDS requested", smem);
@@ -445,6 +461,7 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
     if (m_split < 1) m_split = 1;
     if (m_split > passes) m_split = passes;
     if (KS > 1 && m_split != passes) return fail(DSVC_EINVAL, "tgemm: the split-K tiling needs one output tile per wave (m_split %d, passes %d)", m_split, passes);
+#ifdef DSVC_PROFILING
     static const char* stamp_path = getenv("DSVC_TG_STAMPS");
     if (stamp_path) {
         TStampLog& L = tstamp_log();
@@ -461,9 +478,12 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
             L.used++;
         }
     }
+#endif
     hipLaunchKernelGGL(kern, dim3(n_rows / (32 * NT_N), m_split), dim3(64 * WAVES * KS), smem, stream, a, ea);
     DSVC_HIP(hipGetLastError());
+#ifdef DSVC_PROFILING
     if (stamp_path && tstamp_log().used == tstamp_log().slots) tstamp_dump(stamp_path);
+#endif
     return DSVC_OK;
 }
 

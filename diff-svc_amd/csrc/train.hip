@@ -601,7 +601,11 @@ int dsvc_trainer::wgrad(const float* A, int O, const float* BT, int K, int shift
     // range (144 workgroups, 450 MB of operand traffic for the 384 x 768 gradients: 151 us each, 41 % of the step).  Instead: 128 x 128
     // tiles and the frame range cut into slices over blockIdx.y so that ~400 workgroups exist; partial tiles go to a scratch buffer and a
     // second kernel adds the slices in a fixed order (deterministic, unlike atomics).
+#ifdef DSVC_PROFILING
     static const bool sliced = !(getenv("DSVC_TRAIN_WGRAD_FLAT") && atoi(getenv("DSVC_TRAIN_WGRAD_FLAT")));     // A/B knob
+#else
+    constexpr bool sliced = true;
+#endif
     const int tiles = ceil_div(K, 128) * ceil_div(n_ct, 4);
     if (sliced && rows % 64 == 0 && tiles <= WGRAD_MAX_TILES) {
         int S = WGRAD_MAX_TILES / tiles;

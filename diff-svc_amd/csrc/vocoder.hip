@@ -467,7 +467,11 @@ int pair_mfma_launch(const float* x, float* out, const _Float16* w1, const float
     const size_t smem = (size_t)2 * (32 * 2 * W + 2 * h1) * (C + 8) * sizeof(_Float16);
     if (smem > 64 * 1024) return fail(DSVC_EINVAL, "resblock pair (mfma): %zu B of LDS", smem);
     if (n_rows > 0x7fffff00 - 64 * W) return fail(DSVC_EINVAL, "resblock pair (mfma): %d rows", n_rows);
+#ifdef DSVC_PROFILING
     static const int dbg = getenv("DSVC_PAIR_DBG") ? atoi(getenv("DSVC_PAIR_DBG")) : 0;       // phase ablation (timing only): 1 = no MFMA loops, 2 = no epilogue
+#else
+    constexpr int dbg = 0;
+#endif
     hipLaunchKernelGGL((k_pair_mfma<C, W>), dim3(ceil_div(n_rows, 32 * (2 * W - 1))), dim3(64 * W), smem, st, x, out, w1, b1, w2, b2, k, d, n_rows,
                        stride, len, alpha, accumulate, dbg);
     DSVC_HIP(hipGetLastError());
@@ -844,8 +848,12 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
         for (int j = 0; j < nk; ++j) {
             for (int m = 0; m < 3; ++m) {
                 const size_t idx = ((size_t)i * nk + j) * 3 + m;
+#ifdef DSVC_PROFILING
                 static const bool no_fused = getenv("DSVC_VOC_NO_FUSED") && atoi(getenv("DSVC_VOC_NO_FUSED"));   // A/B knobs
                 static const bool pair_f32 = getenv("DSVC_VOC_PAIR_F32") && atoi(getenv("DSVC_VOC_PAIR_F32"));
+#else
+                constexpr bool no_fused = false, pair_f32 = false;
+#endif
                 const int pk = rb1[idx].taps, pd = rb1[idx].dil;
                 const bool mfma_pair = prec == DSVC_PREC_F16_X3 && !no_fused && !pair_f32 && (cout == 16 || cout == 32 || cout == 64) &&
                                        rb2[idx].taps == pk && rb2[idx].dil == 1 &&

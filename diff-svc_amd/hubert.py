@@ -76,5 +76,5 @@ class HubertencoderHip:
             npy = Path(wav_path).with_suffix(".npy")
             if os.path.exists(npy):
                 return np.load(str(npy))
-        wav16 = read_wav(wav_path, 16000)
+        wav16 = read_wav(wav_path, 16000, mono="mean")                           # librosa.load(path, sr=16000) (hubert_model.py:236)
         return self.hbt_model.units(torch.from_numpy(wav16).cuda())[0].cpu().numpy()

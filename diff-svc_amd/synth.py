@@ -434,6 +434,30 @@ def clip_inputs(clip, T=861, n_units=500, H=256, seed=1234):
     return hub, align_units(T, n_units), f0.astype(np.float32), f0_hz
 
 
+def train_batch_kat(hp, clips, T, n_units, seed):
+    """The synthetic training batch of the training parity tests and of the recipe that mints their golden from the real reference
+    (oracle/make_golden.py::golden_train): content units / alignment / f0 from ``clip_inputs``, target mels and diffusion steps from
+    PCG64(seed), the last five frames of clip 0 padded (mel2ph == 0).  numpy: hubert [B,N,H], mel2ph [B,T], f0 [B,T], mels [B,T,M], t [B]."""
+    hub, m2p, f0 = [], [], []
+    for c in clips:
+        h, m, f, _ = clip_inputs(int(c), T=T, n_units=n_units, H=hp["hidden_size"])
+        hub.append(h); m2p.append(m); f0.append(f)
+    g = np.random.Generator(np.random.PCG64(seed))
+    mels = (g.standard_normal((len(clips), T, hp["audio_num_mel_bins"])) * 0.7 - 2.5).astype(np.float32)
+    t = g.integers(0, hp["timesteps"], size=(len(clips),))
+    m2p = np.stack(m2p)
+    m2p[0, T - 5:] = 0
+    return np.stack(hub), m2p, np.stack(f0), mels, t
+
+
+def train_grad_slices(shape):
+    """Which part of a gradient tensor the 44.1 kHz training golden stores (the full set is 33.7 M floats): tensors up to 80 000
+    elements whole, larger ones on a stride-8 lattice of their two leading dimensions (the L2 norm of EVERY tensor is stored beside)."""
+    if int(np.prod(shape)) <= 80000:
+        return tuple(slice(None) for _ in shape)
+    return (slice(None, None, 8), slice(None, None, 8)) + tuple(slice(None) for _ in shape[2:])
+
+
 def slicer_case(seed, sr=22050, seconds=20.0, floor_db=-62.0, lead_silence=False, tail_silence=False, dense=False,
                 mode="mixed"):
     """Synthetic audio for the slicer KATs: voiced bursts (two partials + noise, random level) separated by pauses whose

@@ -39,19 +39,25 @@ def load_generator_checkpoint(model_path):
     return cp["generator"], h
 
 
-def read_wav(path_or_file, target_sr):
-    """int PCM -> [-1, 1) by the type's magnitude, first channel only, resampled to the model rate (nvSTFT.py:14-44)."""
+def read_wav(path_or_file, target_sr, mono="first"):
+    """int PCM -> [-1, 1) by the type's magnitude, resampled to the model rate.  ``mono='first'`` keeps channel 0 -- what the 44.1 kHz
+    nvSTFT loader does (nvSTFT.py:14-44); ``mono='mean'`` averages the channels -- what ``librosa.load(mono=True)`` does on the 24 kHz
+    front-end (data_gen_utils.py:106) and in ``get_units`` (hubert_model.py:234-247).  Stereo input differs between the two."""
+    if mono not in ("first", "mean"):
+        raise ValueError("mono must be 'first' or 'mean'")
     try:
         import soundfile as sf
         data, sr = sf.read(path_or_file, always_2d=True)
-        data = data[:, 0].astype(np.float32)
+        data = data.astype(np.float32)
     except ImportError:
         with wave.open(path_or_file, "rb") as w:
             sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
             raw = w.readframes(n)
         if width != 2:
             raise RuntimeError("only 16-bit PCM wav is supported without the soundfile package")
-        data = np.frombuffer(raw, dtype="<i2").reshape(-1, nch)[:, 0].astype(np.float32) / 32768.0
+        data = np.frombuffer(raw, dtype="<i2").reshape(-1, nch).astype(np.float32) / 32768.0
+    data = data[:, 0] if mono == "first" or data.shape[1] == 1 else data.mean(axis=1, dtype=np.float32)
+    data = np.ascontiguousarray(data, dtype=np.float32)
     if sr != target_sr:
         data = resample(data, sr, target_sr)
     return data
@@ -222,7 +228,7 @@ class HifiGANHip(BaseVocoder):
         key = ("pwg", sr, hp["fft_size"], hp["win_size"], hop, hp["audio_num_mel_bins"], fmin, fmax, eps)
         if key not in _melspec_cache:
             _melspec_cache[key] = MelspecHandle(sr, hp["fft_size"], hp["win_size"], hop, hp["audio_num_mel_bins"], fmin, fmax, clip_val=eps, mode=1)
-        wav = read_wav(wav_fn, sr)
+        wav = read_wav(wav_fn, sr, mono="mean")                                  # librosa.core.load(wav_path, sr=...) averages channels
         mel = _melspec_cache[key].mel(torch.from_numpy(wav)[None].cuda())[0].cpu().numpy()
         n = mel.shape[0] * hop                                                   # librosa_pad_lr(..., 1) then wav[:T * hop]
         wav = np.pad(wav, (0, max(0, n - len(wav))))[:n]

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DSVC_ABI_VERSION 4
+#define DSVC_ABI_VERSION 5
 
 enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM = 4 };
 
@@ -79,6 +79,16 @@ int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t,
 /* debugging aid for the parity tests: copy an internal frame-major buffer ("xres", "g", "skip", "s2", "eps",
  * "condT", "cproj", "film", "xin", "xh") to a device pointer as fp32; rows/ld receive its logical shape. */
 int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, int64_t numel, int32_t* rows, int32_t* ld);
+
+/* dsvc_denoiser_forward clamps diffusion steps outside [0, max_steps) on the device (the step embedding is tabulated for the integer
+ * steps of the schedule, net.py:32-44,99-103) and raises a sticky flag instead of synchronising on every call of the 1000-calls-per-clip
+ * denoiser seam; the flag is reported by the NEXT dsvc_denoiser_forward call, or by this function, which first waits for `stream`. */
+int dsvc_denoiser_check(dsvc_denoiser* d, void* stream);
+
+/* test support (explicit handle state; the library reads no environment variable): "stop_after_layers" = n >= 0 makes an evaluation
+ * return after n residual layers so that dsvc_denoiser_debug_buffer taps layer n-1 (-1 = off); "two_launch_layer" != 0 runs a residual
+ * layer as its two tgemm launches where the fused layer kernel would apply (bit-equality test of the two forms). */
+int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampler -- replaces GaussianDiffusion.forward(infer=True) from the initial x to mel_out

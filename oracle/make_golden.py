@@ -169,22 +169,30 @@ def golden_vocoder(name, h, wseed, clips, T, seed):
     print(name, "wav rms %.4f max %.3f" % (float(np.sqrt((wav ** 2).mean())), float(np.abs(wav).max())))
 
 
-def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500, seed=2026, wseed=0, vseed=1, K=1000, speedup=1, with_wav=True):
+def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500, seed=2026, wseed=0, vseed=1, K=1000, speedup=1, with_wav=True,
+                    conditioned=None):
     """The BENCHMARKED configuration (BASELINE configs[1]: 10 s clip, T=861, 44.1 kHz architecture, full 1000-step DDPM) through
     the REAL reference end to end: GaussianDiffusion.forward(infer=True) (diffusion.py:227-284) -> the host glue of
     Svc.after_infer (clip to [mel_vmin, mel_vmax], infer_tool.py:177-183) -> Generator.forward (models.py:361-387) for the first
     clip.  ~2 x 1000 reference denoiser evaluations at T=861: minutes on 8 cores.  Inputs are regenerated from synth.clip_inputs
-    on the test side (the cond builder is pinned bit for bit elsewhere), so only the outputs are stored."""
+    on the test side (the cond builder is pinned bit for bit elsewhere), so only the outputs are stored.
+    conditioned = (lam, rho): the checkpoint is synth.acoustic_state_conditioned -- a denoiser whose noise prediction tracks its input
+    (eps ~= lam * x + rho * random net), so that p_sample's clamp(x0, -1, 1) (diffusion.py:149-150) is NOT what decides the output:
+    with a random-init DiffNet 36 % of the reference mel sits exactly on spec_min / spec_max, where any error is invisible; here the
+    fraction on the clamp is asserted below 1 % when minting."""
     import time
     clips = list(clips)
     hp = dict(synth.HPARAMS_44K, K_step=K)
-    sd = synth.acoustic_state(hp, wseed)
+    sd = synth.acoustic_state_conditioned(hp, wseed, *conditioned) if conditioned else synth.acoustic_state(hp, wseed)
     model = build_reference_model(hp, sd)
     hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
     t0 = time.time()
     ret = run_reference_sampler(model, hp, hub, m2p, f0, clips, speedup, seed)
     mel = ret["mel_out"].numpy()
-    print(name, "sampler %.0f s, mel range %.3f..%.3f" % (time.time() - t0, mel.min(), mel.max()))
+    on_clamp = float(((mel <= min(hp["spec_min"])) | (mel >= max(hp["spec_max"]))).mean())
+    print(name, "sampler %.0f s, mel range %.3f..%.3f, %.2f %% of the mel on spec_min/spec_max" % (time.time() - t0, mel.min(), mel.max(), 100 * on_clamp))
+    if conditioned:
+        assert on_clamp < 0.01, (name, on_clamp)
     extra = {}
     if with_wav:
         h = dict(synth.VOCODER_44K)
@@ -195,7 +203,38 @@ def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500,
         print(name, "wav rms %.4f max %.3f" % (float(np.sqrt((wav ** 2).mean())), float(np.abs(wav).max())))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), mel_out=mel, f0_denorm=ret["f0_denorm"].numpy(),
                         pitch=ret["pitch_pred"].numpy().astype(np.int16), wseed=wseed, vseed=vseed, clips=np.array(clips), T=T,
-                        n_units=n_units, speedup=speedup, seed=seed, K_step=K, **extra)
+                        n_units=n_units, speedup=speedup, seed=seed, K_step=K, conditioned=np.array(conditioned if conditioned else []),
+                        on_clamp=on_clamp, **extra)
+
+
+# Round 3: the spread of the 1000-step error is a heavy-tailed statistic (profiles/r2w_precision_spread.txt), so the shipped precision is
+# held to the bar on MANY real-reference realisations, not on four.  All of these share seed 2026 with the two clips of
+# e2e_44k_T861_k1000, so that ONE batch of 32 clips (clips 0..31, seed 2026 -- the per-GPU share of BASELINE configs[3]) contains every
+# one of them: tests/test_gpu_headline.py::test_batch_of_32_* checks each clip of the batch that has a golden.
+SPREAD_SEED = 2026
+SPREAD_CLIPS = (2, 3, 5, 7, 8, 9, 10, 11, 12, 13)                    # random-init checkpoint (wseed 0), seed 2026
+SPREAD_COND = (("ca", (1.5, 0.07), (0, 1)),                            # the PLMS probes' conditioned checkpoint
+               ("cb", (1.2, 0.15), (0, 1, 2, 3)))                      # twice the random-network share: 0.6 % of the mel on the clamp
+
+
+def spread_names():
+    out = [("e2e_44k_T861_k1000_s2026_c%d" % c, c, SPREAD_SEED, None) for c in SPREAD_CLIPS]
+    out.append(("e2e_44k_T861_k1000_c9", 9, 1009, None))               # the shipped round-2 precision's worst (clip, noise) pair
+    for tag, cond, clips in SPREAD_COND:
+        out += [("e2e_44k_T861_k1000_%s_c%d" % (tag, c), c, SPREAD_SEED, cond) for c in clips]
+    return out
+
+
+def golden_headline_spread(only=None):
+    """17 more single-clip runs of the benchmarked configuration through the REAL reference (~80 s each on 8 cores); skips files that
+    exist, so an interrupted run resumes."""
+    for name, clip, seed, cond in spread_names():
+        if only and name not in only:
+            continue
+        if os.path.exists(os.path.join(OUT, name + ".npz")) and "--force" not in sys.argv:
+            print(name, "exists")
+            continue
+        golden_headline(name=name, clips=(clip,), seed=seed, with_wav=False, conditioned=cond)
 
 
 def golden_headline_extra():
@@ -203,6 +242,63 @@ def golden_headline_extra():
     study of the HIP path's 1000-step error (tools/study_headline_spread.py, profiles/r2w_*) found its largest values."""
     golden_headline(name="e2e_44k_T861_k1000_c4", clips=(4,), seed=1004, with_wav=False)
     golden_headline(name="e2e_44k_T861_k1000_c6", clips=(6,), seed=1006, with_wav=False)
+
+
+TRAIN_CASES = (  # name, arch, loss, clips, T, n_units, seed  (the batches of tests/test_gpu_train.py)
+    ("tiny_l2", "tiny", "l2", (0, 1, 2), 40, 23, 5), ("tiny_l1", "tiny", "l1", (0, 1, 2), 40, 23, 5),
+    ("44k_l2", "44k", "l2", (4, 9), 64, 37, 6), ("44k_l1", "44k", "l1", (4, 9), 64, 37, 6))
+
+
+def golden_train():
+    """Training parity pin (BASELINE configs[4]): the REAL GaussianDiffusion.forward(infer=False) ->
+    Batch2Loss.module4 -> p_losses (diffusion.py:207-241, train_pipeline.py:222-238) with torch autograd, on the batches of
+    tests/test_gpu_train.py.  The two random draws of the training forward are injected: ``torch.randint`` (the diffusion steps t,
+    train_pipeline.py:233) returns the batch's t, ``torch.randn_like`` (the noise, diffusion.py:208) the Philox training stream.
+    Stored: the loss, the L2 norm of every parameter gradient, and the gradients themselves (tiny architecture: all of them;
+    44.1 kHz: small tensors whole, large ones on the lattice of synth.train_grad_slices)."""
+    out = {}
+    for name, arch, loss_type, clips, T, n_units, seed in TRAIN_CASES:
+        hp = dict(synth.tiny_hparams(K=50) if arch == "tiny" else synth.HPARAMS_44K, diff_loss_type=loss_type)
+        sd = synth.acoustic_state(hp, 3)
+        model = build_reference_model(hp, sd)
+        model.train()                                   # (DiffNet has no dropout / batch norm: train() == eval() numerically)
+        hub, m2p, f0, mels, t = (torch.from_numpy(v) for v in synth.train_batch_kat(hp, clips, T, n_units, seed))
+        M = hp["audio_num_mel_bins"]
+        noise = O.ddpm_noise_ref_layout(seed, list(clips), 0, T, M, O.PURPOSE_TRAIN_NOISE)
+        orig_randint, orig_randn_like = torch.randint, torch.randn_like
+        calls = {"randint": 0, "randn_like": 0}
+
+        def randint(lo, hi, size, **kw):
+            assert (lo, hi, tuple(size)) == (0, hp["K_step"], (len(clips),)), (lo, hi, size)
+            calls["randint"] += 1
+            return t.clone()
+
+        def randn_like(x, **kw):
+            assert tuple(x.shape) == tuple(noise.shape), x.shape
+            calls["randn_like"] += 1
+            return noise.clone()
+
+        torch.randint, torch.randn_like = randint, randn_like
+        try:
+            ret = model(hub.clone(), mel2ph=m2p.clone(), f0=f0.clone(), uv=None, energy=None, ref_mels=mels.clone(), infer=False)
+            loss = ret["diff_loss"]
+            loss.backward()
+        finally:
+            torch.randint, torch.randn_like = orig_randint, orig_randn_like
+        assert calls == {"randint": 1, "randn_like": 1}, calls
+        out[name + "/loss"] = np.float64(loss.item())
+        names, norms = [], []
+        for k, p in model.named_parameters():
+            if not (k.startswith("denoise_fn.") or k == "fs2.pitch_embed.weight"):
+                continue
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            names.append(k); norms.append(float(g.double().norm().item()))
+            sl = synth.train_grad_slices(tuple(g.shape)) if arch != "tiny" else tuple(slice(None) for _ in g.shape)
+            out[name + "/grad/" + k] = g[sl].detach().numpy().copy()
+        out[name + "/names"] = np.array(names)
+        out[name + "/norms"] = np.array(norms, dtype=np.float64)
+        print("train", name, "loss %.6f, %d gradient tensors, |g| %.4f" % (loss.item(), len(names), float(np.sqrt((np.array(norms) ** 2).sum()))))
+    np.savez_compressed(os.path.join(OUT, "train_grads.npz"), **out)
 
 
 def golden_melspec(name, sr, n_fft, win, hop, n_mels, fmin, fmax, n_samples):
@@ -268,6 +364,10 @@ def main():
         return golden_headline()
     if "--headline-extra" in sys.argv:
         return golden_headline_extra()
+    if "--headline-spread" in sys.argv:
+        return golden_headline_spread()
+    if "--train-only" in sys.argv:
+        return golden_train()
     if "--plms-only" in sys.argv:
         return golden_plms_conditioned()
     if "--hifigan-only" in sys.argv:
@@ -296,6 +396,8 @@ def main():
     golden_pe()
     golden_plms_conditioned()
     golden_headline_extra()
+    golden_headline_spread()
+    golden_train()
     golden_slicer()
     golden_slicer_demo_input()
     golden_schedule()

@@ -183,7 +183,7 @@ def test_throughput_tiling_ddpm_20_steps_vs_oracle(precision):
 
 
 def _tap_errors(den, sd, spec, t, cond, rows_of):
-    """Run the first n layers for n = 1..L (DSVC_DEBUG_STOP_AFTER_LAYERS) and compare the residual stream, the gate output and
+    """Run the first n layers for n = 1..L (dsvc_denoiser_debug_set 'stop_after_layers') and compare the residual stream, the gate output and
     the running skip sum with the oracle's taps.  rows_of(b) -> slice of the frame-major debug buffers holding clip b."""
     L = O.diffnet_layers(sd)
     taps = {}
@@ -192,7 +192,7 @@ def _tap_errors(den, sd, spec, t, cond, rows_of):
     worst = {"x": (0.0, -1), "g": (0.0, -1), "s": (0.0, -1)}
     try:
         for n in range(1, L + 1):
-            os.environ["DSVC_DEBUG_STOP_AFTER_LAYERS"] = str(n)
+            den.debug_set("stop_after_layers", n)
             den.forward(spec.cuda(), t.cuda(), cond.cuda())
             bufs = {"x": den.debug_buffer("xres").cpu(), "g": den.debug_buffer("g").cpu(), "s": den.debug_buffer("skip").cpu()}
             for k in bufs:
@@ -202,7 +202,7 @@ def _tap_errors(den, sd, spec, t, cond, rows_of):
                     if e > worst[k][0]:
                         worst[k] = (e, n - 1)
     finally:
-        os.environ.pop("DSVC_DEBUG_STOP_AFTER_LAYERS", None)
+        den.debug_set("stop_after_layers", -1)
     return worst
 
 
@@ -222,12 +222,8 @@ def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused):
     cond = torch.from_numpy((g.standard_normal((B, 256, T)) * 0.5).astype(np.float32))
     t = torch.from_numpy(g.integers(0, 1000, size=(B,)))
     Tp = (T + 8 + 31) // 32 * 32
-    if not fused:
-        os.environ["DSVC_NO_FUSED_LAYER"] = "1"
-    try:
-        worst = _tap_errors(den, sd, spec, t, cond, lambda b: slice(b * Tp, b * Tp + T))
-    finally:
-        os.environ.pop("DSVC_NO_FUSED_LAYER", None)
+    den.debug_set("two_launch_layer", 0 if fused else 1)
+    worst = _tap_errors(den, sd, spec, t, cond, lambda b: slice(b * Tp, b * Tp + T))
     print("tgemm taps %s B=%d T=%d fused=%d: worst |err| x %.2e (layer %d), g %.2e (layer %d), skip-sum %.2e (layer %d)"
           % (precision, B, T, fused, worst["x"][0], worst["x"][1], worst["g"][0], worst["g"][1], worst["s"][0], worst["s"][1]))
     # fp16 activations: one rounding of an O(1..4) value is 2^-11 relative; 20 layers of it stay well under these bars, a
@@ -262,7 +258,7 @@ def test_end_to_end_waveform_vs_reference(precision):
 @pytest.mark.parametrize("precision", ["f16_m64", "f16_d64", "f16_w2"])
 def test_fused_layer_kernel_equals_the_two_launch_layer_bit_for_bit(precision):
     """The throughput tiling runs a residual layer as ONE kernel (tlayer.h: gate GEMM -> g in LDS -> output projection).  It issues
-    the same MFMAs on the same operands in the same order as the two tgemm launches it replaces (DSVC_NO_FUSED_LAYER=1), so a
+    the same MFMAs on the same operands in the same order as the two tgemm launches it replaces (debug_set two_launch_layer), so a
     20-step DDPM chain at B=8 x T=861 must come out bit-identical -- layer geometry, g hand-off through LDS, the alternating xh
     buffers and the pass rotation are all covered by one equality."""
     hp = dict(synth.HPARAMS_44K, K_step=20)
@@ -272,11 +268,8 @@ def test_fused_layer_kernel_equals_the_two_launch_layer_bit_for_bit(precision):
     cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
     cond = cond.transpose(1, 2).contiguous().cuda()
     fused = smp.sample(cond, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
-    os.environ["DSVC_NO_FUSED_LAYER"] = "1"
-    try:
-        two = smp.sample(cond, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
-    finally:
-        os.environ.pop("DSVC_NO_FUSED_LAYER", None)
+    den.debug_set("two_launch_layer", 1)
+    two = smp.sample(cond, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
     assert torch.isfinite(fused).all()
     d = (fused - two).abs().max().item()
     print("fused vs two-launch layer (%s): max |diff| %.3e" % (precision, d))

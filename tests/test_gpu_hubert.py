@@ -36,7 +36,7 @@ def test_hubert_units_vs_reference_golden(hubert):
         assert err < UNIT_TOL, err
 
 
-@pytest.mark.parametrize("n", [400, 1999, 24001, 160000])
+@pytest.mark.parametrize("n", [320, 400, 1999, 24001, 160000])
 def test_hubert_units_lengths_vs_oracle(hubert, n):
     """Edge lengths: the shortest clip that yields a frame, odd sample counts (odd / even frame counts through the seven strided
     convs), and the benchmark's 10 s clip (500 frames)."""

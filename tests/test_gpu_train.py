@@ -123,3 +123,40 @@ def test_train_step_rejects_bad_arguments():
         tr.h.step(mels, torch.zeros(1, 32, 40), t)                                   # host tensors
     with pytest.raises(ValueError):
         tr.h.step(mels.cuda(), torch.zeros(1, 31, 40, device="cuda"), t.cuda())     # wrong hidden size
+
+
+@pytest.mark.parametrize("case", ["tiny_l2", "tiny_l1", "44k_l2", "44k_l1"])
+def test_train_step_vs_real_reference_golden(case):
+    """The HIP training step against the REAL reference's p_losses + autograd (tests/golden/train_grads.npz, minted by
+    oracle/make_golden.py::golden_train from GaussianDiffusion.forward(infer=False) with t and the Philox noise injected): loss,
+    the L2 norm of every gradient tensor, and the stored gradient values (tiny: all; 44.1 kHz: the small tensors whole, the large ones
+    on a stride-8 lattice).  Nothing of the oracle restatement is in this comparison."""
+    from diffsvc_amd.train import DiffusionTrainerHip
+    from make_golden import TRAIN_CASES
+    from util import load_golden
+    g = load_golden("train_grads")
+    name, arch, loss_type, clips, T, n_units, seed = next(c for c in TRAIN_CASES if c[0] == case)
+    hp = dict(synth.tiny_hparams(K=50) if arch == "tiny" else synth.HPARAMS_44K, diff_loss_type=loss_type)
+    sd = synth.acoustic_state(hp, 3)
+    hub, m2p, f0, mels, t = (torch.from_numpy(v).cuda() for v in synth.train_batch_kat(hp, clips, T, n_units, seed))
+    tr = DiffusionTrainerHip(hp, sd)
+    loss = tr.forward_backward(hub, m2p, f0, mels, t, seed=seed, clip_ids=torch.tensor(list(clips), dtype=torch.int32, device="cuda"))
+    ref_loss = float(g[case + "/loss"])
+    assert abs(loss.item() - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
+    worst, worst_name, worst_norm = 0.0, None, 0.0
+    for k, ref_norm in zip((str(n) for n in g[case + "/names"]), g[case + "/norms"]):
+        got = tr.view(tr.grads, k).cpu()
+        worst_norm = max(worst_norm, abs(float(got.double().norm()) - ref_norm) / max(ref_norm, 1e-6))
+        ref = torch.from_numpy(g[case + "/grad/" + k])
+        part = got[synth.train_grad_slices(tuple(got.shape))] if arch != "tiny" else got
+        assert part.shape == ref.shape, k
+        den = ref.norm().item()
+        if den == 0:
+            assert part.abs().max().item() == 0.0, k
+            continue
+        err = (part - ref).norm().item() / den
+        if err > worst:
+            worst, worst_name = err, k
+    print("train step %s vs the real reference: loss %.6f (ref %.6f), worst gradient rel-L2 err %.2e (%s), worst |norm| err %.2e"
+          % (case, loss.item(), ref_loss, worst, worst_name, worst_norm))
+    assert worst < 1e-3 and worst_norm < 1e-3, (worst, worst_name, worst_norm)

@@ -334,31 +334,24 @@ def test_formats_indexed_dataset_singer_features_and_wire_payload(tmp_path):
         assert w.getframerate() == 22050 and abs(w.getnframes() - tone.size // 2) <= 1
 
 
-def test_infer_driver_host_logic(tmp_path):
-    """diffsvc_amd.infer: norm_interp_f0 (utils/pitch_utils.py:45-60) reproduces the interpolated log2-f0 the goldens were minted with;
-    load_ckpt (utils/__init__.py:178-209) takes a file or the highest model_ckpt_steps_<N>.ckpt of a directory, strips the prefix, loads
-    strictly and asserts on a missing checkpoint."""
-    from diffsvc_amd.infer import load_ckpt, norm_interp_f0
-    hp = dict(synth.HPARAMS_44K)
-    _, _, f0_log, f0_hz = synth.clip_inputs(3, T=200, n_units=100)
-    f0, uv = norm_interp_f0(f0_hz, hp)
-    assert torch.equal(f0, torch.from_numpy(f0_log)) and torch.equal(uv, torch.from_numpy((f0_hz == 0).astype(np.float32)))
-    f0, uv = norm_interp_f0(np.zeros(7, np.float32), hp)
-    assert (f0 == 0).all() and (uv == 1).all()
-    lin = torch.nn.Linear(3, 2)
-    d = tmp_path / "ck"
-    d.mkdir()
-    for n, scale in ((5, 0.0), (120, 1.0), (37, 2.0)):
-        torch.save({"state_dict": {"model.weight": torch.full((2, 3), scale), "model.bias": torch.zeros(2), "other.x": torch.ones(1)}},
-                   str(d / ("model_ckpt_steps_%d.ckpt" % n)))
-    assert load_ckpt(lin, str(d)).endswith("model_ckpt_steps_120.ckpt") and (lin.weight == 1.0).all()
-    assert load_ckpt(lin, str(d / "model_ckpt_steps_37.ckpt")).endswith("37.ckpt") and (lin.weight == 2.0).all()
-    torch.save({"state_dict": {"model.weight": torch.zeros(2, 3)}}, str(d / "model_ckpt_steps_999.ckpt"))
-    with pytest.raises(RuntimeError):
-        load_ckpt(lin, str(d))                                 # strict: bias missing
-    with pytest.raises(AssertionError):
-        load_ckpt(lin, str(tmp_path / "nowhere"))
-    assert load_ckpt(lin, str(tmp_path / "nowhere"), force=False) is None
+def test_read_wav_mono_modes(tmp_path):
+    """read_wav: 'first' keeps channel 0 (the 44.1 kHz nvSTFT loader, nvSTFT.py:14-44), 'mean' averages the channels
+    (librosa.load(mono=True) on the 24 kHz front-end and in get_units); a mono file reads the same either way."""
+    import wave
+    from diffsvc_amd.vocoder import read_wav
+    g = np.random.Generator(np.random.PCG64(3))
+    st = (g.standard_normal((500, 2)) * 8000).astype("<i2")
+    p2, p1 = str(tmp_path / "st.wav"), str(tmp_path / "mono.wav")
+    for path, data, nch in ((p2, st, 2), (p1, st[:, :1], 1)):
+        with wave.open(path, "wb") as w:
+            w.setnchannels(nch); w.setsampwidth(2); w.setframerate(16000); w.writeframes(np.ascontiguousarray(data).tobytes())
+    first, mean = read_wav(p2, 16000, mono="first"), read_wav(p2, 16000, mono="mean")
+    assert first.dtype == np.float32 and first.shape == mean.shape == (500,)
+    assert np.array_equal(first, st[:, 0].astype(np.float32) / 32768.0)
+    assert np.allclose(mean, st.astype(np.float32).mean(axis=1) / 32768.0, atol=1e-7) and not np.allclose(first, mean)
+    assert np.array_equal(read_wav(p1, 16000, mono="first"), read_wav(p1, 16000, mono="mean"))
+    with pytest.raises(ValueError):
+        read_wav(p1, 16000, mono="left")
 
 
 def test_shard_clips_by_length_balances_and_is_deterministic():

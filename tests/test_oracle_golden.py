@@ -173,3 +173,39 @@ def test_pitch_extractor_matches_reference():
         assert torch.equal(f0 == 0, ref == 0)
         assert ((f0 - ref).abs() / ref.clamp(min=1)).max().item() < 1e-5
 
+
+
+@pytest.mark.parametrize("case", ["tiny_l2", "tiny_l1", "44k_l2", "44k_l1"])
+def test_training_loss_and_gradients_match_the_real_p_losses(case):
+    """The training oracle (O.train_loss_and_grads: q_sample -> DiffNet -> l1 / l2, torch autograd) against the REAL
+    GaussianDiffusion.forward(infer=False) -> Batch2Loss.module4 -> p_losses + loss.backward() (diffusion.py:207-241,
+    train_pipeline.py:222-238), minted with the diffusion steps and the Philox training noise injected (tests/golden/train_grads.npz,
+    oracle/make_golden.py::golden_train): the loss, the L2 norm of every one of the 43 / 171 gradient tensors, and the stored gradient
+    values (tiny: every element; 44.1 kHz: small tensors whole -- input / output / skip projections, biases, fs2.pitch_embed -- the large
+    ones on a stride-8 lattice)."""
+    from make_golden import TRAIN_CASES
+    g = load_golden("train_grads")
+    name, arch, loss_type, clips, T, n_units, seed = next(c for c in TRAIN_CASES if c[0] == case)
+    hp = dict(synth.tiny_hparams(K=50) if arch == "tiny" else synth.HPARAMS_44K, diff_loss_type=loss_type)
+    sd = synth.acoustic_state(hp, 3)
+    hub, m2p, f0, mels, t = (torch.from_numpy(v) for v in synth.train_batch_kat(hp, clips, T, n_units, seed))
+    noise = O.ddpm_noise_ref_layout(seed, list(clips), 0, T, hp["audio_num_mel_bins"], O.PURPOSE_TRAIN_NOISE)
+    loss, grads = O.train_loss_and_grads(sd, hub, m2p, f0, mels, t, noise, hp)
+    ref_loss = float(g[case + "/loss"])
+    assert abs(loss.item() - ref_loss) <= 2e-6 * abs(ref_loss), (loss.item(), ref_loss)
+    names = [str(n) for n in g[case + "/names"]]
+    assert sorted(names) == sorted(grads.keys())
+    worst = 0.0
+    for k, ref_norm in zip(names, g[case + "/norms"]):
+        got = grads[k]
+        assert abs(float(got.double().norm()) - ref_norm) <= 2e-5 * max(ref_norm, 1e-6), (k, float(got.double().norm()), ref_norm)
+        ref = torch.from_numpy(g[case + "/grad/" + k])
+        sl = synth.train_grad_slices(tuple(got.shape)) if arch != "tiny" else tuple(slice(None) for _ in got.shape)
+        part = got[sl]
+        assert part.shape == ref.shape, k
+        den = ref.norm().item()
+        if den == 0:
+            assert part.abs().max().item() == 0.0, k
+            continue
+        worst = max(worst, (part - ref).norm().item() / den)
+    assert worst < 2e-5, worst           # the same fp32 math in another summation order

@@ -30,6 +30,24 @@ def test_drop_ins_through_the_real_reference_seams():
 
 
 @needs_ref
+def test_reference_svc_driver_runs_wav_to_wav_over_the_drop_ins():
+    """BASELINE configs[0] (plumbing, no GPU): the REAL ``Svc.infer`` / ``pre`` / ``after_infer`` of infer_tools/infer_tool.py:104-345 over
+    GaussianDiffusionHip(DiffNetHip) + NsfHifiGANHip, checkpoint loaded by the reference's own strict loader, vocoder resolved through
+    the reference's registry -- 20-step-class PLMS (pndm_speedup 10 over a 40-step schedule), wav in -> wav out.  The C-ABI handles are
+    oracle-backed stand-ins here (no device in this container; tests/ref_infer_driver.py), so the equality below is about the host
+    glue: the driver's output equals the same conversion written as plain oracle calls."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_infer_driver.py")], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, r.stdout[-2000:]
+    d = json.loads(line[-1][7:])
+    assert d["sampler_calls"] == [{"t_start": 40, "speedup": 10, "seed": 5, "T": d["frames"]}] and d["pndm_speedup_set_by_pre"]
+    assert d["wav_len_ok"] and d["f0_gt_is_shifted_input"] and d["wav_rms"] > 0.05
+    assert d["wav_max_abs_diff"] < 1e-6 and d["f0_pred_max_abs_diff"] == 0.0
+
+
+@needs_ref
 def test_slicer_on_the_reference_demo_input_matches_the_real_slicer():
     """raw/test_input.wav (mono 16-bit 22 050 Hz, 22.6 s -- the only real audio the reference ships) through diffsvc_amd.slicer at six
     parameter sets against chunk dicts minted from the real infer_tools/slicer.py (tests/golden/slicer_test_input.json, written by
