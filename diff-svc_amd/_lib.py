@@ -109,6 +109,8 @@ SYMBOLS = [
     ("dsvc_melspec_frames", ctypes.c_int, [_VP, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]),
     ("dsvc_melspec_run", ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int64, _VP]),
     ("dsvc_pitch_coarse", ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int64, _VP, _VP, _VP]),
+    ("dsvc_cond_build", ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, ctypes.c_int32, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.c_int32, _VP, _VP, _VP, _VP, _VP]),
     ("dsvc_hubert_create", ctypes.c_int, [ctypes.POINTER(_VP)]),
     ("dsvc_hubert_load_tensor", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64]),
     ("dsvc_hubert_finalize", ctypes.c_int, [_VP]),

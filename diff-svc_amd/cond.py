@@ -113,6 +113,33 @@ class CondBuilder(nn.Module):
                                       x.numel(), ptr(f0_denorm), ptr(coarse), stream_ptr()))
         return f0_denorm, coarse
 
+    def _build_device(self, hubert, mel2ph, f0, uv):
+        """The whole builder in ONE launch (dsvc_cond_build, csrc/cond.hip): pitch bins, gather, embedding, mask, the [B, H, T] transpose
+        and the reference's in-place ``f0[mel2ph == 0] = 0`` -- no torch launches, no synchronisation."""
+        import ctypes
+        from ._lib import check, lib, ptr, stream_ptr
+        hp, dev = self.hp, hubert.device
+        if self._thr_dev is None or self._thr_dev[0] != dev:
+            self._thr_dev = (dev, coarse_thresholds(hp).to(dev))
+        thr = self._thr_dev[1]
+        B, N, H = hubert.shape
+        T = mel2ph.shape[1]
+        hub = hubert.detach().to(torch.float32).contiguous()
+        m2p = mel2ph.to(torch.int64).contiguous()
+        x = f0 if (f0.dtype == torch.float32 and f0.is_contiguous()) else f0.detach().to(torch.float32).contiguous()
+        uv_t = uv.to(dev, torch.float32).contiguous() if (uv is not None and hp.get("use_uv")) else None
+        emb = self.pitch_embed.weight.detach()
+        emb = emb if (emb.dtype == torch.float32 and emb.is_contiguous()) else emb.to(torch.float32).contiguous()
+        dec = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+        cond = torch.empty(B, H, T, device=dev, dtype=torch.float32)
+        f0_denorm = torch.empty(B, T, device=dev, dtype=torch.float32)
+        coarse = torch.empty(B, T, device=dev, dtype=torch.int64)
+        check(lib().dsvc_cond_build(ptr(hub), ptr(m2p), ptr(x), ptr(uv_t) if uv_t is not None else ctypes.c_void_p(0), ptr(thr), thr.numel(),
+                                    ptr(emb), B, N, T, H, ptr(dec), ptr(cond), ptr(f0_denorm), ptr(coarse), stream_ptr()))
+        if x is not f0:
+            f0.copy_(x)                                                        # the reference mutates its argument (fs2.py:231)
+        return dec, cond, f0_denorm, coarse
+
     def _pitch_host(self, f0, mel2ph, uv):
         hp = self.hp
         # ---- index work on the host, bit-exact with the reference CPU path (fs2.py:229-233, pitch_utils.py) ----
@@ -146,6 +173,12 @@ class CondBuilder(nn.Module):
             raise NotImplementedError("only the no_fs2 / pitch-embed configuration of the reference is supported")
         ret = {"mel2ph": mel2ph}
         dev = hubert.device
+        if hp.get("pitch_norm", "log") != "log":
+            raise NotImplementedError("pitch_norm must be 'log'")
+        if hubert.is_cuda:                                   # (no autograd through it: the drop-ins are inference modules, the trainer
+            dec, cond, f0_denorm, coarse = self._build_device(hubert, mel2ph, f0, uv)      # differentiates the embedding by hand)
+            ret.update(f0_denorm=f0_denorm, pitch_pred=coarse.unsqueeze(-1), decoder_inp=dec, cond_bht=cond)
+            return ret
         padded = F.pad(hubert, [0, 0, 1, 0])
         idx = mel2ph[..., None].repeat([1, 1, hubert.shape[-1]])
         gathered = torch.gather(padded, 1, idx)                               # [B, T, H]

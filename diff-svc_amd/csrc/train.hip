@@ -186,6 +186,11 @@ __global__ void k_bct_to_rows(const float* __restrict__ src, float* __restrict__
     }
 }
 
+__global__ void k_clamp_copy(int* __restrict__ dst, const int* __restrict__ src, int lo, int hi, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int v = src[i]; dst[i] = v < lo ? lo : (v > hi ? hi : v); }
+}
+
 // x_t = sa[t_b] * norm_spec(mel) + sb[t_b] * noise   (diffusion.py:200-205,286-287); mel [B][T][M] -> frame-major [B*stride][M]
 __global__ void k_make_xt(const float* __restrict__ mel, float* __restrict__ xt, const int* __restrict__ tstep, const float* __restrict__ sa,
                           const float* __restrict__ sb, const float* __restrict__ spec_min, const float* __restrict__ spec_max, int n_spec,
@@ -536,6 +541,10 @@ int dsvc_trainer::repack(hipStream_t st) {
     return DSVC_OK;
 }
 
+// The workspace layout depends on (B, T): clips sit Tp rows apart with ZERO gap rows (the convs' padding, and rows the weight-gradient
+// contractions sum over), so a new shape re-zeroes it -- ~1.3 GB of memset (~0.4 ms) at the 64 x 128-frame batch; allocations are kept
+// and only grow.  A loader that changes B and T every step (the reference's max_tokens batching) pays that per step: bucket T
+// (e.g. multiples of 32 frames: Tp already rounds to 32) to keep the layout stable.
 int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     if (B == wsB && T == wsT) return DSVC_OK;
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
@@ -637,7 +646,8 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     DSVC_HIP(hipMemsetAsync(grads, 0, (size_t)total * 4, st));
     DSVC_HIP(hipMemsetAsync(loss.p, 0, 16, st));
     // ---- inputs ----
-    DSVC_HIP(hipMemcpyAsync(tstep.p, ta->t, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    // the diffusion steps index the noise schedule (k_make_xt) and the step embedding: clamped into [0, timesteps) on the way in
+    hipLaunchKernelGGL(k_clamp_copy, dim3(ceil_div(B, 256)), dim3(256), 0, st, tstep.as<int>(), ta->t, 0, cfg.timesteps - 1, B);
     if (ta->clip_ids) DSVC_HIP(hipMemcpyAsync(clipid.p, ta->clip_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     else hipLaunchKernelGGL(k_iota, dim3(ceil_div(B, 256)), dim3(256), 0, st, clipid.as<int>(), ta->first_clip, B);
     hipLaunchKernelGGL(k_make_xt, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, ta->mel, xt.as<float>(), tstep.as<int>(), sa.as<float>(),

@@ -81,6 +81,10 @@ class GaussianDiffusionHip(nn.Module):
         slot = self.denoise_fn.precision_for(use, speedup)
         cur = self._samplers.get(slot)
         if cur is None or cur[1] != key:
+            # a sampler handle keeps its denoiser handle (up to 3 GB of packed weights) alive: drop every slot whose denoiser handle
+            # is no longer one the denoiser module itself holds (load_state_dict / .to() rebuilt them), not only the slot in use
+            live = {id(hk[0]) for hk in self.denoise_fn._handles.values()}
+            self._samplers = {s: c for s, c in self._samplers.items() if c[1][0] in live and s != slot}
             cur = (SamplerHandle(den, {k: v for k, v in self.state_dict().items() if "." not in k}), key)
             self._samplers[slot] = cur
         return cur[0]
@@ -88,7 +92,9 @@ class GaussianDiffusionHip(nn.Module):
     def forward(self, hubert, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None, infer=False,
                 **kwargs):
         ret = self.fs2(hubert, mel2ph, spk_embed, None, f0, uv, energy, skip_decoder=True, infer=infer)
-        cond = ret["decoder_inp"].transpose(1, 2).contiguous()
+        cond = ret.pop("cond_bht", None)                     # the device builder emits the [B, H, T] layout alongside (one launch)
+        if cond is None:
+            cond = ret["decoder_inp"].transpose(1, 2).contiguous()
         if not infer:
             raise NotImplementedError("training (p_losses, diffusion.py:207-225) stays on the reference autograd path")
         hp = self.hp

@@ -51,6 +51,8 @@ class TrainerHandle:
         for x in (mel, cond, t, pitch, mel2ph, clip_ids):
             if x is not None and not x.is_cuda:
                 raise RuntimeError("diffsvc_amd: training tensors must live on the HIP device; there is no CPU path")
+        # (diffusion steps outside [0, timesteps) are clamped inside dsvc_trainer_step -- k_make_xt reads the noise schedule at t --
+        #  without a device-to-host check; train_step() draws them in range)
         if tuple(cond.shape) != (B, self.cfg.hidden, T) or t.numel() != B:
             raise ValueError("shape mismatch: mel %s cond %s t %s" % (tuple(mel.shape), tuple(cond.shape), tuple(t.shape)))
         a = _lib.TrainArgs(B, T, mel.data_ptr(), cond.data_ptr(), t.data_ptr(), pitch.data_ptr() if pitch is not None else None,
@@ -124,7 +126,11 @@ class DiffusionTrainerHip:
         return sd
 
     def lr(self):
-        return self.lr0 * 0.5 ** (self.global_step // int(self.hp.get("decay_steps", 40000)))          # StepLR(decay_steps, gamma=0.5)
+        """The rate the NEXT optimisation step runs at.  The reference steps its StepLR(decay_steps, gamma=0.5) AFTER optimizer.step() and
+        with an explicit epoch -- ``scheduler.step(global_step)`` (SVC_task.py:119-125, global_step still k while step k is being
+        taken, pl_utils.py:1426) -- which sets lr0 * 0.5 ** (k // decay_steps) for step k + 1: step k runs at
+        lr0 * 0.5 ** ((k - 1) // decay_steps), one step later than a plain per-step StepLR would halve."""
+        return self.lr0 * 0.5 ** (max(self.global_step - 1, 0) // int(self.hp.get("decay_steps", 40000)))
 
     @torch.no_grad()
     def forward_backward(self, hubert, mel2ph, f0, mels, t, seed=0, first_clip=0, clip_ids=None):
@@ -149,7 +155,7 @@ class DiffusionTrainerHip:
     def optimizer_step(self):
         """What follows the backward pass: all-reduce (mean) of ``self.grads`` over the ranks, clip_grad_norm_, AdamW at the StepLR rate."""
         allreduce_mean_(self.grads, self.group)
-        lr = self.lr()                                       # StepLR: the k-th step (0-based) runs at lr0 * 0.5 ** (k // decay_steps)
+        lr = self.lr()                                       # step k (0-based) runs at lr0 * 0.5 ** (max(k - 1, 0) // decay_steps)
         self.global_step += 1
         hp, n = self.hp, self.h.n_floats
         clip = float(hp.get("clip_grad_norm", 1.0))

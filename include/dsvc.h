@@ -207,6 +207,17 @@ int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, i
 int dsvc_pitch_coarse(const float* f0_log2, const int64_t* mel2ph, const float* uv, const float* thresholds, int32_t n_thresholds,
                       int64_t n, float* f0_denorm, int64_t* coarse, void* stream);
 
+/* The whole condition builder of the no_fs2 configuration in one launch -- replaces FastSpeech2.forward's no_fs2 branch
+ * (modules/fastspeech/fs2.py:133-148: decoder_inp = gather(pad(hubert), mel2ph)), add_pitch (:229-237, as dsvc_pitch_coarse above) and
+ * insert4's (decoder_inp + pitch_embed[coarse]) * (mel2ph > 0) (training/train_pipeline.py:213-218), and the transpose of
+ * GaussianDiffusion.forward (network/diff/diffusion.py:236):
+ *   hubert [B,N,H], mel2ph [B,T] int64 (0 = padding, else 1-based unit index), f0_log2 [B,T] (IN/OUT: zeroed where mel2ph == 0, as the
+ *   reference mutates its argument, fs2.py:231), uv [B,T] or NULL, pitch_embed [vocab,H]  ->  decoder_inp [B,T,H], cond_bht [B,H,T],
+ *   f0_denorm [B,T], coarse [B,T] int64.  All pointers device.  Values are bit-identical to the reference's fp32 expression. */
+int dsvc_cond_build(const float* hubert, const int64_t* mel2ph, float* f0_log2, const float* uv, const float* thresholds,
+                    int32_t n_thresholds, const float* pitch_embed, int32_t B, int32_t N, int32_t T, int32_t H,
+                    float* decoder_inp, float* cond_bht, float* f0_denorm, int64_t* coarse, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Content encoder -- replaces network/hubert/hubert_model.py:67-77 (HubertSoft.units: pad 40|40 -> FeatureExtractor ->
  * FeatureProjection -> + PositionalConvEmbedding -> LayerNorm -> 12 post-LN transformer layers -> proj), loaded by

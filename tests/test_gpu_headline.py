@@ -274,3 +274,101 @@ def test_fused_layer_kernel_equals_the_two_launch_layer_bit_for_bit(precision):
     d = (fused - two).abs().max().item()
     print("fused vs two-launch layer (%s): max |diff| %.3e" % (precision, d))
     assert torch.equal(fused, two), d
+
+
+# ---- round 3: the 1000-step error is a heavy-tailed statistic, so the shipped precision is held to the bar on MANY realisations ----
+SHIP_BAR = 9.0e-4       # the shipped DDPM precision must keep >= 10 % margin under the 1e-3 bar on every real-reference golden
+
+
+def _spread():
+    """(name, clip, seed, conditioned) of every single-clip real-reference golden of the benchmarked configuration."""
+    from make_golden import spread_names
+    out = [("e2e_44k_T861_k1000_c4", 4, 1004, None), ("e2e_44k_T861_k1000_c6", 6, 1006, None)]
+    return out + list(spread_names())
+
+
+def _shipped():
+    from diffsvc_amd.denoiser import DiffNetHip
+    return DiffNetHip.AUTO["ddpm"]
+
+
+def _clip_cond(hp, sd, clip, g):
+    hub, m2p, f0 = clip_batch(hp, [clip], int(g["T"]), int(g["n_units"]))
+    cond, f0_denorm, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    assert np.array_equal(f0_denorm.numpy(), g["f0_denorm"])
+    return cond.transpose(1, 2).contiguous().cuda(), m2p.cuda()
+
+
+@pytest.mark.parametrize("which", ["shipped", "f16_m64", "f16_w2"])
+def test_spread_of_single_clip_chains_vs_reference(which):
+    """B=1, T=861, 1000 steps against NINETEEN further runs of the REAL reference (oracle/make_golden.py::golden_headline_spread + the two
+    round-2 extras): twelve (clip, noise) pairs on the random-init checkpoint -- among them (9, 1009), the round-2 precision's worst --
+    and six on CONDITIONED checkpoints whose reference mel has < 1 % of its values on spec_min / spec_max (p_sample's clamp,
+    diffusion.py:149-150, cannot hide an error there; the random-init goldens have 36 % of their values on it).  The shipped DDPM
+    precision (DiffNetHip.AUTO['ddpm']) must stay <= 9.0e-4 on EVERY one; the other schemes are measured beside it."""
+    precision = _shipped() if which == "shipped" else which
+    if which != "shipped" and precision == _shipped():
+        pytest.skip("is the shipped precision")
+    from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
+    hp = dict(synth.HPARAMS_44K)
+    handles, errs = {}, []
+    for name, clip, seed, cond_par in _spread():
+        g = load_golden(name)
+        assert int(g["seed"]) == seed and [int(c) for c in g["clips"]] == [clip]
+        key = tuple(cond_par) if cond_par else None
+        if key not in handles:
+            handles.clear()                                  # one packed weight set at a time (2.3 GB with 64 dither variants)
+            sd = golden_state(g, hp)
+            den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=precision, prefix="denoise_fn.")
+            handles[key] = (sd, SamplerHandle(den, sd))
+        sd, smp = handles[key]
+        cond, m2p = _clip_cond(hp, sd, clip, g)
+        mel = smp.sample(cond, 1000, mel2ph=m2p, seed=seed, first_clip=clip, use_graph=True).cpu()
+        d = (mel - torch.from_numpy(g["mel_out"])).abs()
+        errs.append((name.replace("e2e_44k_T861_k1000_", ""), d.max().item(), d.pow(2).mean().sqrt().item()))
+    worst = max(e[1] for e in errs)
+    print("spread %s (%s): worst %.2e | " % (which, precision) + "  ".join("%s %.2e/%.1e" % e for e in errs))
+    assert all(np.isfinite(e[1]) for e in errs)
+    if which == "shipped":
+        assert worst <= SHIP_BAR, errs
+    elif precision == "f16_w2":
+        assert worst < MEL_BAR, errs
+
+
+@pytest.mark.parametrize("which", ["shipped", "f16_m64", "f16_w2"])
+@pytest.mark.parametrize("ckpt", ["random", "ca", "cb"])
+def test_batch_of_32_full_chain_every_clip_with_a_golden(ckpt, which):
+    """The per-GPU share of BASELINE configs[3] -- what bench.py's `batched.value` times: 32 clips x T=861 in ONE batch (28 672 rows,
+    the fused layer kernel tlayer_kernel<3, .>), 1000 steps, at the shipped precision.  Clips 0..31 with seed 2026: EVERY clip of
+    the batch that has a real-reference golden is checked (12 on the random-init checkpoint, 2 + 4 on the two conditioned ones).  The
+    other operand schemes are measured beside the shipped one."""
+    precision = _shipped() if which == "shipped" else which
+    if which != "shipped" and precision == _shipped():
+        pytest.skip("is the shipped precision")
+    from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
+    from make_golden import SPREAD_CLIPS, SPREAD_COND, SPREAD_SEED
+    hp = dict(synth.HPARAMS_44K)
+    cond_par = None if ckpt == "random" else dict((t, c) for t, c, _ in SPREAD_COND)[ckpt]
+    have = {0: ("e2e_44k_T861_k1000", 0), 1: ("e2e_44k_T861_k1000", 1)} if ckpt == "random" else {}
+    if ckpt == "random":
+        have.update({c: ("e2e_44k_T861_k1000_s2026_c%d" % c, 0) for c in SPREAD_CLIPS})
+    else:
+        have.update({c: ("e2e_44k_T861_k1000_%s_c%d" % (ckpt, c), 0) for c in dict((t, cl) for t, _, cl in SPREAD_COND)[ckpt]})
+    sd = synth.acoustic_state_conditioned(hp, 0, *cond_par) if cond_par else synth.acoustic_state(hp, 0)
+    den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=precision, prefix="denoise_fn.")
+    smp = SamplerHandle(den, sd)
+    clips = list(range(32))
+    hub, m2p, f0 = clip_batch(hp, clips, 861, 500)
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    mel = smp.sample(cond.transpose(1, 2).contiguous().cuda(), 1000, mel2ph=m2p.cuda(), seed=SPREAD_SEED, first_clip=0, use_graph=True).cpu()
+    assert torch.isfinite(mel).all()
+    errs = []
+    for c, (name, row) in sorted(have.items()):
+        g = load_golden(name)
+        assert int(g["seed"]) == SPREAD_SEED and int(g["clips"][row]) == c
+        errs.append((c, (mel[c] - torch.from_numpy(g["mel_out"][row])).abs().max().item()))
+    print("batch of 32 (%s checkpoint, %s %s): mel max-abs err per golden clip %s" % (ckpt, which, precision, ["%d: %.2e" % e for e in errs]))
+    if which == "shipped":
+        assert max(e[1] for e in errs) <= SHIP_BAR, errs
+    elif precision == "f16_w2":
+        assert max(e[1] for e in errs) < MEL_BAR, errs

@@ -174,10 +174,13 @@ def test_full_size_vocoder_properties():
     assert (short[0, :n] - wav[0, :n]).abs().max().item() < 1e-5
 
 
-def _run_bench(nproc, clips_per_gpu, extra_env=None):
+def _run_bench(nproc, clips_per_gpu, extra_env=None, share_device=True):
     import json, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DSVC_BENCH_SHARE_DEVICE="1", DSVC_BENCH_PCM_STATS="1", **(extra_env or {}))
+    env = dict(os.environ, DSVC_BENCH_PCM_STATS="1", **(extra_env or {}))
+    if share_device:
+        env["DSVC_BENCH_SHARE_DEVICE"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this host driver
     tail = [os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "1", "--warmup", "1", "--ddpm-steps", "20",
             "--clips-per-gpu", str(clips_per_gpu), "--no-cpu-baseline", "--no-batched"]
     if nproc > 1:
@@ -206,6 +209,22 @@ def test_bench_launch_contract_two_ranks_share_the_device():
     assert [s[0] for s in d["pcm_stats"]] == [0, 1, 2, 3] == [s[0] for s in one["pcm_stats"]]
     for a, b in zip(d["pcm_stats"], one["pcm_stats"]):
         assert abs(a[1] - b[1]) <= 1e-3 + 1e-5 * abs(b[1]) and abs(a[2] - b[2]) <= 1e-5 * b[2], (a, b)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices (RCCL over xGMI)")
+@pytest.mark.parametrize("pcm16", [False, True])
+def test_bench_two_gpus_over_rccl_equals_one_gpu(pcm16):
+    """The real multi-GPU launch: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`, one rank per GPU, backend
+    'nccl' (= RCCL over xGMI), clip i on rank i % 2, one all_gather of the finished PCM -- as fp32 and as the 16-bit PCM the reference
+    writes (infer.py:70).  The gathered PCM must equal the 1-GPU job clip for clip (global Philox clip ids)."""
+    extra = {"DSVC_BENCH_PCM16": "1"} if pcm16 else {}
+    d = _run_bench(2, 2, extra_env=extra, share_device=False)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["finite_output"] and d["value"] > 0
+    assert d["config"]["gather"] == ("int16 PCM" if pcm16 else "fp32 PCM")
+    one = _run_bench(1, 4, extra_env=extra)
+    assert [s[0] for s in d["pcm_stats"]] == [0, 1, 2, 3] == [s[0] for s in one["pcm_stats"]]
+    for a, b in zip(d["pcm_stats"], one["pcm_stats"]):
+        assert abs(a[1] - b[1]) <= 1e-3 * (32767.0 if pcm16 else 1.0) + 1e-5 * abs(b[1]) and abs(a[2] - b[2]) <= 1e-5 * b[2], (a, b)
 
 
 def _ragged_inputs(hp, clips, lens, n_units_of, T):
@@ -353,7 +372,8 @@ def test_use_pe_drives_the_vocoder_with_the_extracted_f0():
 
 
 def test_cond_builder_device_pitch_path_equals_host_path():
-    """CondBuilder on device tensors (dsvc_pitch_coarse: threshold search, no host round trip) against the host path (the reference's
+    """CondBuilder on device tensors (dsvc_cond_build: pitch threshold search + gather + embedding + mask + transpose in one launch, no
+    host round trip) against the host path (the reference's
     torch-CPU expression per clip): identical pitch bins and decoder_inp, f0_denorm to the last ulp of exp2 -- on the benchmark inputs,
     a ragged batch with an interior mel2ph == 0 gap and the use_uv branch.  Pitch values sitting exactly on a bin threshold (and one
     ulp below) are checked against the reference expression evaluated one value at a time: there torch's vectorised CPU loop and its
@@ -372,10 +392,14 @@ def test_cond_builder_device_pitch_path_equals_host_path():
     uv = (torch.arange(861)[None].repeat(3, 1) % 97 == 0).float()
     for use_uv in (False, True):
         cb.hp = dict(hp, use_uv=use_uv); cbd.hp = cb.hp
-        a = cb(hub, mel2ph=m2p, f0=f0.clone(), uv=uv)
-        b = cbd(hub.cuda(), mel2ph=m2p.cuda(), f0=f0.clone().cuda(), uv=uv.cuda())
+        f0_host, f0_dev = f0.clone(), f0.clone().cuda()
+        a = cb(hub, mel2ph=m2p, f0=f0_host, uv=uv)
+        b = cbd(hub.cuda(), mel2ph=m2p.cuda(), f0=f0_dev, uv=uv.cuda())
         assert torch.equal(a["pitch_pred"], b["pitch_pred"].cpu())
         assert torch.equal(a["decoder_inp"], b["decoder_inp"].cpu())
+        assert torch.equal(a["decoder_inp"].view(torch.int32), b["decoder_inp"].cpu().view(torch.int32))      # bit for bit, signed zeros included
+        assert torch.equal(b["cond_bht"], b["decoder_inp"].transpose(1, 2))                                  # dsvc_cond_build's second layout
+        assert torch.equal(f0_host, f0_dev.cpu()) and (f0_dev.cpu()[m2p == 0] == 0).all()                    # the in-place f0[mel2ph == 0] = 0 (fs2.py:231)
         fa, fb = a["f0_denorm"], b["f0_denorm"].cpu()
         assert torch.equal(fa == 0, fb == 0)
         assert ((fa - fb).abs() <= 2.4e-7 * fa.abs()).all()

@@ -66,9 +66,8 @@ def test_optimizer_step_matches_torch_adamw_with_grad_clip():
     names = [n for n, _, _ in tr.h.layout]
     ref_p = {k: sd[k].clone().requires_grad_(True) for k in names}
     opt = torch.optim.AdamW([ref_p[k] for k in names], lr=hp["lr"], betas=(0.9, 0.98), weight_decay=0.01)
-    sched = torch.optim.lr_scheduler.StepLR(opt, hp["decay_steps"], gamma=0.5)
     clips, T, n_units = [0, 1, 2], 40, 23
-    for it in range(3):
+    for it in range(4):
         hub, m2p, f0, mels, t = _batch(hp, clips, T, n_units, 20 + it)
         noise = O.ddpm_noise_ref_layout(30 + it, clips, 0, T, hp["audio_num_mel_bins"], O.PURPOSE_TRAIN_NOISE)
         cur = dict(sd, **{k: v.detach() for k, v in ref_p.items()})
@@ -77,11 +76,15 @@ def test_optimizer_step_matches_torch_adamw_with_grad_clip():
             ref_p[k].grad = gr[k].clone()
             tr.view(tr.grads, k).copy_(gr[k])
         torch.nn.utils.clip_grad_norm_([ref_p[k] for k in names], 1.0)
-        opt.step(); opt.zero_grad(); sched.step()
+        # the reference's schedule: optimizer.step(), then scheduler.step(global_step) with global_step still `it` (SVC_task.py:119-125)
+        # -> step `it` runs at lr0 * 0.5 ** (max(it - 1, 0) // decay_steps); with decay_steps = 2: lr0, lr0, lr0, lr0 / 2
+        for grp in opt.param_groups:
+            grp["lr"] = hp["lr"] * 0.5 ** (max(it - 1, 0) // hp["decay_steps"])
+        opt.step(); opt.zero_grad()
         tr.optimizer_step()
     got = tr.state_dict()
     worst = max((got[k] - ref_p[k].detach()).abs().max().item() for k in names)
-    print("optimizer: worst |param diff| after 3 steps %.2e" % worst)
+    print("optimizer: worst |param diff| after 4 steps %.2e" % worst)
     assert worst < 1e-6, worst
     assert set(got) == set(sd) and all(tuple(got[k].shape) == tuple(sd[k].shape) for k in sd)      # a loadable checkpoint comes back
 

@@ -105,9 +105,10 @@ def _gather_worker(rank, world, port, n_clips, L, q):
     ids = shard_clips(n_clips, rank, world)
     local = torch.stack([torch.full((L,), float(i)) + torch.arange(L) * 1e-3 for i in ids])
     full = gather_pcm(local, ids, n_clips)
+    full16 = gather_pcm(local / 8.0, ids, n_clips, as_int16=True)
     dist.barrier()
     if rank == 0:
-        q.put(full.numpy())
+        q.put((full.numpy(), full16.numpy()))
     dist.destroy_process_group()
 
 
@@ -121,12 +122,15 @@ def test_gather_pcm_world2_gloo():
     procs = [ctx.Process(target=_gather_worker, args=(r, world, port, n_clips, L, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full = q.get(timeout=120)
+    full, full16 = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     want = np.stack([np.full(L, float(i), np.float32) + np.arange(L, dtype=np.float32) * 1e-3 for i in range(n_clips)])
     assert np.array_equal(full, want)
+    # the 16-bit form the reference writes (infer.py:70): round(x * 32767) clipped, converted before the exchange
+    assert full16.dtype == np.int16
+    assert np.array_equal(full16, np.clip(np.rint(want / np.float32(8.0) * np.float32(32767.0)), -32768, 32767).astype(np.int16))
 
 
 def test_product_path_has_no_cpu_fallback():

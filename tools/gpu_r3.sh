@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-3 GPU visit: bash tools/gpu_r3.sh <tag> [parts]   parts: any of  overlap tests bench prof1 prof32 pmc32  (default: overlap tests bench prof32)
+TAG=${1:-r3a}
+PARTS=${2:-"overlap tests bench prof32"}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd $ROOT
+export TMPDIR=/tmp
+PREC32=${PREC32:-auto}
+for part in $PARTS; do
+case $part in
+overlap)
+  timeout 120 tools/micro/overlap 4 > $OUT/${TAG}_overlap.txt 2>&1; echo "overlap rc=$?"; cat $OUT/${TAG}_overlap.txt ;;
+tests)
+  timeout 2400 python -m pytest tests -m gpu -q -rP --durations=12 > $OUT/${TAG}_pytest_gpu.txt 2>&1
+  echo "pytest rc=$?" >> $OUT/${TAG}_pytest_gpu.txt
+  grep -E "passed|failed|error" $OUT/${TAG}_pytest_gpu.txt | tail -5
+  grep -E "^(spread|batch of 32|headline|throughput tiling|end to end|train step|train traj|optimizer)" $OUT/${TAG}_pytest_gpu.txt ;;
+bench)
+  timeout 1200 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+  echo "bench rc=$?"; cat $OUT/${TAG}_bench.json; tail -3 $OUT/${TAG}_bench.err ;;
+prof1)
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-batched --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
+  echo "rocprof B1 rc=$?"
+  F=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1)
+  [ -n "$F" ] && head -30 "$F" > $OUT/${TAG}_kernel_stats.csv && head -8 $OUT/${TAG}_kernel_stats.csv
+  rm -rf $OUT/${TAG}_prof; cd $ROOT ;;
+prof32)
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof32 -o bench -- python $ROOT/bench.py --clips-per-gpu 32 --steps 1 --warmup 1 --no-batched --no-cpu-baseline --precision $PREC32 > $OUT/${TAG}_prof32_bench.json 2> $OUT/${TAG}_prof32.err
+  echo "rocprof B32 rc=$?"
+  F=$(find $OUT/${TAG}_prof32 -name "*kernel_stats.csv" | head -1)
+  [ -n "$F" ] && head -30 "$F" > $OUT/${TAG}_kernel_stats_b32.csv && head -8 $OUT/${TAG}_kernel_stats_b32.csv
+  rm -rf $OUT/${TAG}_prof32; cat $OUT/${TAG}_prof32_bench.json; cd $ROOT ;;
+pmc32)
+  cd /tmp
+  P=${PMCPREC:-f16_w2}
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc32_$c -o pmc -- python $ROOT/tools/prof_sampler.py 32 12 $P > $OUT/${TAG}_pmc32_$c.log 2>&1
+  done
+  python $ROOT/tools/rocprof_traffic.py $OUT/${TAG}_pmc32_FETCH_SIZE $OUT/${TAG}_pmc32_WRITE_SIZE "tlayer_kernel" $OUT/${TAG}_layer_traffic_b32.json "tools/prof_sampler.py 32 12 $P (eager launches)"
+  rm -rf $OUT/${TAG}_pmc32_FETCH_SIZE $OUT/${TAG}_pmc32_WRITE_SIZE; cd $ROOT ;;
+esac
+done
