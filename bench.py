@@ -280,7 +280,7 @@ def main():
 
     def one_step(seed):
         # noise streams are keyed by the GLOBAL clip index: clip i produces the same PCM on 1 GPU and on any rank of N GPUs
-        wav = pipe.infer(hub, m2p, f0, speedup=args.speedup, seed=seed, clip_ids=clip_ids, use_graph=not args.no_graph)
+        wav = pipe.infer(hub, m2p, f0, speedup=args.speedup, seed=seed, clip_ids=clip_ids, use_graph=not args.no_graph, full_length=True)
         if world > 1 or pcm16:
             wav = gather_pcm(wav, my_clips, n_clips, as_int16=pcm16)
         return wav

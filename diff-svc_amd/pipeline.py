@@ -58,7 +58,7 @@ class SvcPipeline:
 
     @torch.no_grad()
     def infer(self, hubert, mel2ph, f0, speedup=1, seed=0, first_clip=0, clip_ids=None, use_graph=True, return_mel=False,
-              return_lens=False, use_pe=False):
+              return_lens=False, use_pe=False, full_length=None):
         """hubert [B,N,H], mel2ph [B,T] long, f0 [B,T] log2 (interpolated) -- all device tensors.
         Returns PCM [B, T*hop] on the device (and mel [B,T,M] / the per-clip sample counts if asked).
 
@@ -71,7 +71,10 @@ class SvcPipeline:
         ``kept_frames * hop`` samples.
 
         ``use_pe``: drive the vocoder with the pitch extractor's f0 read off the sampled mel instead of the input f0
-        (Svc.infer's ``use_pe``, infer_tool.py:165-168; needs ``pe_state`` at construction)."""
+        (Svc.infer's ``use_pe``, infer_tool.py:165-168; needs ``pe_state`` at construction).
+
+        ``full_length``: True = the caller guarantees that no clip carries padding frames (fixed-length batches): nothing is read back
+        from the device before the work is enqueued.  None (default) = look (one 1-byte device-to-host read of ``(mel2ph > 0).all()``)."""
         if use_pe and self.pe is None:
             raise RuntimeError("use_pe=True needs a pitch-extractor checkpoint (SvcPipeline(..., pe_state=...))")
         hp = dict(self.hp, pndm_speedup=speedup)
@@ -79,7 +82,7 @@ class SvcPipeline:
         self.model.fs2.hp = hp
         B, T = mel2ph.shape
         valid = mel2ph > 0
-        ragged = not bool(valid.all().item())                  # one tiny D2H before anything is launched
+        ragged = False if full_length else not bool(valid.all().item())       # (one tiny D2H before anything is launched)
         clip_lens = None
         if ragged:
             ar = torch.arange(1, T + 1, device=mel2ph.device)

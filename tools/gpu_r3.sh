@@ -10,6 +10,8 @@ export TMPDIR=/tmp
 PREC32=${PREC32:-auto}
 for part in $PARTS; do
 case $part in
+phase)
+  for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_phase_offset.py $p 128 >> $OUT/${TAG}_phase_offset.txt 2>&1; done; cat $OUT/${TAG}_phase_offset.txt ;;
 overlap)
   timeout 120 tools/micro/overlap 4 > $OUT/${TAG}_overlap.txt 2>&1; echo "overlap rc=$?"; cat $OUT/${TAG}_overlap.txt ;;
 tests)
