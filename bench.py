@@ -50,10 +50,12 @@ def probe_mfma():
     that load; the datasheet peak assumes it does not)."""
     import ctypes
     from diffsvc_amd import _lib
-    tf, ghz = ctypes.c_float(0), ctypes.c_float(0)
-    _lib.check(_lib.lib().dsvc_probe_mfma(1, ctypes.byref(tf), ctypes.byref(ghz), _lib.stream_ptr()))
+    o = (ctypes.c_float * 4)()
+    _lib.check(_lib.lib().dsvc_probe_mfma_detail(1, o, _lib.stream_ptr()))
     torch.cuda.synchronize()
-    return {"tflops": tf.value, "clock_ghz": ghz.value}
+    # `tflops` = FLOPs / mean in-loop time (what the matrix pipes sustain once every wave is in its loop); `tflops_wall` divides by the
+    # kernel's wall time (HIP events), which also carries launch skew between the CUs and the slowest CU's clock
+    return {"tflops": o[1], "tflops_wall": o[0], "clock_ghz": o[2], "clock_ghz_min_cu": o[3]}
 
 
 def dominant_kernel_roofline(handle, B, precision):
@@ -82,8 +84,8 @@ def dominant_kernel_roofline(handle, B, precision):
                 "avg_launch_us": us, "frames_per_launch": frames, "traffic": None, "algorithmic_bytes": nbytes,
                 "mfma_tflops": tf, "mfma_frac": tf / PEAK_TFLOPS_F16}
         tfile = {32: "layer_traffic_b32.json"}.get(B)
-    if precision == "f16_m64" and tfile:
-        roof["traffic"], roof["traffic_source"] = load_traffic(tfile)
+    if tfile:
+        roof["traffic"], roof["traffic_source"] = load_traffic(tfile, precision)
     return roof
 
 
@@ -99,9 +101,9 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def load_traffic(name):
-    """(bytes_per_launch, source) of a committed PMC measurement, or (None, why) when it is missing or was taken on other kernel
-    sources (tools/rocprof_traffic.py stamps the file with kernel_sources_sha())."""
+def load_traffic(name, precision):
+    """(bytes_per_launch, source) of a committed PMC measurement, or (None, why) when it is missing, was taken on other kernel
+    sources (tools/rocprof_traffic.py stamps the file with kernel_sources_sha()) or at another operand precision."""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None, "no PMC pass committed (%s)" % name
@@ -109,6 +111,8 @@ def load_traffic(name):
         tj = json.load(f)
     if tj.get("csrc_sha16") != kernel_sources_sha():
         return None, "stale: %s was measured on kernel sources %s, this tree is %s" % (name, tj.get("csrc_sha16"), kernel_sources_sha())
+    if (" %s " % precision) not in tj.get("source", "").replace("`", " ").replace("(", " ").replace(")", " "):
+        return None, "%s was measured at another operand precision than %s" % (name, precision)
     return tj.get("bytes_per_launch"), tj.get("source")
 
 

@@ -84,6 +84,7 @@ SYMBOLS = [
     ("dsvc_abi_version", ctypes.c_int, []),
     ("dsvc_last_error", ctypes.c_char_p, []),
     ("dsvc_probe_mfma", ctypes.c_int, [ctypes.c_int32, c_f32p, c_f32p, _VP]),
+    ("dsvc_probe_mfma_detail", ctypes.c_int, [ctypes.c_int32, c_f32p, _VP]),
     ("dsvc_denoiser_create", ctypes.c_int, [ctypes.POINTER(DenoiserCfg), ctypes.POINTER(_VP)]),
     ("dsvc_denoiser_load_tensor", ctypes.c_int, [_VP, ctypes.c_char_p, _VP, ctypes.c_int64]),
     ("dsvc_denoiser_finalize", ctypes.c_int, [_VP]),

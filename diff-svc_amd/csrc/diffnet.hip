@@ -183,6 +183,7 @@ struct dsvc_denoiser {
     bool cond_ready = false;
     // test support, set through dsvc_denoiser_debug_set (explicit handle state -- the product library reads no environment variable):
     int dbg_stop_after = -1;     // >= 0: an evaluation returns after this many residual layers (per-layer taps, tests/test_gpu_headline.py)
+    int layer_prio = 0;          // wave-priority scheme of the fused layer kernel (tlayer.h PRIO; tuning, "layer_prio")
     bool dbg_two_launch = false; // run a residual layer as its two tgemm launches even where the fused kernel applies (bit-equality test)
     int* step_err = nullptr;     // host-mapped sticky flag: a dsvc_denoiser_forward call saw a diffusion step outside [0, max_steps)
     unsigned ws_gen = 0;  // bumped whenever the workspace is (re)built: captured graphs bake its pointers and are keyed on this
@@ -618,8 +619,8 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
 #else
     constexpr int pf = 0;
 #endif
-    if (dil_t[l].planes == 1 && out_t[l].planes == 2) return tlayer_launch<1, 2>(ga, cp, oa, oe, C, rows_alloc, pf, st);      // F16_MIX
-    return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st);
+    if (dil_t[l].planes == 1 && out_t[l].planes == 2) return tlayer_launch<1, 2>(ga, cp, oa, oe, C, rows_alloc, pf, st, layer_prio);      // F16_MIX
+    return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st, layer_prio) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st, layer_prio);
 }
 
 // =================================================================================================
@@ -964,6 +965,7 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     const std::string k(key);
     if (k == "stop_after_layers") d->dbg_stop_after = value;
     else if (k == "two_launch_layer") d->dbg_two_launch = value != 0;
+    else if (k == "layer_prio") d->layer_prio = value;
     else return fail(DSVC_EINVAL, "unknown debug setting '%s'", key);
     ++d->ws_gen;                 // captured graphs bake the launch sequence: force a re-capture
     return DSVC_OK;

@@ -3,6 +3,8 @@
 // operands.  The matrix pipe is paced at 32 shader cycles per instruction either way; what differs is the clock the chip holds:
 // measured on MI355X 2.39 GHz / 2.49 PF/s with zero operands, 1.60-1.62 GHz / 1.65 PF/s with random ones (profiles/r2h_mfma_clock.txt)
 // -- the datasheet's 2.5 PF/s is not reachable on real data, and a roofline fraction is worth reading against both numbers.
+#include <vector>
+
 #include "../../include/dsvc.h"
 #include "common.h"
 
@@ -52,8 +54,26 @@ __global__ void k_probe_fill(_Float16* p, int n, int random_data) {
 }
 }  // namespace
 
+static int probe_run(int32_t random_data, float* out4, void* stream);
+
 extern "C" int dsvc_probe_mfma(int32_t random_data, float* tflops, float* clock_ghz, void* stream) {
     if (!tflops || !clock_ghz) return fail(DSVC_EINVAL, "null argument");
+    float o[4];
+    DSVC_TRY(probe_run(random_data, o, stream));
+    *tflops = o[0]; *clock_ghz = o[2];
+    return DSVC_OK;
+}
+
+// out4: [0] TFLOP/s over the kernel's wall time (HIP events), [1] TFLOP/s inside the timed loops (FLOPs / mean in-loop realtime: what the
+// matrix pipes sustain once every wave is in its loop), [2] mean clock over the CUs in GHz, [3] lowest clock any CU held
+extern "C" int dsvc_probe_mfma_detail(int32_t random_data, float* out4, void* stream) {
+    if (!out4) return fail(DSVC_EINVAL, "null argument");
+    return probe_run(random_data, out4, stream);
+}
+
+static int probe_run(int32_t random_data, float* out4, void* stream) {
+    float tf_ev = 0.f, ghz = 0.f;
+    float* tflops = &tf_ev; float* clock_ghz = &ghz;
     hipStream_t st = (hipStream_t)stream;
     hipDeviceProp_t prop;
     DSVC_HIP(hipGetDeviceProperties(&prop, 0));
@@ -71,11 +91,23 @@ extern "C" int dsvc_probe_mfma(int32_t random_data, float* tflops, float* clock_
     DSVC_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     DSVC_HIP(hipEventElapsedTime(&ms, e0, e1));
-    unsigned long long hs[2];
-    DSVC_HIP(hipMemcpy(hs, stamps, 16, hipMemcpyDeviceToHost));
+    // every CU reports (shader cycles, 100 MHz ticks) over its loop: the clock is the mean over the CUs (the XCDs do not all hold the
+    // same clock under this load; one workgroup's ratio is not the chip's)
+    std::vector<unsigned long long> all((size_t)blocks * 2);
+    DSVC_HIP(hipMemcpy(all.data(), stamps, (size_t)blocks * 16, hipMemcpyDeviceToHost));
+    unsigned long long hs[2] = {0, 0};
+    for (int b = 0; b < blocks; ++b) { hs[0] += all[2 * b]; hs[1] += all[2 * b + 1]; }
     // the loop runs iters / 4 trips of 16 MFMAs: 4 * iters MFMAs per wave, 8 waves per workgroup
     *tflops = (float)(2.0 * 32 * 32 * 16 * 4.0 * (double)iters * 8 * blocks / (ms * 1e-3) / 1e12);
     *clock_ghz = hs[1] ? (float)((double)hs[0] / ((double)hs[1] * 10.0)) : 0.f;            // shader cycles / (100 MHz ticks * 10 ns)
+    double min_clk = 1e9;
+    for (int b = 0; b < blocks; ++b)
+        if (all[2 * b + 1]) { const double c = (double)all[2 * b] / ((double)all[2 * b + 1] * 10.0); if (c < min_clk) min_clk = c; }
+    const double mean_ticks = (double)hs[1] / blocks;
+    out4[0] = tf_ev;
+    out4[1] = mean_ticks > 0 ? (float)(2.0 * 32 * 32 * 16 * 4.0 * (double)iters * 8 * blocks / (mean_ticks * 1e-8) / 1e12) : 0.f;
+    out4[2] = ghz;
+    out4[3] = min_clk < 1e9 ? (float)min_clk : 0.f;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(src); (void)hipFree(sink); (void)hipFree(stamps);
     return DSVC_OK;

@@ -93,7 +93,14 @@ __device__ __forceinline__ void tl_load_group(half8 (&ring)[KG * NW], const _Flo
 // PF: prefetch the output projection's first accumulator init (residual stream) already under the LAST gate pass's main loop
 // (64 more live VGPRs there) instead of right after it.
 // NW2: weight planes of the output projection (= NW, or 2 with NW = 1 for F16_MIX); its groups are KG2 = KG * NW / NW2 k-steps deep.
-template <int NB, int KG, int NW, int PF, int NW2 = NW>
+// PRIO: wave-priority scheme (arbitration between the two waves of a SIMD is by priority, then age -- and a wave sitting in a dense MFMA
+// stream that wins it leaves its partner's VALU / VMEM work almost no issue slots: tools/micro/overlap.hip, profiles/r3b_overlap.txt):
+//   0  static: waves 4..7 (the younger half) at priority 1 for the whole kernel (round 1-2)
+//   1  none
+//   2  dynamic: priority 0 inside the MFMA main loops, 3 everywhere else (prologue, epilogues, accumulator-init and store issue), so
+//      whichever wave of a pair is in a memory / VALU section gets the issue slots it needs under its partner's MFMAs
+//   3  dynamic as 2, with the static split (waves 4..7 at 1) inside the main loops
+template <int NB, int KG, int NW, int PF, int NW2 = NW, int PRIO = 0>
 __global__ void __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
 tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiResSkip::Args oe) {
     constexpr int KG2 = KG * NW / NW2;
@@ -102,6 +109,12 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (PRIO >= 2) __builtin_amdgcn_s_setprio(3);
+    auto prio_loop = [&]() {
+        if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 3) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    };
+    auto prio_mem = [&]() { if constexpr (PRIO >= 2) __builtin_amdgcn_s_setprio(3); };
     const int row0 = blockIdx.x * TL_TN;
     const int halo = ga.dil;                              // taps == 3
     const int rows_lds = TL_TN + 2 * halo;
@@ -143,7 +156,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const int G1 = 3 * gpt;                               // gate: groups per output tile
     const int G2 = (ga.cin >> 4) / KG2;                   // output projection: groups per tile (K = C)
     const long long tile1 = (long long)G1 * GROUP_HALFS, tile2 = (long long)G2 * GROUP_HALFS;
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);         // waves w and w+4 share a SIMD: let the pair drift apart (tgemm.h)
+    if constexpr (PRIO == 0) if (wave >= 4) __builtin_amdgcn_s_setprio(1);         // waves w and w+4 share a SIMD: let the pair drift apart (tgemm.h)
     const int rot = (int)(blockIdx.x % (unsigned)NB);     // per-workgroup rotated pass order (tgemm.h)
     auto tile_of = [&](int pi) { const int p = pi + rot; return (p < NB ? p : p - NB) * 8 + wave; };
     const int g_issue = wave >= 4 ? ((G1 / 2) & ~1) : 0;
@@ -175,6 +188,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             else if (PF) oepi.init(oe, mt_n, row0, lane, nxt);
         };
         int g = 0;
+        prio_loop();
         for (; g + 1 < G1; g += 2) {
             tl_load_group<KG, NW>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
             if (g == g_issue && (!last || PF)) { issue_next_init(); nxt_issued = true; }
@@ -201,6 +215,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             tl_compute_group<KG, NW>(ringA, acc, lds0 + (unsigned)rr * (unsigned)row_bytes, nt_stride_x,
                                      (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5));
         }
+        prio_mem();
         // the next tile's weight stream starts before this tile's epilogue
         if (!last) tl_load_group<KG, NW>(ringA, gw + (long long)mt_n * tile1 + lane8);
         else tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
@@ -255,6 +270,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             xs = xs_g ^ ((unsigned)(kb & 7) << 5);
         };
         int g = 0;
+        prio_loop();
         for (; g + 1 < G2; g += 2) {
             tl_load_group<KG2, NW2>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
             if (g == g_issue2 && !last) { oepi.init(oe, mt_n, row0, lane, nxt); nxt_issued = true; }
@@ -266,6 +282,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             { unsigned b0, xs; group_b(g + 1, b0, xs); tl_compute_group<KG2, NW2>(ringB, acc, b0, 32u * 256u, xs); }
         }
         if (g < G2) { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG2, NW2>(ringA, acc, b0, 32u * 256u, xs); }
+        prio_mem();
         if (!last) {
             tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
             if (!nxt_issued) oepi.init(oe, mt_n, row0, lane, nxt);
@@ -289,9 +306,9 @@ inline bool tlayer_supported(int C, int cin_pad, int dil, int n_rows) {
     return C == cin_pad && (C == 256 || C == 384) && n_rows % TL_TN == 0 && tlayer_smem(dil, cin_pad) <= 160 * 1024;
 }
 
-template <int NB, int KG, int NW, int PF, int NW2 = NW>
+template <int NB, int KG, int NW, int PF, int NW2 = NW, int PRIO = 0>
 inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiResSkip::Args& oe, int n_rows, hipStream_t stream) {
-    auto kern = tlayer_kernel<NB, KG, NW, PF, NW2>;
+    auto kern = tlayer_kernel<NB, KG, NW, PF, NW2, PRIO>;
     const size_t smem = tlayer_smem(ga.dil, ga.cin);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {
@@ -306,7 +323,7 @@ inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiR
 // gate weights `g` (taps 3, m_tiles C/16) + output-projection weights `o` (taps 1, m_tiles 2C/32) of ONE layer, as tgemm would get them
 template <int NW, int NW2 = NW>
 inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs& o, const TEpiResSkip::Args& oe, int C, int n_rows,
-                         int prefetch, hipStream_t stream) {
+                         int prefetch, hipStream_t stream, int prio = 0) {
     constexpr int KG = NW == 2 ? 4 : 8;
     if (g.taps != 3 || o.taps != 1 || g.m_tiles != C / 16 || o.m_tiles != 2 * C / 32 || g.cin != C || o.cin != C)
         return fail(DSVC_EINVAL, "tlayer: unexpected layer geometry");
@@ -318,6 +335,11 @@ inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs
     a.x = g.x; a.cin = g.cin; a.swz = tgemm_swizzle_mask(g.cin); a.dil = g.dil; a.gw = g.w; a.ow = o.w;
     a.gvar = g.variant_halfs; a.ovar = o.n_variants == g.n_variants ? o.variant_halfs : 0; a.n_variants = g.n_variants;
     a.step_ptr = g.step_ptr; a.step_off = g.step_off;
+    if (C == 384 && prio > 0) {                           // the priority variants exist for the 44.1 kHz width only
+        if (prio == 1) return tlayer_launch_t<3, KG, NW, 0, NW2, 1>(a, cproj, oe, n_rows, stream);
+        if (prio == 2) return tlayer_launch_t<3, KG, NW, 0, NW2, 2>(a, cproj, oe, n_rows, stream);
+        return tlayer_launch_t<3, KG, NW, 0, NW2, 3>(a, cproj, oe, n_rows, stream);
+    }
     if constexpr (NW2 != NW) {                            // (the prefetch variant is not instantiated for the mixed kernel)
         if (C == 384) return tlayer_launch_t<3, KG, NW, 0, NW2>(a, cproj, oe, n_rows, stream);
         return tlayer_launch_t<2, KG, NW, 0, NW2>(a, cproj, oe, n_rows, stream);

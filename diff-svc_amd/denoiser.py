@@ -7,16 +7,19 @@ in libdsvc_hip.so.  Register it in the reference's seam with
     DIFF_DECODERS['wavenet'] = lambda hp: DiffNetHip(hp['audio_num_mel_bins'])
 
 (infer_tools/infer_tool.py:107-111).  ``precision`` selects the operand scheme of the two big per-layer contractions
-(include/dsvc.h): ``"f16_d64"`` is one fp16 MFMA per product with 64 time-dithered weight roundings; ``"f16_m64"`` the same for
-the dilated conv with exact (hi + lo) weights for the output 1x1 (what bench.py measures for the 1000-step DDPM and the 1000-step
-parity tests hold to the bar); ``"f16_w2"`` / ``"f16_x3"`` spend 2 / 3 MFMAs everywhere.  The default ``"auto"`` picks per sampler:
-``f16_m64`` for DDPM -- the dither's rounding noise averages out over the chain, and the output projection, whose error goes
-straight into the residual stream and the skip sum, is exact (fourteen (clip, noise) pairs against the reference: 6.7e-4 ... 9.7e-4;
-all-dithered f16_d64 7.8e-4 ... 1.27e-3, over the bar on two of them); for PLMS/PNDM, whose Adams-Bashforth extrapolation amplifies a
-single evaluation's rounding, the fp32-class ``f16_x3`` (split activations as well: 1e-5): with fp16 activations even exact weights
-(``f16_w2``) leave the 50-iteration chain at T=861 at (8.2 +- 1.2)e-4 -- ten (clip, noise) pairs, one of them at 1.08e-3, over the bar
-(profiles/r2w_precision_spread.txt) -- and ``f16_d64`` at 3e-3; coarser schedules (20 iterations at pndm_speedup 50) need it anyway
-(9e-3 with f16_w2, 1.2e-5 with f16_x3).
+(include/dsvc.h): ``"f16_w2"`` = exact weights as fp16 hi + lo planes (2 MFMAs per product), fp16 activations; ``"f16_dN"`` = one fp16
+MFMA per product with N time-dithered weight roundings; ``"f16_mN"`` the same for the dilated conv with exact (hi + lo) weights for the
+output 1x1; ``"f16_x3"`` splits the activations as well (3 MFMAs, fp32-class).  The default ``"auto"`` picks per sampler:
+
+* DDPM: ``f16_w2``.  The maximum mel error of a 1000-step chain is a heavy-tailed statistic, so the shipped scheme is held to
+  <= 9.0e-4 (10 % under the 1e-3 bar) on EVERY real-reference golden of the benchmarked sizes -- 21 single-clip runs and three batches
+  of 32 (tests/test_gpu_headline.py).  f16_w2: worst 8.0e-4.  The faster f16_m64 (round 2's default) measures (8.0 +- 0.9)e-4 with
+  1.14e-3 on one clip of the batch of 32 -- over the bar, as its round-2 spread predicted -- and is no longer shipped
+  (profiles/r3_precision_spread.txt).
+* PLMS/PNDM, whose Adams-Bashforth extrapolation amplifies a single evaluation's rounding: the fp32-class ``f16_x3`` (1e-5); with fp16
+  activations even exact weights leave the 50-iteration chain at T=861 at (8.2 +- 1.2)e-4 over ten (clip, noise) pairs, one of them
+  at 1.08e-3 (profiles/r2w_precision_spread.txt), and f16_d64 at 3e-3; coarser schedules (20 iterations at pndm_speedup 50) need it
+  anyway (9e-3 with f16_w2, 1.2e-5 with f16_x3).
 Inference only: there is no autograd through the HIP kernels, so
 ``infer=False`` training keeps using the reference module.
 """
@@ -49,7 +52,7 @@ class _ResidualBlockParams(nn.Module):
 
 
 class DiffNetHip(nn.Module):
-    AUTO = {"ddpm": "f16_m64", "plms": "f16_x3", "plms_coarse": "f16_x3", "forward": "f16_m64"}
+    AUTO = {"ddpm": "f16_w2", "plms": "f16_x3", "plms_coarse": "f16_x3", "forward": "f16_w2"}
 
     def __init__(self, in_dims=80, hparams=None, precision="auto"):
         super().__init__()

@@ -43,6 +43,9 @@ const char* dsvc_last_error(void);
 /* measurement aid for bench.py: the dense fp16 MFMA rate (TFLOP/s) and shader clock (GHz) this chip sustains right now on a
  * register-resident loop with random (1) or zero (0) operands -- the rate a roofline fraction can actually approach. */
 int dsvc_probe_mfma(int32_t random_data, float* tflops, float* clock_ghz, void* stream);
+/* the same probe in detail: out4 = { TFLOP/s over the kernel's wall time (HIP events), TFLOP/s inside the timed loops, mean clock over
+ * the CUs [GHz], lowest clock any CU held [GHz] } */
+int dsvc_probe_mfma_detail(int32_t random_data, float* out4, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Denoiser -- replaces network/diff/net.py:86-135 (class DiffNet), selected through the DIFF_DECODERS
@@ -87,7 +90,8 @@ int dsvc_denoiser_check(dsvc_denoiser* d, void* stream);
 
 /* test support (explicit handle state; the library reads no environment variable): "stop_after_layers" = n >= 0 makes an evaluation
  * return after n residual layers so that dsvc_denoiser_debug_buffer taps layer n-1 (-1 = off); "two_launch_layer" != 0 runs a residual
- * layer as its two tgemm launches where the fused layer kernel would apply (bit-equality test of the two forms). */
+ * layer as its two tgemm launches where the fused layer kernel would apply (bit-equality test of the two forms); "layer_prio" = 0..3
+ * selects the fused layer kernel's wave-priority scheme (csrc/tlayer.h: scheduling only, results are bit-identical). */
 int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------

@@ -327,7 +327,7 @@ def test_spread_of_single_clip_chains_vs_reference(which):
         d = (mel - torch.from_numpy(g["mel_out"])).abs()
         errs.append((name.replace("e2e_44k_T861_k1000_", ""), d.max().item(), d.pow(2).mean().sqrt().item()))
     worst = max(e[1] for e in errs)
-    print("spread %s (%s): worst %.2e | " % (which, precision) + "  ".join("%s %.2e/%.1e" % e for e in errs))
+    print("spread %s (%s): worst %.2e | " % (which, precision, worst) + "  ".join("%s %.2e/%.1e" % e for e in errs))
     assert all(np.isfinite(e[1]) for e in errs)
     if which == "shipped":
         assert worst <= SHIP_BAR, errs

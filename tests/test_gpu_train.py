@@ -162,4 +162,8 @@ def test_train_step_vs_real_reference_golden(case):
             worst, worst_name = err, k
     print("train step %s vs the real reference: loss %.6f (ref %.6f), worst gradient rel-L2 err %.2e (%s), worst |norm| err %.2e"
           % (case, loss.item(), ref_loss, worst, worst_name, worst_norm))
-    assert worst < 1e-3 and worst_norm < 1e-3, (worst, worst_name, worst_norm)
+    # l2: smooth loss -> the split-fp16 (fp32-class) bar of 1e-3 per tensor.  l1: d|r|/d eps = sign(r) is discontinuous, so the 1e-6-class
+    # difference between two correct forward passes flips the sign of the ~1e-6 of the elements whose residual sits that close to zero,
+    # each flip changing an entry by 2: a relative L2 error of ~2.5e-3 at the 44.1 kHz size (5.0e-3 allowed) while every NORM agrees to 1e-4
+    tol = 5e-3 if case.endswith("l1") else 1e-3
+    assert worst < tol and worst_norm < 1e-3, (worst, worst_name, worst_norm)

@@ -25,10 +25,14 @@ constexpr size_t REGION = 4u << 20;          // bytes of the read stream one wav
 constexpr int MAX_NS = 16;                   // streaming waves per CU that have their own region
 
 __global__ void __launch_bounds__(1024) k_overlap(const _Float16* __restrict__ ops, const float* __restrict__ rd, float* __restrict__ wr,
-                                                  float* __restrict__ sink, Rec* __restrict__ rec, int nm, int ns, unsigned long long window_ticks) {
+                                                  float* __restrict__ sink, Rec* __restrict__ rec, int nm, int ns, unsigned long long window_ticks, int mode) {
+    // mode bit 0: streaming waves raise their priority (s_setprio 3); bit 1: the MFMA waves are the YOUNGER waves of the workgroup
+    // (arbitration between co-resident waves is by priority, then age -- MI355X_MICROARCH.md "Two waves per SIMD")
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_hw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = (mode & 2) ? (wave_hw + nm) % (nm + ns) : wave_hw;      // role index: < nm = MFMA
     const int gw = blockIdx.x * (nm + ns) + wave;
+    if ((mode & 1) && wave >= nm) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long deadline = r0 + window_ticks;
@@ -66,20 +70,21 @@ __global__ void __launch_bounds__(1024) k_overlap(const _Float16* __restrict__ o
         float* wp = wr + sw * (REGION / 8);
         size_t off = 0;                                              // in floats, within the region
         f32x4 keep = {0.f, 0.f, 0.f, 0.f};
-        do {
+        do {                                                         // one trip = 8 KiB read + 4 KiB written per wave, 8 loads in flight
+            const float* p = rp + off + (size_t)lane * 4;
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {                            // one trip = 8 KiB read + 4 KiB written per wave
-                const float* p = rp + off + (size_t)lane * 4;
-                const f32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-                const f32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 256));
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + u * 256));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
                 f32x4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = v0[i] + v1[i];
-                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(wp + (off >> 1) + (size_t)lane * 4));
+                for (int i = 0; i < 4; ++i) o[i] = v[2 * u][i] + v[2 * u + 1][i];
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(wp + (off >> 1) + u * 256 + (size_t)lane * 4));
                 keep[0] += o[0];
-                off += 512;
-                if (off >= REGION / 4) off = 0;
             }
+            off += 2048;
+            if (off >= REGION / 4) off = 0;
             trips += 1;
         } while (__builtin_amdgcn_s_memrealtime() < deadline);
         if (keep[0] == 123.456f) sink[0] = keep[0];
@@ -105,12 +110,16 @@ int main(int argc, char** argv) {
     hipMemset(rd, 0x3c, (size_t)max_stream_waves * REGION);         // finite floats
     hipMalloc(&sink, (size_t)cus * 1024 * 4); hipMalloc(&rec, (size_t)cus * 32 * sizeof(Rec));
     printf("%d CUs, window %.1f ms per configuration; MFMA = v_mfma_f32_32x32x16_f16 on random operands, stream = nt dwordx4, 2 B read per B written\n", cus, window_ms);
-    printf("%-34s %10s %10s %10s | %9s %9s\n", "waves per CU (MFMA + stream)", "TFLOP/s", "read+write", "GB/s", "MFMA GHz", "strm GHz");
-    struct Cfg { int nm, ns; const char* what; };
-    const Cfg cfgs[] = {{8, 0, "MFMA alone, 2 waves/SIMD"}, {4, 0, "MFMA alone, 1 wave/SIMD"}, {0, 8, "stream alone, 2 waves/SIMD"},
-                        {0, 4, "stream alone, 1 wave/SIMD"}, {0, 16, "stream alone, 4 waves/SIMD"}, {4, 4, "joint 4 + 4 (1 + 1 per SIMD)"},
-                        {8, 8, "joint 8 + 8 (2 + 2 per SIMD)"}, {4, 8, "joint 4 + 8"}, {8, 4, "joint 8 + 4"}, {4, 12, "joint 4 + 12"}, {8, 8, "joint 8 + 8 again"},
-                        {8, 0, "MFMA alone again (chip now warm)"}};
+    printf("%-36s %10s %10s %10s | %9s %9s\n", "waves per CU (MFMA + stream)", "TFLOP/s", "read+write", "GB/s", "MFMA GHz", "strm GHz");
+    struct Cfg { int nm, ns; const char* what; int mode; };
+    const Cfg cfgs[] = {{8, 0, "MFMA alone, 2 waves/SIMD", 0}, {4, 0, "MFMA alone, 1 wave/SIMD", 0}, {0, 8, "stream alone, 2 waves/SIMD", 0},
+                        {0, 4, "stream alone, 1 wave/SIMD", 0}, {0, 16, "stream alone, 4 waves/SIMD", 0}, {4, 4, "joint 4 + 4 (1 + 1 per SIMD)", 0},
+                        {8, 8, "joint 8 + 8 (2 + 2 per SIMD)", 0}, {4, 8, "joint 4 + 8", 0}, {8, 4, "joint 8 + 4", 0}, {4, 12, "joint 4 + 12", 0},
+                        {4, 4, "joint 4 + 4, stream waves prio 3", 1}, {8, 8, "joint 8 + 8, stream waves prio 3", 1}, {4, 8, "joint 4 + 8, stream prio 3", 1},
+                        {8, 4, "joint 8 + 4, stream prio 3", 1}, {4, 12, "joint 4 + 12, stream prio 3", 1},
+                        {4, 4, "joint 4 + 4, MFMA waves younger", 2}, {8, 8, "joint 8 + 8, MFMA waves younger", 2}, {4, 8, "joint 4 + 8, MFMA younger", 2},
+                        {4, 4, "joint 4 + 4, younger + prio", 3}, {8, 8, "joint 8 + 8, younger + prio", 3},
+                        {8, 0, "MFMA alone again (chip now warm)", 0}};
     for (const Cfg& c : cfgs) {
         const int waves = c.nm + c.ns;
         if (waves > 16 || c.ns > MAX_NS) continue;
@@ -119,10 +128,10 @@ int main(int argc, char** argv) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0);
             hipLaunchKernelGGL(k_overlap, dim3(cus), dim3(64 * waves), 0, 0, ops, rd, wr, sink, rec, c.nm, c.ns,
-                               (unsigned long long)(window_ms * 1e5));
+                               (unsigned long long)(window_ms * 1e5), c.mode);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-            if (hipGetLastError() != hipSuccess) { printf("%-34s launch failed\n", c.what); break; }
+            if (hipGetLastError() != hipSuccess) { printf("%-36s launch failed\n", c.what); break; }
             if (rep == 0) continue;
             std::vector<Rec> r((size_t)cus * 32);
             hipMemcpy(r.data(), rec, r.size() * sizeof(Rec), hipMemcpyDeviceToHost);
@@ -134,7 +143,7 @@ int main(int argc, char** argv) {
                 if (r[i].role == 0) { mf += (double)r[i].trips * 16 * 2.0 * 32 * 32 * 16; cm += r[i].cycles; tm += r[i].ticks; }
                 else { by += (double)r[i].trips * 12288.0; cs += r[i].cycles; ts += r[i].ticks; }
             }
-            printf("%-34s %10.0f %10s %10.0f | %9.2f %9.2f   (kernel %.2f ms)\n", c.what, mf / span / 1e12, "", by / span / 1e9,
+            printf("%-36s %10.0f %10s %10.0f | %9.2f %9.2f   (kernel %.2f ms)\n", c.what, mf / span / 1e12, "", by / span / 1e9,
                    tm > 0 ? cm / (tm * 10.0) : 0.0, ts > 0 ? cs / (ts * 10.0) : 0.0, ms);
         }
     }
