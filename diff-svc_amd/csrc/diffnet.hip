@@ -11,6 +11,7 @@
 #include "../../include/dsvc.h"
 #include "diffnet_t.h"
 #include "tlayer.h"
+#include "tskip.h"
 
 using namespace dsvc;
 
@@ -170,6 +171,8 @@ struct dsvc_denoiser {
     bool tpath = false;
     int Cp = 0, Mp = 0, guard = 8;
     TPacked in_t, skip_t, fin_t;
+    TPacked skipall_t;                // deferred skip path (tskip.h): W_sp W_out,l[C:2C] / sqrt(L) for all layers as one [C x L*C] operand
+    DevBuf gall;                      // fp16 gate outputs of all layers [L][rows_alloc][Cp]: written by the fused layer kernels, read by tskip
     std::vector<TPacked> dil_t, out_t;
     DevBuf xh, gh, skiph, s2h, xsh;   // fp16: layer operand (with guard rows), gate output, skip sum, relu(skip proj), sampler state
     DevBuf xh2;                       // second layer-operand buffer: the fused layer kernel (tlayer.h) reads xh of layer l while other
@@ -183,21 +186,21 @@ struct dsvc_denoiser {
     bool cond_ready = false;
     // test support, set through dsvc_denoiser_debug_set (explicit handle state -- the product library reads no environment variable):
     int dbg_stop_after = -1;     // >= 0: an evaluation returns after this many residual layers (per-layer taps, tests/test_gpu_headline.py)
-    int layer_prio = 0;          // wave-priority scheme of the fused layer kernel (tlayer.h PRIO; tuning, "layer_prio")
+    bool dbg_no_defer = false;   // run the fused layer with its in-layer skip accumulation instead of the deferred skip contraction
     bool dbg_two_launch = false; // run a residual layer as its two tgemm launches even where the fused kernel applies (bit-equality test)
     int* step_err = nullptr;     // host-mapped sticky flag: a dsvc_denoiser_forward call saw a diffusion step outside [0, max_steps)
     unsigned ws_gen = 0;  // bumped whenever the workspace is (re)built: captured graphs bake its pointers and are keyed on this
 
     ~dsvc_denoiser() {
         if (step_err) (void)hipHostFree(step_err);
-        for (DevBuf* b : {&film, &xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps, &lens, &clipid, &rowclip, &xh, &xh2, &gh, &skiph, &s2h, &xsh}) b->release();
+        for (DevBuf* b : {&film, &xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps, &lens, &clipid, &rowclip, &xh, &xh2, &gh, &skiph, &s2h, &xsh, &gall}) b->release();
         auto rel = [](PackedConv& p) { p.w.release(); p.bias.release(); };
         rel(in_proj); rel(skip_proj); rel(fin_proj);
         for (auto& p : dil) rel(p);
         for (auto& p : outp) rel(p);
         for (auto& p : condp) rel(p);
         auto relt = [](TPacked& p) { p.w.release(); p.bias.release(); };
-        relt(in_t); relt(skip_t); relt(fin_t);
+        relt(in_t); relt(skip_t); relt(fin_t); relt(skipall_t);
         for (auto& p : dil_t) relt(p);
         for (auto& p : out_t) relt(p);
     }
@@ -234,6 +237,7 @@ struct dsvc_denoiser {
     int finalize_t();
     // the whole residual layer as one kernel (tlayer.h) -- the throughput tiling only
     bool fused_layer_ok() const;
+    bool defer_ok() const { return fused_layer_ok() && !dbg_no_defer && skipall_t.m_tiles > 0 && tskip_supported(cfg.channels, rows_alloc); }
     int launch_fused_layer(int l, const StepRef& step, hipStream_t st, int host_step);
 };
 
@@ -386,6 +390,37 @@ int dsvc_denoiser::finalize_t() {
         DSVC_TRY(tpack(skip_t, *w, C, C, 1, C / 32, 2, 1, 1.0f / sqrtf((float)L), 12u, true,    // sum(skip)/sqrt(L) (net.py:131)
                        [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, b->data(), C));
     }
+    if (C == Cp && (C == 256 || C == 384)) {
+        // deferred skip path (tskip.h): W'_l = W_sp W_out,l[C:2C] / sqrt(L), b' = b_sp + W_sp sum_l b_out,l[C:2C] / sqrt(L), composed in fp64
+        GET(wsp, "skip_projection.weight", C * C);
+        GET(bsp, "skip_projection.bias", C);
+        std::vector<float> wcat((size_t)C * C * L);          // [o][c][l]: Conv1d layout with the layers as taps
+        std::vector<double> bsum(C, 0.0), row(C);
+        const double isl = 1.0 / sqrt((double)L);
+        for (int l = 0; l < L; ++l) {
+            const std::string q = "residual_layers." + std::to_string(l) + ".";
+            GET(wo, q + "output_projection.weight", 2 * C * C);
+            GET(bo, q + "output_projection.bias", 2 * C);
+            for (int j = 0; j < C; ++j) bsum[j] += (double)(*bo)[C + j];
+            for (int o = 0; o < C; ++o) {
+                for (int c = 0; c < C; ++c) row[c] = 0.0;
+                for (int j = 0; j < C; ++j) {
+                    const double ws = (double)(*wsp)[(size_t)o * C + j];
+                    const float* wr = wo->data() + (size_t)(C + j) * C;
+                    for (int c = 0; c < C; ++c) row[c] += ws * (double)wr[c];
+                }
+                for (int c = 0; c < C; ++c) wcat[((size_t)o * C + c) * L + l] = (float)(row[c] * isl);
+            }
+        }
+        std::vector<float> bcomp(C);
+        for (int o = 0; o < C; ++o) {
+            double acc = (double)(*bsp)[o];
+            for (int j = 0; j < C; ++j) acc += (double)(*wsp)[(size_t)o * C + j] * bsum[j] * isl;
+            bcomp[o] = (float)acc;
+        }
+        DSVC_TRY(tpack(skipall_t, wcat, C, C, L, C / 32, 2, 1, 1.0f, 14u, false,
+                       [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, bcomp.data(), C));
+    }
     {
         GET(w, "output_projection.weight", M * C);
         GET(b, "output_projection.bias", M);
@@ -423,6 +458,10 @@ int dsvc_denoiser::ensure_ws(int B, int T, hipStream_t st) {
         // fp16 operands: zero once -- gap rows, guard rows and pad columns are never written afterwards
         const size_t nxh = (r + 2 * (size_t)guard) * Cp * 2, nh = r * Cp * 2, ns = r * Mp * 2;
         DSVC_TRY(xh.alloc(nxh)); DSVC_TRY(xh2.alloc(nxh)); DSVC_TRY(gh.alloc(nh));
+        if (rows_alloc / 128 >= 48 && skipall_t.m_tiles > 0) {      // the fused-layer regime: every row is written by the gate epilogues before tskip reads it
+            DSVC_TRY(gall.alloc((size_t)L * nh));
+            DSVC_HIP(hipMemsetAsync(gall.p, 0, (size_t)L * nh, st));
+        }
         DSVC_HIP(hipMemsetAsync(xh2.p, 0, nxh, st)); DSVC_TRY(skiph.alloc(2 * nh)); DSVC_TRY(s2h.alloc(2 * nh)); DSVC_TRY(xsh.alloc(2 * ns));
         DSVC_HIP(hipMemsetAsync(xh.p, 0, nxh, st)); DSVC_HIP(hipMemsetAsync(gh.p, 0, nh, st)); DSVC_HIP(hipMemsetAsync(skiph.p, 0, 2 * nh, st));   // hi|lo planes
         DSVC_HIP(hipMemsetAsync(s2h.p, 0, 2 * nh, st)); DSVC_HIP(hipMemsetAsync(xsh.p, 0, 2 * ns, st));
@@ -568,7 +607,11 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
             DSVC_TRY(tlaunch_prec<TEpiResSkip>(a, e, out_t[l].planes, rows_alloc, st));
         }
     }
-    {   // K9a: skip projection + ReLU (net.py:132-133)
+    if (fused && defer_ok()) {   // K8 (skip halves of all layers) + K9a in one contraction over the stored gate outputs (tskip.h)
+        TSkipArgs a{gall.as<_Float16>(), (long long)rows_alloc * Cp, Cp, L, skipall_t.w.as<_Float16>()};
+        TEpiReluHalf::Args e{s2h.as<_Float16>(), Cp, skipall_t.bias.as<float>(), C};
+        DSVC_TRY(tskip_launch(a, e, rows_alloc, st));
+    } else {   // K9a: skip projection + ReLU (net.py:132-133)
         TGemmArgs a = targs(skiph.as<_Float16>(), 2 * Cp, skip_t, 1, 1);
         TEpiReluHalf::Args e{s2h.as<_Float16>(), Cp, skip_t.bias.as<float>(), C};
         DSVC_TRY(tlaunch_prec<TEpiReluHalf>(a, e, 2, rows_alloc, st));
@@ -611,7 +654,9 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
     const TGemmArgs ga = wargs(dil_t[l], 3, 1 << (l % cfg.dilation_cycle));
     const TGemmArgs oa = wargs(out_t[l], 1, 1);
     const float* cp = cproj.as<float>() + (size_t)l * rows_alloc * 2 * C;
-    TEpiResSkip::Args oe{xres.as<float>(), last ? nullptr : xh_buf(l + 1), skip.as<float>(), last ? skiph.as<_Float16>() : nullptr,
+    const bool defer = defer_ok();
+    _Float16* gl = defer ? gall.as<_Float16>() + (size_t)l * rows_alloc * Cp : nullptr;
+    TEpiResSkip::Args oe{xres.as<float>(), last ? nullptr : xh_buf(l + 1), skip.as<float>(), (last && !defer) ? skiph.as<_Float16>() : nullptr,
                          out_t[l].bias.as<float>(), last ? nullptr : film.as<float>() + (size_t)(l + 1) * C, L * C, step, C, Cp,
                          l == 0 ? 1 : 0, rowmap(), 1};
 #ifdef DSVC_PROFILING
@@ -619,8 +664,8 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
 #else
     constexpr int pf = 0;
 #endif
-    if (dil_t[l].planes == 1 && out_t[l].planes == 2) return tlayer_launch<1, 2>(ga, cp, oa, oe, C, rows_alloc, pf, st, layer_prio);      // F16_MIX
-    return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st, layer_prio) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st, layer_prio);
+    if (dil_t[l].planes == 1 && out_t[l].planes == 2) return tlayer_launch<1, 2>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl);      // F16_MIX
+    return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl);
 }
 
 // =================================================================================================
@@ -917,7 +962,12 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
     size_t hoff = 0;
     if (n == "xin") { b = &d->xin; width = M; }
     else if (n == "xres") { b = &d->xres; width = C; }
-    else if (n == "g") { if (d->tpath) { hb = &d->gh; hld = d->Cp; } else b = &d->g; width = C; }
+    else if (n == "g") {
+        if (d->tpath && d->defer_ok() && d->dbg_stop_after > 0) {       // deferred skip path: the layer kernels leave every layer's g in HBM
+            hb = &d->gall; hld = d->Cp; hoff = (size_t)(d->dbg_stop_after - 1) * d->rows_alloc * d->Cp;
+        } else if (d->tpath) { hb = &d->gh; hld = d->Cp; } else b = &d->g;
+        width = C;
+    }
     else if (n == "skip") { b = &d->skip; width = C; }
     else if (n == "s2") { if (d->tpath) { hb = &d->s2h; hld = 2 * d->Cp; } else b = &d->s2; width = C; }
     else if (n == "xh") { if (!d->tpath) return fail(DSVC_EINVAL, "'xh' exists on the tgemm path only"); hb = &d->xh; hld = d->Cp; hoff = (size_t)d->guard * d->Cp; width = C; }
@@ -965,7 +1015,7 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     const std::string k(key);
     if (k == "stop_after_layers") d->dbg_stop_after = value;
     else if (k == "two_launch_layer") d->dbg_two_launch = value != 0;
-    else if (k == "layer_prio") d->layer_prio = value;
+    else if (k == "defer_skip") d->dbg_no_defer = value == 0;
     else return fail(DSVC_EINVAL, "unknown debug setting '%s'", key);
     ++d->ws_gen;                 // captured graphs bake the launch sequence: force a re-capture
     return DSVC_OK;

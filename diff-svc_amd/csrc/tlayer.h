@@ -35,6 +35,7 @@ struct TLayerArgs {
     const _Float16* gw;         // gate weights  [variant][C/16 m_tiles][3 taps][C/16][planes][lane][8]
     const _Float16* ow;         // output 1x1    [variant][2C/32 m_tiles][C/16][planes][lane][8]
     long long gvar, ovar;       // halfs between dither variants
+    _Float16* gall;             // DEFER: this layer's slab of the gate-output buffer [rows][cin] fp16 (read by tskip.h); else null
     int n_variants;             // > 1: variant = (*step_ptr - step_off) mod n_variants is resolved in the kernel; the sampler passes
     const int* step_ptr;        //      the variant by value (gw / ow already offset, n_variants = 1)
     int step_off;
@@ -46,37 +47,37 @@ struct TLayerArgs {
 //   xs        (((row & swz) ^ (lane >> 5)) << 4) ^ (first k16 step of the group << 5)
 // (rings are flat arrays of KG * NW fragments -- [k-step][plane] -- so that the two phases of a layer can use different (KG, NW) splits of
 //  the same eight registers: F16_MIX streams one dithered plane for the gate and hi + lo planes for the output projection)
-template <int KG, int NW>
-__device__ __forceinline__ void tl_compute_group(const half8 (&ring)[KG * NW], f32x16 (&acc)[4], unsigned base0, unsigned nt_stride, unsigned xs) {
+template <int KG, int NW, int NT = 4>
+__device__ __forceinline__ void tl_compute_group(const half8 (&ring)[KG * NW], f32x16 (&acc)[NT], unsigned base0, unsigned nt_stride, unsigned xs) {
     typedef const half8 __attribute__((address_space(3))) * lds_frag_ptr;
-    unsigned base[4];
+    unsigned base[NT];
     base[0] = base0;
 #pragma unroll
-    for (int nt = 1; nt < 4; ++nt) base[nt] = base[nt - 1] + nt_stride;
+    for (int nt = 1; nt < NT; ++nt) base[nt] = base[nt - 1] + nt_stride;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(base[nt]));      // keep the bases materialised (see tgemm.h)
-    half8 bq[2][4];
+    for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(base[nt]));      // keep the bases materialised (see tgemm.h)
+    half8 bq[2][NT];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bq[0][nt] = *(lds_frag_ptr)(size_t)(base[nt] + xs);
+    for (int nt = 0; nt < NT; ++nt) bq[0][nt] = *(lds_frag_ptr)(size_t)(base[nt] + xs);
 #pragma unroll
     for (int kk = 0; kk < KG; ++kk) {
         if (kk + 1 < KG) {
             const unsigned off = ((unsigned)(kk + 1) << 5) ^ xs;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bq[(kk + 1) & 1][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
+            for (int nt = 0; nt < NT; ++nt) bq[(kk + 1) & 1][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk * NW], bq[kk & 1][nt], acc[nt], 0, 0, 0);
             if constexpr (NW == 2) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk * NW + 1], bq[kk & 1][nt], acc[nt], 0, 0, 0);
         }
     }
     // pin the software pipeline: one B-fragment read of step kk+1 behind each MFMA (pair) of step kk
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
 #pragma unroll
     for (int kk = 0; kk < KG; ++kk) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             __builtin_amdgcn_sched_group_barrier(0x008, NW, 0);
             if (kk + 1 < KG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
@@ -93,14 +94,13 @@ __device__ __forceinline__ void tl_load_group(half8 (&ring)[KG * NW], const _Flo
 // PF: prefetch the output projection's first accumulator init (residual stream) already under the LAST gate pass's main loop
 // (64 more live VGPRs there) instead of right after it.
 // NW2: weight planes of the output projection (= NW, or 2 with NW = 1 for F16_MIX); its groups are KG2 = KG * NW / NW2 k-steps deep.
-// PRIO: wave-priority scheme (arbitration between the two waves of a SIMD is by priority, then age -- and a wave sitting in a dense MFMA
-// stream that wins it leaves its partner's VALU / VMEM work almost no issue slots: tools/micro/overlap.hip, profiles/r3b_overlap.txt):
-//   0  static: waves 4..7 (the younger half) at priority 1 for the whole kernel (round 1-2)
-//   1  none
-//   2  dynamic: priority 0 inside the MFMA main loops, 3 everywhere else (prologue, epilogues, accumulator-init and store issue), so
-//      whichever wave of a pair is in a memory / VALU section gets the issue slots it needs under its partner's MFMAs
-//   3  dynamic as 2, with the static split (waves 4..7 at 1) inside the main loops
-template <int NB, int KG, int NW, int PF, int NW2 = NW, int PRIO = 0>
+// (Wave-priority schemes beyond the static split below -- none, or dynamic: low inside the MFMA loops, high in the memory / VALU sections --
+//  measured within +-0.5 % of it at 32 clips for f16_w2 and f16_m64: profiles/r3b_layer_prio.txt.)
+// DEFER: the skip half of the output projection is NOT computed here (net.py:80-84: skip = second half of the 1x1).  The gate output g is
+// written to HBM as well (fp16, 768 B per frame) and ONE K = L*C contraction per evaluation (tskip.h) produces relu(skip_projection(sum of
+// the skips) / sqrt(L)) from all layers' g with pre-composed weights.  The layer then moves 8.5 KB per frame instead of 10.8 (no fp32 skip
+// read-modify-write), and on a part whose matrix and HBM phases do not overlap (profiles/r3c_overlap.txt) bytes are time.
+template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0>
 __global__ void __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
 tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiResSkip::Args oe) {
     constexpr int KG2 = KG * NW / NW2;
@@ -109,12 +109,6 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if constexpr (PRIO >= 2) __builtin_amdgcn_s_setprio(3);
-    auto prio_loop = [&]() {
-        if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
-        if constexpr (PRIO == 3) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-    };
-    auto prio_mem = [&]() { if constexpr (PRIO >= 2) __builtin_amdgcn_s_setprio(3); };
     const int row0 = blockIdx.x * TL_TN;
     const int halo = ga.dil;                              // taps == 3
     const int rows_lds = TL_TN + 2 * halo;
@@ -156,7 +150,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const int G1 = 3 * gpt;                               // gate: groups per output tile
     const int G2 = (ga.cin >> 4) / KG2;                   // output projection: groups per tile (K = C)
     const long long tile1 = (long long)G1 * GROUP_HALFS, tile2 = (long long)G2 * GROUP_HALFS;
-    if constexpr (PRIO == 0) if (wave >= 4) __builtin_amdgcn_s_setprio(1);         // waves w and w+4 share a SIMD: let the pair drift apart (tgemm.h)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);         // waves w and w+4 share a SIMD: let the pair drift apart (tgemm.h)
     const int rot = (int)(blockIdx.x % (unsigned)NB);     // per-workgroup rotated pass order (tgemm.h)
     auto tile_of = [&](int pi) { const int p = pi + rot; return (p < NB ? p : p - NB) * 8 + wave; };
     const int g_issue = wave >= 4 ? ((G1 / 2) & ~1) : 0;
@@ -181,14 +175,13 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
         const int mt = tile_of(pi);
         const _Float16* wp = gw + (long long)mt * tile1;
         const bool last = pi == NB - 1;
-        const int mt_n = last ? tile_of(0) : tile_of(pi + 1);          // last gate pass: the next "tile" is output pass 0
+        const int mt_n = last ? (DEFER ? wave : tile_of(0)) : tile_of(pi + 1);          // last gate pass: the next "tile" is output pass 0
         bool nxt_issued = false;
         auto issue_next_init = [&]() {
             if (!last) gepi.init(ge, mt_n, row0, lane, nxt);
             else if (PF) oepi.init(oe, mt_n, row0, lane, nxt);
         };
         int g = 0;
-        prio_loop();
         for (; g + 1 < G1; g += 2) {
             tl_load_group<KG, NW>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
             if (g == g_issue && (!last || PF)) { issue_next_init(); nxt_issued = true; }
@@ -215,7 +208,6 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             tl_compute_group<KG, NW>(ringA, acc, lds0 + (unsigned)rr * (unsigned)row_bytes, nt_stride_x,
                                      (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5));
         }
-        prio_mem();
         // the next tile's weight stream starts before this tile's epilogue
         if (!last) tl_load_group<KG, NW>(ringA, gw + (long long)mt_n * tile1 + lane8);
         else tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
@@ -226,6 +218,11 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 8; ++r) gq[nt][r] = (_Float16)gate_act_scaled(acc[nt][r], acc[nt][8 + r]);
+        if constexpr (DEFER) {                             // g also goes to HBM: the step's one skip contraction reads it (tskip.h)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                __builtin_nontemporal_store(gq[nt], reinterpret_cast<half8*>(ga.gall + (size_t)(row0 + 32 * nt + (lane & 31)) * ga.cin + mt * 16 + 8 * (lane >> 5)));
+        }
         // lane (h = lane >> 5) holds g-channels 16*wave + 8h .. +7 of its block for frames 32*nt + (lane & 31): chunk 2*wave + h
         auto store_block = [&](int pos, const half8 (&v)[4]) {
             const unsigned bb = block_base(pos);
@@ -256,6 +253,57 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     // =========================== phase 2: output projection passes ===========================
     const unsigned xs_g = (unsigned)((((lane & 31) & 15) ^ (lane >> 5)) << 4);
     const int g_issue2 = wave >= 4 ? ((G2 / 2) & ~1) : 0;
+    if constexpr (DEFER) {
+        // residual half only: C/32 = 4*NB output tiles.  Pass 0: tile `wave`, all 128 frames.  NB == 3 leaves four tiles: pass 1 gives tile
+        // 8 + (wave & 3) to TWO waves, 64 frames each, so all eight waves stay busy.  (acc holds tile `wave`'s residual-stream init.)
+        constexpr bool HALF = NB == 3;
+        const int mt1 = 8 + (wave & 3), nh = wave >> 2;
+        const int rowh = row0 + 64 * nh;
+        f32x16 acc2[2];
+        auto group_b = [&](int g, unsigned frame0, unsigned& base0, unsigned& xs) {
+            const int kb = g * KG2;                          // first k16 step of the group; 8 steps per 128-channel block
+            int pos = (kb >> 3) - rot; if (pos < 0) pos += NB;
+            base0 = block_base(pos) + (frame0 + (unsigned)(lane & 31)) * 256u;
+            xs = xs_g ^ ((unsigned)(kb & 7) << 5);
+        };
+        {
+            const _Float16* wp = ow + (long long)wave * tile2;
+            bool issued = false;
+            int g = 0;
+            for (; g + 1 < G2; g += 2) {
+                tl_load_group<KG2, NW2>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
+                if (HALF && g == g_issue2) { oepi.template init<2>(oe, mt1, rowh, lane, acc2); issued = true; }
+                __builtin_amdgcn_sched_barrier(0);
+                { unsigned b0, xs; group_b(g, 0u, b0, xs); tl_compute_group<KG2, NW2>(ringA, acc, b0, 32u * 256u, xs); }
+                const int gn = g + 2 < G2 ? g + 2 : G2 - 1;
+                tl_load_group<KG2, NW2>(ringA, wp + (long long)gn * GROUP_HALFS + lane8);
+                __builtin_amdgcn_sched_barrier(0);
+                { unsigned b0, xs; group_b(g + 1, 0u, b0, xs); tl_compute_group<KG2, NW2>(ringB, acc, b0, 32u * 256u, xs); }
+            }
+            if (g < G2) { unsigned b0, xs; group_b(g, 0u, b0, xs); tl_compute_group<KG2, NW2>(ringA, acc, b0, 32u * 256u, xs); }
+            if (HALF) {
+                tl_load_group<KG2, NW2>(ringA, ow + (long long)mt1 * tile2 + lane8);
+                if (!issued) oepi.template init<2>(oe, mt1, rowh, lane, acc2);
+            }
+            oepi.finish(oe, wave, row0, lane, acc);
+        }
+        if constexpr (HALF) {
+            const _Float16* wp = ow + (long long)mt1 * tile2;
+            int g = 0;
+            for (; g + 1 < G2; g += 2) {
+                tl_load_group<KG2, NW2>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
+                __builtin_amdgcn_sched_barrier(0);
+                { unsigned b0, xs; group_b(g, 64u * nh, b0, xs); tl_compute_group<KG2, NW2, 2>(ringA, acc2, b0, 32u * 256u, xs); }
+                const int gn = g + 2 < G2 ? g + 2 : G2 - 1;
+                tl_load_group<KG2, NW2>(ringA, wp + (long long)gn * GROUP_HALFS + lane8);
+                __builtin_amdgcn_sched_barrier(0);
+                { unsigned b0, xs; group_b(g + 1, 64u * nh, b0, xs); tl_compute_group<KG2, NW2, 2>(ringB, acc2, b0, 32u * 256u, xs); }
+            }
+            if (g < G2) { unsigned b0, xs; group_b(g, 64u * nh, b0, xs); tl_compute_group<KG2, NW2, 2>(ringA, acc2, b0, 32u * 256u, xs); }
+            oepi.template finish<2>(oe, mt1, rowh, lane, acc2);
+        }
+        return;
+    }
 #pragma unroll
     for (int po = 0; po < NB; ++po) {
         const int mt = tile_of(po);
@@ -270,7 +318,6 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             xs = xs_g ^ ((unsigned)(kb & 7) << 5);
         };
         int g = 0;
-        prio_loop();
         for (; g + 1 < G2; g += 2) {
             tl_load_group<KG2, NW2>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
             if (g == g_issue2 && !last) { oepi.init(oe, mt_n, row0, lane, nxt); nxt_issued = true; }
@@ -282,7 +329,6 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             { unsigned b0, xs; group_b(g + 1, b0, xs); tl_compute_group<KG2, NW2>(ringB, acc, b0, 32u * 256u, xs); }
         }
         if (g < G2) { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG2, NW2>(ringA, acc, b0, 32u * 256u, xs); }
-        prio_mem();
         if (!last) {
             tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
             if (!nxt_issued) oepi.init(oe, mt_n, row0, lane, nxt);
@@ -306,9 +352,9 @@ inline bool tlayer_supported(int C, int cin_pad, int dil, int n_rows) {
     return C == cin_pad && (C == 256 || C == 384) && n_rows % TL_TN == 0 && tlayer_smem(dil, cin_pad) <= 160 * 1024;
 }
 
-template <int NB, int KG, int NW, int PF, int NW2 = NW, int PRIO = 0>
+template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0>
 inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiResSkip::Args& oe, int n_rows, hipStream_t stream) {
-    auto kern = tlayer_kernel<NB, KG, NW, PF, NW2, PRIO>;
+    auto kern = tlayer_kernel<NB, KG, NW, PF, NW2, DEFER>;
     const size_t smem = tlayer_smem(ga.dil, ga.cin);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {
@@ -323,7 +369,7 @@ inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiR
 // gate weights `g` (taps 3, m_tiles C/16) + output-projection weights `o` (taps 1, m_tiles 2C/32) of ONE layer, as tgemm would get them
 template <int NW, int NW2 = NW>
 inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs& o, const TEpiResSkip::Args& oe, int C, int n_rows,
-                         int prefetch, hipStream_t stream, int prio = 0) {
+                         int prefetch, hipStream_t stream, _Float16* gall = nullptr) {
     constexpr int KG = NW == 2 ? 4 : 8;
     if (g.taps != 3 || o.taps != 1 || g.m_tiles != C / 16 || o.m_tiles != 2 * C / 32 || g.cin != C || o.cin != C)
         return fail(DSVC_EINVAL, "tlayer: unexpected layer geometry");
@@ -335,10 +381,10 @@ inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs
     a.x = g.x; a.cin = g.cin; a.swz = tgemm_swizzle_mask(g.cin); a.dil = g.dil; a.gw = g.w; a.ow = o.w;
     a.gvar = g.variant_halfs; a.ovar = o.n_variants == g.n_variants ? o.variant_halfs : 0; a.n_variants = g.n_variants;
     a.step_ptr = g.step_ptr; a.step_off = g.step_off;
-    if (C == 384 && prio > 0) {                           // the priority variants exist for the 44.1 kHz width only
-        if (prio == 1) return tlayer_launch_t<3, KG, NW, 0, NW2, 1>(a, cproj, oe, n_rows, stream);
-        if (prio == 2) return tlayer_launch_t<3, KG, NW, 0, NW2, 2>(a, cproj, oe, n_rows, stream);
-        return tlayer_launch_t<3, KG, NW, 0, NW2, 3>(a, cproj, oe, n_rows, stream);
+    if (gall) {                                           // skip-deferred form: g also goes to HBM, residual half of the 1x1 only
+        a.gall = gall;
+        if (C == 384) return tlayer_launch_t<3, KG, NW, 0, NW2, 1>(a, cproj, oe, n_rows, stream);
+        return tlayer_launch_t<2, KG, NW, 0, NW2, 1>(a, cproj, oe, n_rows, stream);
     }
     if constexpr (NW2 != NW) {                            // (the prefetch variant is not instantiated for the mixed kernel)
         if (C == 384) return tlayer_launch_t<3, KG, NW, 0, NW2>(a, cproj, oe, n_rows, stream);

@@ -90,8 +90,9 @@ int dsvc_denoiser_check(dsvc_denoiser* d, void* stream);
 
 /* test support (explicit handle state; the library reads no environment variable): "stop_after_layers" = n >= 0 makes an evaluation
  * return after n residual layers so that dsvc_denoiser_debug_buffer taps layer n-1 (-1 = off); "two_launch_layer" != 0 runs a residual
- * layer as its two tgemm launches where the fused layer kernel would apply (bit-equality test of the two forms); "layer_prio" = 0..3
- * selects the fused layer kernel's wave-priority scheme (csrc/tlayer.h: scheduling only, results are bit-identical). */
+ * layer as its two tgemm launches where the fused layer kernel would apply (bit-equality test of the two forms); "defer_skip" = 0 makes
+ * the fused layer kernel accumulate the skip sum in every layer (the round-2 form) instead of leaving it to the one deferred skip
+ * contraction per evaluation (csrc/tskip.h; default on wherever the fused layer kernel runs). */
 int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------

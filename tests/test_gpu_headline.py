@@ -223,6 +223,7 @@ def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused):
     t = torch.from_numpy(g.integers(0, 1000, size=(B,)))
     Tp = (T + 8 + 31) // 32 * 32
     den.debug_set("two_launch_layer", 0 if fused else 1)
+    den.debug_set("defer_skip", 0)                           # the in-layer skip accumulation: its running sum is what this test taps
     worst = _tap_errors(den, sd, spec, t, cond, lambda b: slice(b * Tp, b * Tp + T))
     print("tgemm taps %s B=%d T=%d fused=%d: worst |err| x %.2e (layer %d), g %.2e (layer %d), skip-sum %.2e (layer %d)"
           % (precision, B, T, fused, worst["x"][0], worst["x"][1], worst["g"][0], worst["g"][1], worst["s"][0], worst["s"][1]))
@@ -267,6 +268,7 @@ def test_fused_layer_kernel_equals_the_two_launch_layer_bit_for_bit(precision):
     hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
     cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
     cond = cond.transpose(1, 2).contiguous().cuda()
+    den.debug_set("defer_skip", 0)                           # (the deferred skip contraction sums the skips in another order: next test)
     fused = smp.sample(cond, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
     den.debug_set("two_launch_layer", 1)
     two = smp.sample(cond, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
@@ -372,3 +374,55 @@ def test_batch_of_32_full_chain_every_clip_with_a_golden(ckpt, which):
         assert max(e[1] for e in errs) <= SHIP_BAR, errs
     elif precision == "f16_w2":
         assert max(e[1] for e in errs) < MEL_BAR, errs
+
+
+@pytest.mark.parametrize("precision", ["f16_w2", "f16_m64"])
+def test_deferred_skip_contraction_taps_and_equivalence(precision):
+    """The throughput tiling's default since round 3: the layer kernels write the gate output g to HBM and compute only the residual half
+    of the 1x1; ONE [C x L*C] contraction per evaluation (tskip.h) produces relu(skip_projection(sum of skips / sqrt(L))) from all layers' g
+    with weights composed at load time.  Checked at 8 x 861: (1) per-layer residual stream x_l and gate output g_l against the oracle
+    (g_l is now tappable in the fused form: it is in HBM), (2) the contraction's output against relu(skip_projection(.)) of the oracle,
+    (3) a 20-step DDPM chain against the in-layer form of the same kernels -- equal up to fp32 summation order."""
+    import torch.nn.functional as F
+    hp = dict(synth.HPARAMS_44K, K_step=20)
+    sd, den, smp = make_handles(hp, 0, precision)
+    B, T = 8, 861
+    g = np.random.Generator(np.random.PCG64(23))
+    spec = torch.from_numpy(g.standard_normal((B, 1, 128, T)).astype(np.float32))
+    cond = torch.from_numpy((g.standard_normal((B, 256, T)) * 0.5).astype(np.float32))
+    t = torch.from_numpy(g.integers(0, 1000, size=(B,)))
+    Tp = (T + 8 + 31) // 32 * 32
+    taps = {}
+    with torch.no_grad():
+        ref_out = O.diffnet_forward(sd, spec, t, cond, 4, taps=taps)
+        s_ref = F.relu(F.conv1d(taps["skip"], sd["denoise_fn.skip_projection.weight"], sd["denoise_fn.skip_projection.bias"]))
+    L = O.diffnet_layers(sd)
+    worst = {"x": 0.0, "g": 0.0}
+    try:
+        for n in (1, 2, 7, L):
+            den.debug_set("stop_after_layers", n)
+            den.forward(spec.cuda(), t.cuda(), cond.cuda())
+            bx, bg = den.debug_buffer("xres").cpu(), den.debug_buffer("g").cpu()
+            for b in range(B):
+                rows = slice(b * Tp, b * Tp + T)
+                worst["x"] = max(worst["x"], (bx[rows] - taps["x%d" % (n - 1)][b].T).abs().max().item())
+                worst["g"] = max(worst["g"], (bg[rows] - taps["g%d" % (n - 1)][b].T).abs().max().item())
+    finally:
+        den.debug_set("stop_after_layers", -1)
+    out = den.forward(spec.cuda(), t.cuda(), cond.cuda()).cpu()
+    s2 = den.debug_buffer("s2").cpu()                          # hi plane of relu(skip projection)
+    es = max((s2[b * Tp:b * Tp + T] - s_ref[b].T).abs().max().item() for b in range(B))
+    eo = (out - ref_out).abs().max().item()
+    print("deferred skip path %s: worst |err| x %.2e, g %.2e, relu(skip proj) %.2e (fp16 hi plane), eps %.2e" % (precision, worst["x"], worst["g"], es, eo))
+    tol = 1.5e-2 if precision != "f16_w2" else 1e-2
+    assert worst["x"] < tol and worst["g"] < tol and es < 2 * tol and eo < FWD_TOL[precision]
+    clips, n_units, seed = list(range(8)), 500, 77
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    cnd, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    cnd = cnd.transpose(1, 2).contiguous().cuda()
+    a = smp.sample(cnd, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
+    den.debug_set("defer_skip", 0)
+    b = smp.sample(cnd, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
+    d = (a - b).abs().max().item()
+    print("deferred vs in-layer skip accumulation (%s), 20 DDPM steps at 8 x 861: max |diff| of the state %.2e" % (precision, d))
+    assert torch.isfinite(a).all() and 0.0 < d < 2e-4

@@ -27,7 +27,9 @@ constexpr int MAX_NS = 16;                   // streaming waves per CU that have
 __global__ void __launch_bounds__(1024) k_overlap(const _Float16* __restrict__ ops, const float* __restrict__ rd, float* __restrict__ wr,
                                                   float* __restrict__ sink, Rec* __restrict__ rec, int nm, int ns, unsigned long long window_ticks, int mode) {
     // mode bit 0: streaming waves raise their priority (s_setprio 3); bit 1: the MFMA waves are the YOUNGER waves of the workgroup
-    // (arbitration between co-resident waves is by priority, then age -- MI355X_MICROARCH.md "Two waves per SIMD")
+    // (arbitration between co-resident waves is by priority, then age -- MI355X_MICROARCH.md "Two waves per SIMD");
+    // bit 2: every streaming wave walks an 8 KB region only (L2-resident: is it HBM or the memory pipeline that MFMAs exclude?);
+    // bit 3: the MFMA waves run at ~50 % duty (a burst of 512 MFMAs, then s_sleep for about as long): is the trade linear in time?
     const int lane = threadIdx.x & 63;
     const int wave_hw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = (mode & 2) ? (wave_hw + nm) % (nm + ns) : wave_hw;      // role index: < nm = MFMA
@@ -57,6 +59,10 @@ __global__ void __launch_bounds__(1024) k_overlap(const _Float16* __restrict__ o
                     for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[(i + j) & 3], acc[i], 0, 0, 0);
             }
             trips += 32;
+            if (mode & 8) {                                          // ~512 MFMAs x 32 cycles x (2 waves per SIMD when nm == 8) of idling
+                const int naps = nm > 4 ? 4 : 2;
+                for (int z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(127);           // 127 x 64 cycles each
+            }
         } while (__builtin_amdgcn_s_memrealtime() < deadline);
         float s = 0.f;
 #pragma unroll
@@ -84,7 +90,7 @@ __global__ void __launch_bounds__(1024) k_overlap(const _Float16* __restrict__ o
                 keep[0] += o[0];
             }
             off += 2048;
-            if (off >= REGION / 4) off = 0;
+            if (off >= ((mode & 4) ? (size_t)2048 : REGION / 4)) off = 0;
             trips += 1;
         } while (__builtin_amdgcn_s_memrealtime() < deadline);
         if (keep[0] == 123.456f) sink[0] = keep[0];
@@ -119,6 +125,10 @@ int main(int argc, char** argv) {
                         {8, 4, "joint 8 + 4, stream prio 3", 1}, {4, 12, "joint 4 + 12, stream prio 3", 1},
                         {4, 4, "joint 4 + 4, MFMA waves younger", 2}, {8, 8, "joint 8 + 8, MFMA waves younger", 2}, {4, 8, "joint 4 + 8, MFMA younger", 2},
                         {4, 4, "joint 4 + 4, younger + prio", 3}, {8, 8, "joint 8 + 8, younger + prio", 3},
+                        {0, 8, "stream alone, L2-resident (8 KB/wave)", 4}, {4, 4, "joint 4 + 4, L2-resident stream", 4},
+                        {8, 8, "joint 8 + 8, L2-resident stream", 4}, {4, 8, "joint 4 + 8, L2-resident stream", 4},
+                        {8, 0, "MFMA alone at ~50 % duty", 8}, {8, 8, "joint 8 + 8, MFMA ~50 % duty", 8}, {4, 4, "joint 4 + 4, MFMA ~50 % duty", 8},
+                        {4, 8, "joint 4 + 8, MFMA ~50 % duty", 8}, {8, 8, "joint 8 + 8, 50 % duty, stream prio 3", 9},
                         {8, 0, "MFMA alone again (chip now warm)", 0}};
     for (const Cfg& c : cfgs) {
         const int waves = c.nm + c.ns;
