@@ -12,8 +12,8 @@ for part in $PARTS; do
 case $part in
 phase)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_phase_offset.py $p 128 >> $OUT/${TAG}_phase_offset.txt 2>&1; done; cat $OUT/${TAG}_phase_offset.txt ;;
-prio)
-  for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_layer_prio.py $p 128 >> $OUT/${TAG}_layer_prio.txt 2>&1; done; cat $OUT/${TAG}_layer_prio.txt ;;
+defer)
+  for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_defer_ab.py $p 128 >> $OUT/${TAG}_defer_ab.txt 2>&1; done; cat $OUT/${TAG}_defer_ab.txt ;;
 spread)
   timeout 900 python -m pytest tests/test_gpu_headline.py -q -s -k "spread" > $OUT/${TAG}_spread.txt 2>&1; grep -E "^spread|passed|failed" $OUT/${TAG}_spread.txt ;;
 overlap)
