@@ -186,7 +186,10 @@ struct dsvc_denoiser {
     bool cond_ready = false;
     // test support, set through dsvc_denoiser_debug_set (explicit handle state -- the product library reads no environment variable):
     int dbg_stop_after = -1;     // >= 0: an evaluation returns after this many residual layers (per-layer taps, tests/test_gpu_headline.py)
-    bool dbg_no_defer = false;   // run the fused layer with its in-layer skip accumulation instead of the deferred skip contraction
+    bool defer_skip = false;     // "defer_skip": the fused layer kernels leave the skip halves to ONE contraction per evaluation (tskip.h).
+                                 // Measured at 32 clips (profiles/r3e_*): layer kernel 132 -> 123 us and 14 % fewer HBM bytes, but the skip
+                                 // halves' MFMAs, which hide under the layer's memory-bound output phase, then cost 342 us per step as their
+                                 // own kernel: the step time is unchanged (+-1 %).  Built, parity-tested, not the default.
     bool dbg_two_launch = false; // run a residual layer as its two tgemm launches even where the fused kernel applies (bit-equality test)
     int* step_err = nullptr;     // host-mapped sticky flag: a dsvc_denoiser_forward call saw a diffusion step outside [0, max_steps)
     unsigned ws_gen = 0;  // bumped whenever the workspace is (re)built: captured graphs bake its pointers and are keyed on this
@@ -237,7 +240,7 @@ struct dsvc_denoiser {
     int finalize_t();
     // the whole residual layer as one kernel (tlayer.h) -- the throughput tiling only
     bool fused_layer_ok() const;
-    bool defer_ok() const { return fused_layer_ok() && !dbg_no_defer && skipall_t.m_tiles > 0 && tskip_supported(cfg.channels, rows_alloc); }
+    bool defer_ok() const { return fused_layer_ok() && defer_skip && skipall_t.m_tiles > 0 && gall.p && tskip_supported(cfg.channels, rows_alloc); }
     int launch_fused_layer(int l, const StepRef& step, hipStream_t st, int host_step);
 };
 
@@ -458,7 +461,7 @@ int dsvc_denoiser::ensure_ws(int B, int T, hipStream_t st) {
         // fp16 operands: zero once -- gap rows, guard rows and pad columns are never written afterwards
         const size_t nxh = (r + 2 * (size_t)guard) * Cp * 2, nh = r * Cp * 2, ns = r * Mp * 2;
         DSVC_TRY(xh.alloc(nxh)); DSVC_TRY(xh2.alloc(nxh)); DSVC_TRY(gh.alloc(nh));
-        if (rows_alloc / 128 >= 48 && skipall_t.m_tiles > 0) {      // the fused-layer regime: every row is written by the gate epilogues before tskip reads it
+        if (defer_skip && rows_alloc / 128 >= 48 && skipall_t.m_tiles > 0) {      // the fused-layer regime: every row is written by the gate epilogues before tskip reads it
             DSVC_TRY(gall.alloc((size_t)L * nh));
             DSVC_HIP(hipMemsetAsync(gall.p, 0, (size_t)L * nh, st));
         }
@@ -969,6 +972,10 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
         width = C;
     }
     else if (n == "skip") { b = &d->skip; width = C; }
+    else if (n == "gall") {          // every layer's gate output (deferred skip path): [L * rows][C]
+        if (!d->tpath || !d->gall.p) return fail(DSVC_EINVAL, "'gall' exists in the deferred skip path only");
+        hb = &d->gall; hld = d->Cp; width = C;
+    }
     else if (n == "s2") { if (d->tpath) { hb = &d->s2h; hld = 2 * d->Cp; } else b = &d->s2; width = C; }
     else if (n == "xh") { if (!d->tpath) return fail(DSVC_EINVAL, "'xh' exists on the tgemm path only"); hb = &d->xh; hld = d->Cp; hoff = (size_t)d->guard * d->Cp; width = C; }
     else if (n == "eps") { b = &d->eps; width = M; }
@@ -976,8 +983,8 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
     else if (n == "cproj") { b = &d->cproj; width = 2 * C; }
     else if (n == "film") { b = &d->film; width = C; }
     else return fail(DSVC_EINVAL, "unknown debug buffer '%s'", name);
-    const int r_ws = d->rows_alloc;
-    if (rows) *rows = (n == "film") ? d->cfg.max_steps * d->cfg.layers : (n == "cproj" ? r_ws * d->cfg.layers : r_ws);
+    const int r_ws = n == "gall" ? d->rows_alloc * d->cfg.layers : d->rows_alloc;
+    if (rows) *rows = (n == "film") ? d->cfg.max_steps * d->cfg.layers : (n == "cproj" ? d->rows_alloc * d->cfg.layers : r_ws);
     if (ld) *ld = width;
     if (dst && numel > 0) {
         DSVC_HIP(hipDeviceSynchronize());
@@ -987,7 +994,7 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
             DSVC_HIP(hipGetLastError());
             DSVC_HIP(hipDeviceSynchronize());
         } else if (d->tpath && (n == "xres" || n == "skip" || n == "cproj")) {
-            const int nr = (n == "cproj") ? r_ws * d->cfg.layers : r_ws;       // every layer slab is a whole number of frame tiles
+            const int nr = (n == "cproj") ? d->rows_alloc * d->cfg.layers : r_ws;       // every layer slab is a whole number of frame tiles
             if ((size_t)numel < (size_t)nr * width) return fail(DSVC_EINVAL, "debug buffer '%s' needs %zu elements", name, (size_t)nr * width);
             hipLaunchKernelGGL(k_untile, dim3(2048), dim3(256), 0, 0, b->as<float>(), dst, width, nr, n == "cproj" ? 1 : 0);
             DSVC_HIP(hipGetLastError());
@@ -1015,7 +1022,10 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     const std::string k(key);
     if (k == "stop_after_layers") d->dbg_stop_after = value;
     else if (k == "two_launch_layer") d->dbg_two_launch = value != 0;
-    else if (k == "defer_skip") d->dbg_no_defer = value == 0;
+    else if (k == "defer_skip") {
+        d->defer_skip = value != 0;
+        if (d->defer_skip && d->wsB > 0 && !d->gall.p) { d->wsB = 0; d->wsT = 0; }      // rebuild the workspace with the gate-output buffer
+    }
     else return fail(DSVC_EINVAL, "unknown debug setting '%s'", key);
     ++d->ws_gen;                 // captured graphs bake the launch sequence: force a re-capture
     return DSVC_OK;

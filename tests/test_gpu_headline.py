@@ -223,7 +223,6 @@ def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused):
     t = torch.from_numpy(g.integers(0, 1000, size=(B,)))
     Tp = (T + 8 + 31) // 32 * 32
     den.debug_set("two_launch_layer", 0 if fused else 1)
-    den.debug_set("defer_skip", 0)                           # the in-layer skip accumulation: its running sum is what this test taps
     worst = _tap_errors(den, sd, spec, t, cond, lambda b: slice(b * Tp, b * Tp + T))
     print("tgemm taps %s B=%d T=%d fused=%d: worst |err| x %.2e (layer %d), g %.2e (layer %d), skip-sum %.2e (layer %d)"
           % (precision, B, T, fused, worst["x"][0], worst["x"][1], worst["g"][0], worst["g"][1], worst["s"][0], worst["s"][1]))
@@ -268,7 +267,6 @@ def test_fused_layer_kernel_equals_the_two_launch_layer_bit_for_bit(precision):
     hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
     cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
     cond = cond.transpose(1, 2).contiguous().cuda()
-    den.debug_set("defer_skip", 0)                           # (the deferred skip contraction sums the skips in another order: next test)
     fused = smp.sample(cond, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
     den.debug_set("two_launch_layer", 1)
     two = smp.sample(cond, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
@@ -378,14 +376,15 @@ def test_batch_of_32_full_chain_every_clip_with_a_golden(ckpt, which):
 
 @pytest.mark.parametrize("precision", ["f16_w2", "f16_m64"])
 def test_deferred_skip_contraction_taps_and_equivalence(precision):
-    """The throughput tiling's default since round 3: the layer kernels write the gate output g to HBM and compute only the residual half
-    of the 1x1; ONE [C x L*C] contraction per evaluation (tskip.h) produces relu(skip_projection(sum of skips / sqrt(L))) from all layers' g
-    with weights composed at load time.  Checked at 8 x 861: (1) per-layer residual stream x_l and gate output g_l against the oracle
+    """The deferred skip path (debug_set 'defer_skip' 1; not the default: time-neutral): the layer kernels write the gate
+    output g to HBM and compute only the residual half of the 1x1; ONE [C x L*C] contraction per evaluation (tskip.h) produces
+    relu(skip_projection(sum of skips / sqrt(L))) from all layers' g with weights composed at load time.  Checked at 8 x 861: (1) per-layer residual stream x_l and gate output g_l against the oracle
     (g_l is now tappable in the fused form: it is in HBM), (2) the contraction's output against relu(skip_projection(.)) of the oracle,
     (3) a 20-step DDPM chain against the in-layer form of the same kernels -- equal up to fp32 summation order."""
     import torch.nn.functional as F
     hp = dict(synth.HPARAMS_44K, K_step=20)
     sd, den, smp = make_handles(hp, 0, precision)
+    den.debug_set("defer_skip", 1)
     B, T = 8, 861
     g = np.random.Generator(np.random.PCG64(23))
     spec = torch.from_numpy(g.standard_normal((B, 1, 128, T)).astype(np.float32))

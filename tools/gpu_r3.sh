@@ -12,6 +12,8 @@ for part in $PARTS; do
 case $part in
 phase)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_phase_offset.py $p 128 >> $OUT/${TAG}_phase_offset.txt 2>&1; done; cat $OUT/${TAG}_phase_offset.txt ;;
+tailcheck)
+  timeout 300 python tools/gpu_tail_check.py f16_w2 > $OUT/${TAG}_tail_check.txt 2>&1; cat $OUT/${TAG}_tail_check.txt ;;
 defer)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_defer_ab.py $p 128 >> $OUT/${TAG}_defer_ab.txt 2>&1; done; cat $OUT/${TAG}_defer_ab.txt ;;
 spread)
@@ -40,6 +42,14 @@ prof32)
   F=$(find $OUT/${TAG}_prof32 -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && head -30 "$F" > $OUT/${TAG}_kernel_stats_b32.csv && head -8 $OUT/${TAG}_kernel_stats_b32.csv
   rm -rf $OUT/${TAG}_prof32; cat $OUT/${TAG}_prof32_bench.json; cd $ROOT ;;
+pmc1)
+  cd /tmp
+  P=${PMCPREC:-f16_w2}
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc1_$c -o pmc -- python $ROOT/tools/prof_sampler.py 1 60 $P > $OUT/${TAG}_pmc1_$c.log 2>&1
+  done
+  python $ROOT/tools/rocprof_traffic.py $OUT/${TAG}_pmc1_FETCH_SIZE $OUT/${TAG}_pmc1_WRITE_SIZE "TEpiGate" $OUT/${TAG}_gate_traffic.json "tools/prof_sampler.py 1 60 $P (eager launches)"
+  rm -rf $OUT/${TAG}_pmc1_FETCH_SIZE $OUT/${TAG}_pmc1_WRITE_SIZE; cd $ROOT ;;
 pmc32)
   cd /tmp
   P=${PMCPREC:-f16_w2}
