@@ -43,8 +43,8 @@ const char* dsvc_last_error(void);
 /* measurement aid for bench.py: the dense fp16 MFMA rate (TFLOP/s) and shader clock (GHz) this chip sustains right now on a
  * register-resident loop with random (1) or zero (0) operands -- the rate a roofline fraction can actually approach. */
 int dsvc_probe_mfma(int32_t random_data, float* tflops, float* clock_ghz, void* stream);
-/* the same probe in detail: out4 = { TFLOP/s over the kernel's wall time (HIP events), TFLOP/s inside the timed loops, mean clock over
- * the CUs [GHz], lowest clock any CU held [GHz] } */
+/* the same probe in detail: out4 = { TFLOP/s over the kernel's wall time (HIP events), TFLOP/s over the 4 ms in-kernel window every wave
+ * issues MFMAs for, mean shader clock over all waves [GHz], lowest clock any wave saw [GHz] } */
 int dsvc_probe_mfma_detail(int32_t random_data, float* out4, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
