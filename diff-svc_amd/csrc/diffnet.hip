@@ -1007,6 +1007,18 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
     return DSVC_OK;
 }
 
+#ifdef DSVC_PROFILING
+// profiling build only (not part of the ABI): the fused layer kernel's per-wave phase stamps of the last launch -> host
+int dsvc_profile_layer_stamps(unsigned long long* dst, int32_t* groups) {
+    if (!dst || !groups) return fail(DSVC_EINVAL, "null argument");
+    *groups = tl_stamp_groups();
+    if (!tl_stamp_buffer() || *groups < 1) return fail(DSVC_ESTATE, "no stamps recorded (DSVC_TL_STAMPS unset?)");
+    DSVC_HIP(hipDeviceSynchronize());
+    DSVC_HIP(hipMemcpy(dst, tl_stamp_buffer(), (size_t)*groups * 8 * 16 * 8, hipMemcpyDeviceToHost));
+    return DSVC_OK;
+}
+#endif
+
 int dsvc_denoiser_check(dsvc_denoiser* d, void* stream) {
     if (!d) return fail(DSVC_EINVAL, "null handle");
     DSVC_HIP(hipStreamSynchronize((hipStream_t)stream));

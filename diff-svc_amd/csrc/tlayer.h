@@ -39,7 +39,18 @@ struct TLayerArgs {
     int n_variants;             // > 1: variant = (*step_ptr - step_off) mod n_variants is resolved in the kernel; the sampler passes
     const int* step_ptr;        //      the variant by value (gw / ow already offset, n_variants = 1)
     int step_off;
+#ifdef DSVC_PROFILING
+    unsigned long long* stamps; // profiling build: 16 s_memrealtime stamps per wave of the LAST launch (tools/gpu_layer_stamps.py)
+#endif
 };
+
+#ifdef DSVC_PROFILING
+#define TL_STAMP(i) do { if (ga.stamps && lane == 0) ga.stamps[((size_t)blockIdx.x * 8 + wave) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+inline unsigned long long*& tl_stamp_buffer() { static unsigned long long* p = nullptr; return p; }
+inline int& tl_stamp_groups() { static int n = 0; return n; }
+#else
+#define TL_STAMP(i) do { } while (0)
+#endif
 
 // KG k16-steps of one output tile against 4 N-tiles of 32 frames: tgemm's compute_group with the LDS geometry passed in.
 //   base0     LDS byte address of this lane's row of N-tile 0
@@ -109,6 +120,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    TL_STAMP(0);
     const int row0 = blockIdx.x * TL_TN;
     const int halo = ga.dil;                              // taps == 3
     const int rows_lds = TL_TN + 2 * halo;
@@ -165,8 +177,11 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     // first operands in flight before the barrier
     tl_load_group<KG, NW>(ringA, gw + (long long)tile_of(0) * tile1 + lane8);
     gepi.init(ge, tile_of(0), row0, lane, acc);
+    TL_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL_STAMP(2);
     __syncthreads();
+    TL_STAMP(3);
 
     const unsigned nt_stride_x = 32u * (unsigned)row_bytes;
     // =========================== phase 1: gate passes ===========================
@@ -208,6 +223,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             tl_compute_group<KG, NW>(ringA, acc, lds0 + (unsigned)rr * (unsigned)row_bytes, nt_stride_x,
                                      (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5));
         }
+        TL_STAMP(4 + pi);                                  // (4, 5, 6: end of a gate pass's main loop)
         // the next tile's weight stream starts before this tile's epilogue
         if (!last) tl_load_group<KG, NW>(ringA, gw + (long long)mt_n * tile1 + lane8);
         else tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
@@ -245,6 +261,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             if (NB == 3) store_block(1, gmid);
             store_block(NB - 1, gq);
             __syncthreads();                               // g complete
+            TL_STAMP(7);
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = nxt[nt];
@@ -329,16 +346,21 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             { unsigned b0, xs; group_b(g + 1, b0, xs); tl_compute_group<KG2, NW2>(ringB, acc, b0, 32u * 256u, xs); }
         }
         if (g < G2) { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG2, NW2>(ringA, acc, b0, 32u * 256u, xs); }
+        TL_STAMP(8 + 2 * po);                              // (8, 10, 12: end of an output pass's main loop; 9, 11, 13: its stores issued)
         if (!last) {
             tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
             if (!nxt_issued) oepi.init(oe, mt_n, row0, lane, nxt);
         }
         oepi.finish(oe, mt, row0, lane, acc);
+        TL_STAMP(9 + 2 * po);
         if (!last) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = nxt[nt];
         }
     }
+#ifdef DSVC_PROFILING
+    if (ga.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TL_STAMP(14); }      // every store acknowledged
+#endif
 }
 
 inline size_t tlayer_smem(int dil, int cin) {
@@ -381,6 +403,12 @@ inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs
     a.x = g.x; a.cin = g.cin; a.swz = tgemm_swizzle_mask(g.cin); a.dil = g.dil; a.gw = g.w; a.ow = o.w;
     a.gvar = g.variant_halfs; a.ovar = o.n_variants == g.n_variants ? o.variant_halfs : 0; a.n_variants = g.n_variants;
     a.step_ptr = g.step_ptr; a.step_off = g.step_off;
+#ifdef DSVC_PROFILING
+    if (getenv("DSVC_TL_STAMPS")) {
+        if (!tl_stamp_buffer()) { DSVC_HIP(hipMalloc(&tl_stamp_buffer(), (size_t)4096 * 8 * 16 * 8)); }
+        if (n_rows / TL_TN <= 4096) { a.stamps = tl_stamp_buffer(); tl_stamp_groups() = n_rows / TL_TN; }
+    }
+#endif
     if (gall) {                                           // skip-deferred form: g also goes to HBM, residual half of the 1x1 only
         a.gall = gall;
         if (C == 384) return tlayer_launch_t<3, KG, NW, 0, NW2, 1>(a, cproj, oe, n_rows, stream);

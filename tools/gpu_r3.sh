@@ -14,6 +14,8 @@ phase)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_phase_offset.py $p 128 >> $OUT/${TAG}_phase_offset.txt 2>&1; done; cat $OUT/${TAG}_phase_offset.txt ;;
 tailcheck)
   timeout 300 python tools/gpu_tail_check.py f16_w2 > $OUT/${TAG}_tail_check.txt 2>&1; cat $OUT/${TAG}_tail_check.txt ;;
+stamps)
+  for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_layer_stamps.py $p >> $OUT/${TAG}_layer_stamps.txt 2>&1; done; cat $OUT/${TAG}_layer_stamps.txt ;;
 defer)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_defer_ab.py $p 128 >> $OUT/${TAG}_defer_ab.txt 2>&1; done; cat $OUT/${TAG}_defer_ab.txt ;;
 spread)
