@@ -186,6 +186,7 @@ struct dsvc_denoiser {
     bool cond_ready = false;
     // test support, set through dsvc_denoiser_debug_set (explicit handle state -- the product library reads no environment variable):
     int dbg_stop_after = -1;     // >= 0: an evaluation returns after this many residual layers (per-layer taps, tests/test_gpu_headline.py)
+    int layer_prio = 0;          // "layer_prio": tlayer.h PRIOV (tuning)
     bool defer_skip = false;     // "defer_skip": the fused layer kernels leave the skip halves to ONE contraction per evaluation (tskip.h).
                                  // Measured at 32 clips (profiles/r3e_*): layer kernel 132 -> 123 us and 14 % fewer HBM bytes, but the skip
                                  // halves' MFMAs, which hide under the layer's memory-bound output phase, then cost 342 us per step as their
@@ -667,8 +668,8 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
 #else
     constexpr int pf = 0;
 #endif
-    if (dil_t[l].planes == 1 && out_t[l].planes == 2) return tlayer_launch<1, 2>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl);      // F16_MIX
-    return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl);
+    if (dil_t[l].planes == 1 && out_t[l].planes == 2) return tlayer_launch<1, 2>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl, layer_prio);      // F16_MIX
+    return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl, layer_prio) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl, layer_prio);
 }
 
 // =================================================================================================
@@ -1034,6 +1035,7 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     const std::string k(key);
     if (k == "stop_after_layers") d->dbg_stop_after = value;
     else if (k == "two_launch_layer") d->dbg_two_launch = value != 0;
+    else if (k == "layer_prio") d->layer_prio = value;
     else if (k == "defer_skip") {
         d->defer_skip = value != 0;
         if (d->defer_skip && d->wsB > 0 && !d->gall.p) { d->wsB = 0; d->wsT = 0; }      // rebuild the workspace with the gate-output buffer

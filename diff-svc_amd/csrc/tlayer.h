@@ -111,7 +111,7 @@ __device__ __forceinline__ void tl_load_group(half8 (&ring)[KG * NW], const _Flo
 // written to HBM as well (fp16, 768 B per frame) and ONE K = L*C contraction per evaluation (tskip.h) produces relu(skip_projection(sum of
 // the skips) / sqrt(L)) from all layers' g with pre-composed weights.  The layer then moves 8.5 KB per frame instead of 10.8 (no fp32 skip
 // read-modify-write), and on a part whose matrix and HBM phases do not overlap (profiles/r3c_overlap.txt) bytes are time.
-template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0>
+template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0, int PRIOV = 0>
 __global__ void __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
 tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiResSkip::Args oe) {
     constexpr int KG2 = KG * NW / NW2;
@@ -162,7 +162,14 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const int G1 = 3 * gpt;                               // gate: groups per output tile
     const int G2 = (ga.cin >> 4) / KG2;                   // output projection: groups per tile (K = C)
     const long long tile1 = (long long)G1 * GROUP_HALFS, tile2 = (long long)G2 * GROUP_HALFS;
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);         // waves w and w+4 share a SIMD: let the pair drift apart (tgemm.h)
+    // PRIOV: how the two waves of a SIMD (w and w + 4) share its matrix pipe.  0 = static (waves 4..7 at priority 1 throughout: the in-kernel
+    // timeline, profiles/r3g_layer_stamps.txt, shows them finishing the gate phase 20 us before their partners, which then run alone --
+    // one wave per SIMD cannot keep the pipe busy); 1 = the favoured half alternates from pass to pass; 2 = it alternates from weight
+    // group to weight group (round-robin at ~1k-cycle granularity)
+    const int half = wave >> 2;
+    auto prio_pass = [&](int pass) { if constexpr (PRIOV == 1) { if ((pass + half) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } };
+    auto prio_group = [&](int g) { if constexpr (PRIOV == 2) { if ((g + half) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } };
+    if constexpr (PRIOV == 0) if (wave >= 4) __builtin_amdgcn_s_setprio(1);         // waves w and w+4 share a SIMD: let the pair drift apart (tgemm.h)
     const int rot = (int)(blockIdx.x % (unsigned)NB);     // per-workgroup rotated pass order (tgemm.h)
     auto tile_of = [&](int pi) { const int p = pi + rot; return (p < NB ? p : p - NB) * 8 + wave; };
     const int g_issue = wave >= 4 ? ((G1 / 2) & ~1) : 0;
@@ -197,7 +204,9 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             else if (PF) oepi.init(oe, mt_n, row0, lane, nxt);
         };
         int g = 0;
+        prio_pass(pi + 1);
         for (; g + 1 < G1; g += 2) {
+            prio_group(g >> 1);
             tl_load_group<KG, NW>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
             if (g == g_issue && (!last || PF)) { issue_next_init(); nxt_issued = true; }
             __builtin_amdgcn_sched_barrier(0);
@@ -335,7 +344,9 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             xs = xs_g ^ ((unsigned)(kb & 7) << 5);
         };
         int g = 0;
+        prio_pass(po);
         for (; g + 1 < G2; g += 2) {
+            prio_group(g >> 1);
             tl_load_group<KG2, NW2>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
             if (g == g_issue2 && !last) { oepi.init(oe, mt_n, row0, lane, nxt); nxt_issued = true; }
             __builtin_amdgcn_sched_barrier(0);
@@ -374,9 +385,9 @@ inline bool tlayer_supported(int C, int cin_pad, int dil, int n_rows) {
     return C == cin_pad && (C == 256 || C == 384) && n_rows % TL_TN == 0 && tlayer_smem(dil, cin_pad) <= 160 * 1024;
 }
 
-template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0>
+template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0, int PRIOV = 0>
 inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiResSkip::Args& oe, int n_rows, hipStream_t stream) {
-    auto kern = tlayer_kernel<NB, KG, NW, PF, NW2, DEFER>;
+    auto kern = tlayer_kernel<NB, KG, NW, PF, NW2, DEFER, PRIOV>;
     const size_t smem = tlayer_smem(ga.dil, ga.cin);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {
@@ -391,7 +402,7 @@ inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiR
 // gate weights `g` (taps 3, m_tiles C/16) + output-projection weights `o` (taps 1, m_tiles 2C/32) of ONE layer, as tgemm would get them
 template <int NW, int NW2 = NW>
 inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs& o, const TEpiResSkip::Args& oe, int C, int n_rows,
-                         int prefetch, hipStream_t stream, _Float16* gall = nullptr) {
+                         int prefetch, hipStream_t stream, _Float16* gall = nullptr, int priov = 0) {
     constexpr int KG = NW == 2 ? 4 : 8;
     if (g.taps != 3 || o.taps != 1 || g.m_tiles != C / 16 || o.m_tiles != 2 * C / 32 || g.cin != C || o.cin != C)
         return fail(DSVC_EINVAL, "tlayer: unexpected layer geometry");
@@ -414,6 +425,8 @@ inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs
         if (C == 384) return tlayer_launch_t<3, KG, NW, 0, NW2, 1>(a, cproj, oe, n_rows, stream);
         return tlayer_launch_t<2, KG, NW, 0, NW2, 1>(a, cproj, oe, n_rows, stream);
     }
+    if (C == 384 && priov == 1) return tlayer_launch_t<3, KG, NW, 0, NW2, 0, 1>(a, cproj, oe, n_rows, stream);
+    if (C == 384 && priov == 2) return tlayer_launch_t<3, KG, NW, 0, NW2, 0, 2>(a, cproj, oe, n_rows, stream);
     if constexpr (NW2 != NW) {                            // (the prefetch variant is not instantiated for the mixed kernel)
         if (C == 384) return tlayer_launch_t<3, KG, NW, 0, NW2>(a, cproj, oe, n_rows, stream);
         return tlayer_launch_t<2, KG, NW, 0, NW2>(a, cproj, oe, n_rows, stream);

@@ -12,10 +12,12 @@ from diffsvc_amd import _lib, synth
 _lib.use_profiling_build()
 from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16_w2"
+prio = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 hp = dict(synth.HPARAMS_44K)
 sd = synth.acoustic_state(hp, 0)
 den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=prec, prefix="denoise_fn.")
 smp = SamplerHandle(den, sd)
+den.debug_set("layer_prio", prio)
 cond = torch.randn(32, 256, 861, device="cuda") * 0.5
 smp.sample(cond, 24, seed=1, use_graph=False)
 torch.cuda.synchronize()
@@ -30,6 +32,7 @@ t0 = st[:, :, 0].min()
 rel = (st - t0) * 0.01                                     # us since the first wave of the launch entered
 names = ["entry", "prologue issued", "prologue landed", "barrier", "gate loop 0", "gate loop 1", "gate loop 2", "g complete",
          "out loop 0", "out stores 0", "out loop 1", "out stores 1", "out loop 2", "out stores 2", "stores acked"]
+print("layer_prio %d; " % prio, end="")
 print("%s, last layer of the chain (dilation 8), %d workgroups x 8 waves; us since the first wave's entry: mean [min .. max] | mean step" % (prec, g))
 prev = None
 for i, n in enumerate(names):

@@ -14,8 +14,12 @@ phase)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_phase_offset.py $p 128 >> $OUT/${TAG}_phase_offset.txt 2>&1; done; cat $OUT/${TAG}_phase_offset.txt ;;
 tailcheck)
   timeout 300 python tools/gpu_tail_check.py f16_w2 > $OUT/${TAG}_tail_check.txt 2>&1; cat $OUT/${TAG}_tail_check.txt ;;
+stamps2)
+  for q in 1 2; do timeout 300 python tools/gpu_layer_stamps.py f16_w2 $q >> $OUT/${TAG}_layer_stamps.txt 2>&1; done; cat $OUT/${TAG}_layer_stamps.txt ;;
 stamps)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_layer_stamps.py $p >> $OUT/${TAG}_layer_stamps.txt 2>&1; done; cat $OUT/${TAG}_layer_stamps.txt ;;
+prio)
+  for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_layer_prio.py $p 128 >> $OUT/${TAG}_layer_prio.txt 2>&1; done; cat $OUT/${TAG}_layer_prio.txt ;;
 defer)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_defer_ab.py $p 128 >> $OUT/${TAG}_defer_ab.txt 2>&1; done; cat $OUT/${TAG}_defer_ab.txt ;;
 spread)
