@@ -70,7 +70,7 @@ def dominant_kernel_roofline(handle, B, precision):
         roof = {"bound": "mfma", "kernel": "tgemm_kernel<TEpiGate> (dilated k=3 conv + hoisted cond projection + gate, one residual layer)",
                 "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_F16,
                 "avg_launch_us": us, "frames_per_launch": frames, "traffic": None,
-                "algorithmic_bytes": BYTES_PER_FRAME_GATE * frames + WEIGHT_BYTES_GATE}
+                "algorithmic_bytes": BYTES_PER_FRAME_GATE * frames + (2 if precision == "f16_w2" else 1) * WEIGHT_BYTES_GATE}
         tfile = {1: "gate_traffic.json", 32: "gate_traffic_b32.json"}.get(B)
     else:
         out_planes = 2 if (precision.startswith("f16_m") or precision == "f16_w2") else 1
