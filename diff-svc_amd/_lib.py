@@ -10,12 +10,13 @@ LIB_PATH = os.path.join(HERE, "libdsvc_hip.so")
 
 PREC_F16, PREC_F16_W2, PREC_F16_X3 = 0, 1, 2
 PREC_F16_MIX = 3
-PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3}
+PREC_F16_X3T = 4
+PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3, "f16_x3t": PREC_F16_X3T}
 ABI_VERSION = 5
 
 
 def parse_precision(p):
-    """'f16' | 'f16_w2' | 'f16_x3' | 'f16_dN' (fp16 operands, N time-dithered weight roundings) | 'f16_mN' (the same for the dilated
+    """'f16' | 'f16_w2' | 'f16_x3' | 'f16_x3t' (f16_x3's operand scheme on the tgemm engine) | 'f16_dN' (fp16 operands, N time-dithered weight roundings) | 'f16_mN' (the same for the dilated
     conv, exact hi+lo weights for the output 1x1) -> (enum, variants)."""
     if isinstance(p, (tuple, list)):
         return int(p[0]), int(p[1])

@@ -121,9 +121,23 @@ int tpack(TPacked& tp, const std::vector<float>& src, int O, int I, int taps, in
 
 // tiling choice of the tgemm path: 128-frame tiles x 8 waves when the batch fills the chip, otherwise 32-frame tiles
 // x 4 waves with the output-channel passes spread over blockIdx.y
-template <class Epi, int NW>
+template <class Epi, int NW, int NA = 1>
 int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hipStream_t st) {
     constexpr int KG = NW == 2 ? 4 : 8;                  // two planes: half the ring depth, same bytes in flight
+    if constexpr (NA == 2) {
+        // split activations (F16_X3T): rows are [hi | lo] planes, twice the LDS per frame -> 64-frame tiles for big batches, the same
+        // split-K / small-batch tilings otherwise
+        if (rows_alloc / 128 >= 48) {
+            const int tiles = rows_alloc / 64, passes = ceil_div(a.m_tiles, 8);
+            int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
+            return tgemm_launch<2, 8, 2, KG, NW, Epi, 1, 1, 2>(a, e, rows_alloc, ms, st);
+        }
+        const int tiles = rows_alloc / 32, passes = ceil_div(a.m_tiles, 4);
+        int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
+        if (tiles * ceil_div(a.m_tiles, 3) <= 256)
+            return tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 3, 2>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st);
+        return tgemm_launch<1, 4, 2, KG, NW, Epi, 1, 1, 2>(a, e, rows_alloc, ms, st);
+    }
     if (rows_alloc / 128 >= 48) {
         // (64-frame tiles x 4 waves, two workgroups per CU, measured 2.41 vs 2.22 ms per step: every weight is streamed twice as
         //  often and the gate kernel slows from 60 to 71 us -- profiles/r2c_ab.txt; not kept)
@@ -151,7 +165,11 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
 }
 
 template <class Epi>
-int tlaunch_prec(const TGemmArgs& a, const typename Epi::Args& e, int planes, int rows_alloc, hipStream_t st) {
+int tlaunch_prec(const TGemmArgs& a, const typename Epi::Args& e, int planes, int rows_alloc, hipStream_t st, int na = 1) {
+    if (na == 2) {
+        if (planes != 2) return fail(DSVC_EINVAL, "tgemm: split activations need hi + lo weight planes");
+        return tlaunch<Epi, 2, 2>(a, e, rows_alloc, st);
+    }
     return planes == 2 ? tlaunch<Epi, 2>(a, e, rows_alloc, st) : tlaunch<Epi, 1>(a, e, rows_alloc, st);
 }
 
@@ -169,6 +187,7 @@ struct dsvc_denoiser {
 
     // tgemm path (precision F16 [+ dither variants] and F16_W2): fp16 activation buffers, device-packed A fragments
     bool tpath = false;
+    int NA = 1;                       // activation planes of the two big contractions: 2 = split [hi | lo] rows (DSVC_PREC_F16_X3T)
     int Cp = 0, Mp = 0, guard = 8;
     TPacked in_t, skip_t, fin_t;
     TPacked skipall_t;                // deferred skip path (tskip.h): W_sp W_out,l[C:2C] / sqrt(L) for all layers as one [C x L*C] operand
@@ -210,8 +229,8 @@ struct dsvc_denoiser {
     }
 
     RowMap rowmap() const { return RowMap{Tp, rowclip.as<int>()}; }
-    _Float16* xh_row0() const { return xh.as<_Float16>() + (size_t)guard * Cp; }
-    _Float16* xh_buf(int i) const { return ((i & 1) ? xh2 : xh).as<_Float16>() + (size_t)guard * Cp; }
+    _Float16* xh_row0() const { return xh.as<_Float16>() + (size_t)guard * Cp * NA; }
+    _Float16* xh_buf(int i) const { return ((i & 1) ? xh2 : xh).as<_Float16>() + (size_t)guard * Cp * NA; }
 
     const std::vector<float>* get(const std::string& k, size_t numel) {
         auto it = host.find(k);
@@ -257,6 +276,7 @@ int dsvc_denoiser::finalize() {
     }
     // F16 (optionally time-dithered) and F16_W2 run on the tgemm engine; F16_X3 (split activations) on conv_gemm
     tpath = cfg.precision != DSVC_PREC_F16_X3;
+    NA = cfg.precision == DSVC_PREC_F16_X3T ? 2 : 1;
 #define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
     if (!tpath) {
         {
@@ -359,7 +379,7 @@ int dsvc_denoiser::finalize_t() {
     int max_dil = 1;
     for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     guard = round_up(max_dil, 8);
-    const int planes = cfg.precision == DSVC_PREC_F16_W2 ? 2 : 1;
+    const int planes = (cfg.precision == DSVC_PREC_F16_W2 || cfg.precision == DSVC_PREC_F16_X3T) ? 2 : 1;
     const int nvar = (planes == 1 && cfg.weight_variants > 1) ? cfg.weight_variants : 1;       // (F16 and F16_MIX)
 #define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
     {
@@ -460,14 +480,14 @@ int dsvc_denoiser::ensure_ws(int B, int T, hipStream_t st) {
     hipLaunchKernelGGL(k_build_rowclip, dim3(ceil_div(rows_alloc, 256)), dim3(256), 0, st, rowclip.as<int>(), lens.as<int>(), Tp, rows, rows_alloc);
     if (tpath) {
         // fp16 operands: zero once -- gap rows, guard rows and pad columns are never written afterwards
-        const size_t nxh = (r + 2 * (size_t)guard) * Cp * 2, nh = r * Cp * 2, ns = r * Mp * 2;
-        DSVC_TRY(xh.alloc(nxh)); DSVC_TRY(xh2.alloc(nxh)); DSVC_TRY(gh.alloc(nh));
+        const size_t nxh = (r + 2 * (size_t)guard) * Cp * 2 * NA, nh = r * Cp * 2, ns = r * Mp * 2;
+        DSVC_TRY(xh.alloc(nxh)); DSVC_TRY(xh2.alloc(nxh)); DSVC_TRY(gh.alloc(nh * NA));
         if (defer_skip && rows_alloc / 128 >= 48 && skipall_t.m_tiles > 0) {      // the fused-layer regime: every row is written by the gate epilogues before tskip reads it
             DSVC_TRY(gall.alloc((size_t)L * nh));
             DSVC_HIP(hipMemsetAsync(gall.p, 0, (size_t)L * nh, st));
         }
         DSVC_HIP(hipMemsetAsync(xh2.p, 0, nxh, st)); DSVC_TRY(skiph.alloc(2 * nh)); DSVC_TRY(s2h.alloc(2 * nh)); DSVC_TRY(xsh.alloc(2 * ns));
-        DSVC_HIP(hipMemsetAsync(xh.p, 0, nxh, st)); DSVC_HIP(hipMemsetAsync(gh.p, 0, nh, st)); DSVC_HIP(hipMemsetAsync(skiph.p, 0, 2 * nh, st));   // hi|lo planes
+        DSVC_HIP(hipMemsetAsync(xh.p, 0, nxh, st)); DSVC_HIP(hipMemsetAsync(gh.p, 0, nh * NA, st)); DSVC_HIP(hipMemsetAsync(skiph.p, 0, 2 * nh, st));   // hi|lo planes
         DSVC_HIP(hipMemsetAsync(s2h.p, 0, 2 * nh, st)); DSVC_HIP(hipMemsetAsync(xsh.p, 0, 2 * ns, st));
         DSVC_HIP(hipMemsetAsync(xres.p, 0, r * C * 4, st)); DSVC_HIP(hipMemsetAsync(skip.p, 0, r * C * 4, st));
         DSVC_HIP(hipMemsetAsync(condT.p, 0, r * H * 4, st)); DSVC_HIP(hipMemsetAsync(cproj.p, 0, r * 2 * C * L * 4, st));
@@ -586,7 +606,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
                            x_fm, xsh.as<_Float16>(), M, Mp, rm, rows);
     {   // K1: input projection + ReLU (net.py:120-123); emits layer 0's operand xh = fp16(x + film_0)
         TGemmArgs a = targs(xsh.as<_Float16>(), 2 * Mp, in_t, 1, 1);
-        TEpiInProj::Args e{xres.as<float>(), xh_row0(), in_t.bias.as<float>(), film.as<float>(), L * C, step, C, Cp, rm};
+        TEpiInProj::Args e{xres.as<float>(), xh_row0(), in_t.bias.as<float>(), film.as<float>(), L * C, step, C, Cp * NA, rm, NA == 2 ? Cp : 0};
         DSVC_TRY(tlaunch_prec<TEpiInProj>(a, e, 2, rows_alloc, st));
     }
     const int stop_after = dbg_stop_after;
@@ -599,16 +619,16 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         }
         {   // K5+K6 (+ hoisted K4, K3 already folded into xh): dilated conv, gate (net.py:67-77)
             TGemmArgs a = targs(xh_row0(), Cp, dil_t[l], 3, 1 << (l % cfg.dilation_cycle));
-            TEpiGate::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, gh.as<_Float16>(), C, Cp};
-            DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, dil_t[l].planes, rows_alloc, st));
+            TEpiGate::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, gh.as<_Float16>(), C, Cp * NA, NA == 2 ? Cp : 0};
+            DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, dil_t[l].planes, rows_alloc, st, NA));
         }
         {   // K7+K8: output projection, residual / skip (net.py:79-84,131) + next layer's FiLM (K3)
             const bool last = l + 1 == L;
             TGemmArgs a = targs(gh.as<_Float16>(), Cp, out_t[l], 1, 1);
             TEpiResSkip::Args e{xres.as<float>(), last ? nullptr : xh_row0(), skip.as<float>(), last ? skiph.as<_Float16>() : nullptr,
-                                out_t[l].bias.as<float>(), last ? nullptr : film.as<float>() + (size_t)(l + 1) * C, L * C, step, C, Cp,
-                                l == 0 ? 1 : 0, rm, stream_big};
-            DSVC_TRY(tlaunch_prec<TEpiResSkip>(a, e, out_t[l].planes, rows_alloc, st));
+                                out_t[l].bias.as<float>(), last ? nullptr : film.as<float>() + (size_t)(l + 1) * C, L * C, step, C, Cp * NA,
+                                l == 0 ? 1 : 0, rm, stream_big, NA == 2 ? Cp : 0};
+            DSVC_TRY(tlaunch_prec<TEpiResSkip>(a, e, out_t[l].planes, rows_alloc, st, NA));
         }
     }
     if (fused && defer_ok()) {   // K8 (skip halves of all layers) + K9a in one contraction over the stored gate outputs (tskip.h)
@@ -634,7 +654,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
 }
 
 bool dsvc_denoiser::fused_layer_ok() const {
-    if (dbg_two_launch || !tpath || rows_alloc / 128 < 48) return false;
+    if (dbg_two_launch || !tpath || NA != 1 || rows_alloc / 128 < 48) return false;
     int max_dil = 1;
     for (int l = 0; l < cfg.layers; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     return tlayer_supported(cfg.channels, Cp, max_dil, rows_alloc);
@@ -899,7 +919,7 @@ int dsvc_abi_version(void) { return DSVC_ABI_VERSION; }
 
 int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out) {
     if (!cfg || !out) return fail(DSVC_EINVAL, "null argument");
-    if (cfg->precision < DSVC_PREC_F16 || cfg->precision > DSVC_PREC_F16_MIX) return fail(DSVC_EINVAL, "unknown precision %d", cfg->precision);
+    if (cfg->precision < DSVC_PREC_F16 || cfg->precision > DSVC_PREC_F16_X3T) return fail(DSVC_EINVAL, "unknown precision %d", cfg->precision);
     int ndev = 0;
     DSVC_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(DSVC_EHIP, "no HIP device visible");
@@ -969,7 +989,7 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
     else if (n == "g") {
         if (d->tpath && d->defer_ok() && d->dbg_stop_after > 0) {       // deferred skip path: the layer kernels leave every layer's g in HBM
             hb = &d->gall; hld = d->Cp; hoff = (size_t)(d->dbg_stop_after - 1) * d->rows_alloc * d->Cp;
-        } else if (d->tpath) { hb = &d->gh; hld = d->Cp; } else b = &d->g;
+        } else if (d->tpath) { hb = &d->gh; hld = d->Cp * d->NA; } else b = &d->g;
         width = C;
     }
     else if (n == "skip") { b = &d->skip; width = C; }
@@ -978,7 +998,7 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
         hb = &d->gall; hld = d->Cp; width = C;
     }
     else if (n == "s2") { if (d->tpath) { hb = &d->s2h; hld = 2 * d->Cp; } else b = &d->s2; width = C; }
-    else if (n == "xh") { if (!d->tpath) return fail(DSVC_EINVAL, "'xh' exists on the tgemm path only"); hb = &d->xh; hld = d->Cp; hoff = (size_t)d->guard * d->Cp; width = C; }
+    else if (n == "xh") { if (!d->tpath) return fail(DSVC_EINVAL, "'xh' exists on the tgemm path only"); hb = &d->xh; hld = d->Cp * d->NA; hoff = (size_t)d->guard * d->Cp * d->NA; width = C; }
     else if (n == "eps") { b = &d->eps; width = M; }
     else if (n == "condT") { b = &d->condT; width = H; }
     else if (n == "cproj") { b = &d->cproj; width = 2 * C; }

@@ -85,6 +85,7 @@ struct TEpiGate {
                                 // folded in, pre-scaled like the weights (see gate_act_scaled)
         _Float16* g;            // [rows][ldg] fp16
         int C, ldg;
+        int lo_off;             // > 0: also store the lo plane fp16(g - fp16(g)) lo_off halfs into the row (split activations, tgemm NA = 2)
     };
     template <int NT_N>
     __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
@@ -102,10 +103,15 @@ struct TEpiGate {
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) {
             const int frame = row0 + 32 * nt + (lane & 31);
-            half8 o;
+            half8 o, ol;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) o[r] = (_Float16)gate_act_scaled(acc[nt][r], acc[nt][8 + r]);
+            for (int r = 0; r < 8; ++r) {
+                const float v = gate_act_scaled(acc[nt][r], acc[nt][8 + r]);
+                o[r] = (_Float16)v;
+                ol[r] = (_Float16)(v - (float)o[r]);
+            }
             *reinterpret_cast<half8*>(e.g + (size_t)frame * e.ldg + mt * 16 + 8 * (lane >> 5)) = o;
+            if (e.lo_off > 0) *reinterpret_cast<half8*>(e.g + (size_t)frame * e.ldg + e.lo_off + mt * 16 + 8 * (lane >> 5)) = ol;
         }
     }
 };
@@ -127,6 +133,7 @@ struct TEpiResSkip {
         RowMap rm;
         int stream;             // large batches: the fp32 residual / skip tiles are touched once per layer and do not fit any
                                 // cache -> non-temporal loads and stores (no dirty-line build-up to flush at the kernel boundary)
+        int xh_lo;              // > 0: xh rows are [hi | lo] planes (ldh halfs per row, lo plane xh_lo halfs in): split activations
     };
     template <int NT_N>
     __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
@@ -196,12 +203,16 @@ struct TEpiResSkip {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) hv[i] = 0.f;
                 }
-                half8 o0, o1;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)hv[i]; o1[i] = (_Float16)hv[8 + i]; }
                 _Float16* q = e.xh + (size_t)frame * e.ldh + cb;
-                *reinterpret_cast<half8*>(q) = o0;
-                *reinterpret_cast<half8*>(q + 8) = o1;
+                if (e.xh_lo > 0) {
+                    store_hi_lo16(q, e.xh_lo, hv);
+                } else {
+                    half8 o0, o1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)hv[i]; o1[i] = (_Float16)hv[8 + i]; }
+                    *reinterpret_cast<half8*>(q) = o0;
+                    *reinterpret_cast<half8*>(q + 8) = o1;
+                }
             }
             if (!res && e.skiph) {
                 int clip, tl;
@@ -221,6 +232,7 @@ struct TEpiInProj {
         float* x32; _Float16* xh;
         const float* bias; const float* film; int film_step_stride; StepRef step;
         int C, ldh; RowMap rm;
+        int xh_lo;              // > 0: xh rows are [hi | lo] planes, lo plane xh_lo halfs in (split activations)
     };
     template <int NT_N>
     __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
@@ -247,18 +259,25 @@ struct TEpiInProj {
             for (int q = 0; q < 4; ++q) st4(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
             int clip, tl;
             const bool ok = e.rm.valid(frame, clip, tl);
-            half8 o0, o1;
+            float hv[16];
             if (ok) {
                 const float* fp = e.film + (size_t)e.step.get(clip) * e.film_step_stride + cb;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)(v[i] + fp[i]); o1[i] = (_Float16)(v[8 + i] + fp[8 + i]); }
+                for (int i = 0; i < 16; ++i) hv[i] = v[i] + fp[i];
             } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)0.f; o1[i] = (_Float16)0.f; }
+                for (int i = 0; i < 16; ++i) hv[i] = 0.f;
             }
             _Float16* q = e.xh + (size_t)frame * e.ldh + cb;
-            *reinterpret_cast<half8*>(q) = o0;
-            *reinterpret_cast<half8*>(q + 8) = o1;
+            if (e.xh_lo > 0) {
+                store_hi_lo16(q, e.xh_lo, hv);
+            } else {
+                half8 o0, o1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)hv[i]; o1[i] = (_Float16)hv[8 + i]; }
+                *reinterpret_cast<half8*>(q) = o0;
+                *reinterpret_cast<half8*>(q + 8) = o1;
+            }
         }
     }
 };

@@ -87,9 +87,14 @@ __host__ __device__ inline int trow_to_ch8(int i) { return 8 * ((i >> 2) & 1) + 
 // KS > 1 (small batches only, one output tile per wave): the K loop of a tile is split over KS waves, which reduce through
 // LDS before the epilogue -- a lone wave per SIMD issues its loads, LDS reads and MFMAs strictly one after the other
 // (measured ~85 cycles per k-step), so at B = 1 the way to shorten a kernel is more waves per tile, not a better loop.
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1>
+// NA = 2 (round 3, the fp32-class scheme on this engine: DSVC_PREC_F16_X3T): the activation rows hold TWO fp16 planes [x_hi | x_lo] (row =
+// 2 * cin halfs, x_lo = fp16(x - x_hi)); a k-step issues W_hi x_hi + W_lo x_hi + W_hi x_lo (the 2^-22 W_lo x_lo term is dropped, as conv_gemm's
+// split scheme does): 3 MFMAs per product from the SAME weight fragments -- the weight stream, which is what bounds the small-batch
+// kernels, is that of f16_w2.
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1>
 __global__ void __launch_bounds__(64 * WAVES * KS, MINW) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
+    static_assert(NA == 1 || NW == 2, "split activations are combined with hi + lo weight planes");
     constexpr int TN = 32 * NT_N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -112,8 +117,9 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     stamp(0);
     const int halo = (a.taps >> 1) * a.dil;
     const int rows_lds = TN + 2 * halo;
-    const int chunks = a.cin >> 3;                       // 16-B chunks per row
-    const int row_bytes = a.cin * 2;
+    const int row_halfs = a.cin * NA;                    // NA = 2: [hi plane | lo plane]
+    const int chunks = row_halfs >> 3;                   // 16-B chunks per row
+    const int row_bytes = row_halfs * 2;
 
     // ---- stage the time tile: HBM/L2 -> LDS by DMA, swizzled on the source side ----
     {
@@ -121,10 +127,10 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         const int dq = (WAVES * KS * 64) / chunks, dr = (WAVES * KS * 64) - dq * chunks;
         int slot = wave_all * 64 + lane;
         int r = slot / chunks, c = slot - r * chunks;
-        const _Float16* xrow0 = a.x + (long long)(row0 - halo) * a.cin;
+        const _Float16* xrow0 = a.x + (long long)(row0 - halo) * row_halfs;
         for (int it = wave_all; it * 64 < total && !TG_DBG(a, 4); it += WAVES * KS) {
             const int rc = r < rows_lds ? r : rows_lds - 1;            // lanes past the tile re-read its last row
-            const _Float16* src = xrow0 + (long long)rc * a.cin + ((c ^ (rc & a.swz)) << 3);
+            const _Float16* src = xrow0 + (long long)rc * row_halfs + ((c ^ (rc & a.swz)) << 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(smem + it * 1024), 16, 0, 0);
             c += dr; r += dq;
@@ -177,13 +183,18 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         for (int nt = 0; nt < NT_N; ++nt) asm volatile("" : "+v"(base[nt]));
         // B fragments: BQ-deep software pipeline -- step kk computes from bq[kk % BQ] while steps kk+1 .. kk+BQ-1 are in flight
         constexpr int BQ = 2;                                          // (3- and 4-deep pipelines measured 3-4 % slower)
-        half8 bq[BQ][NT_N];
+        half8 bq[BQ][NT_N], bl[BQ][NA == 2 ? NT_N : 1];
+        const unsigned lo_off = (unsigned)a.cin * 2u;                  // the lo plane of a row starts cin halfs in: the swizzle only touches the low
+                                                                       // four chunk bits and cin / 8 is a multiple of 16, so lo = hi address + cin * 2
 #pragma unroll
         for (int d = 0; d < BQ - 1; ++d) {
             if (d < KG) {
                 const unsigned off = ((unsigned)d << 5) ^ xs;
 #pragma unroll
-                for (int nt = 0; nt < NT_N; ++nt) bq[d][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
+                for (int nt = 0; nt < NT_N; ++nt) {
+                    bq[d][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
+                    if constexpr (NA == 2) bl[d][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off + lo_off);
+                }
             }
         }
 #pragma unroll
@@ -191,31 +202,36 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
             if (kk + BQ - 1 < KG) {
                 const unsigned off = ((unsigned)(kk + BQ - 1) << 5) ^ xs;
 #pragma unroll
-                for (int nt = 0; nt < NT_N; ++nt) bq[(kk + BQ - 1) % BQ][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
+                for (int nt = 0; nt < NT_N; ++nt) {
+                    bq[(kk + BQ - 1) % BQ][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off);
+                    if constexpr (NA == 2) bl[(kk + BQ - 1) % BQ][nt] = *(lds_frag_ptr)(size_t)(base[nt] + off + lo_off);
+                }
             }
 #pragma unroll
             for (int nt = 0; nt < NT_N; ++nt) {
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][0], bq[kk % BQ][nt], acc[nt], 0, 0, 0);
                 if constexpr (NW == 2)
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][1], bq[kk % BQ][nt], acc[nt], 0, 0, 0);
+                if constexpr (NA == 2)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][0], bl[kk % BQ][nt], acc[nt], 0, 0, 0);
             }
         }
         // pin the software pipeline: left alone, the scheduler sinks every ds_read to just above its MFMA (register
         // pressure heuristic) and the wave then eats the full LDS latency once per MFMA
 #pragma unroll
         for (int d = 0; d < BQ - 1; ++d)
-            if (d < KG) __builtin_amdgcn_sched_group_barrier(0x100, NT_N, 0);         // B fragments of the first BQ-1 steps
+            if (d < KG) __builtin_amdgcn_sched_group_barrier(0x100, NT_N * NA, 0);    // B fragments of the first BQ-1 steps
 #pragma unroll
         for (int kk = 0; kk < KG; ++kk) {
             if constexpr (SCHED == 0) {                   // block form: all reads of step kk+1, then all MFMAs of step kk
-                if (kk + BQ - 1 < KG) __builtin_amdgcn_sched_group_barrier(0x100, NT_N, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NT_N * NW, 0);
+                if (kk + BQ - 1 < KG) __builtin_amdgcn_sched_group_barrier(0x100, NT_N * NA, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NT_N * (NW + NA - 1), 0);
             } else {                                       // 1:1 interleave (default, measured 1-3 % faster): one read of step kk+1
                                                            // behind each MFMA of step kk
 #pragma unroll
                 for (int nt = 0; nt < NT_N; ++nt) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, NW, 0);
-                    if (kk + BQ - 1 < KG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NW + NA - 1, 0);
+                    if (kk + BQ - 1 < KG) __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
                 }
             }
         }
@@ -403,7 +419,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
 }
 
 template <int NT_N>
-inline size_t tgemm_smem(int taps, int dil, int cin) {
+inline size_t tgemm_smem(int taps, int dil, int cin) {                 // cin = halfs per activation row (both planes when they are split)
     const size_t bytes = (size_t)(32 * NT_N + 2 * (taps / 2) * dil) * cin * 2;
     return (bytes + 1023) & ~(size_t)1023;               // whole 1 KiB DMA pieces
 }
@@ -439,18 +455,19 @@ inline void tstamp_dump(const char* prefix) {
 }
 
 // n_rows must be a multiple of 32*NT_N; m_split = number of blockIdx.y slices the output-channel passes are dealt over
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1>
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1>
 inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, int m_split, hipStream_t stream) {
     if (a.cin % (16 * KG) != 0) return fail(DSVC_EINVAL, "tgemm: cin %d not a multiple of %d", a.cin, 16 * KG);
     if (n_rows % (32 * NT_N) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N);
     if (a.w_planes != NW) return fail(DSVC_EINVAL, "tgemm: weights packed with %d plane(s), kernel streams %d", a.w_planes, NW);
-    a.swz = tgemm_swizzle_mask(a.cin);
+    a.swz = tgemm_swizzle_mask(a.cin * NA);
+    if (NA == 2 && (a.cin / 8) % 16 != 0) return fail(DSVC_EINVAL, "tgemm: split activations need cin %% 128 == 0 (got %d)", a.cin);
 #ifdef DSVC_PROFILING
     const char* dbg_s = getenv("DSVC_TG_DEBUG");           // profiling ablations only; results are WRONG when set
     a.dbg = dbg_s ? atoi(dbg_s) : 0;
 #endif
-    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS>;
-    const size_t smem = tgemm_smem<NT_N>(a.taps, a.dil, a.cin) + (size_t)(KS - 1) * WAVES * NT_N * 4096;
+    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS, NA>;
+    const size_t smem = tgemm_smem<NT_N>(a.taps, a.dil, a.cin * NA) + (size_t)(KS - 1) * WAVES * NT_N * 4096;
     if (smem > 160 * 1024) return fail(DSVC_EINVAL, "tgemm: %zu B of LDS requested", smem);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {

@@ -33,10 +33,14 @@ enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM
  *            average to w (time-dithered rounding, step t uses copy t % N): N = 64 measures ~7e-4, inside the bar.
  *            (measured over eight (clip, noise) pairs against the real reference: 7.8e-4 ... 1.27e-3, two of fourteen over -- NOT robustly inside the bar)
  *   F16_MIX: F16 with N dithered copies for the dilated conv, w = w_hi + w_lo for the output 1x1 (whose error goes straight
- *            into the residual stream and the skip sum): 6.7e-4 ... 9.7e-4 over fourteen pairs (all inside).  The shipped DDPM precision.
- *   F16_W2 : w = w_hi + w_lo, x fp16                   2 MFMAs              (6.2e-4 ... 7.3e-4 mel after 1000 steps)
- *   F16_X3 : w = w_hi + w_lo, x = x_hi + x_lo          3 MFMAs              (fp32-class, ~1e-5)           */
-enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2, DSVC_PREC_F16_MIX = 3 };
+ *            into the residual stream and the skip sum): 6.7e-4 ... 9.7e-4 on single clips, 1.14e-3 on one clip of a batch of 32
+ *            (over the bar): round 2's DDPM default, no longer shipped.
+ *   F16_W2 : w = w_hi + w_lo, x fp16                   2 MFMAs              (6.2e-4 ... 8.8e-4 mel after 1000 steps over 27 goldens;
+ *            2.3e-4 on conditioned checkpoints).  The shipped DDPM precision.
+ *   F16_X3 : w = w_hi + w_lo, x = x_hi + x_lo          3 MFMAs              (fp32-class, ~1e-5) on the conv_gemm engine
+ *   F16_X3T: the same operand scheme on the tgemm engine (activation rows hold [x_hi | x_lo] planes; the weight stream is F16_W2's):
+ *            the fp32-class scheme at the speed class of the small-batch tgemm kernels.                                       */
+enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2, DSVC_PREC_F16_MIX = 3, DSVC_PREC_F16_X3T = 4 };
 
 int dsvc_abi_version(void);
 const char* dsvc_last_error(void);
