@@ -1167,16 +1167,17 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
                 a.step_ptr = s->step_dev.as<int>(); a.step_off = 0; a.clip_rows = d->Tp;
                 TEpiResSkip::Args e{d->xres.as<float>(), last ? nullptr : d->xh_row0(), d->skip.as<float>(), last ? d->skiph.as<_Float16>() : nullptr,
                                     d->out_t[l].bias.as<float>(), last ? nullptr : d->film.as<float>() + (size_t)(l + 1) * C, L * C,
-                                    StepRef{s->step_dev.as<int>(), 0, 0}, C, d->Cp, l == 0 ? 1 : 0, d->rowmap(), d->rows_alloc >= 6144 ? 1 : 0};
-                DSVC_TRY(tlaunch_prec<TEpiResSkip>(a, e, d->out_t[l].planes, d->rows_alloc, st));
+                                    StepRef{s->step_dev.as<int>(), 0, 0}, C, d->Cp * d->NA, l == 0 ? 1 : 0, d->rowmap(), d->rows_alloc >= 6144 ? 1 : 0,
+                                    d->NA == 2 ? d->Cp : 0};
+                DSVC_TRY(tlaunch_prec<TEpiResSkip>(a, e, d->out_t[l].planes, d->rows_alloc, st, d->NA));
             } else if (d->tpath) {
                 TGemmArgs a{};
                 a.x = d->xh_row0(); a.cin = d->Cp; a.taps = 3; a.dil = 1 << (l % d->cfg.dilation_cycle);
                 a.w = d->dil_t[l].w.as<_Float16>(); a.m_tiles = d->dil_t[l].m_tiles; a.w_planes = d->dil_t[l].planes;
                 a.variant_halfs = (long long)d->dil_t[l].variant_halfs; a.n_variants = d->dil_t[l].n_variants;
                 a.step_ptr = s->step_dev.as<int>(); a.step_off = 0; a.clip_rows = d->Tp;
-                TEpiGate::Args e{d->cproj.as<float>() + (size_t)l * d->rows_alloc * 2 * C, d->gh.as<_Float16>(), C, d->Cp};
-                DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, d->dil_t[l].planes, d->rows_alloc, st));
+                TEpiGate::Args e{d->cproj.as<float>() + (size_t)l * d->rows_alloc * 2 * C, d->gh.as<_Float16>(), C, d->Cp * d->NA, d->NA == 2 ? d->Cp : 0};
+                DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, d->dil_t[l].planes, d->rows_alloc, st, d->NA));
             } else {
                 ConvGemmArgs a{};
                 a.x = d->xres.as<float>(); a.ldx = C; a.n_rows = d->rows; a.clip_stride = d->Tp; a.clip_len = d->wsT; a.clip_lens = d->lens.as<int>();

@@ -220,7 +220,8 @@ struct TEpiResSkip {
                 float hv[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) hv[i] = ok ? v[i] : 0.f;
-                store_hi_lo16(e.skiph + (size_t)frame * (2 * e.ldh) + cb, e.ldh, hv);
+                const int cp = e.xh_lo > 0 ? e.xh_lo : e.ldh;          // padded channel count (ldh is twice that when the xh rows are split)
+                store_hi_lo16(e.skiph + (size_t)frame * (2 * cp) + cb, cp, hv);
             }
         }
     }

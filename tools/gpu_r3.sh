@@ -23,6 +23,8 @@ prio)
 x3t)
   timeout 600 python tools/gpu_x3t_time.py > $OUT/${TAG}_x3t_time.txt 2>&1; cat $OUT/${TAG}_x3t_time.txt
   timeout 900 python -m pytest tests/test_gpu_diffnet.py tests/test_gpu_headline.py -q -k "x3t" -rP > $OUT/${TAG}_x3t_tests.txt 2>&1; grep -E "passed|failed|^sampler golden|^PLMS|^end to end" $OUT/${TAG}_x3t_tests.txt ;;
+bisect)
+  for a in tiny 44k; do timeout 300 python tools/gpu_x3t_bisect.py $a >> $OUT/${TAG}_bisect.txt 2>&1; done; cat $OUT/${TAG}_bisect.txt ;;
 defer)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_defer_ab.py $p 128 >> $OUT/${TAG}_defer_ab.txt 2>&1; done; cat $OUT/${TAG}_defer_ab.txt ;;
 spread)
