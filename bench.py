@@ -70,7 +70,8 @@ def dominant_kernel_roofline(handle, B, precision):
         roof = {"bound": "mfma", "kernel": "tgemm_kernel<TEpiGate> (dilated k=3 conv + hoisted cond projection + gate, one residual layer)",
                 "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_F16,
                 "avg_launch_us": us, "frames_per_launch": frames, "traffic": None,
-                "algorithmic_bytes": BYTES_PER_FRAME_GATE * frames + (2 if precision == "f16_w2" else 1) * WEIGHT_BYTES_GATE}
+                "algorithmic_bytes": ((814 * 2 + 3072 + 768 * 2) if precision == "f16_x3t" else BYTES_PER_FRAME_GATE) * frames
+                                     + (2 if precision in ("f16_w2", "f16_x3t") else 1) * WEIGHT_BYTES_GATE}
         tfile = {1: "gate_traffic.json", 32: "gate_traffic_b32.json"}.get(B)
     else:
         out_planes = 2 if (precision.startswith("f16_m") or precision == "f16_w2") else 1
@@ -275,8 +276,9 @@ def main():
         return
     pipe = SvcPipeline(hp, sd, vs, h, precision=args.precision, vocoder_precision="f16_x3")
 
-    prec = pipe.model.denoise_fn.precision_for("plms" if args.speedup > 1 else "ddpm", args.speedup)      # what the timed chain runs at
     B = args.clips_per_gpu if args.clips_per_gpu > 0 else (1 if world == 1 else 32)
+    # what the timed chain runs at: precision="auto" picks by sampler and by the size of the call (DiffNetHip.precision_for)
+    prec = pipe.model.denoise_fn.precision_for("plms" if args.speedup > 1 else "ddpm", args.speedup, frames=B * T_FRAMES)
     n_clips = B * world
     my_clips = shard_clips(n_clips, rank, world) if world > 1 else list(range(B))
     hub, m2p, f0 = make_inputs(my_clips, dev)
@@ -312,13 +314,15 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel (dilated conv + gate), HIP events on the launch stream ----
-        roof = dominant_kernel_roofline(pipe.model._handle("plms" if args.speedup > 1 else "ddpm", args.speedup), B, prec)
+        roof = dominant_kernel_roofline(pipe.model._handle("plms" if args.speedup > 1 else "ddpm", args.speedup, frames=B * T_FRAMES), B, prec)
         result = {
             "metric": "audio-sec/wall-sec (RTF) end-to-end 44.1kHz %d-step %s + NSF-HiFiGAN" % (
                 args.ddpm_steps, "DDPM" if args.speedup <= 1 else "PLMS/%d" % args.speedup),
             "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "dtype_detail": "fp16 MFMA operands (%s), fp32 accumulate, fp32 residual/skip/state" % prec, "data": "synthetic",
+            "dtype": "f16", "dtype_detail": "fp16 MFMA operands (%s%s), fp32 accumulate, fp32 residual/skip/state" % (
+                prec, ": hi + lo weight planes and split hi | lo activations, 3 MFMAs per product -- fp32-class" if prec.startswith("f16_x3") else ""),
+            "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: single 10 s clip per GPU, 44.1 kHz, full %d-step DDPM + NSF-HiFiGAN" % args.ddpm_steps) if B == 1 else
                                    ("BASELINE configs[3] share: %d x 10 s clips per GPU in one batch (%d clips over %d GPU(s)), 44.1 kHz, full %d-step DDPM "
                                     "+ NSF-HiFiGAN, gather of the PCM; the same per-GPU workload on 1 GPU is `batched.value` of the --gpus 1 line"
@@ -367,9 +371,10 @@ def main():
             torch.cuda.synchronize(); tb = time.perf_counter()
             pipe.infer(hb, mb, fb, seed=2)
             torch.cuda.synchronize(); tb = time.perf_counter() - tb
-            broof = dominant_kernel_roofline(pipe.model._handle("ddpm"), Bb, prec)
+            precb = pipe.model.denoise_fn.precision_for("ddpm", 1, frames=Bb * T_FRAMES)
+            broof = dominant_kernel_roofline(pipe.model._handle("ddpm", 1, frames=Bb * T_FRAMES), Bb, precb)
             result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
-                                 "clips_per_gpu": Bb, "precision": prec, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
+                                 "clips_per_gpu": Bb, "precision": precb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
                                  "s_per_batch": tb, "roofline": broof}
             # the sustained MFMA rate again, on the chip as the batched run leaves it (hot, clocks settled)
             sustained["after_batched"] = probe_mfma()
@@ -382,7 +387,7 @@ def main():
                     r_["frac_of_sustained"] = tf_ / sustained["cold"]["tflops"]       # MFMA side, against what the part holds on real data
                 if r_["bound"] == "hbm":
                     r_["frac_of_stream_copy"] = r_["achieved"] / 6290.0               # against the 6.29 TB/s a float4 copy reaches (MI355X_MICROARCH.md)
-            if FAST_SIDE and prec != FAST_SIDE:
+            if FAST_SIDE and precb != FAST_SIDE:
                 # the faster operand scheme beside the shipped one (not held to the <= 9.0e-4 bar on every golden: see DESIGN.md 4.2)
                 try:
                     pf = SvcPipeline(hp, sd, vs, h, precision=FAST_SIDE, vocoder_precision="f16_x3")
@@ -419,10 +424,10 @@ def main():
                 stages["host_round_trip_ms"] = timed(lambda: (mel1.cpu().numpy(), f01.cpu().numpy(), wav[:1].cpu().numpy()))
                 from diffsvc_amd.hubert import HubertSoftHip
                 from diffsvc_amd.pe import PitchExtractorHip
-                hb = HubertSoftHip(synth.hubert_state(11))
+                hsoft = HubertSoftHip(synth.hubert_state(11))
                 w16 = torch.from_numpy(synth.speech_like_wav(1, 160000)).to(dev)
-                stages["hubert_soft_ms"] = timed(lambda: hb.units(w16))
-                del hb
+                stages["hubert_soft_ms"] = timed(lambda: hsoft.units(w16))
+                del hsoft
                 hp24 = dict(synth.HPARAMS_24K)
                 pe = PitchExtractorHip(hparams=hp24).cuda()
                 pe.load_state_dict(synth.pe_state(hp24, 5))
@@ -434,19 +439,25 @@ def main():
                 result["stages"] = stages
             except Exception as ex:
                 result["stages"] = {"error": repr(ex)[:300]}
-        if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched and prec != "f16_x3":
-            # like-for-like operand precision with the fp32 reference: the same clip at f16_x3 (split fp16 operands, 3 MFMAs per
-            # product, 1e-5-class single evaluations) -- what the path costs when nothing is traded for the fp16 operand rounding
-            del pipe
-            torch.cuda.empty_cache()
-            pipe3 = SvcPipeline(hp, sd, vs, h, precision="f16_x3", vocoder_precision="f16_x3")
-            pipe3.infer(hub, m2p, f0, seed=3, clip_ids=clip_ids)
-            torch.cuda.synchronize(); t3 = time.perf_counter()
-            pipe3.infer(hub, m2p, f0, seed=4, clip_ids=clip_ids)
-            torch.cuda.synchronize(); t3 = time.perf_counter() - t3
-            result["fp32_class"] = {"precision": "f16_x3", "value": CLIP_SECONDS / t3, "unit": "audio-sec/wall-sec", "ms_per_clip": t3 * 1e3,
-                                    "workload": "BASELINE configs[1] at split-fp16 (fp32-class) operands"}
-            del pipe3
+        if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched:
+            # fp32-class operands (f16_x3t: split activations + hi/lo weights, 1e-5-class evaluations) where they are NOT the default: the
+            # 32-clip batch -- what the batched configuration costs when nothing is traded for the fp16 activation rounding
+            try:
+                pipe = None
+                torch.cuda.empty_cache()
+                pipe3 = SvcPipeline(hp, sd, vs, h, precision="f16_x3t", vocoder_precision="f16_x3")
+                pipe3.model.hp = dict(hp, K_step=30); pipe3.model.K_step = 30
+                pipe3.infer(hb, mb, fb, seed=1)
+                pipe3.model.K_step = args.ddpm_steps
+                torch.cuda.synchronize(); t3 = time.perf_counter()
+                pipe3.infer(hb, mb, fb, seed=2)
+                torch.cuda.synchronize(); t3 = time.perf_counter() - t3
+                result["fp32_class"] = {"precision": "f16_x3t", "batched_value": 32 * CLIP_SECONDS / t3, "unit": "audio-sec/wall-sec", "s_per_batch": t3,
+                                        "workload": "32 x 10 s clips in one batch at split-fp16 (fp32-class) operands; the single clip (`value`) "
+                                                    "runs at this precision by default"}
+                del pipe3
+            except Exception as ex:
+                result["fp32_class"] = {"error": repr(ex)[:300]}
         if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched:
             # BASELINE configs[4]: the training step (64 clips x 128 frames: diffusion loss forward + backward + clip + AdamW)
             try:

@@ -11,15 +11,16 @@ in libdsvc_hip.so.  Register it in the reference's seam with
 MFMA per product with N time-dithered weight roundings; ``"f16_mN"`` the same for the dilated conv with exact (hi + lo) weights for the
 output 1x1; ``"f16_x3"`` splits the activations as well (3 MFMAs, fp32-class).  The default ``"auto"`` picks per sampler:
 
-* DDPM: ``f16_w2``.  The maximum mel error of a 1000-step chain is a heavy-tailed statistic, so the shipped scheme is held to
-  <= 9.0e-4 (10 % under the 1e-3 bar) on EVERY real-reference golden of the benchmarked sizes -- 21 single-clip runs and three batches
-  of 32 (tests/test_gpu_headline.py).  f16_w2: worst 8.0e-4.  The faster f16_m64 (round 2's default) measures (8.0 +- 0.9)e-4 with
-  1.14e-3 on one clip of the batch of 32 -- over the bar, as its round-2 spread predicted -- and is no longer shipped
-  (profiles/r3_precision_spread.txt).
-* PLMS/PNDM, whose Adams-Bashforth extrapolation amplifies a single evaluation's rounding: the fp32-class ``f16_x3`` (1e-5); with fp16
-  activations even exact weights leave the 50-iteration chain at T=861 at (8.2 +- 1.2)e-4 over ten (clip, noise) pairs, one of them
-  at 1.08e-3 (profiles/r2w_precision_spread.txt), and f16_d64 at 3e-3; coarser schedules (20 iterations at pndm_speedup 50) need it
-  anyway (9e-3 with f16_w2, 1.2e-5 with f16_x3).
+* DDPM, up to ~13 ten-second clips per call (< ``BATCHED_FRAMES`` mel frames): ``f16_x3t`` -- fp32-class (hi + lo weights AND split
+  activations, 3 MFMAs) on the tgemm engine, whose small-batch kernels are bound by the weight stream, not by MFMAs: 0.415 ms per step for one
+  clip against 0.366 at f16_w2, and 3.3e-5 mel error after 1000 steps instead of 6e-4 ... 9e-4 (round 3; profiles/r3k_x3t_time.txt).
+* DDPM, larger batches (the fused layer kernel's regime): ``f16_w2`` -- exact weights, fp16 activations, 2 MFMAs; f16_x3t would cost 1.6x
+  there.  The maximum mel error of a 1000-step chain is a heavy-tailed statistic, so the scheme is held to <= 9.0e-4 on EVERY
+  real-reference golden of the batch of 32 (worst 8.0e-4; 21 single clips: worst 8.8e-4; conditioned checkpoints 2.3e-4).  The faster
+  f16_m64 (round 2's default) measured 1.14e-3 on one clip of that batch and is no longer shipped (profiles/r3_precision_spread.txt).
+* PLMS/PNDM, whose Adams-Bashforth extrapolation amplifies a single evaluation's rounding: ``f16_x3t`` (7e-6 on the 50-iteration golden
+  at T=861; 26 ms per 10 s clip).  With fp16 activations even exact weights leave that chain at (8.2 +- 1.2)e-4 over ten (clip, noise)
+  pairs, one of them at 1.08e-3 (profiles/r2w_precision_spread.txt).
 Inference only: there is no autograd through the HIP kernels, so
 ``infer=False`` training keeps using the reference module.
 """
@@ -52,7 +53,9 @@ class _ResidualBlockParams(nn.Module):
 
 
 class DiffNetHip(nn.Module):
-    AUTO = {"ddpm": "f16_w2", "plms": "f16_x3", "plms_coarse": "f16_x3", "forward": "f16_w2"}
+    AUTO = {"ddpm": "f16_x3t", "ddpm_batched": "f16_w2", "plms": "f16_x3t", "plms_coarse": "f16_x3t", "forward": "f16_x3t"}
+    BATCHED_FRAMES = 12000         # B * T from which a DDPM call takes the batched precision (~14 ten-second clips: where the fused layer kernel
+                                   # at f16_w2 overtakes the two-launch layer at f16_x3t)
 
     def __init__(self, in_dims=80, hparams=None, precision="auto"):
         super().__init__()
@@ -81,17 +84,20 @@ class DiffNetHip(nn.Module):
     def _params_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.precision,)
 
-    def precision_for(self, use, speedup=1):
-        """The operand precision used for ``use`` in {'ddpm', 'plms', 'forward'} (PLMS: also by its step interval)."""
+    def precision_for(self, use, speedup=1, frames=None):
+        """The operand precision used for ``use`` in {'ddpm', 'plms', 'forward'} (PLMS: also by its step interval; DDPM: also by the
+        call's size, ``frames`` = B * T)."""
         if self.precision != "auto":
             return self.precision
         if use == "plms" and speedup > 20:
             use = "plms_coarse"
+        if use == "ddpm" and frames is not None and frames >= self.BATCHED_FRAMES:
+            use = "ddpm_batched"
         return self.AUTO[use]
 
-    def handle(self, use="forward", speedup=1):
+    def handle(self, use="forward", speedup=1, frames=None):
         """The C handle for a use; rebuilt whenever a parameter tensor changes (load_state_dict, .to(), in-place edits)."""
-        prec = self.precision_for(use, speedup)
+        prec = self.precision_for(use, speedup, frames)
         key = self._params_key()
         cur = self._handles.get(prec)
         if cur is None or cur[1] != key:

@@ -75,10 +75,10 @@ class GaussianDiffusionHip(nn.Module):
         self.register_buffer("spec_max", torch.FloatTensor(spec_max)[None, None, :kb])
         self._samplers = {}            # 'ddpm' / 'plms' -> (SamplerHandle, key): the two loops may run at different precisions
 
-    def _handle(self, use="ddpm", speedup=1):
-        den = self.denoise_fn.handle(use, speedup)
+    def _handle(self, use="ddpm", speedup=1, frames=None):
+        den = self.denoise_fn.handle(use, speedup, frames)
         key = (id(den),) + tuple((b.data_ptr(), b._version) for b in self.buffers(recurse=False))
-        slot = self.denoise_fn.precision_for(use, speedup)
+        slot = self.denoise_fn.precision_for(use, speedup, frames)
         cur = self._samplers.get(slot)
         if cur is None or cur[1] != key:
             # a sampler handle keeps its denoiser handle (up to 3 GB of packed weights) alive: drop every slot whose denoiser handle
@@ -102,7 +102,7 @@ class GaussianDiffusionHip(nn.Module):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         speedup = hp.get("pndm_speedup") or 1
-        smp = self._handle("plms" if speedup > 1 else "ddpm", speedup)
+        smp = self._handle("plms" if speedup > 1 else "ddpm", speedup, frames=cond.shape[0] * cond.shape[2])
         x_init = ref = None
         if kwargs.get("use_gt_mel"):
             # diffusion.py:255-261: x = q_sample(norm_spec(ref_mels), t-1); norm_spec, q_sample and the noise draw (x_T Philox

@@ -287,9 +287,10 @@ def _spread():
     return out + list(spread_names())
 
 
-def _shipped():
+def _shipped(batched=False):
+    """What precision='auto' runs a DDPM call at: by size (DiffNetHip.precision_for)."""
     from diffsvc_amd.denoiser import DiffNetHip
-    return DiffNetHip.AUTO["ddpm"]
+    return DiffNetHip.AUTO["ddpm_batched" if batched else "ddpm"]
 
 
 def _clip_cond(hp, sd, clip, g):
@@ -305,7 +306,8 @@ def test_spread_of_single_clip_chains_vs_reference(which):
     round-2 extras): twelve (clip, noise) pairs on the random-init checkpoint -- among them (9, 1009), the round-2 precision's worst --
     and six on CONDITIONED checkpoints whose reference mel has < 1 % of its values on spec_min / spec_max (p_sample's clamp,
     diffusion.py:149-150, cannot hide an error there; the random-init goldens have 36 % of their values on it).  The shipped DDPM
-    precision (DiffNetHip.AUTO['ddpm']) must stay <= 9.0e-4 on EVERY one; the other schemes are measured beside it."""
+    precision (DiffNetHip.AUTO['ddpm'] -- since round 3 the fp32-class f16_x3t for calls of this size) must stay <= 9.0e-4 on EVERY one; the
+    other schemes are measured beside it (f16_w2, the batched precision, is held to the 1e-3 bar here too)."""
     precision = _shipped() if which == "shipped" else which
     if which != "shipped" and precision == _shipped():
         pytest.skip("is the shipped precision")
@@ -342,8 +344,8 @@ def test_batch_of_32_full_chain_every_clip_with_a_golden(ckpt, which):
     the fused layer kernel tlayer_kernel<3, .>), 1000 steps, at the shipped precision.  Clips 0..31 with seed 2026: EVERY clip of
     the batch that has a real-reference golden is checked (12 on the random-init checkpoint, 2 + 4 on the two conditioned ones).  The
     other operand schemes are measured beside the shipped one."""
-    precision = _shipped() if which == "shipped" else which
-    if which != "shipped" and precision == _shipped():
+    precision = _shipped(batched=True) if which == "shipped" else which
+    if which != "shipped" and precision == _shipped(batched=True):
         pytest.skip("is the shipped precision")
     from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
     from make_golden import SPREAD_CLIPS, SPREAD_COND, SPREAD_SEED

@@ -1,0 +1,32 @@
+"""Where precision="auto" should hand a DDPM call from f16_x3t (fp32-class) to f16_w2: ms per DDPM step of both over the clip count.
+   python tools/gpu_auto_sweep.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import diffsvc_amd
+from diffsvc_amd import synth
+from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
+hp = dict(synth.HPARAMS_44K)
+sd = synth.acoustic_state_conditioned(hp, 0, 1.5, 0.07)
+BS = (1, 2, 4, 6, 8, 10, 12, 14, 16, 20, 24, 32)
+res = {}
+for prec in ("f16_w2", "f16_x3t"):
+    den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=prec, prefix="denoise_fn.")
+    smp = SamplerHandle(den, sd)
+    for B in BS:
+        steps = max(24, 240 // B)
+        cond = torch.randn(B, 256, 861, device="cuda") * 0.5
+        smp.sample(cond, 25, seed=1, use_graph=True)
+        best = 1e9
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.time()
+            smp.sample(cond, steps, seed=2 + rep, use_graph=True)
+            torch.cuda.synchronize(); best = min(best, (time.time() - t0) / steps * 1e3)
+        res[(prec, B)] = best
+    del smp, den
+    torch.cuda.empty_cache()
+print("clips  frames   f16_w2 ms/step  f16_x3t ms/step  x3t/w2")
+for B in BS:
+    a, b = res[("f16_w2", B)], res[("f16_x3t", B)]
+    print("%5d %7d %14.3f %16.3f %7.2f" % (B, B * 861, a, b, b / a), flush=True)

@@ -29,6 +29,8 @@ defer)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_defer_ab.py $p 128 >> $OUT/${TAG}_defer_ab.txt 2>&1; done; cat $OUT/${TAG}_defer_ab.txt ;;
 spread)
   timeout 900 python -m pytest tests/test_gpu_headline.py -q -s -k "spread" > $OUT/${TAG}_spread.txt 2>&1; grep -E "^spread|passed|failed" $OUT/${TAG}_spread.txt ;;
+sweep)
+  timeout 600 python tools/gpu_auto_sweep.py > $OUT/${TAG}_auto_sweep.txt 2>&1; cat $OUT/${TAG}_auto_sweep.txt ;;
 overlap)
   timeout 120 tools/micro/overlap 4 > $OUT/${TAG}_overlap.txt 2>&1; echo "overlap rc=$?"; cat $OUT/${TAG}_overlap.txt ;;
 tests)
@@ -55,7 +57,7 @@ prof32)
   rm -rf $OUT/${TAG}_prof32; cat $OUT/${TAG}_prof32_bench.json; cd $ROOT ;;
 pmc1)
   cd /tmp
-  P=${PMCPREC:-f16_w2}
+  P=${PMCPREC1:-f16_x3t}
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc1_$c -o pmc -- python $ROOT/tools/prof_sampler.py 1 60 $P > $OUT/${TAG}_pmc1_$c.log 2>&1
   done
@@ -63,7 +65,7 @@ pmc1)
   rm -rf $OUT/${TAG}_pmc1_FETCH_SIZE $OUT/${TAG}_pmc1_WRITE_SIZE; cd $ROOT ;;
 pmc32)
   cd /tmp
-  P=${PMCPREC:-f16_w2}
+  P=${PMCPREC32:-f16_w2}
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc32_$c -o pmc -- python $ROOT/tools/prof_sampler.py 32 12 $P > $OUT/${TAG}_pmc32_$c.log 2>&1
   done
