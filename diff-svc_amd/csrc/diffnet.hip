@@ -210,7 +210,8 @@ struct dsvc_denoiser {
                                  // Measured at 32 clips (profiles/r3e_*): layer kernel 132 -> 123 us and 14 % fewer HBM bytes, but the skip
                                  // halves' MFMAs, which hide under the layer's memory-bound output phase, then cost 342 us per step as their
                                  // own kernel: the step time is unchanged (+-1 %).  Built, parity-tested, not the default.
-    bool dbg_two_launch = false; // run a residual layer as its two tgemm launches even where the fused kernel applies (bit-equality test)
+    int dbg_two_launch = 0;      // 1: run a residual layer as its two tgemm launches even where the fused kernel is the choice (bit-equality
+                                 // test); -1: the fused kernel wherever it is SUPPORTED (>= 48 tiles), not only where it is faster (>= 120)
     int* step_err = nullptr;     // host-mapped sticky flag: a dsvc_denoiser_forward call saw a diffusion step outside [0, max_steps)
     unsigned ws_gen = 0;  // bumped whenever the workspace is (re)built: captured graphs bake its pointers and are keyed on this
 
@@ -654,7 +655,10 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
 }
 
 bool dsvc_denoiser::fused_layer_ok() const {
-    if (dbg_two_launch || !tpath || NA != 1 || rows_alloc / 128 < 48) return false;
+    // one workgroup per 128-frame tile and no channel split: below ~120 tiles (18 x 10 s clips) the chip is better filled by the two
+    // launches with their output channels spread over blockIdx.y (profiles/r3l_auto_sweep.txt: 8 clips 1.11 vs 2.10 ms per step,
+    // 16 clips 2.05 vs 2.21, 20 clips 2.48 vs 2.32)
+    if (dbg_two_launch > 0 || !tpath || NA != 1 || rows_alloc / 128 < (dbg_two_launch < 0 ? 48 : 120)) return false;
     int max_dil = 1;
     for (int l = 0; l < cfg.layers; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     return tlayer_supported(cfg.channels, Cp, max_dil, rows_alloc);
@@ -1054,7 +1058,7 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     if (!d || !key) return fail(DSVC_EINVAL, "null argument");
     const std::string k(key);
     if (k == "stop_after_layers") d->dbg_stop_after = value;
-    else if (k == "two_launch_layer") d->dbg_two_launch = value != 0;
+    else if (k == "two_launch_layer") d->dbg_two_launch = value > 0 ? 1 : (value < 0 ? -1 : 0);
     else if (k == "layer_prio") d->layer_prio = value;
     else if (k == "defer_skip") {
         d->defer_skip = value != 0;

@@ -244,18 +244,37 @@ __global__ void k_loss(const float* __restrict__ eps, float* __restrict__ deps, 
     if (threadIdx.x == 0) atomicAdd(loss, red[0] * inv_n);
 }
 
-// dst[c] += sum over rows of src[row][c]   (bias gradients); grid (ceil(C/64), row chunks)
-__global__ void k_colsum(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld, int rows_per_block) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+// dst[c] += sum over rows of src[row][c]   (bias gradients); grid (ceil(C/256), row chunks): a thread owns four adjacent columns (one
+// 16-byte load per row) and every fourth row of the chunk, four loads in flight; C, ld % 4 == 0
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld, int rows_per_block) {
+    const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
     const int sub = threadIdx.x >> 6;                        // 4 row phases
     const int r0 = blockIdx.y * rows_per_block;
-    float s = 0.f;
-    if (c < C)
-        for (int r = r0 + sub; r < r0 + rows_per_block && r < rows; r += 4) s += src[(size_t)r * ld + c];
-    __shared__ float red[4][64];
-    red[sub][threadIdx.x & 63] = s;
+    const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (c < C) {
+        int r = r0 + sub;
+        for (; r + 4 < r1; r += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+            const float4 b = *reinterpret_cast<const float4*>(src + (size_t)(r + 4) * ld + c);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (r < r1) {
+            const float4 a = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    __shared__ float4 red[4][64];
+    red[sub][threadIdx.x & 63] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
     __syncthreads();
-    if (sub == 0 && c < C) atomicAdd(dst + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sub == 0 && c < C) {
+        const int i = threadIdx.x;
+        atomicAdd(dst + c + 0, red[0][i].x + red[1][i].x + red[2][i].x + red[3][i].x);
+        atomicAdd(dst + c + 1, red[0][i].y + red[1][i].y + red[2][i].y + red[3][i].y);
+        atomicAdd(dst + c + 2, red[0][i].z + red[1][i].z + red[2][i].z + red[3][i].z);
+        atomicAdd(dst + c + 3, red[0][i].w + red[1][i].w + red[2][i].w + red[3][i].w);
+    }
 }
 
 // dst[clip][c] = sum_t src[clip*stride + t][c]   (FiLM gradient); grid (ceil(C/64), B)
@@ -298,44 +317,55 @@ __global__ void k_relu_bwd(const float* __restrict__ in, const float* __restrict
         out[i] = mask[i] > 0.f ? in[i] : 0.f;
 }
 
-// small dense fp32 GEMM for the [B x C]-sized step-embedding path:  C[m][n] (+)= sum_k A(m,k) * B(k,n),
-// A(m,k) = ta ? A[k*lda + m] : A[m*lda + k],  B(k,n) = tb ? B[n*ldb + k] : B[k*ldb + n].  One thread per output.
-__global__ void k_gemm_small(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm, int M, int N, int K,
-                             int lda, int ldb, int ldc, int ta, int tb, int accumulate, const float* __restrict__ bias) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)M * N) return;
-    const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
-    float s = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float a = ta ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
-        const float b = tb ? Bm[(size_t)n * ldb + k] : Bm[(size_t)k * ldb + n];
-        s = fmaf(a, b, s);
-    }
-    if (bias) s += bias[n];
-    float* p = Cm + (size_t)m * ldc + n;
-    *p = accumulate ? *p + s : s;
-}
-
-// the per-layer [B x C] GEMMs of the step-embedding path (20 diffusion_projection layers: forward, weight gradient, input gradient)
-// as ONE launch: entry z = blockIdx.y has its own operand pointers (sum_batch: one entry that adds all of them up instead)
+// small dense fp32 GEMMs of the [B x C]-sized step-embedding path:  C[m][n] (+)= sum_k A(m,k) * B(k,n) (+ bias[n]),
+// A(m,k) = ta ? A[k*lda + m] : A[m*lda + k],  B(k,n) = tb ? B[n*ldb + k] : B[k*ldb + n].  64 x 64 output tiles, 16-deep k chunks staged
+// in LDS with the global loads running along whichever index is contiguous in memory (one thread per output with a stride-ldb operand
+// measured 357 us for the 20 diffusion projections); blockIdx.z walks a batch of independent problems (one per residual layer).
 struct SmallBatch { const float* A[32]; const float* B[32]; float* C[32]; const float* bias[32]; int n; };
-__global__ void k_gemm_small_b(const SmallBatch t, int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int sum_batch) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)M * N) return;
-    const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
-    const int z0 = sum_batch ? 0 : blockIdx.y, z1 = sum_batch ? t.n : z0 + 1;
-    float s = 0.f;
-    for (int z = z0; z < z1; ++z) {
-        const float* A = t.A[z];
-        const float* Bm = t.B[z];
-        for (int k = 0; k < K; ++k) {
-            const float a = ta ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
-            const float b = tb ? Bm[(size_t)n * ldb + k] : Bm[(size_t)k * ldb + n];
-            s = fmaf(a, b, s);
+__global__ __launch_bounds__(256) void k_gemm_small_b(const SmallBatch t, int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int accumulate) {
+    __shared__ float As[16][65], Bs[16][65];
+    const float* __restrict__ A = t.A[blockIdx.z];
+    const float* __restrict__ Bm = t.B[blockIdx.z];
+    float* __restrict__ Cm = t.C[blockIdx.z];
+    const float* __restrict__ bias = t.bias[blockIdx.z];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // thread -> outputs (m0 + ty + 16 i, n0 + tx + 16 j)
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            int kk, mm;
+            if (ta) { mm = e & 63; kk = e >> 6; } else { kk = e & 15; mm = e >> 4; }       // fastest index = the contiguous one
+            const int m = m0 + mm, k = k0 + kk;
+            As[kk][mm] = (m < M && k < K) ? (ta ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]) : 0.f;
+            int kb, nn;
+            if (tb) { kb = e & 15; nn = e >> 4; } else { nn = e & 63; kb = e >> 6; }
+            const int n = n0 + nn, k2 = k0 + kb;
+            Bs[kb][nn] = (n < N && k2 < K) ? (tb ? Bm[(size_t)n * ldb + k2] : Bm[(size_t)k2 * ldb + n]) : 0.f;
         }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty + 16 * i]; b[i] = Bs[kk][tx + 16 * i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
     }
-    if (t.bias[z0]) s += t.bias[z0][n];
-    t.C[z0][(size_t)m * ldc + n] = s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+            if (m < M && n < N) {
+                float v = acc[i][j] + (bias ? bias[n] : 0.f);
+                float* p = Cm + (size_t)m * ldc + n;
+                *p = accumulate ? *p + v : v;
+            }
+        }
 }
 
 // SinusoidalPosEmb (net.py:32-44) for the batch's steps
@@ -659,13 +689,17 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         a.cin = cin; a.taps = pk.taps; a.dil = dil; a.w = pk.w.as<_Float16>(); a.n_ctiles = pk.n_ctiles; a.w_planes = 2; a.in_slope = 1.0f;
         return a;
     };
+    auto small_b = [&](const SmallBatch& sb, int Mm, int N, int K, int lda, int ldb, int ldc, int tA, int tB, int acc) {
+        hipLaunchKernelGGL(k_gemm_small_b, dim3(ceil_div(N, 64), ceil_div(Mm, 64), sb.n), dim3(256), 0, st, sb, Mm, N, K, lda, ldb, ldc, tA, tB, acc);
+    };
     auto small = [&](const float* A, const float* Bm, float* Cm, int Mm, int N, int K, int lda, int ldb, int ldc, int tA, int tB, int acc,
                      const float* bias) {
-        const long long n = (long long)Mm * N;
-        hipLaunchKernelGGL(k_gemm_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, Bm, Cm, Mm, N, K, lda, ldb, ldc, tA, tB, acc, bias);
+        SmallBatch sb{};
+        sb.n = 1; sb.A[0] = A; sb.B[0] = Bm; sb.C[0] = Cm; sb.bias[0] = bias;
+        small_b(sb, Mm, N, K, lda, ldb, ldc, tA, tB, acc);
     };
     auto colsum = [&](const float* src, float* dst, int Cc, int ld) {
-        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(Cc, 64), ceil_div(nr, 512)), dim3(256), 0, st, src, dst, nr, Cc, ld, 512);
+        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(Cc, 256), ceil_div(nr, 64)), dim3(256), 0, st, src, dst, nr, Cc, ld, 64);
     };
     const int ew = 2048;
     // ---- step embedding: emb -> Linear -> Mish -> Linear -> per-layer diffusion_projection  (net.py:99-103,124-125,67) ----
@@ -681,7 +715,7 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
             const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
             sb.A[l] = e2.as<float>(); sb.B[l] = P(q + "weight"); sb.C[l] = filmB.as<float>() + (size_t)l * C; sb.bias[l] = P(q + "bias");
         }
-        hipLaunchKernelGGL(k_gemm_small_b, dim3(ceil_div(B * C, 256), L), dim3(256), 0, st, sb, B, C, C, C, C, L * C, 0, 1, 0);
+        small_b(sb, B, C, C, C, C, L * C, 0, 1, 0);
     } else for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
         small(e2.as<float>(), P(q + "weight"), filmB.as<float>() + (size_t)l * C, B, C, C, C, C, L * C, 0, 1, 0, P(q + "bias"));
@@ -809,26 +843,26 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
             const float* df = dfilm.as<float>() + (size_t)l * C;
             dw.A[l] = df; dw.B[l] = e2.as<float>(); dw.C[l] = G(q + "weight");                          // dWp[o][i] = sum_b dfilm[b][o] e2[b][i]
             dx2.A[l] = df; dx2.B[l] = P(q + "weight"); dx2.C[l] = de2.as<float>();                      // de2[b][i] = sum_l sum_o dfilm[b][o] Wp[o][i]
-            hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);   // dbp = sum_b dfilm[b]
+            hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);   // dbp = sum_b dfilm[b]
         }
-        hipLaunchKernelGGL(k_gemm_small_b, dim3(ceil_div(C * C, 256), L), dim3(256), 0, st, dw, C, C, B, L * C, C, C, 1, 0, 0);
+        small_b(dw, C, C, B, L * C, C, C, 1, 0, 0);
         // de2 = sum over the layers: per-layer partials into the (idle) weight-gradient scratch, then a fixed-order sum
         for (int l = 0; l < L; ++l) dx2.C[l] = wpart.as<float>() + (size_t)l * B * C;
-        hipLaunchKernelGGL(k_gemm_small_b, dim3(ceil_div(B * C, 256), L), dim3(256), 0, st, dx2, B, C, C, L * C, C, C, 0, 0, 0);
+        small_b(dx2, B, C, C, L * C, C, C, 0, 0, 0);
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, wpart.as<float>(), de2.as<float>(), L, B, C, C, 1LL, (long long)C, 0LL);
     } else for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
         const float* df = dfilm.as<float>() + (size_t)l * C;
         small(df, e2.as<float>(), G(q + "weight"), C, C, B, L * C, C, C, 1, 0, 0, nullptr);            // dWp[o][i] = sum_b dfilm[b][o] e2[b][i]
         small(df, P(q + "weight"), de2.as<float>(), B, C, C, L * C, C, C, 0, 0, 1, nullptr);           // de2[b][i] += sum_o dfilm[b][o] Wp[o][i]
-        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);   // dbp = sum_b dfilm[b]
+        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);   // dbp = sum_b dfilm[b]
     }
     small(de2.as<float>(), e1.as<float>(), G("denoise_fn.mlp.2.weight"), C, 4 * C, B, C, 4 * C, 4 * C, 1, 0, 0, nullptr);
-    hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, de2.as<float>(), G("denoise_fn.mlp.2.bias"), B, C, C, B);
+    hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, de2.as<float>(), G("denoise_fn.mlp.2.bias"), B, C, C, B);
     small(de2.as<float>(), P("denoise_fn.mlp.2.weight"), de1.as<float>(), B, 4 * C, C, C, 4 * C, 4 * C, 0, 0, 0, nullptr);
     hipLaunchKernelGGL(k_mish_bwd, dim3(ceil_div(B * 4 * C, 256)), dim3(256), 0, st, e1pre.as<float>(), de1.as<float>(), de1pre.as<float>(), (size_t)B * 4 * C);
     small(de1pre.as<float>(), e0.as<float>(), G("denoise_fn.mlp.0.weight"), 4 * C, C, B, 4 * C, C, C, 1, 0, 0, nullptr);
-    hipLaunchKernelGGL(k_colsum, dim3(ceil_div(4 * C, 64), 1), dim3(256), 0, st, de1pre.as<float>(), G("denoise_fn.mlp.0.bias"), B, 4 * C, 4 * C, B);
+    hipLaunchKernelGGL(k_colsum, dim3(ceil_div(4 * C, 256), 1), dim3(256), 0, st, de1pre.as<float>(), G("denoise_fn.mlp.0.bias"), B, 4 * C, 4 * C, B);
     // ---- pitch embedding (through cond) ----
     if (ta->pitch) {
         const size_t n = (size_t)B * T * H;

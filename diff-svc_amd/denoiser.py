@@ -11,13 +11,14 @@ in libdsvc_hip.so.  Register it in the reference's seam with
 MFMA per product with N time-dithered weight roundings; ``"f16_mN"`` the same for the dilated conv with exact (hi + lo) weights for the
 output 1x1; ``"f16_x3"`` splits the activations as well (3 MFMAs, fp32-class).  The default ``"auto"`` picks per sampler:
 
-* DDPM, up to ~13 ten-second clips per call (< ``BATCHED_FRAMES`` mel frames): ``f16_x3t`` -- fp32-class (hi + lo weights AND split
-  activations, 3 MFMAs) on the tgemm engine, whose small-batch kernels are bound by the weight stream, not by MFMAs: 0.415 ms per step for one
-  clip against 0.366 at f16_w2, and 3.3e-5 mel error after 1000 steps instead of 6e-4 ... 9e-4 (round 3; profiles/r3k_x3t_time.txt).
-* DDPM, larger batches (the fused layer kernel's regime): ``f16_w2`` -- exact weights, fp16 activations, 2 MFMAs; f16_x3t would cost 1.6x
-  there.  The maximum mel error of a 1000-step chain is a heavy-tailed statistic, so the scheme is held to <= 9.0e-4 on EVERY
-  real-reference golden of the batch of 32 (worst 8.0e-4; 21 single clips: worst 8.8e-4; conditioned checkpoints 2.3e-4).  The faster
-  f16_m64 (round 2's default) measured 1.14e-3 on one clip of that batch and is no longer shipped (profiles/r3_precision_spread.txt).
+* DDPM, up to 6 ten-second clips per call (< ``BATCHED_FRAMES`` mel frames): ``f16_x3t`` -- fp32-class (hi + lo weights AND split
+  activations, 3 MFMAs) on the tgemm engine.  The small-batch kernels are bound by the weight stream and by latency, not by MFMAs, so the
+  third MFMA costs 14 ... 20 % there (0.418 ms per step for one clip against 0.366 at f16_w2) and buys 3.3e-5 ... 4.9e-5 mel error after 1000
+  steps on every real-reference golden instead of 6e-4 ... 9e-4 (round 3; profiles/r3l_auto_sweep.txt, r3l_pytest_gpu.txt).
+* DDPM, larger calls: ``f16_w2`` -- exact weights, fp16 activations, 2 MFMAs; f16_x3t costs 1.5 ... 1.9x there.  The maximum mel error
+  of a 1000-step chain is a heavy-tailed statistic, so the scheme is held to <= 9.0e-4 on EVERY real-reference golden of the batch of
+  32 (worst 8.0e-4; 21 single clips: worst 8.8e-4; conditioned checkpoints 2.3e-4).  The faster f16_m64 (round 2's default) measured
+  1.14e-3 on one clip of that batch and is no longer shipped (profiles/r3_precision_spread.txt).
 * PLMS/PNDM, whose Adams-Bashforth extrapolation amplifies a single evaluation's rounding: ``f16_x3t`` (7e-6 on the 50-iteration golden
   at T=861; 26 ms per 10 s clip).  With fp16 activations even exact weights leave that chain at (8.2 +- 1.2)e-4 over ten (clip, noise)
   pairs, one of them at 1.08e-3 (profiles/r2w_precision_spread.txt).
@@ -54,8 +55,8 @@ class _ResidualBlockParams(nn.Module):
 
 class DiffNetHip(nn.Module):
     AUTO = {"ddpm": "f16_x3t", "ddpm_batched": "f16_w2", "plms": "f16_x3t", "plms_coarse": "f16_x3t", "forward": "f16_x3t"}
-    BATCHED_FRAMES = 12000         # B * T from which a DDPM call takes the batched precision (~14 ten-second clips: where the fused layer kernel
-                                   # at f16_w2 overtakes the two-launch layer at f16_x3t)
+    BATCHED_FRAMES = 6000          # B * T from which a DDPM call takes the batched precision (7 ten-second clips: f16_x3t costs +14 ... 20 % below
+                                   # that and +50 ... 90 % above, profiles/r3l_auto_sweep.txt)
 
     def __init__(self, in_dims=80, hparams=None, precision="auto"):
         super().__init__()

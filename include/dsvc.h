@@ -93,8 +93,9 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
 int dsvc_denoiser_check(dsvc_denoiser* d, void* stream);
 
 /* test support (explicit handle state; the library reads no environment variable): "stop_after_layers" = n >= 0 makes an evaluation
- * return after n residual layers so that dsvc_denoiser_debug_buffer taps layer n-1 (-1 = off); "two_launch_layer" != 0 runs a residual
- * layer as its two tgemm launches where the fused layer kernel would apply (bit-equality test of the two forms); "defer_skip" != 0 makes
+ * return after n residual layers so that dsvc_denoiser_debug_buffer taps layer n-1 (-1 = off); "two_launch_layer" = 1 runs a residual
+ * layer as its two tgemm launches even where the fused layer kernel is the automatic choice, -1 runs the fused kernel wherever it is
+ * supported (>= 48 frame tiles) and not only where it is faster (>= 120 tiles), 0 = automatic (bit-equality test of the two forms); "defer_skip" != 0 makes
  * the fused layer kernels write the gate output to HBM and leave the skip halves of all layers to ONE contraction per evaluation with
  * pre-composed skip-projection weights (csrc/tskip.h: 14 % fewer HBM bytes per layer, measured time-neutral; default off). */
 int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);

@@ -11,8 +11,10 @@ hp = dict(synth.HPARAMS_44K)
 sd = synth.acoustic_state_conditioned(hp, 0, 1.5, 0.07)
 BS = (1, 2, 4, 6, 8, 10, 12, 14, 16, 20, 24, 32)
 res = {}
-for prec in ("f16_w2", "f16_x3t"):
-    den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=prec, prefix="denoise_fn.")
+for prec in ("f16_w2", "f16_w2/two-launch", "f16_x3t"):
+    den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=prec.split("/")[0], prefix="denoise_fn.")
+    if "/" in prec:
+        den.debug_set("two_launch_layer", 1)       # the layer as gate + output launches (channel passes over blockIdx.y) at every size
     smp = SamplerHandle(den, sd)
     for B in BS:
         steps = max(24, 240 // B)
@@ -26,7 +28,7 @@ for prec in ("f16_w2", "f16_x3t"):
         res[(prec, B)] = best
     del smp, den
     torch.cuda.empty_cache()
-print("clips  frames   f16_w2 ms/step  f16_x3t ms/step  x3t/w2")
+print("clips  frames   f16_w2 ms/step  w2 two-launch  f16_x3t ms/step  x3t/min(w2)")
 for B in BS:
-    a, b = res[("f16_w2", B)], res[("f16_x3t", B)]
-    print("%5d %7d %14.3f %16.3f %7.2f" % (B, B * 861, a, b, b / a), flush=True)
+    a, a2, b = res[("f16_w2", B)], res[("f16_w2/two-launch", B)], res[("f16_x3t", B)]
+    print("%5d %7d %14.3f %14.3f %16.3f %9.2f" % (B, B * 861, a, a2, b, b / min(a, a2)), flush=True)

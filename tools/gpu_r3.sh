@@ -29,6 +29,13 @@ defer)
   for p in f16_w2 f16_m64; do timeout 300 python tools/gpu_defer_ab.py $p 128 >> $OUT/${TAG}_defer_ab.txt 2>&1; done; cat $OUT/${TAG}_defer_ab.txt ;;
 spread)
   timeout 900 python -m pytest tests/test_gpu_headline.py -q -s -k "spread" > $OUT/${TAG}_spread.txt 2>&1; grep -E "^spread|passed|failed" $OUT/${TAG}_spread.txt ;;
+train)
+  timeout 600 python -m pytest tests/test_gpu_train.py -q -rP > $OUT/${TAG}_train_tests.txt 2>&1; grep -E "passed|failed|^train|^optimizer" $OUT/${TAG}_train_tests.txt
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_proft -o bench -- python $ROOT/bench.py --train --steps 5 --warmup 2 > $OUT/${TAG}_train_bench.json 2> $OUT/${TAG}_train.err
+  F=$(find $OUT/${TAG}_proft -name "*kernel_stats.csv" | head -1)
+  [ -n "$F" ] && head -40 "$F" > $OUT/${TAG}_kernel_stats_train.csv && cut -c1-200 $OUT/${TAG}_kernel_stats_train.csv | head -24
+  rm -rf $OUT/${TAG}_proft; cat $OUT/${TAG}_train_bench.json; cd $ROOT ;;
 sweep)
   timeout 600 python tools/gpu_auto_sweep.py > $OUT/${TAG}_auto_sweep.txt 2>&1; cat $OUT/${TAG}_auto_sweep.txt ;;
 overlap)

@@ -18,6 +18,7 @@ spec = torch.from_numpy(g.standard_normal((B, 1, M, T)).astype(np.float32)).cuda
 cond = torch.from_numpy((g.standard_normal((B, 256, T)) * 0.5).astype(np.float32)).cuda()
 t = torch.from_numpy(g.integers(0, 1000, size=(B,))).cuda()
 Tp = (T + 8 + 31) // 32 * 32
+den.debug_set("two_launch_layer", -1)
 den.debug_set("defer_skip", 1)
 out_d = den.forward(spec, t, cond).cpu()
 gall = den.debug_buffer("gall").cpu().double()              # [L * rows, C]
