@@ -10,9 +10,11 @@
 //   forward   y = conv_dil(x + film) + W_c cond + b ;  g = sigmoid(y_a) tanh(y_b) ;  [r; s] = W_o g + b ;  x' = (x + r)/sqrt2 ; skip += s
 //             (sigma, tau, g and every layer's x are kept: ~1.3 GB for the 64 x 128-frame batch)
 //   backward  dO = [dx/sqrt2 ; dskip] ;  dg = W_o^T dO ;  dy = dg (tau sigma(1-sigma) ; sigma(1-tau^2)) ;  dx = dx/sqrt2 + convT(dy) ;
-//             dcond += W_c^T dy ;  weight gradients dW[o][k] = sum_n A[n][o] B[n][k] as the SAME engine on transposed operands:
-//             A^T is packed into MFMA weight fragments on the device (k_pack_cols), B^T is a transposed copy (k_transpose), the
-//             contraction index is the frame index.
+//             dcond += W_c^T dy ;  weight gradients dW[o][k] = sum_n A[n][o] B[n][k] on channel-major fp16 hi|lo planes of both
+//             operands (wgrad.h: k_split_t + wgrad_nt_kernel; the contraction index is the frame index).
+//   loss scaling: d loss / d eps is ~1/(B M T) ~ 1e-6, inside fp16's SUBNORMAL range where a hi + lo split keeps 4 bits; the backward
+//             pass is linear in it, so it runs on deps * 2^k (k chosen from 1/(B M T): operands in fp16's normal range) and the flat
+//             gradient buffer is multiplied by 2^-k once at the end -- exact, powers of two.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,6 +25,7 @@
 
 #include "../../include/dsvc.h"
 #include "cg_util.h"
+#include "wgrad.h"
 
 using namespace dsvc;
 
@@ -111,26 +114,7 @@ struct EpBwd {
     }
 };
 
-// weight gradient: the GEMM ran on transposed operands, "row" = input channel k, "col" = output channel o
-struct EpWgrad {
-    static constexpr bool PAIRED = false;
-    struct Args { float* dst; long long stride_o, stride_k, off; int n_o; };
-    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
-        if (col >= e.n_o) return;
-        e.dst[(long long)col * e.stride_o + (long long)row * e.stride_k + e.off] = v;
-    }
-};
-
-// the same GEMM cut into k-slices over blockIdx.y (conv_gemm's k_slices): slice s parks its partial tile in part[s][row][col]
-constexpr int WGRAD_MAX_TILES = 448;     // k-slices x output tiles of a sliced weight-gradient GEMM (workgroups per launch)
-
-struct EpWgradPart {
-    static constexpr bool PAIRED = false;
-    struct Args { float* part; int n_k, ld; };
-    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
-        e.part[((size_t)blockIdx.y * e.n_k + row) * e.ld + col] = v;
-    }
-};
+constexpr int WGRAD_MAX_TILES = 288;     // frame slices x output tiles of one weight-gradient GEMM (workgroups per launch; 128 KB of scratch each)
 
 // ------------------------------------------------------------------------------------------------
 // small kernels
@@ -144,29 +128,6 @@ __global__ void k_wgrad_reduce(const float* __restrict__ part, float* __restrict
     float s = 0.f;
     for (int z = 0; z < n_slices; ++z) s += part[((size_t)z * n_k + row) * ld + col];
     dst[(long long)col * stride_o + (long long)row * stride_k + off] = s;
-}
-
-// transpose with optional additive per-clip vector (film) and validity mask:  dst[c][pad + n] = valid(n) ? src[n][c] + add[clip][c] : 0
-// dst is [C][ld] with ld >= rows + 2*pad; the pad columns are zeroed once at allocation.
-__global__ void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld, int pad,
-                            const float* __restrict__ add, int add_stride, int clip_stride, int clip_len, int n_valid, int shift) {
-    __shared__ float tile[32][33];
-    const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) {
-        const int n = n0 + i + shift, c = c0 + tx;          // column n0+i of the output holds source row n0+i+shift (a conv tap)
-        float v = 0.f;
-        if (n >= 0 && n < n_valid && c < C) {
-            const int clip = n / clip_stride;
-            if (n - clip * clip_stride < clip_len) v = src[(size_t)n * C + c] + (add ? add[(size_t)clip * add_stride + c] : 0.f);
-        }
-        tile[i][tx] = v;
-    }
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-        const int c = c0 + i, n = n0 + tx;
-        if (c < C && n < rows) dst[(size_t)c * ld + pad + n] = tile[tx][i];
-    }
 }
 
 // [B, C, T] (reference layout) -> frame-major [B*stride][C] on valid rows (gap rows stay zero)
@@ -216,7 +177,7 @@ __global__ void k_make_xt(const float* __restrict__ mel, float* __restrict__ xt,
 
 // loss (diffusion.py:213-223) and its gradient w.r.t. eps on valid rows: l1 mean |noise - eps|, l2 mean (noise - eps)^2
 __global__ void k_loss(const float* __restrict__ eps, float* __restrict__ deps, float* __restrict__ loss, int B, int T, int M, int stride,
-                       unsigned long long seed, const int* __restrict__ clipid, int l1, float inv_n) {
+                       unsigned long long seed, const int* __restrict__ clipid, int l1, float inv_n, float gscale) {
     const int quads = T * M / 4;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
@@ -229,8 +190,8 @@ __global__ void k_loss(const float* __restrict__ eps, float* __restrict__ deps, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float d = eps[o + i] - z[i];
-            if (l1) { part += fabsf(d); deps[o + i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_n; }
-            else { part += d * d; deps[o + i] = 2.0f * d * inv_n; }
+            if (l1) { part += fabsf(d); deps[o + i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (inv_n * gscale); }
+            else { part += d * d; deps[o + i] = 2.0f * d * (inv_n * gscale); }
         }
     }
     // block reduction -> one atomic per block
@@ -309,6 +270,18 @@ __global__ void k_copy_cols(const float* __restrict__ src, float* __restrict__ d
         const int row = (int)(i / C), c = (int)(i - (size_t)row * C);
         dst[(size_t)row * ld_dst + off + c] = src[i] * scale;
     }
+}
+
+// p[i] *= scale (the loss scale leaves the gradients: a power of two, exact); n % 4 == 0 is not required
+__global__ void k_scale_inplace(float* __restrict__ p, size_t n, float scale) {
+    const size_t n4 = n / 4;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = p4[i];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        p4[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] *= scale;
 }
 
 // out[i] = in[i] * (mask[i] > 0)
@@ -475,21 +448,23 @@ struct dsvc_trainer {
     int n_spec = 0;
 
     // workspace for (B, T)
-    int wsB = 0, wsT = 0, Tp = 0, rows = 0, nr = 0, padc = 64;      // nr = B*Tp data rows; rows = nr rounded up to 128
-    DevBuf xt, xs, sig, tau, g, skip, ypre, s2pre, eps, deps, condT, condTT, tstep, clipid, iotaB;
+    int wsB = 0, wsT = 0, Tp = 0, rows = 0, nr = 0;                 // nr = B*Tp data rows; rows = nr rounded up to 128
+    int ldT = 0, a_rows = 0, b_rows = 0, cp128 = 0, hp128 = 0;      // operand planes of the weight-gradient GEMMs (wgrad.h)
+    float loss_scale = 1.0f;                                        // 2^k the backward pass is scaled by (see the header)
+    DevBuf xt, xs, sig, tau, g, skip, ypre, s2pre, eps, deps, condT, tstep, clipid, iotaB;
     DevBuf e0, e1pre, e1, e2, filmB, dfilm, de2, de1, de1pre;
-    DevBuf dx, dxin, dO, dy, ds2pre, dcond, dh0, TT, loss;
-    DevBuf packA;                                  // activation-as-weights fragments for the weight-gradient GEMMs
-    DevBuf wpart;                                  // k-slice partial tiles of one weight-gradient GEMM
+    DevBuf dx, dxin, dO, dy, ds2pre, dcond, dh0, loss;
+    DevBuf AT, BT;                                 // dY^T and X^T as channel-major fp16 hi|lo planes: [2][a_rows | b_rows][ldT]
+    DevBuf wpart;                                  // frame-slice partial tiles of one weight-gradient GEMM
     // per-step repacked weights
     Packed w_in, w_skip, w_fin, w_finT, w_skipT;
     std::vector<Packed> w_d, w_c, w_o, w_oT, w_cT, w_dT;
     DevBuf gatemap;                                // packed column -> conv channel of the paired gate layout
 
     ~dsvc_trainer() {
-        for (DevBuf* b : {&sa, &sb, &spec_min, &spec_max, &xt, &xs, &sig, &tau, &g, &skip, &ypre, &s2pre, &eps, &deps, &condT, &condTT, &tstep,
+        for (DevBuf* b : {&sa, &sb, &spec_min, &spec_max, &xt, &xs, &sig, &tau, &g, &skip, &ypre, &s2pre, &eps, &deps, &condT, &tstep,
                           &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre, &dcond,
-                          &dh0, &TT, &loss, &packA, &wpart, &gatemap})
+                          &dh0, &loss, &AT, &BT, &wpart, &gatemap})
             b->release();
         auto rel = [](Packed& p) { p.w.release(); };
         rel(w_in); rel(w_skip); rel(w_fin); rel(w_finT); rel(w_skipT);
@@ -506,10 +481,10 @@ struct dsvc_trainer {
     int pack(Packed& pk, const float* src, const int* colmap, int cout_pad, int taps, int cin, int cout, long long s_col, long long s_ci,
              long long s_tap, int flip, float scale, hipStream_t st);
     int repack(hipStream_t st);
-    // dW[o][k] = sum_n A[n][o] * Bsrc[n + shift][k]: A [rows x O] (ldA = O), Bsrc [rows x K]; writes dst[o*stride_o + k*stride_k + off]
-    int wgrad(const float* A, int O, const float* BT, int K, int shift, float* dst, long long stride_o, long long stride_k, long long off,
-              bool repack_a, hipStream_t st);
-    int transpose(const float* src, int C, const float* add, int add_stride, int shift, hipStream_t st);
+    // operand planes: rows [row0, row0 + C) of AT (a_side) or BT <- src[n + shift][0..C) (+ add[clip]) on real frames, 0 elsewhere
+    int split_t(bool a_side, int row0, const float* src, int ld_src, int C, const float* add, int add_stride, int shift, hipStream_t st);
+    // dW[o][k] = sum_n AT[o][n] * BT[k][n] for o < O over the first K_pad rows of BT; the k axis is cut into the segments of `segs`
+    int wgrad_nt(int O, int K_pad, const WgradSegs& segs, float scale, hipStream_t st);
     int step(const dsvc_train_args* a, float* loss_out, hipStream_t st);
 };
 
@@ -580,7 +555,7 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
     int max_dil = 1;
     for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
-    if (max_dil > padc) return fail(DSVC_EINVAL, "trainer: dilation %d too large", max_dil);
+    if (max_dil > 64) return fail(DSVC_EINVAL, "trainer: dilation %d too large", max_dil);
     Tp = round_up(T + max_dil, 32);
     nr = B * Tp;
     rows = round_up(nr, 128);                   // the contraction length of the weight-gradient GEMMs: a multiple of the staged chunk
@@ -595,11 +570,21 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     DSVC_TRY(z(de1, (size_t)B * 4 * C * 4)); DSVC_TRY(z(de1pre, (size_t)B * 4 * C * 4));
     DSVC_TRY(z(dx, r * C * 4)); DSVC_TRY(z(dxin, r * C * 4)); DSVC_TRY(z(dO, r * 2 * C * 4)); DSVC_TRY(z(dy, r * 2 * C * 4));
     DSVC_TRY(z(ds2pre, r * C * 4)); DSVC_TRY(z(dcond, r * H * 4)); DSVC_TRY(z(dh0, r * C * 4)); DSVC_TRY(z(loss, 16));
-    const size_t ldT = r + 2 * (size_t)padc;
-    DSVC_TRY(z(TT, ldT * (size_t)(2 * C) * 4));      // transposed operand [<= 2C][rows + 2 pad]; pads stay zero
-    DSVC_TRY(z(condTT, ldT * (size_t)H * 4));
-    DSVC_TRY(packA.alloc(packed_halfs(round_up(ceil_div(2 * C, 32), 2), 1, rows, 2) * 2));
-    DSVC_TRY(wpart.alloc((size_t)WGRAD_MAX_TILES * 128 * 128 * 4));
+    // weight-gradient operands (wgrad.h): frames contiguous, zero beyond the data rows and in the channel padding
+    ldT = rows;                                                  // % 128 == 0: whole 32-frame stages, 64-frame split tiles
+    cp128 = round_up(C, 128); hp128 = round_up(H, 128);
+    a_rows = round_up(2 * C > M ? 2 * C : M, 256);
+    b_rows = 3 * cp128 + hp128;                                  // [tap 0 | tap 1 | tap 2 | cond] of a layer's dilated conv + conditioner projection
+    if (b_rows < round_up(M, 128)) b_rows = round_up(M, 128);
+    DSVC_TRY(z(AT, (size_t)2 * a_rows * ldT * 2));
+    DSVC_TRY(z(BT, (size_t)2 * b_rows * ldT * 2));
+    DSVC_TRY(wpart.alloc((size_t)WGRAD_MAX_TILES * 256 * 128 * 4));
+    {   // loss scale: the largest power of two that keeps |d loss / d eps| * scale <= 2^-6 for the l1 loss (the l2 gradient is 2 d times that)
+        const double inv_n = 1.0 / ((double)B * M * T);
+        int k = 0;
+        while (k < 24 && inv_n * ldexp(1.0, k + 1) <= 1.0 / 64.0) ++k;
+        loss_scale = (float)ldexp(1.0, k);
+    }
     hipLaunchKernelGGL(k_iota, dim3(ceil_div(B, 256)), dim3(256), 0, st, iotaB.as<int>(), 0, B);
     if (!gatemap.p) {
         // packed column p of a gate GEMM <-> conv channel: group = p/64, half = (p/32)&1, j = p%32  ->  half*C + group*32 + j
@@ -613,58 +598,42 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     return DSVC_OK;
 }
 
-int dsvc_trainer::transpose(const float* src, int C, const float* add, int add_stride, int shift, hipStream_t st) {
-    const int ld = rows + 2 * padc;
-    hipLaunchKernelGGL(k_transpose, dim3(ceil_div(rows, 32), ceil_div(C, 32)), dim3(256), 0, st, src, TT.as<float>(), rows, C, ld, padc,
-                       add, add_stride, Tp, wsT, nr, shift);
+int dsvc_trainer::split_t(bool a_side, int row0, const float* src, int ld_src, int C, const float* add, int add_stride, int shift, hipStream_t st) {
+    DevBuf& buf = a_side ? AT : BT;
+    const int nrows = a_side ? a_rows : b_rows;
+    if (row0 < 0 || row0 + C > nrows) return fail(DSVC_EINVAL, "split_t: rows [%d, %d) outside the %d-row operand planes", row0, row0 + C, nrows);
+    const long long plane = (long long)nrows * ldT;
+    hipLaunchKernelGGL(k_split_t, dim3(ldT / 64, ceil_div(C, 32)), dim3(256), 0, st, src, ld_src, buf.as<_Float16>() + (size_t)row0 * ldT, plane, ldT, C,
+                       add, add_stride, SplitRows{Tp, wsT, nr}, shift, 1.0f);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
 
-int dsvc_trainer::wgrad(const float* A, int O, const float* BT, int K, int shift, float* dst, long long stride_o, long long stride_k,
-                        long long off, bool repack_a, hipStream_t st) {
-    // A^T as MFMA weight fragments: W(col = o, ci = n) = A[n][o]
-    const int n_ct = round_up(ceil_div(O, 32), 2);
-    if (repack_a) {
-        const long long total_el = (long long)n_ct * (rows / 16) * 512;
-        const int blocks = (int)((total_el + 255) / 256 < 16384 ? (total_el + 255) / 256 : 16384);
-        hipLaunchKernelGGL(k_pack_w, dim3(blocks), dim3(256), 0, st, A, (const int*)nullptr, packA.as<_Float16>(), n_ct, 1, rows, O, rows,
-                           1LL, (long long)O, 0LL, 0, 1.0f);
+int dsvc_trainer::wgrad_nt(int O, int K_pad, const WgradSegs& segs, float scale, hipStream_t st) {
+    const int O_pad = round_up(O, 256);
+    if (O_pad > a_rows || K_pad > b_rows || K_pad % 128) return fail(DSVC_EINVAL, "wgrad_nt: %d x %d outside the operand planes", O_pad, K_pad);
+    const int tiles = (O_pad / 256) * (K_pad / 128);
+    // a handful of output tiles does not fill 256 CUs: the frame range is cut into slices (one workgroup per tile and slice)
+    int S = WGRAD_MAX_TILES / tiles;
+    if (S < 1) return fail(DSVC_EINVAL, "wgrad_nt: %d output tiles exceed the partial-tile scratch", tiles);
+    if (S > ldT / 128) S = ldT / 128;                            // at least four 32-frame stages per slice
+    const int slice_len = round_up(ceil_div(ldT, S), 32);
+    S = ceil_div(ldT, slice_len);
+    WgradNtArgs a{};
+    a.at = AT.as<_Float16>(); a.bt = BT.as<_Float16>();
+    a.a_plane = (long long)a_rows * ldT; a.b_plane = (long long)b_rows * ldT;
+    a.ldT = ldT; a.n_total = ldT; a.slice_len = slice_len;
+    a.part = wpart.as<float>(); a.O_pad = O_pad; a.K_pad = K_pad;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DSVC_HIP(hipFuncSetAttribute((const void*)wgrad_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_STAGES * WG_STAGE_BYTES));
+        attr_set = true;
     }
-    ConvGemmArgs a{};
-    const int ld = rows + 2 * padc;
-    (void)shift;                                          // taps are materialised by transpose(..., shift): every staged row stays 16-byte aligned
-    a.x = BT + padc; a.ldx = ld; a.n_rows = K; a.clip_stride = K < 32 ? 32 : K; a.clip_len = a.clip_stride;
-    a.cin = rows; a.taps = 1; a.dil = 1; a.w = packA.as<_Float16>(); a.n_ctiles = n_ct; a.w_planes = 2; a.in_slope = 1.0f;
-    // A [K x O] result reduced over ~10^4 frames: as 32 x 64 output tiles every workgroup re-reads both operands over the whole frame
-    // range (144 workgroups, 450 MB of operand traffic for the 384 x 768 gradients: 151 us each, 41 % of the step).  Instead: 128 x 128
-    // tiles and the frame range cut into slices over blockIdx.y so that ~400 workgroups exist; partial tiles go to a scratch buffer and a
-    // second kernel adds the slices in a fixed order (deterministic, unlike atomics).
-#ifdef DSVC_PROFILING
-    static const bool sliced = !(getenv("DSVC_TRAIN_WGRAD_FLAT") && atoi(getenv("DSVC_TRAIN_WGRAD_FLAT")));     // A/B knob
-#else
-    constexpr bool sliced = true;
-#endif
-    const int tiles = ceil_div(K, 128) * ceil_div(n_ct, 4);
-    if (sliced && rows % 64 == 0 && tiles <= WGRAD_MAX_TILES) {
-        int S = WGRAD_MAX_TILES / tiles;
-        if (S > rows / 64) S = rows / 64;
-        const int slice_len = round_up(ceil_div(rows, S), 64);
-        S = ceil_div(rows, slice_len);
-        a.k_slices = S; a.k_slice_len = slice_len;
-        if (S > 1) {
-            const int ldp = n_ct * 32;
-            if ((size_t)S * K * ldp * 4 > wpart.bytes) return fail(DSVC_EINVAL, "wgrad: partial-tile scratch too small (%d slices of %d x %d)", S, K, ldp);
-            EpWgradPart::Args e{wpart.as<float>(), K, ldp};
-            DSVC_TRY((conv_gemm_launch<4, 2, 1, 64, 4, 5, 2, 2, EpWgradPart>(a, e, st)));
-            hipLaunchKernelGGL(k_wgrad_reduce, dim3(ceil_div(K * O, 256)), dim3(256), 0, st, wpart.as<float>(), dst, S, K, ldp, O, stride_o, stride_k, off);
-            DSVC_HIP(hipGetLastError());
-            return DSVC_OK;
-        }
-        a.k_slices = 0; a.k_slice_len = 0;
-    }
-    EpWgrad::Args e{dst, stride_o, stride_k, off, O};
-    return launch<EpWgrad>(a, e, st);
+    hipLaunchKernelGGL(wgrad_nt_kernel, dim3(K_pad / 128, O_pad / 256, S), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, a);
+    DSVC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_wgrad_nt_reduce, dim3(ceil_div(K_pad, 256), O), dim3(256), 0, st, wpart.as<float>(), S, O_pad, K_pad, O, segs, scale);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
 }
 
 int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t st) {
@@ -760,24 +729,28 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     // ---- loss and d eps ----
     const float inv_n = 1.0f / ((float)B * (float)M * (float)T);
     hipLaunchKernelGGL(k_loss, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, eps.as<float>(), deps.as<float>(), loss.as<float>(), B, T, M, Tp,
-                       ta->seed, clipid.as<int>(), cfg.loss_l1, inv_n);
+                       ta->seed, clipid.as<int>(), cfg.loss_l1, inv_n, loss_scale);
     // ---- backward: tail ----
     colsum(deps.as<float>(), G("denoise_fn.output_projection.bias"), M, M);
+    auto seg1 = [&](float* dst, int K, long long stride_o) {
+        WgradSegs sg{};
+        sg.n = 1; sg.s[0] = WgradSeg{dst, 0, K, stride_o, 1, 0};
+        return sg;
+    };
     {   // dW_out[m][c] = sum_n deps[n][m] relu(s2pre)[n][c]
         hipLaunchKernelGGL(k_relu_bwd, dim3(ew), dim3(256), 0, st, s2pre.as<float>(), s2pre.as<float>(), dh0.as<float>(), r * C);   // dh0 = relu(s2pre) (scratch)
-        DSVC_TRY(transpose(dh0.as<float>(), C, nullptr, 0, 0, st));
-        DSVC_TRY(wgrad(deps.as<float>(), M, TT.as<float>(), C, 0, G("denoise_fn.output_projection.weight"), C, 1, 0, true, st));
+        DSVC_TRY(split_t(true, 0, deps.as<float>(), M, M, nullptr, 0, 0, st));
+        DSVC_TRY(split_t(false, 0, dh0.as<float>(), C, C, nullptr, 0, 0, st));
+        DSVC_TRY(wgrad_nt(M, cp128, seg1(G("denoise_fn.output_projection.weight"), C, C), 1.0f, st));
         // d s2pre = (W_out^T deps) * [s2pre > 0]
         ConvGemmArgs a = base(deps.as<float>(), M, M, w_finT, 1);
         EpBwd::Args e{ds2pre.as<float>(), C, C, s2pre.as<float>(), C, 1.0f, 0, ri};
         DSVC_TRY(launch<EpBwd>(a, e, st));
         colsum(ds2pre.as<float>(), G("denoise_fn.skip_projection.bias"), C, C);
         // dW_s[o][c] = sum_n ds2pre[n][o] skip[n][c] / sqrt(L)
-        DSVC_TRY(transpose(skip.as<float>(), C, nullptr, 0, 0, st));
-        DSVC_TRY(wgrad(ds2pre.as<float>(), C, TT.as<float>(), C, 0, G("denoise_fn.skip_projection.weight"), C, 1, 0, true, st));
-        const long long nws = (long long)C * C;
-        hipLaunchKernelGGL(k_copy_cols, dim3(ceil_div((int)nws, 256)), dim3(256), 0, st, G("denoise_fn.skip_projection.weight"),
-                           G("denoise_fn.skip_projection.weight"), 1, (int)nws, (int)nws, 0, 1.0f / sqrtf((float)L));
+        DSVC_TRY(split_t(true, 0, ds2pre.as<float>(), C, C, nullptr, 0, 0, st));
+        DSVC_TRY(split_t(false, 0, skip.as<float>(), C, C, nullptr, 0, 0, st));
+        DSVC_TRY(wgrad_nt(C, cp128, seg1(G("denoise_fn.skip_projection.weight"), C, C), 1.0f / sqrtf((float)L), st));
         // dskip = W_s^T ds2pre / sqrt(L)  -> the skip half of dO (the same for every layer)
         ConvGemmArgs a2 = base(ds2pre.as<float>(), C, C, w_skipT, 1);
         EpBwd::Args e2{dO.as<float>() + C, 2 * C, C, nullptr, 0, 1.0f, 0, ri};
@@ -785,12 +758,8 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     }
     DSVC_HIP(hipMemsetAsync(dx.p, 0, r * C * 4, st));                                                                 // d x^L = 0: the loss sees x only through skip
     hipLaunchKernelGGL(k_copy_cols, dim3(ew), dim3(256), 0, st, dx.as<float>(), dO.as<float>(), nr, C, 2 * C, 0, 0.0f);   // ... so the residual half of dO starts at 0
-    // cond^T once (weight gradients of every conditioner projection)
-    {
-        const int ld = rows + 2 * padc;
-        hipLaunchKernelGGL(k_transpose, dim3(ceil_div(rows, 32), ceil_div(H, 32)), dim3(256), 0, st, condT.as<float>(), condTT.as<float>(), rows, H, ld,
-                           padc, (const float*)nullptr, 0, Tp, T, nr, 0);
-    }
+    // cond^T planes once (weight gradients of every conditioner projection): the last segment of the layers' k axis, which nothing else writes
+    DSVC_TRY(split_t(false, 3 * cp128, condT.as<float>(), H, H, nullptr, 0, 0, st));
     // ---- backward: layers ----
     for (int l = L - 1; l >= 0; --l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
@@ -798,8 +767,9 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         const float* xl = xs.as<float>() + (size_t)l * slab;
         const float* gl = g.as<float>() + (size_t)l * slab;
         colsum(dO.as<float>(), G(q + "output_projection.bias"), 2 * C, 2 * C);
-        DSVC_TRY(transpose(gl, C, nullptr, 0, 0, st));
-        DSVC_TRY(wgrad(dO.as<float>(), 2 * C, TT.as<float>(), C, 0, G(q + "output_projection.weight"), C, 1, 0, true, st));
+        DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st));
+        DSVC_TRY(split_t(false, 0, gl, C, C, nullptr, 0, 0, st));
+        DSVC_TRY(wgrad_nt(2 * C, cp128, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
         {   // dg = W_o^T dO -> dy
             ConvGemmArgs a = base(dO.as<float>(), 2 * C, 2 * C, w_oT[l], 1);
             EpGateBwd::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(), C, ri};
@@ -807,12 +777,17 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         }
         colsum(dy.as<float>(), G(q + "dilated_conv.bias"), 2 * C, 2 * C);
         DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
-        // dW_c[o][h] = sum_n dy[n][o] cond[n][h]   (packs dy^T once; the three taps below reuse the fragments)
-        DSVC_TRY(wgrad(dy.as<float>(), 2 * C, condTT.as<float>(), H, 0, G(q + "conditioner_projection.weight"), H, 1, 0, true, st));
-        // dW_d[o][c][tap] = sum_n dy[n][o] (x^l + film)[n + (tap-1) d][c]
-        for (int tap = 0; tap < 3; ++tap) {
-            DSVC_TRY(transpose(xl, C, filmB.as<float>() + (size_t)l * C, L * C, (tap - 1) * d, st));
-            DSVC_TRY(wgrad(dy.as<float>(), 2 * C, TT.as<float>(), C, 0, G(q + "dilated_conv.weight"), (long long)C * 3, 3, tap, false, st));
+        // dW_d[o][c][tap] = sum_n dy[n][o] (x^l + film)[n + (tap-1) d][c]  and  dW_c[o][h] = sum_n dy[n][o] cond[n][h]  share dy^T: ONE
+        // contraction over the k axis [tap 0 | tap 1 | tap 2 | cond]
+        DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st));
+        for (int tap = 0; tap < 3; ++tap)
+            DSVC_TRY(split_t(false, tap * cp128, xl, C, C, filmB.as<float>() + (size_t)l * C, L * C, (tap - 1) * d, st));
+        {
+            WgradSegs sg{};
+            sg.n = 4;
+            for (int tap = 0; tap < 3; ++tap) sg.s[tap] = WgradSeg{G(q + "dilated_conv.weight"), tap * cp128, C, (long long)C * 3, 3, tap};
+            sg.s[3] = WgradSeg{G(q + "conditioner_projection.weight"), 3 * cp128, H, H, 1, 0};
+            DSVC_TRY(wgrad_nt(2 * C, 3 * cp128 + hp128, sg, 1.0f, st));
         }
         {   // dcond += W_c^T dy
             ConvGemmArgs a = base(dy.as<float>(), 2 * C, 2 * C, w_cT[l], 1);
@@ -830,8 +805,9 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     {   // input projection: d h0pre = dx^0 [x^0 > 0]
         hipLaunchKernelGGL(k_relu_bwd, dim3(ew), dim3(256), 0, st, dx.as<float>(), xs.as<float>(), dh0.as<float>(), r * C);
         colsum(dh0.as<float>(), G("denoise_fn.input_projection.bias"), C, C);
-        DSVC_TRY(transpose(xt.as<float>(), M, nullptr, 0, 0, st));
-        DSVC_TRY(wgrad(dh0.as<float>(), C, TT.as<float>(), M, 0, G("denoise_fn.input_projection.weight"), M, 1, 0, true, st));
+        DSVC_TRY(split_t(true, 0, dh0.as<float>(), C, C, nullptr, 0, 0, st));
+        DSVC_TRY(split_t(false, 0, xt.as<float>(), M, M, nullptr, 0, 0, st));
+        DSVC_TRY(wgrad_nt(C, round_up(M, 128), seg1(G("denoise_fn.input_projection.weight"), M, M), 1.0f, st));
     }
     // ---- backward: step embedding ----
     DSVC_HIP(hipMemsetAsync(de2.p, 0, (size_t)B * C * 4, st));
@@ -869,6 +845,7 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         hipLaunchKernelGGL(k_embed_bwd, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, dcond.as<float>(), ta->pitch,
                            ta->mel2ph, G("fs2.pitch_embed.weight"), B, T, H, Tp, cfg.pitch_vocab);
     }
+    if (loss_scale != 1.0f) hipLaunchKernelGGL(k_scale_inplace, dim3(ew), dim3(256), 0, st, grads, (size_t)total, 1.0f / loss_scale);
     if (loss_out) DSVC_HIP(hipMemcpyAsync(loss_out, loss.p, 4, hipMemcpyDeviceToDevice, st));
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
