@@ -341,6 +341,50 @@ __global__ __launch_bounds__(256) void k_gemm_small_b(const SmallBatch t, int M,
         }
 }
 
+// the Linear-forward shape of the same path:  C[m][n] = sum_k A[m*lda + k] * B[n*ldb + k] (+ bias[n]) with BOTH operands k-contiguous and
+// only B x C outputs: a wave owns a 4 x 4 output block and its lanes split k (16-byte loads, coalesced), then reduce across the wave --
+// hundreds of waves instead of the 6 ... 24 workgroups a 64 x 64 tiling gives these shapes.  K, lda, ldb % 4 == 0.
+__global__ __launch_bounds__(256) void k_gemm_nt_dot(const SmallBatch t, int M, int N, int K, int lda, int ldb, int ldc) {
+    const float* __restrict__ A = t.A[blockIdx.z];
+    const float* __restrict__ Bm = t.B[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 4, n0 = (blockIdx.x * 4 + wave) * 4;
+    if (n0 >= N) return;
+    float acc[4][4] = {};
+    for (int k = lane * 4; k < K; k += 256) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = m0 + i < M ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + i) * lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[i] = n0 + i < N ? *reinterpret_cast<const float4*>(Bm + (size_t)(n0 + i) * ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] += a[i].x * b[j].x + a[i].y * b[j].y + a[i].z * b[j].z + a[i].w * b[j].w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[i][j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            acc[i][j] = v;
+        }
+    if (lane < 16) {
+        const int i = lane >> 2, j = lane & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (ii == i && jj == j) v = acc[ii][jj];
+        if (m0 + i < M && n0 + j < N) t.C[blockIdx.z][(size_t)(m0 + i) * ldc + n0 + j] = v + (t.bias[blockIdx.z] ? t.bias[blockIdx.z][n0 + j] : 0.f);
+    }
+}
+
 // SinusoidalPosEmb (net.py:32-44) for the batch's steps
 __global__ void k_sin_emb_b(float* __restrict__ emb, const int* __restrict__ tstep, int B, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -481,10 +525,13 @@ struct dsvc_trainer {
     int pack(Packed& pk, const float* src, const int* colmap, int cout_pad, int taps, int cin, int cout, long long s_col, long long s_ci,
              long long s_tap, int flip, float scale, hipStream_t st);
     int repack(hipStream_t st);
-    // operand planes: rows [row0, row0 + C) of AT (a_side) or BT <- src[n + shift][0..C) (+ add[clip]) on real frames, 0 elsewhere
-    int split_t(bool a_side, int row0, const float* src, int ld_src, int C, const float* add, int add_stride, int shift, hipStream_t st);
-    // dW[o][k] = sum_n AT[o][n] * BT[k][n] for o < O over the first K_pad rows of BT; the k axis is cut into the segments of `segs`
-    int wgrad_nt(int O, int K_pad, const WgradSegs& segs, float scale, hipStream_t st);
+    // operand planes: rows [row0, row0 + C) of AT (a_side) or BT <- src[frame][0..C) (+ add[clip]) over the real frames; dil > 0: the three
+    // taps of a dilated conv's input (frames t - dil, t, t + dil) into rows row0 + {0, 1, 2} * cp128
+    // colsum != nullptr (dil == 0 only): colsum[c] += sum over the frames of src[.][c] -- the bias gradient rides on the pass that reads dY anyway
+    int split_t(bool a_side, int row0, const float* src, int ld_src, int C, const float* add, int add_stride, int dil, hipStream_t st,
+                float* colsum = nullptr);
+    // dW[o][k] = sum_n AT[o][n] * BT[b_row0 + k][n] for o < O, k < K_pad; the k axis is cut into the segments of `segs`
+    int wgrad_nt(int O, int K_pad, int b_row0, const WgradSegs& segs, float scale, hipStream_t st);
     int step(const dsvc_train_args* a, float* loss_out, hipStream_t st);
 };
 
@@ -549,14 +596,14 @@ int dsvc_trainer::repack(hipStream_t st) {
 // The workspace layout depends on (B, T): clips sit Tp rows apart with ZERO gap rows (the convs' padding, and rows the weight-gradient
 // contractions sum over), so a new shape re-zeroes it -- ~1.3 GB of memset (~0.4 ms) at the 64 x 128-frame batch; allocations are kept
 // and only grow.  A loader that changes B and T every step (the reference's max_tokens batching) pays that per step: bucket T
-// (e.g. multiples of 32 frames: Tp already rounds to 32) to keep the layout stable.
+// (e.g. multiples of 32 frames) to keep the layout stable.
 int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     if (B == wsB && T == wsT) return DSVC_OK;
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
     int max_dil = 1;
     for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     if (max_dil > 64) return fail(DSVC_EINVAL, "trainer: dilation %d too large", max_dil);
-    Tp = round_up(T + max_dil, 32);
+    Tp = round_up((T + max_dil < 32 ? 32 : T + max_dil), 8);                       // gap >= the largest dilation (the convs' zero padding); every gap row is work for the conv kernels
     nr = B * Tp;
     rows = round_up(nr, 128);                   // the contraction length of the weight-gradient GEMMs: a multiple of the staged chunk
     const size_t r = (size_t)rows;
@@ -571,7 +618,7 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     DSVC_TRY(z(dx, r * C * 4)); DSVC_TRY(z(dxin, r * C * 4)); DSVC_TRY(z(dO, r * 2 * C * 4)); DSVC_TRY(z(dy, r * 2 * C * 4));
     DSVC_TRY(z(ds2pre, r * C * 4)); DSVC_TRY(z(dcond, r * H * 4)); DSVC_TRY(z(dh0, r * C * 4)); DSVC_TRY(z(loss, 16));
     // weight-gradient operands (wgrad.h): frames contiguous, zero beyond the data rows and in the channel padding
-    ldT = rows;                                                  // % 128 == 0: whole 32-frame stages, 64-frame split tiles
+    ldT = round_up(B * T, 128);                                  // real frames only (no gap rows); whole 32-frame stages, 64-frame split tiles
     cp128 = round_up(C, 128); hp128 = round_up(H, 128);
     a_rows = round_up(2 * C > M ? 2 * C : M, 256);
     b_rows = 3 * cp128 + hp128;                                  // [tap 0 | tap 1 | tap 2 | cond] of a layer's dilated conv + conditioner projection
@@ -598,38 +645,42 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     return DSVC_OK;
 }
 
-int dsvc_trainer::split_t(bool a_side, int row0, const float* src, int ld_src, int C, const float* add, int add_stride, int shift, hipStream_t st) {
+int dsvc_trainer::split_t(bool a_side, int row0, const float* src, int ld_src, int C, const float* add, int add_stride, int dil, hipStream_t st,
+                          float* colsum) {
     DevBuf& buf = a_side ? AT : BT;
     const int nrows = a_side ? a_rows : b_rows;
-    if (row0 < 0 || row0 + C > nrows) return fail(DSVC_EINVAL, "split_t: rows [%d, %d) outside the %d-row operand planes", row0, row0 + C, nrows);
+    if (row0 < 0 || row0 + (dil > 0 ? 2 * cp128 : 0) + C > nrows || dil > 64) return fail(DSVC_EINVAL, "split_t: rows [%d, %d) outside the %d-row operand planes", row0, row0 + C, nrows);
     const long long plane = (long long)nrows * ldT;
     hipLaunchKernelGGL(k_split_t, dim3(ldT / 64, ceil_div(C, 32)), dim3(256), 0, st, src, ld_src, buf.as<_Float16>() + (size_t)row0 * ldT, plane, ldT, C,
-                       add, add_stride, SplitRows{Tp, wsT, nr}, shift, 1.0f);
+                       add, add_stride, SplitRows{Tp, wsT, wsB}, dil > 0 ? 3 : 1, dil, (long long)cp128 * ldT, 1.0f, dil > 0 ? nullptr : colsum);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
 
-int dsvc_trainer::wgrad_nt(int O, int K_pad, const WgradSegs& segs, float scale, hipStream_t st) {
+int dsvc_trainer::wgrad_nt(int O, int K_pad, int b_row0, const WgradSegs& segs, float scale, hipStream_t st) {
     const int O_pad = round_up(O, 256);
-    if (O_pad > a_rows || K_pad > b_rows || K_pad % 128) return fail(DSVC_EINVAL, "wgrad_nt: %d x %d outside the operand planes", O_pad, K_pad);
+    if (O_pad > a_rows || b_row0 + K_pad > b_rows || K_pad % 128) return fail(DSVC_EINVAL, "wgrad_nt: %d x %d outside the operand planes", O_pad, K_pad);
     const int tiles = (O_pad / 256) * (K_pad / 128);
-    // a handful of output tiles does not fill 256 CUs: the frame range is cut into slices (one workgroup per tile and slice)
-    int S = WGRAD_MAX_TILES / tiles;
-    if (S < 1) return fail(DSVC_EINVAL, "wgrad_nt: %d output tiles exceed the partial-tile scratch", tiles);
-    if (S > ldT / 128) S = ldT / 128;                            // at least four 32-frame stages per slice
+    // a handful of output tiles does not fill 256 CUs: the frame range is cut into slices (one workgroup per tile and slice).  Slices come in
+    // multiples of 8 and every XCD gets whole slices, as many as fit its 32 CUs -- the tiles of a slice walk the same frames of the same
+    // operand rows, so they are served by ONE L2 (with a plain grid every XCD's L2 pulled every operand byte: 4.7 TB/s through the fabric
+    // at 440 TFLOP/s, profiles/r3n_kernel_stats_train.csv)
+    int per_xcd = tiles <= 32 ? 32 / tiles : 1;
+    int S = 8 * per_xcd, xcd_map = 1;
+    if (S > ldT / 128) { S = ldT / 128 < 1 ? 1 : ldT / 128; xcd_map = S % 8 == 0; }      // at least four 32-frame stages per slice
+    if ((long long)S * tiles > WGRAD_MAX_TILES) return fail(DSVC_EINVAL, "wgrad_nt: %d slices x %d output tiles exceed the partial-tile scratch", S, tiles);
     const int slice_len = round_up(ceil_div(ldT, S), 32);
-    S = ceil_div(ldT, slice_len);
     WgradNtArgs a{};
-    a.at = AT.as<_Float16>(); a.bt = BT.as<_Float16>();
+    a.at = AT.as<_Float16>(); a.bt = BT.as<_Float16>() + (size_t)b_row0 * ldT;
     a.a_plane = (long long)a_rows * ldT; a.b_plane = (long long)b_rows * ldT;
     a.ldT = ldT; a.n_total = ldT; a.slice_len = slice_len;
-    a.part = wpart.as<float>(); a.O_pad = O_pad; a.K_pad = K_pad;
+    a.part = wpart.as<float>(); a.O_pad = O_pad; a.K_pad = K_pad; a.tiles = tiles; a.xcd_map = xcd_map;
     static bool attr_set = false;
     if (!attr_set) {
         DSVC_HIP(hipFuncSetAttribute((const void*)wgrad_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_STAGES * WG_STAGE_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_nt_kernel, dim3(K_pad / 128, O_pad / 256, S), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, a);
+    hipLaunchKernelGGL(wgrad_nt_kernel, dim3(tiles * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, a);
     DSVC_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_wgrad_nt_reduce, dim3(ceil_div(K_pad, 256), O), dim3(256), 0, st, wpart.as<float>(), S, O_pad, K_pad, O, segs, scale);
     DSVC_HIP(hipGetLastError());
@@ -659,6 +710,10 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         return a;
     };
     auto small_b = [&](const SmallBatch& sb, int Mm, int N, int K, int lda, int ldb, int ldc, int tA, int tB, int acc) {
+        if (!tA && tB && !acc && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0) {       // Linear forward: both operands k-contiguous
+            hipLaunchKernelGGL(k_gemm_nt_dot, dim3(ceil_div(N, 16), ceil_div(Mm, 4), sb.n), dim3(256), 0, st, sb, Mm, N, K, lda, ldb, ldc);
+            return;
+        }
         hipLaunchKernelGGL(k_gemm_small_b, dim3(ceil_div(N, 64), ceil_div(Mm, 64), sb.n), dim3(256), 0, st, sb, Mm, N, K, lda, ldb, ldc, tA, tB, acc);
     };
     auto small = [&](const float* A, const float* Bm, float* Cm, int Mm, int N, int K, int lda, int ldb, int ldc, int tA, int tB, int acc,
@@ -666,9 +721,6 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         SmallBatch sb{};
         sb.n = 1; sb.A[0] = A; sb.B[0] = Bm; sb.C[0] = Cm; sb.bias[0] = bias;
         small_b(sb, Mm, N, K, lda, ldb, ldc, tA, tB, acc);
-    };
-    auto colsum = [&](const float* src, float* dst, int Cc, int ld) {
-        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(Cc, 256), ceil_div(nr, 64)), dim3(256), 0, st, src, dst, nr, Cc, ld, 64);
     };
     const int ew = 2048;
     // ---- step embedding: emb -> Linear -> Mish -> Linear -> per-layer diffusion_projection  (net.py:99-103,124-125,67) ----
@@ -731,7 +783,6 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     hipLaunchKernelGGL(k_loss, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, eps.as<float>(), deps.as<float>(), loss.as<float>(), B, T, M, Tp,
                        ta->seed, clipid.as<int>(), cfg.loss_l1, inv_n, loss_scale);
     // ---- backward: tail ----
-    colsum(deps.as<float>(), G("denoise_fn.output_projection.bias"), M, M);
     auto seg1 = [&](float* dst, int K, long long stride_o) {
         WgradSegs sg{};
         sg.n = 1; sg.s[0] = WgradSeg{dst, 0, K, stride_o, 1, 0};
@@ -739,18 +790,17 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     };
     {   // dW_out[m][c] = sum_n deps[n][m] relu(s2pre)[n][c]
         hipLaunchKernelGGL(k_relu_bwd, dim3(ew), dim3(256), 0, st, s2pre.as<float>(), s2pre.as<float>(), dh0.as<float>(), r * C);   // dh0 = relu(s2pre) (scratch)
-        DSVC_TRY(split_t(true, 0, deps.as<float>(), M, M, nullptr, 0, 0, st));
+        DSVC_TRY(split_t(true, 0, deps.as<float>(), M, M, nullptr, 0, 0, st, G("denoise_fn.output_projection.bias")));
         DSVC_TRY(split_t(false, 0, dh0.as<float>(), C, C, nullptr, 0, 0, st));
-        DSVC_TRY(wgrad_nt(M, cp128, seg1(G("denoise_fn.output_projection.weight"), C, C), 1.0f, st));
+        DSVC_TRY(wgrad_nt(M, cp128, 0, seg1(G("denoise_fn.output_projection.weight"), C, C), 1.0f, st));
         // d s2pre = (W_out^T deps) * [s2pre > 0]
         ConvGemmArgs a = base(deps.as<float>(), M, M, w_finT, 1);
         EpBwd::Args e{ds2pre.as<float>(), C, C, s2pre.as<float>(), C, 1.0f, 0, ri};
         DSVC_TRY(launch<EpBwd>(a, e, st));
-        colsum(ds2pre.as<float>(), G("denoise_fn.skip_projection.bias"), C, C);
         // dW_s[o][c] = sum_n ds2pre[n][o] skip[n][c] / sqrt(L)
-        DSVC_TRY(split_t(true, 0, ds2pre.as<float>(), C, C, nullptr, 0, 0, st));
+        DSVC_TRY(split_t(true, 0, ds2pre.as<float>(), C, C, nullptr, 0, 0, st, G("denoise_fn.skip_projection.bias")));
         DSVC_TRY(split_t(false, 0, skip.as<float>(), C, C, nullptr, 0, 0, st));
-        DSVC_TRY(wgrad_nt(C, cp128, seg1(G("denoise_fn.skip_projection.weight"), C, C), 1.0f / sqrtf((float)L), st));
+        DSVC_TRY(wgrad_nt(C, cp128, 0, seg1(G("denoise_fn.skip_projection.weight"), C, C), 1.0f / sqrtf((float)L), st));
         // dskip = W_s^T ds2pre / sqrt(L)  -> the skip half of dO (the same for every layer)
         ConvGemmArgs a2 = base(ds2pre.as<float>(), C, C, w_skipT, 1);
         EpBwd::Args e2{dO.as<float>() + C, 2 * C, C, nullptr, 0, 1.0f, 0, ri};
@@ -766,28 +816,26 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         const int d = 1 << (l % cfg.dilation_cycle);
         const float* xl = xs.as<float>() + (size_t)l * slab;
         const float* gl = g.as<float>() + (size_t)l * slab;
-        colsum(dO.as<float>(), G(q + "output_projection.bias"), 2 * C, 2 * C);
-        DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st));
+        DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias")));
         DSVC_TRY(split_t(false, 0, gl, C, C, nullptr, 0, 0, st));
-        DSVC_TRY(wgrad_nt(2 * C, cp128, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
+        DSVC_TRY(wgrad_nt(2 * C, cp128, 0, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
         {   // dg = W_o^T dO -> dy
             ConvGemmArgs a = base(dO.as<float>(), 2 * C, 2 * C, w_oT[l], 1);
             EpGateBwd::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(), C, ri};
             DSVC_TRY(launch<EpGateBwd>(a, e, st));
         }
-        colsum(dy.as<float>(), G(q + "dilated_conv.bias"), 2 * C, 2 * C);
-        DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
         // dW_d[o][c][tap] = sum_n dy[n][o] (x^l + film)[n + (tap-1) d][c]  and  dW_c[o][h] = sum_n dy[n][o] cond[n][h]  share dy^T: ONE
         // contraction over the k axis [tap 0 | tap 1 | tap 2 | cond]
-        DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st));
-        for (int tap = 0; tap < 3; ++tap)
-            DSVC_TRY(split_t(false, tap * cp128, xl, C, C, filmB.as<float>() + (size_t)l * C, L * C, (tap - 1) * d, st));
+        DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "dilated_conv.bias")));
+        DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
+        DSVC_TRY(split_t(false, 0, xl, C, C, filmB.as<float>() + (size_t)l * C, L * C, d, st));
         {
             WgradSegs sg{};
-            sg.n = 4;
+            sg.n = 3;
             for (int tap = 0; tap < 3; ++tap) sg.s[tap] = WgradSeg{G(q + "dilated_conv.weight"), tap * cp128, C, (long long)C * 3, 3, tap};
-            sg.s[3] = WgradSeg{G(q + "conditioner_projection.weight"), 3 * cp128, H, H, 1, 0};
-            DSVC_TRY(wgrad_nt(2 * C, 3 * cp128 + hp128, sg, 1.0f, st));
+            DSVC_TRY(wgrad_nt(2 * C, 3 * cp128, 0, sg, 1.0f, st));
+            // (one launch over [taps | cond] is 33 tiles at C = 384: one more than an XCD has CUs)
+            DSVC_TRY(wgrad_nt(2 * C, hp128, 3 * cp128, seg1(G(q + "conditioner_projection.weight"), H, H), 1.0f, st));
         }
         {   // dcond += W_c^T dy
             ConvGemmArgs a = base(dy.as<float>(), 2 * C, 2 * C, w_cT[l], 1);
@@ -804,10 +852,9 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     }
     {   // input projection: d h0pre = dx^0 [x^0 > 0]
         hipLaunchKernelGGL(k_relu_bwd, dim3(ew), dim3(256), 0, st, dx.as<float>(), xs.as<float>(), dh0.as<float>(), r * C);
-        colsum(dh0.as<float>(), G("denoise_fn.input_projection.bias"), C, C);
-        DSVC_TRY(split_t(true, 0, dh0.as<float>(), C, C, nullptr, 0, 0, st));
+        DSVC_TRY(split_t(true, 0, dh0.as<float>(), C, C, nullptr, 0, 0, st, G("denoise_fn.input_projection.bias")));
         DSVC_TRY(split_t(false, 0, xt.as<float>(), M, M, nullptr, 0, 0, st));
-        DSVC_TRY(wgrad_nt(C, round_up(M, 128), seg1(G("denoise_fn.input_projection.weight"), M, M), 1.0f, st));
+        DSVC_TRY(wgrad_nt(C, round_up(M, 128), 0, seg1(G("denoise_fn.input_projection.weight"), M, M), 1.0f, st));
     }
     // ---- backward: step embedding ----
     DSVC_HIP(hipMemsetAsync(de2.p, 0, (size_t)B * C * 4, st));

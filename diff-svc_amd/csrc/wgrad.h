@@ -9,8 +9,8 @@
 //   * k_split_t  writes an operand ONCE as channel-major fp16 planes  T[plane hi|lo][channel][n]  (v = hi + lo, fp32-class), with the
 //                validity mask, the FiLM shift of the dilated conv's input and the conv tap's frame shift folded in.
 //   * wgrad_nt_kernel  is then a plain "NT" GEMM on those planes: a 256 (o) x 128 (k) output tile per workgroup, 8 waves of 64 x 64,
-//                three MFMAs per product (hi*hi + lo*hi + hi*lo).  The frame range is cut into slices over blockIdx.z (a handful of
-//                output tiles would not fill 256 CUs) whose partial tiles a second kernel adds in a fixed order (deterministic).
+//                three MFMAs per product (hi*hi + lo*hi + hi*lo).  The frame range is cut into slices (a handful of output tiles would
+//                not fill 256 CUs) whose partial tiles a second kernel adds in a fixed order (deterministic); every XCD gets whole slices.
 //                Operands are staged 32 frames at a time by LDS-DMA (global_load_lds_dwordx4) in FRAGMENT order: lane l of a 1 KiB
 //                piece loads row (l & 31), frames 8 (l >> 5) .. +7 and the DMA drops it at piece + 16 l -- exactly what ds_read_b128 at
 //                lane*16 hands to the MFMA, so there is no swizzle and no bank conflict.  Three stages (144 KB) in flight, one bare
@@ -21,36 +21,54 @@
 namespace dsvc {
 
 // ---- operand planes -------------------------------------------------------------------------------------------------------------
-// dst[plane][c][n] for n in [0, n_out): v = (n + shift is a real frame) ? (src[n + shift][c] + add[clip][c]) * scale : 0
-// grid (n_out / 64, ceil(C / 32)), 256 threads; n_out % 64 == 0; channels >= C of a padded plane are left as they are (callers ignore them)
-struct SplitRows { int clip_stride, clip_len, n_valid; };
+// The planes hold the REAL frames only (the gap rows between clips would be 20 % zeros in the contraction): plane column m = clip * clip_len + t.
+// n_taps = 1:  dst[plane][c][m] = (src[clip * clip_stride + t][c] + add[clip][c]) * scale                                  for m in [0, n_out)
+// n_taps = 3:  the three taps of a dilated conv's input in one pass over src: tap j goes to plane rows + j * tap_rows and holds the frame
+//              t + (j - 1) * dil of the SAME clip, or the conv's zero padding when that leaves the clip.
+// colsum (n_taps = 1): colsum[c] += sum_m of the values written (a bias gradient: dY is read here anyway).
+// Columns past the last real frame are written as zeros.  grid (n_out / 64, ceil(C / 32)), 256 threads; n_out % 64 == 0, dil <= 64; channels >= C
+// of a padded plane are left as they are (callers ignore them).
+struct SplitRows { int clip_stride, clip_len, n_clips; };
 
 __global__ __launch_bounds__(256) void k_split_t(const float* __restrict__ src, int ld_src, _Float16* __restrict__ dst, long long plane_halfs,
-                                                 int ldT, int C, const float* __restrict__ add, int add_stride, SplitRows ri, int shift,
-                                                 float scale) {
-    __shared__ float tile[64][33];
+                                                 int ldT, int C, const float* __restrict__ add, int add_stride, SplitRows ri, int n_taps, int dil,
+                                                 long long tap_halfs, float scale, float* __restrict__ colsum) {
+    __shared__ float tile[64 + 128][33];
     const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-    for (int i = ty; i < 64; i += 8) {
-        const int n = n0 + i + shift, c = c0 + tx;
+    const int halo = n_taps == 3 ? dil : 0;
+    const int n_real = ri.n_clips * ri.clip_len;
+    for (int i = ty; i < 64 + 2 * halo; i += 8) {
+        const int m = n0 - halo + i, c = c0 + tx;
         float v = 0.f;
-        if (n >= 0 && n < ri.n_valid && c < C) {
-            const int clip = n / ri.clip_stride;
-            if (n - clip * ri.clip_stride < ri.clip_len) v = (src[(size_t)n * ld_src + c] + (add ? add[(size_t)clip * add_stride + c] : 0.f)) * scale;
+        if (m >= 0 && m < n_real && c < C) {
+            const int clip = m / ri.clip_len, t = m - clip * ri.clip_len;
+            v = (src[((size_t)clip * ri.clip_stride + t) * ld_src + c] + (add ? add[(size_t)clip * add_stride + c] : 0.f)) * scale;
         }
         tile[i][tx] = v;
     }
     __syncthreads();
+    if (colsum && threadIdx.x < 32 && c0 + tx < C) {          // the bias gradient of the layer dY belongs to: column sums of this tile (n_taps == 1)
+        float sum = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) sum += tile[i][tx];
+        atomicAdd(colsum + c0 + tx, sum);
+    }
     const int tn = threadIdx.x & 63, tc = threadIdx.x >> 6;
+    const int m = n0 + tn, t = m % ri.clip_len;
+    for (int j = 0; j < n_taps; ++j) {
+        const int ts = t + (j - (n_taps >> 1)) * halo;               // the tap's source frame inside the clip
+        const bool ok = m < n_real && ts >= 0 && ts < ri.clip_len;
+        _Float16* d0 = dst + (size_t)j * tap_halfs + n0 + tn;
 #pragma unroll
-    for (int c = tc; c < 32; c += 4) {
-        if (c0 + c >= C) break;
-        const float v = tile[tn][c];
-        const _Float16 hi = (_Float16)v;
-        _Float16* p = dst + (size_t)(c0 + c) * ldT + n0 + tn;
-        p[0] = hi;
-        p[plane_halfs] = (_Float16)(v - (float)hi);
+        for (int c = tc; c < 32; c += 4) {
+            if (c0 + c >= C) break;
+            const float v = ok ? tile[tn + j * halo][c] : 0.f;
+            const _Float16 hi = (_Float16)v;
+            _Float16* p = d0 + (size_t)(c0 + c) * ldT;
+            p[0] = hi;
+            p[plane_halfs] = (_Float16)(v - (float)hi);
+        }
     }
 }
 
@@ -64,6 +82,9 @@ struct WgradNtArgs {
     int slice_len;              // frames per blockIdx.z slice (% 32 == 0)
     float* part;                // [slices][O_pad][K_pad] partial tiles
     int O_pad, K_pad;           // % 256 == 0, % 128 == 0
+    int tiles;                  // output tiles per slice = (O_pad / 256) * (K_pad / 128); grid = tiles * slices workgroups (1-D)
+    int xcd_map;                // slices % 8 == 0: workgroup i runs on XCD i % 8 (round-robin dispatch) -- give every XCD whole slices, so that
+                                // the tiles that share operand rows share an L2 (otherwise each of the 8 L2s pulls every operand byte)
 };
 
 constexpr int WG_STAGE_BYTES = 48 * 1024;       // 32 frames: A 8 tiles x 2 planes x 2 k-steps + B 4 x 2 x 2 pieces of 1 KiB
@@ -76,8 +97,16 @@ wgrad_nt_kernel(const WgradNtArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave >> 1, wk = wave & 1;                 // this wave's 64 x 64 corner of the 256 x 128 tile
-    const int o0 = blockIdx.y * 256, k0 = blockIdx.x * 128;
-    const int n_begin = blockIdx.z * a.slice_len;
+    int slice, tile;
+    if (a.xcd_map) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        slice = xcd + 8 * (j / a.tiles); tile = j % a.tiles;
+    } else {
+        slice = blockIdx.x / a.tiles; tile = blockIdx.x % a.tiles;
+    }
+    const int kt = a.K_pad >> 7;
+    const int o0 = (tile / kt) * 256, k0 = (tile % kt) * 128;
+    const int n_begin = slice * a.slice_len;
     int n_end = n_begin + a.slice_len;
     if (n_end > a.n_total) n_end = a.n_total;
     const int stages = n_end > n_begin ? (n_end - n_begin) >> 5 : 0;
@@ -144,7 +173,7 @@ wgrad_nt_kernel(const WgradNtArgs a) {
         }
     }
     // partial tile: accumulator register r of lane l = row 8 (r >> 2) + 4 (l >> 5) + (r & 3), column l & 31
-    float* out = a.part + ((size_t)blockIdx.z * a.O_pad + o0 + wo * 64) * a.K_pad + k0 + wk * 64 + (lane & 31);
+    float* out = a.part + ((size_t)slice * a.O_pad + o0 + wo * 64) * a.K_pad + k0 + wk * 64 + (lane & 31);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
