@@ -26,6 +26,7 @@
 #include "../../include/dsvc.h"
 #include "cg_util.h"
 #include "wgrad.h"
+#include "pgemm.h"
 
 using namespace dsvc;
 
@@ -54,12 +55,24 @@ struct EpStore {
     }
 };
 
+// the stacked conditioner projection: column block l (of `cw` columns) goes to its own [rows][cw] slab, so that a layer's gate epilogue
+// reads rows 3 KB apart, not L * 3 KB
+struct EpStoreSlabs {
+    static constexpr bool PAIRED = false;
+    struct Args { float* out; int cw; long long slab; RowInfo ri; };
+    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
+        const int l = col / e.cw;
+        e.out[(size_t)l * e.slab + (size_t)row * e.cw + (col - l * e.cw)] = e.ri.valid(row) ? v : 0.f;
+    }
+};
+
 // gate forward (net.py:71-77): packed column pairs (tile 2q = gate half, 2q+1 = filter half of channels 32q..32q+31)
 struct EpGateFwd {
     static constexpr bool PAIRED = true;
-    struct Args { const float* ypre; const float* bd; const float* bc; float* sig; float* tau; float* g; int C; RowInfo ri; };
+    // ldy: row stride of ypre (all layers' conditioner projections side by side)
+    struct Args { const float* ypre; const float* bd; const float* bc; float* sig; float* tau; float* g; int C; RowInfo ri; int ldy; };
     __device__ __forceinline__ void pair(const Args& e, int row, int ct0, int j, float vg, float vf) const {
-        const float* yp = e.ypre + (size_t)row * (2 * e.C) + ct0 * 32 + j;
+        const float* yp = e.ypre + (size_t)row * e.ldy + ct0 * 32 + j;
         const int c = (ct0 >> 1) * 32 + j;                  // g-channel: conv channels c (gate -> sigmoid) and C + c (filter -> tanh)
         const float a = vg + yp[0] + e.bd[c] + e.bc[c], b = vf + yp[32] + e.bd[e.C + c] + e.bc[e.C + c];
         const float s = 1.0f / (1.0f + expf(-a)), t = tanhf(b);
@@ -477,6 +490,19 @@ struct Packed {
     int n_ctiles = 0, taps = 1, cin_pad = 0;
 };
 
+// pgemm.h operands: weight planes [2][rows_pad][taps * K_pad], activation planes [2][64 guard + rows_p + 64 guard][ld] (zero outside the data)
+struct WPlanes {
+    DevBuf w;
+    int rows_pad = 0, taps = 1, K_pad = 0;
+    long long plane() const { return (long long)rows_pad * taps * K_pad; }
+};
+struct APlanes {
+    DevBuf buf;
+    int ld = 0;
+    long long plane = 0;
+    _Float16* base() const { return buf.as<_Float16>(); }       // fragment-tiled (wgrad.h pl_off); data row r is tiled row r + 64
+};
+
 }  // namespace
 
 // =================================================================================================
@@ -499,10 +525,15 @@ struct dsvc_trainer {
     DevBuf e0, e1pre, e1, e2, filmB, dfilm, de2, de1, de1pre;
     DevBuf dx, dxin, dO, dy, ds2pre, dcond, dh0, loss;
     DevBuf AT, BT;                                 // dY^T and X^T as channel-major fp16 hi|lo planes: [2][a_rows | b_rows][ldT]
+    APlanes condP, dyP;                            // fragment-tiled fp16 hi|lo planes of cond and of a layer's dy (pgemm.h operands)
+    int rows_p = 0;                                // nr rounded up to the 256-row tile
+    WPlanes wp_call;                               // every layer's conditioner projection, stacked: [L * 2C][H]
+    std::vector<WPlanes> wp_dT, wp_cT;
+    std::vector<Packed> w_d, w_o, w_oT;
     DevBuf wpart;                                  // frame-slice partial tiles of one weight-gradient GEMM
     // per-step repacked weights
     Packed w_in, w_skip, w_fin, w_finT, w_skipT;
-    std::vector<Packed> w_d, w_c, w_o, w_oT, w_cT, w_dT;
+
     DevBuf gatemap;                                // packed column -> conv channel of the paired gate layout
 
     ~dsvc_trainer() {
@@ -510,10 +541,14 @@ struct dsvc_trainer {
                           &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre, &dcond,
                           &dh0, &loss, &AT, &BT, &wpart, &gatemap})
             b->release();
+        for (APlanes* a : {&condP, &dyP}) a->buf.release();
+        wp_call.w.release();
+        for (auto* v : {&wp_dT, &wp_cT})
+            for (auto& p : *v) p.w.release();
         auto rel = [](Packed& p) { p.w.release(); };
-        rel(w_in); rel(w_skip); rel(w_fin); rel(w_finT); rel(w_skipT);
-        for (auto* v : {&w_d, &w_c, &w_o, &w_oT, &w_cT, &w_dT})
+        for (auto* v : {&w_d, &w_o, &w_oT})
             for (auto& p : *v) rel(p);
+        rel(w_in); rel(w_skip); rel(w_fin); rel(w_finT); rel(w_skipT);
     }
 
     void add(const std::string& n, int64_t numel) { names.push_back(n); index[n] = {total, numel}; total += numel; }
@@ -525,11 +560,16 @@ struct dsvc_trainer {
     int pack(Packed& pk, const float* src, const int* colmap, int cout_pad, int taps, int cin, int cout, long long s_col, long long s_ci,
              long long s_tap, int flip, float scale, hipStream_t st);
     int repack(hipStream_t st);
+    int wplanes(WPlanes& wp, int row0, int rows_total, const float* src, const int* rowmap, int n_rows, int taps, int cin, long long s_row, long long s_ci,
+                long long s_tap, int flip, float scale, hipStream_t st);
+    int aplanes(APlanes& ap, int ld, hipStream_t st);
+    int split_rows(const APlanes& ap, const float* src, int ld_src, int C, const float* add, int add_stride, hipStream_t st);
+    template <class Epi> int pg(const APlanes& ap, const WPlanes& wp, int b_row0, int n_cols, int taps, int dil, const typename Epi::Args& e, hipStream_t st);
     // operand planes: rows [row0, row0 + C) of AT (a_side) or BT <- src[frame][0..C) (+ add[clip]) over the real frames; dil > 0: the three
     // taps of a dilated conv's input (frames t - dil, t, t + dil) into rows row0 + {0, 1, 2} * cp128
     // colsum != nullptr (dil == 0 only): colsum[c] += sum over the frames of src[.][c] -- the bias gradient rides on the pass that reads dY anyway
     int split_t(bool a_side, int row0, const float* src, int ld_src, int C, const float* add, int add_stride, int dil, hipStream_t st,
-                float* colsum = nullptr);
+                float* colsum = nullptr, const APlanes* rowp = nullptr);
     // dW[o][k] = sum_n AT[o][n] * BT[b_row0 + k][n] for o < O, k < K_pad; the k axis is cut into the segments of `segs`
     int wgrad_nt(int O, int K_pad, int b_row0, const WgradSegs& segs, float scale, hipStream_t st);
     int step(const dsvc_train_args* a, float* loss_out, hipStream_t st);
@@ -568,6 +608,50 @@ int dsvc_trainer::pack(Packed& pk, const float* src, const int* colmap, int cout
     return DSVC_OK;
 }
 
+// rows [row0, row0 + round_up(n_rows, 128)) of a weight-plane set with rows_total rows (a stacked set is filled by several calls)
+int dsvc_trainer::wplanes(WPlanes& wp, int row0, int rows_total, const float* src, const int* rowmap, int n_rows, int taps, int cin, long long s_row,
+                          long long s_ci, long long s_tap, int flip, float scale, hipStream_t st) {
+    wp.rows_pad = round_up(rows_total, 128); wp.taps = taps; wp.K_pad = round_up(cin, 32);
+    const int ldb = taps * wp.K_pad;
+    DSVC_TRY(wp.w.alloc((size_t)2 * wp.rows_pad * ldb * 2));
+    const int rows_here = round_up(n_rows, 128) < wp.rows_pad - row0 ? round_up(n_rows, 128) : wp.rows_pad - row0;
+    const long long total = (long long)rows_here * (ldb / 8);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_wplanes, dim3(blocks), dim3(256), 0, st, src, rowmap, wp.w.as<_Float16>() + (size_t)row0 * ldb, wp.plane(), rows_here, n_rows, taps,
+                       wp.K_pad, cin, s_row, s_ci, s_tap, flip, scale);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+int dsvc_trainer::aplanes(APlanes& ap, int ld, hipStream_t st) {
+    ap.ld = ld;
+    ap.plane = (long long)(rows_p + 128) * ld;
+    const size_t bytes = (size_t)2 * ap.plane * 2;
+    DSVC_TRY(ap.buf.alloc(bytes));
+    DSVC_HIP(hipMemsetAsync(ap.buf.p, 0, bytes, st));
+    return DSVC_OK;
+}
+
+int dsvc_trainer::split_rows(const APlanes& ap, const float* src, int ld_src, int C, const float* add, int add_stride, hipStream_t st) {
+    if (C % 8 || C > ap.ld) return fail(DSVC_EINVAL, "split_rows: %d channels into planes of %d", C, ap.ld);
+    hipLaunchKernelGGL(k_split_rows, dim3(2048), dim3(256), 0, st, src, ld_src, ap.base(), ap.plane, ap.ld, nr, C, add, add_stride, Tp, wsT, nr);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+// C[row][col] = EPI(sum A[row + tap shift][k] * B[b_row0 + col][tap, k]) over the data rows, n_cols output columns (pgemm.h)
+template <class Epi>
+int dsvc_trainer::pg(const APlanes& ap, const WPlanes& wp, int b_row0, int n_cols, int taps, int dil, const typename Epi::Args& e, hipStream_t st) {
+    if (taps != wp.taps || wp.K_pad > ap.ld || b_row0 + round_up(n_cols, 128) > wp.rows_pad || dil > 64)
+        return fail(DSVC_EINVAL, "pgemm: operand planes do not match (taps %d/%d, K %d/%d, rows %d+%d/%d)", taps, wp.taps, wp.K_pad, ap.ld, b_row0, n_cols, wp.rows_pad);
+    PGemmArgs a{};
+    a.a = ap.base(); a.a_plane = ap.plane; a.lda = ap.ld;
+    a.b = wp.w.as<_Float16>() + (size_t)b_row0 * wp.taps * wp.K_pad; a.b_plane = wp.plane(); a.ldb = wp.taps * wp.K_pad;
+    a.n_rows = nr; a.row_blocks = rows_p / 256; a.col_blocks = round_up(n_cols, 128) / 128;
+    a.K = wp.K_pad; a.taps = taps; a.dil = dil;
+    return pgemm_launch<Epi>(a, e, st);
+}
+
 int dsvc_trainer::repack(hipStream_t st) {
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
     const float isl = 1.0f / sqrtf((float)L);
@@ -579,16 +663,23 @@ int dsvc_trainer::repack(hipStream_t st) {
     // transposed (data gradients): W^T(col = input channel, ci = output channel) = W[ci][col]
     DSVC_TRY(pack(w_finT, P("denoise_fn.output_projection.weight"), nullptr, C, 1, M, C, 1, C, 0, 0, 1.0f, st));
     DSVC_TRY(pack(w_skipT, P("denoise_fn.skip_projection.weight"), nullptr, C, 1, C, C, 1, C, 0, 0, isl, st));
-    w_d.resize(L); w_c.resize(L); w_o.resize(L); w_oT.resize(L); w_cT.resize(L); w_dT.resize(L);
+    // Which engine runs which layer GEMM was measured (profiles/r3u_kernel_stats_train.csv against r3p): the gate conv, the output projection and
+    // dg = W_o^T dO stay on conv_gemm (79 / 60 / 80 us against 88 / 80 / 81 on pgemm.h -- both engines pull ~8 TB/s through the L2s at these
+    // tile shapes); the transposed conv, the conditioner data gradient and ALL layers' conditioner projections as one stacked operand run on
+    // pgemm.h (99 / 60 / 489 us against 110 / 65 / 20 x 32).  pgemm operands: weights as fragment-tiled fp16 hi|lo planes, rows = output channels.
+    const int c2p = round_up(2 * C, 128);
+    w_d.resize(L); w_o.resize(L); w_oT.resize(L); wp_dT.resize(L); wp_cT.resize(L);
     for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
         DSVC_TRY(pack(w_d[l], P(q + "dilated_conv.weight"), gm, 2 * C, 3, C, 2 * C, (long long)C * 3, 3, 1, 0, 1.0f, st));
-        DSVC_TRY(pack(w_c[l], P(q + "conditioner_projection.weight"), gm, 2 * C, 1, H, 2 * C, H, 1, 0, 0, 1.0f, st));
         DSVC_TRY(pack(w_o[l], P(q + "output_projection.weight"), nullptr, 2 * C, 1, C, 2 * C, C, 1, 0, 0, 1.0f, st));
+        // transposed (data gradients): W^T(col = input channel, ci = output channel) = W[ci][col]
         DSVC_TRY(pack(w_oT[l], P(q + "output_projection.weight"), nullptr, C, 1, 2 * C, C, 1, C, 0, 0, 1.0f, st));
-        DSVC_TRY(pack(w_cT[l], P(q + "conditioner_projection.weight"), nullptr, H, 1, 2 * C, H, 1, H, 0, 0, 1.0f, st));
+        // the conditioner projections of all layers in the gates' paired gate | filter row order, stacked
+        DSVC_TRY(wplanes(wp_call, l * c2p, L * c2p, P(q + "conditioner_projection.weight"), gm, 2 * C, 1, H, H, 1, 0, 0, 1.0f, st));
+        DSVC_TRY(wplanes(wp_cT[l], 0, H, P(q + "conditioner_projection.weight"), nullptr, H, 1, 2 * C, 1, H, 0, 0, 1.0f, st));
         // transposed conv: dxin[c] = sum_tap sum_o W_d[o][c][2 - tap] * dy[row + (tap-1)*d][o]
-        DSVC_TRY(pack(w_dT[l], P(q + "dilated_conv.weight"), nullptr, C, 3, 2 * C, C, 3, (long long)C * 3, 1, 1, 1.0f, st));
+        DSVC_TRY(wplanes(wp_dT[l], 0, C, P(q + "dilated_conv.weight"), nullptr, C, 3, 2 * C, 3, (long long)C * 3, 1, 1, 1.0f, st));
     }
     return DSVC_OK;
 }
@@ -609,7 +700,7 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     const size_t r = (size_t)rows;
     auto z = [&](DevBuf& b, size_t bytes) -> int { DSVC_TRY(b.alloc(bytes)); DSVC_HIP(hipMemsetAsync(b.p, 0, bytes, st)); return DSVC_OK; };
     DSVC_TRY(z(xt, r * M * 4)); DSVC_TRY(z(xs, r * C * 4 * (L + 1))); DSVC_TRY(z(sig, r * C * 4 * L)); DSVC_TRY(z(tau, r * C * 4 * L));
-    DSVC_TRY(z(g, r * C * 4 * L)); DSVC_TRY(z(skip, r * C * 4)); DSVC_TRY(z(ypre, r * 2 * C * 4)); DSVC_TRY(z(s2pre, r * C * 4));
+    DSVC_TRY(z(g, r * C * 4 * L)); DSVC_TRY(z(skip, r * C * 4)); DSVC_TRY(z(ypre, r * (size_t)L * round_up(2 * C, 128) * 4)); DSVC_TRY(z(s2pre, r * C * 4));
     DSVC_TRY(z(eps, r * M * 4)); DSVC_TRY(z(deps, r * M * 4)); DSVC_TRY(z(condT, r * H * 4));
     DSVC_TRY(z(tstep, (size_t)B * 4)); DSVC_TRY(z(clipid, (size_t)B * 4)); DSVC_TRY(z(iotaB, (size_t)B * 4));
     DSVC_TRY(z(e0, (size_t)B * C * 4)); DSVC_TRY(z(e1pre, (size_t)B * 4 * C * 4)); DSVC_TRY(z(e1, (size_t)B * 4 * C * 4)); DSVC_TRY(z(e2, (size_t)B * C * 4));
@@ -617,6 +708,8 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     DSVC_TRY(z(de1, (size_t)B * 4 * C * 4)); DSVC_TRY(z(de1pre, (size_t)B * 4 * C * 4));
     DSVC_TRY(z(dx, r * C * 4)); DSVC_TRY(z(dxin, r * C * 4)); DSVC_TRY(z(dO, r * 2 * C * 4)); DSVC_TRY(z(dy, r * 2 * C * 4));
     DSVC_TRY(z(ds2pre, r * C * 4)); DSVC_TRY(z(dcond, r * H * 4)); DSVC_TRY(z(dh0, r * C * 4)); DSVC_TRY(z(loss, 16));
+    rows_p = round_up(nr, 256);
+    DSVC_TRY(aplanes(condP, round_up(H, 32), st)); DSVC_TRY(aplanes(dyP, 2 * C, st));
     // weight-gradient operands (wgrad.h): frames contiguous, zero beyond the data rows and in the channel padding
     ldT = round_up(B * T, 128);                                  // real frames only (no gap rows); whole 32-frame stages, 64-frame split tiles
     cp128 = round_up(C, 128); hp128 = round_up(H, 128);
@@ -646,13 +739,14 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
 }
 
 int dsvc_trainer::split_t(bool a_side, int row0, const float* src, int ld_src, int C, const float* add, int add_stride, int dil, hipStream_t st,
-                          float* colsum) {
+                          float* colsum, const APlanes* rowp) {
     DevBuf& buf = a_side ? AT : BT;
     const int nrows = a_side ? a_rows : b_rows;
     if (row0 < 0 || row0 + (dil > 0 ? 2 * cp128 : 0) + C > nrows || dil > 64) return fail(DSVC_EINVAL, "split_t: rows [%d, %d) outside the %d-row operand planes", row0, row0 + C, nrows);
     const long long plane = (long long)nrows * ldT;
     hipLaunchKernelGGL(k_split_t, dim3(ldT / 64, ceil_div(C, 32)), dim3(256), 0, st, src, ld_src, buf.as<_Float16>() + (size_t)row0 * ldT, plane, ldT, C,
-                       add, add_stride, SplitRows{Tp, wsT, wsB}, dil > 0 ? 3 : 1, dil, (long long)cp128 * ldT, 1.0f, dil > 0 ? nullptr : colsum);
+                       add, add_stride, SplitRows{Tp, wsT, wsB}, dil > 0 ? 3 : 1, dil, (long long)cp128 * ldT, 1.0f, dil > 0 ? nullptr : colsum,
+                       rowp && dil == 0 ? rowp->base() : nullptr, rowp ? rowp->plane : 0, rowp ? rowp->ld : 0);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
@@ -747,20 +841,22 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         EpStore::Args e{xs.as<float>(), C, P("denoise_fn.input_projection.bias"), C, 1, ri};
         DSVC_TRY(launch<EpStore>(a, e, st));
     }
+    const int c2p = round_up(2 * C, 128);
+    {   // ypre_l = W_c,l cond for ALL layers in one launch (pgemm.h: cond as fp16 hi|lo planes, the stacked projection weights), in the gates'
+        // packed column order (both biases are added, in natural order, by the gate epilogue)
+        DSVC_TRY(split_rows(condP, condT.as<float>(), H, H, nullptr, 0, st));
+        EpStoreSlabs::Args e{ypre.as<float>(), c2p, (long long)r * c2p, RowInfo{Tp, Tp, nr}};
+        DSVC_TRY(pg<EpStoreSlabs>(condP, wp_call, 0, L * c2p, 1, 1, e, st));
+    }
     for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
         const int d = 1 << (l % cfg.dilation_cycle);
         float* xl = xs.as<float>() + (size_t)l * slab;
-        {   // ypre = W_c cond in the gate's packed column order (both biases are added, in natural order, by the gate epilogue)
-            ConvGemmArgs a = base(condT.as<float>(), H, H, w_c[l], 1);
-            EpStore::Args e{ypre.as<float>(), 2 * C, nullptr, 2 * C, 0, RowInfo{Tp, Tp, nr}};
-            DSVC_TRY(launch<EpStore>(a, e, st));
-        }
         {   // gate: y = conv_dil(x + film) + ypre + biases
             ConvGemmArgs a = base(xl, C, C, w_d[l], d);
             a.film = filmB.as<float>() + (size_t)l * C; a.film_step_stride = L * C; a.step_ptr = iotaB.as<int>(); a.step_off = 0; a.step_per_clip = 1;
-            EpGateFwd::Args e{ypre.as<float>(), P(q + "dilated_conv.bias"), P(q + "conditioner_projection.bias"), sig.as<float>() + (size_t)l * slab,
-                              tau.as<float>() + (size_t)l * slab, g.as<float>() + (size_t)l * slab, C, ri};
+            EpGateFwd::Args e{ypre.as<float>() + (size_t)l * r * c2p, P(q + "dilated_conv.bias"), P(q + "conditioner_projection.bias"),
+                              sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, g.as<float>() + (size_t)l * slab, C, ri, c2p};
             DSVC_TRY(launch<EpGateFwd>(a, e, st));
         }
         {   // [r; s] = W_o g + b   (net.py:79-84)
@@ -819,14 +915,14 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias")));
         DSVC_TRY(split_t(false, 0, gl, C, C, nullptr, 0, 0, st));
         DSVC_TRY(wgrad_nt(2 * C, cp128, 0, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
-        {   // dg = W_o^T dO -> dy
+        {   // dg = W_o^T dO -> dy (fp32 for the weight-gradient planes, fp16 hi|lo planes for the two data gradients below)
             ConvGemmArgs a = base(dO.as<float>(), 2 * C, 2 * C, w_oT[l], 1);
             EpGateBwd::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(), C, ri};
             DSVC_TRY(launch<EpGateBwd>(a, e, st));
         }
         // dW_d[o][c][tap] = sum_n dy[n][o] (x^l + film)[n + (tap-1) d][c]  and  dW_c[o][h] = sum_n dy[n][o] cond[n][h]  share dy^T: ONE
         // contraction over the k axis [tap 0 | tap 1 | tap 2 | cond]
-        DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "dilated_conv.bias")));
+        DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "dilated_conv.bias"), &dyP));   // + dy as pgemm planes
         DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
         DSVC_TRY(split_t(false, 0, xl, C, C, filmB.as<float>() + (size_t)l * C, L * C, d, st));
         {
@@ -838,14 +934,12 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
             DSVC_TRY(wgrad_nt(2 * C, hp128, 3 * cp128, seg1(G(q + "conditioner_projection.weight"), H, H), 1.0f, st));
         }
         {   // dcond += W_c^T dy
-            ConvGemmArgs a = base(dy.as<float>(), 2 * C, 2 * C, w_cT[l], 1);
             EpBwd::Args e{dcond.as<float>(), H, H, nullptr, 0, 1.0f, l == L - 1 ? 0 : 1, ri};
-            DSVC_TRY(launch<EpBwd>(a, e, st));
+            DSVC_TRY(pg<EpBwd>(dyP, wp_cT[l], 0, H, 1, 1, e, st));
         }
         {   // dxin = convT(dy)
-            ConvGemmArgs a = base(dy.as<float>(), 2 * C, 2 * C, w_dT[l], d);
             EpBwd::Args e{dxin.as<float>(), C, C, nullptr, 0, 1.0f, 0, ri};
-            DSVC_TRY(launch<EpBwd>(a, e, st));
+            DSVC_TRY(pg<EpBwd>(dyP, wp_dT[l], 0, C, 3, d, e, st));
         }
         hipLaunchKernelGGL(k_clip_colsum, dim3(ceil_div(C, 64), B), dim3(256), 0, st, dxin.as<float>(), dfilm.as<float>() + (size_t)l * C, T, C, Tp, L * C);
         hipLaunchKernelGGL(k_dx_update, dim3(ew), dim3(256), 0, st, dx.as<float>(), dxin.as<float>(), dO.as<float>(), nr, C);

@@ -20,19 +20,31 @@
 
 namespace dsvc {
 
+// ---- fragment-tiled planes ------------------------------------------------------------------------------------------------------------
+// Every fp16 operand plane of wgrad.h / pgemm.h is stored in the order an MFMA fragment wants it: a [R rows][K] plane is cut into pieces of
+// 32 rows x 16 k, piece (row / 32, k / 16) is 1 KiB and holds, for lane l = (row % 32) + 32 * ((k / 8) % 2), the 8 halves k % 8 = 0..7.
+// A piece is then ONE contiguous 1 KiB global_load_lds per wave (a row-major plane made that instruction touch 32 cache lines for 32 bytes
+// each: 17 GB/s per CU, profiles/r3t_kernel_stats_train.csv), and a row-shifted piece (a conv tap) is two contiguous runs.
+__host__ __device__ __forceinline__ size_t pl_off(int row, int k, int K) {
+    return ((size_t)(row >> 5) * (size_t)(K >> 4) + (size_t)(k >> 4)) * 512 + (size_t)((((row & 31) + 32 * ((k >> 3) & 1)) << 3) + (k & 7));
+}
+
 // ---- operand planes -------------------------------------------------------------------------------------------------------------
 // The planes hold the REAL frames only (the gap rows between clips would be 20 % zeros in the contraction): plane column m = clip * clip_len + t.
 // n_taps = 1:  dst[plane][c][m] = (src[clip * clip_stride + t][c] + add[clip][c]) * scale                                  for m in [0, n_out)
 // n_taps = 3:  the three taps of a dilated conv's input in one pass over src: tap j goes to plane rows + j * tap_rows and holds the frame
 //              t + (j - 1) * dil of the SAME clip, or the conv's zero padding when that leaves the clip.
 // colsum (n_taps = 1): colsum[c] += sum_m of the values written (a bias gradient: dY is read here anyway).
+// rowp (n_taps = 1): the values once more as frame-major tiled planes with the clips' gap rows (dY as the A operand of pgemm.h's data gradients).
 // Columns past the last real frame are written as zeros.  grid (n_out / 64, ceil(C / 32)), 256 threads; n_out % 64 == 0, dil <= 64; channels >= C
 // of a padded plane are left as they are (callers ignore them).
 struct SplitRows { int clip_stride, clip_len, n_clips; };
 
+// dst = the planes' base + first_row * ldT (first_row % 32 == 0); tap_halfs = tap row offset * ldT
 __global__ __launch_bounds__(256) void k_split_t(const float* __restrict__ src, int ld_src, _Float16* __restrict__ dst, long long plane_halfs,
                                                  int ldT, int C, const float* __restrict__ add, int add_stride, SplitRows ri, int n_taps, int dil,
-                                                 long long tap_halfs, float scale, float* __restrict__ colsum) {
+                                                 long long tap_halfs, float scale, float* __restrict__ colsum, _Float16* __restrict__ rowp,
+                                                 long long rowp_plane, int rowp_ld) {
     __shared__ float tile[64 + 128][33];
     const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -54,20 +66,40 @@ __global__ __launch_bounds__(256) void k_split_t(const float* __restrict__ src, 
         for (int i = 0; i < 64; ++i) sum += tile[i][tx];
         atomicAdd(colsum + c0 + tx, sum);
     }
-    const int tn = threadIdx.x & 63, tc = threadIdx.x >> 6;
-    const int m = n0 + tn, t = m % ri.clip_len;
-    for (int j = 0; j < n_taps; ++j) {
-        const int ts = t + (j - (n_taps >> 1)) * halo;               // the tap's source frame inside the clip
-        const bool ok = m < n_real && ts >= 0 && ts < ri.clip_len;
-        _Float16* d0 = dst + (size_t)j * tap_halfs + n0 + tn;
+    if (rowp) {          // the same values as FRAME-major tiled planes (a pgemm.h A operand: row = clip * clip_stride + t + 64 guard rows, k = channel)
+        const int tn = threadIdx.x & 63, cg = threadIdx.x >> 6;          // frame n0 + tn, channels c0 + 8 cg .. + 7
+        const int m = n0 + tn;
+        if (m < n_real && c0 + cg * 8 < C) {
+            const int clip = m / ri.clip_len, t = m - clip * ri.clip_len;
+            half8 hi, lo;
 #pragma unroll
-        for (int c = tc; c < 32; c += 4) {
-            if (c0 + c >= C) break;
-            const float v = ok ? tile[tn + j * halo][c] : 0.f;
-            const _Float16 hi = (_Float16)v;
-            _Float16* p = d0 + (size_t)(c0 + c) * ldT;
-            p[0] = hi;
-            p[plane_halfs] = (_Float16)(v - (float)hi);
+            for (int e = 0; e < 8; ++e) {
+                const float v = tile[tn][cg * 8 + e];
+                hi[e] = (_Float16)v;
+                lo[e] = (_Float16)(v - (float)hi[e]);
+            }
+            _Float16* p = rowp + pl_off(clip * ri.clip_stride + t + 64, c0 + cg * 8, rowp_ld);
+            *reinterpret_cast<half8*>(p) = hi;
+            *reinterpret_cast<half8*>(p + rowp_plane) = lo;
+        }
+    }
+    // write: thread = (channel c0 + cw, frames n0 + 8 * g .. + 7) -> one 16-byte store per plane into the fragment-tiled layout
+    const int cw = threadIdx.x & 31, g8 = threadIdx.x >> 5;
+    if (c0 + cw < C) {
+        for (int j = 0; j < n_taps; ++j) {
+            half8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int tn = g8 * 8 + e, m = n0 + tn, t = m % ri.clip_len;
+                const int ts = t + (j - (n_taps >> 1)) * halo;           // the tap's source frame inside the clip
+                const bool ok = m < n_real && ts >= 0 && ts < ri.clip_len;
+                const float v = ok ? tile[tn + j * halo][cw] : 0.f;
+                hi[e] = (_Float16)v;
+                lo[e] = (_Float16)(v - (float)hi[e]);
+            }
+            _Float16* p = dst + (size_t)j * tap_halfs + pl_off(c0 + cw, n0 + g8 * 8, ldT);
+            *reinterpret_cast<half8*>(p) = hi;
+            *reinterpret_cast<half8*>(p + plane_halfs) = lo;
         }
     }
 }
@@ -112,8 +144,8 @@ wgrad_nt_kernel(const WgradNtArgs a) {
     const int stages = n_end > n_begin ? (n_end - n_begin) >> 5 : 0;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    // lane's source offset inside a 32-row x 16-frame piece
-    const long long lane_off = (long long)(lane & 31) * a.ldT + (lane >> 5) * 8;
+    // fragment-tiled planes: a 32-row x 16-frame piece is 1 KiB contiguous, lane l reads its 16 bytes at + 16 l
+    const int kp = a.ldT >> 4;                                 // pieces per 32-row block
     auto dma = [&](int s) {
         char* dst = smem + (s % WG_STAGES) * WG_STAGE_BYTES;
         const int n = n_begin + s * 32;
@@ -123,10 +155,10 @@ wgrad_nt_kernel(const WgradNtArgs a) {
             const _Float16* src;
             if (i < 4) {
                 const int r = pc >> 2, p = (pc >> 1) & 1, j = pc & 1;
-                src = a.at + (long long)p * a.a_plane + (long long)(o0 + r * 32) * a.ldT + n + j * 16 + lane_off;
+                src = a.at + (long long)p * a.a_plane + ((long long)((o0 >> 5) + r) * kp + (n >> 4) + j) * 512 + lane * 8;
             } else {
                 const int q = pc - 32, c = q >> 2, p = (q >> 1) & 1, j = q & 1;
-                src = a.bt + (long long)p * a.b_plane + (long long)(k0 + c * 32) * a.ldT + n + j * 16 + lane_off;
+                src = a.bt + (long long)p * a.b_plane + ((long long)((k0 >> 5) + c) * kp + (n >> 4) + j) * 512 + lane * 8;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
