@@ -12,7 +12,7 @@ PREC_F16, PREC_F16_W2, PREC_F16_X3 = 0, 1, 2
 PREC_F16_MIX = 3
 PREC_F16_X3T = 4
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3, "f16_x3t": PREC_F16_X3T}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def parse_precision(p):
@@ -133,6 +133,9 @@ SYMBOLS = [
     ("dsvc_trainer_bind", ctypes.c_int, [_VP, _VP, _VP]),
     ("dsvc_trainer_set_schedule", ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int32, _VP, _VP, ctypes.c_int32]),
     ("dsvc_trainer_step", ctypes.c_int, [_VP, ctypes.POINTER(TrainArgs), _VP, _VP]),
+    ("dsvc_trainer_step_begin", ctypes.c_int, [_VP, ctypes.POINTER(TrainArgs), _VP]),
+    ("dsvc_trainer_step_layers", ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, _VP]),
+    ("dsvc_trainer_step_end", ctypes.c_int, [_VP, _VP, _VP]),
     ("dsvc_adamw_step", ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_int64, _VP, ctypes.c_float, _VP]),
     ("dsvc_grad_clip_coef", ctypes.c_int, [_VP, ctypes.c_int64, ctypes.c_float, _VP, _VP, _VP]),

@@ -572,7 +572,15 @@ struct dsvc_trainer {
                 float* colsum = nullptr, const APlanes* rowp = nullptr);
     // dW[o][k] = sum_n AT[o][n] * BT[b_row0 + k][n] for o < O, k < K_pad; the k axis is cut into the segments of `segs`
     int wgrad_nt(int O, int K_pad, int b_row0, const WgradSegs& segs, float scale, hipStream_t st);
-    int step(const dsvc_train_args* a, float* loss_out, hipStream_t st);
+    // one training step in phases (so that a data-parallel host can all-reduce the gradients of finished layers while the backward pass of
+    // the earlier ones still runs): PH_BEGIN = inputs, forward, loss, backward of the tail; PH_LAYERS = backward of residual layers
+    // [l_lo, l_hi) from the top down, their gradients final (diffusion_projection included, loss scale removed); PH_END = input projection,
+    // step-embedding MLP, pitch embedding.  Gradient slices that are final after each phase: dsvc.h.
+    enum { PH_BEGIN = 1, PH_LAYERS = 2, PH_END = 4, PH_ALL = 7 };
+    dsvc_train_args cur{};                                          // the arguments of the step in flight (phases after PH_BEGIN)
+    int next_layer = -1;                                            // the layer PH_LAYERS continues from (-1: no step in flight)
+    int run(int phases, int l_hi, int l_lo, const dsvc_train_args* a, float* loss_out, hipStream_t st);
+    int step(const dsvc_train_args* a, float* loss_out, hipStream_t st) { return run(PH_ALL, cfg.layers, 0, a, loss_out, st); }
 };
 
 void dsvc_trainer::layout() {
@@ -781,22 +789,29 @@ int dsvc_trainer::wgrad_nt(int O, int K_pad, int b_row0, const WgradSegs& segs, 
     return DSVC_OK;
 }
 
-int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t st) {
+int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_in, float* loss_out, hipStream_t st) {
+    if (phases & PH_BEGIN) {
+        if (!ta_in) return fail(DSVC_EINVAL, "trainer: null step arguments");
+        cur = *ta_in;
+    } else if (next_layer < 0) return fail(DSVC_ESTATE, "trainer: no step in flight (call dsvc_trainer_step_begin first)");
+    const dsvc_train_args* ta = &cur;
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers, B = ta->B, T = ta->T;
-    DSVC_TRY(ensure_ws(B, T, st));
-    DSVC_TRY(repack(st));
+    if (phases & PH_LAYERS) {
+        if (l_lo < 0 || l_hi > L || l_lo >= l_hi) return fail(DSVC_EINVAL, "trainer: layer range [%d, %d) of %d", l_lo, l_hi, L);
+        if (!(phases & PH_BEGIN) && l_hi != next_layer) return fail(DSVC_ESTATE, "trainer: layers must be walked from the top down (expected %d, got %d)", next_layer, l_hi);
+    }
+    if ((phases & PH_END) && !(phases & PH_LAYERS) && next_layer != 0) return fail(DSVC_ESTATE, "trainer: %d residual layers still to go", next_layer);
+    if (phases & PH_BEGIN) {
+        DSVC_TRY(ensure_ws(B, T, st));
+        DSVC_TRY(repack(st));
+    }
     const RowInfo ri{Tp, T, nr};
     const size_t r = (size_t)rows, slab = r * C;
-    DSVC_HIP(hipMemsetAsync(grads, 0, (size_t)total * 4, st));
-    DSVC_HIP(hipMemsetAsync(loss.p, 0, 16, st));
-    // ---- inputs ----
-    // the diffusion steps index the noise schedule (k_make_xt) and the step embedding: clamped into [0, timesteps) on the way in
-    hipLaunchKernelGGL(k_clamp_copy, dim3(ceil_div(B, 256)), dim3(256), 0, st, tstep.as<int>(), ta->t, 0, cfg.timesteps - 1, B);
-    if (ta->clip_ids) DSVC_HIP(hipMemcpyAsync(clipid.p, ta->clip_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
-    else hipLaunchKernelGGL(k_iota, dim3(ceil_div(B, 256)), dim3(256), 0, st, clipid.as<int>(), ta->first_clip, B);
-    hipLaunchKernelGGL(k_make_xt, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, ta->mel, xt.as<float>(), tstep.as<int>(), sa.as<float>(),
-                       sb.as<float>(), spec_min.as<float>(), spec_max.as<float>(), n_spec, B, T, M, Tp, ta->seed, clipid.as<int>());
-    hipLaunchKernelGGL(k_bct_to_rows, dim3(ceil_div(T, 32), ceil_div(H, 32), B), dim3(256), 0, st, ta->cond, condT.as<float>(), B, H, T, Tp);
+    const float unscale = 1.0f / loss_scale;
+    auto unscale_range = [&](const std::string& first, const std::string& last) {       // the loss scale leaves the gradients of [first, last]
+        const int64_t o0 = index.at(first).first, o1 = index.at(last).first + index.at(last).second;
+        if (loss_scale != 1.0f) hipLaunchKernelGGL(k_scale_inplace, dim3(512), dim3(256), 0, st, grads + o0, (size_t)(o1 - o0), unscale);
+    };
     auto base = [&](const float* x, int ldx, int cin, const Packed& pk, int dil) {
         ConvGemmArgs a{};
         a.x = x; a.ldx = ldx; a.n_rows = nr; a.clip_stride = Tp; a.clip_len = T;
@@ -817,12 +832,28 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         small_b(sb, Mm, N, K, lda, ldb, ldc, tA, tB, acc);
     };
     const int ew = 2048;
+    const bool batched_small = L <= 32 && (size_t)L * B * C * 4 <= wpart.bytes;
+    auto seg1 = [&](float* dst, int K, long long stride_o) {
+        WgradSegs sg{};
+        sg.n = 1; sg.s[0] = WgradSeg{dst, 0, K, stride_o, 1, 0};
+        return sg;
+    };
+  if (phases & PH_BEGIN) {
+    DSVC_HIP(hipMemsetAsync(grads, 0, (size_t)total * 4, st));
+    DSVC_HIP(hipMemsetAsync(loss.p, 0, 16, st));
+    // ---- inputs ----
+    // the diffusion steps index the noise schedule (k_make_xt) and the step embedding: clamped into [0, timesteps) on the way in
+    hipLaunchKernelGGL(k_clamp_copy, dim3(ceil_div(B, 256)), dim3(256), 0, st, tstep.as<int>(), ta->t, 0, cfg.timesteps - 1, B);
+    if (ta->clip_ids) DSVC_HIP(hipMemcpyAsync(clipid.p, ta->clip_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    else hipLaunchKernelGGL(k_iota, dim3(ceil_div(B, 256)), dim3(256), 0, st, clipid.as<int>(), ta->first_clip, B);
+    hipLaunchKernelGGL(k_make_xt, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, ta->mel, xt.as<float>(), tstep.as<int>(), sa.as<float>(),
+                       sb.as<float>(), spec_min.as<float>(), spec_max.as<float>(), n_spec, B, T, M, Tp, ta->seed, clipid.as<int>());
+    hipLaunchKernelGGL(k_bct_to_rows, dim3(ceil_div(T, 32), ceil_div(H, 32), B), dim3(256), 0, st, ta->cond, condT.as<float>(), B, H, T, Tp);
     // ---- step embedding: emb -> Linear -> Mish -> Linear -> per-layer diffusion_projection  (net.py:99-103,124-125,67) ----
     hipLaunchKernelGGL(k_sin_emb_b, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, e0.as<float>(), tstep.as<int>(), B, C);
     small(e0.as<float>(), P("denoise_fn.mlp.0.weight"), e1pre.as<float>(), B, 4 * C, C, C, C, 4 * C, 0, 1, 0, P("denoise_fn.mlp.0.bias"));
     hipLaunchKernelGGL(k_mish, dim3(ceil_div(B * 4 * C, 256)), dim3(256), 0, st, e1pre.as<float>(), e1.as<float>(), (size_t)B * 4 * C);
     small(e1.as<float>(), P("denoise_fn.mlp.2.weight"), e2.as<float>(), B, C, 4 * C, 4 * C, 4 * C, C, 0, 1, 0, P("denoise_fn.mlp.2.bias"));
-    const bool batched_small = L <= 32 && (size_t)L * B * C * 4 <= wpart.bytes;
     if (batched_small) {   // film_l = e2 W_l^T + b_l for all layers in one launch
         SmallBatch sb{};
         sb.n = L;
@@ -879,11 +910,6 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     hipLaunchKernelGGL(k_loss, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, eps.as<float>(), deps.as<float>(), loss.as<float>(), B, T, M, Tp,
                        ta->seed, clipid.as<int>(), cfg.loss_l1, inv_n, loss_scale);
     // ---- backward: tail ----
-    auto seg1 = [&](float* dst, int K, long long stride_o) {
-        WgradSegs sg{};
-        sg.n = 1; sg.s[0] = WgradSeg{dst, 0, K, stride_o, 1, 0};
-        return sg;
-    };
     {   // dW_out[m][c] = sum_n deps[n][m] relu(s2pre)[n][c]
         hipLaunchKernelGGL(k_relu_bwd, dim3(ew), dim3(256), 0, st, s2pre.as<float>(), s2pre.as<float>(), dh0.as<float>(), r * C);   // dh0 = relu(s2pre) (scratch)
         DSVC_TRY(split_t(true, 0, deps.as<float>(), M, M, nullptr, 0, 0, st, G("denoise_fn.output_projection.bias")));
@@ -906,8 +932,12 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
     hipLaunchKernelGGL(k_copy_cols, dim3(ew), dim3(256), 0, st, dx.as<float>(), dO.as<float>(), nr, C, 2 * C, 0, 0.0f);   // ... so the residual half of dO starts at 0
     // cond^T planes once (weight gradients of every conditioner projection): the last segment of the layers' k axis, which nothing else writes
     DSVC_TRY(split_t(false, 3 * cp128, condT.as<float>(), H, H, nullptr, 0, 0, st));
+    unscale_range("denoise_fn.skip_projection.weight", "denoise_fn.output_projection.bias");      // final: the tail's four tensors
+    next_layer = L;
+  }
+  if (phases & PH_LAYERS) {
     // ---- backward: layers ----
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = l_hi - 1; l >= l_lo; --l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
         const int d = 1 << (l % cfg.dilation_cycle);
         const float* xl = xs.as<float>() + (size_t)l * slab;
@@ -944,35 +974,49 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         hipLaunchKernelGGL(k_clip_colsum, dim3(ceil_div(C, 64), B), dim3(256), 0, st, dxin.as<float>(), dfilm.as<float>() + (size_t)l * C, T, C, Tp, L * C);
         hipLaunchKernelGGL(k_dx_update, dim3(ew), dim3(256), 0, st, dx.as<float>(), dxin.as<float>(), dO.as<float>(), nr, C);
     }
+    // the step-embedding side of these layers: d diffusion_projection from dfilm_l (the FiLM gradient) -- with them the layers' gradients are final
+    if (batched_small) {
+        SmallBatch dw{};
+        dw.n = l_hi - l_lo;
+        for (int l = l_lo; l < l_hi; ++l) {
+            const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
+            const float* df = dfilm.as<float>() + (size_t)l * C;
+            dw.A[l - l_lo] = df; dw.B[l - l_lo] = e2.as<float>(); dw.C[l - l_lo] = G(q + "weight");     // dWp[o][i] = sum_b dfilm[b][o] e2[b][i]
+            hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);   // dbp = sum_b dfilm[b]
+        }
+        small_b(dw, C, C, B, L * C, C, C, 1, 0, 0);
+    } else for (int l = l_lo; l < l_hi; ++l) {
+        const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
+        const float* df = dfilm.as<float>() + (size_t)l * C;
+        small(df, e2.as<float>(), G(q + "weight"), C, C, B, L * C, C, C, 1, 0, 0, nullptr);
+        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);
+    }
+    unscale_range("denoise_fn.residual_layers." + std::to_string(l_lo) + ".dilated_conv.weight",
+                  "denoise_fn.residual_layers." + std::to_string(l_hi - 1) + ".output_projection.bias");
+    next_layer = l_lo;
+  }
+  if (phases & PH_END) {
     {   // input projection: d h0pre = dx^0 [x^0 > 0]
         hipLaunchKernelGGL(k_relu_bwd, dim3(ew), dim3(256), 0, st, dx.as<float>(), xs.as<float>(), dh0.as<float>(), r * C);
         DSVC_TRY(split_t(true, 0, dh0.as<float>(), C, C, nullptr, 0, 0, st, G("denoise_fn.input_projection.bias")));
         DSVC_TRY(split_t(false, 0, xt.as<float>(), M, M, nullptr, 0, 0, st));
         DSVC_TRY(wgrad_nt(C, round_up(M, 128), 0, seg1(G("denoise_fn.input_projection.weight"), M, M), 1.0f, st));
     }
-    // ---- backward: step embedding ----
+    // ---- backward: step embedding:  de2[b][i] = sum_l sum_o dfilm_l[b][o] Wp_l[o][i] ----
     DSVC_HIP(hipMemsetAsync(de2.p, 0, (size_t)B * C * 4, st));
     if (batched_small) {
-        SmallBatch dw{}, dx2{};
-        dw.n = dx2.n = L;
+        SmallBatch dx2{};
+        dx2.n = L;
         for (int l = 0; l < L; ++l) {
             const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
-            const float* df = dfilm.as<float>() + (size_t)l * C;
-            dw.A[l] = df; dw.B[l] = e2.as<float>(); dw.C[l] = G(q + "weight");                          // dWp[o][i] = sum_b dfilm[b][o] e2[b][i]
-            dx2.A[l] = df; dx2.B[l] = P(q + "weight"); dx2.C[l] = de2.as<float>();                      // de2[b][i] = sum_l sum_o dfilm[b][o] Wp[o][i]
-            hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);   // dbp = sum_b dfilm[b]
+            dx2.A[l] = dfilm.as<float>() + (size_t)l * C; dx2.B[l] = P(q + "weight");
+            dx2.C[l] = wpart.as<float>() + (size_t)l * B * C;       // per-layer partials into the (idle) weight-gradient scratch, then a fixed-order sum
         }
-        small_b(dw, C, C, B, L * C, C, C, 1, 0, 0);
-        // de2 = sum over the layers: per-layer partials into the (idle) weight-gradient scratch, then a fixed-order sum
-        for (int l = 0; l < L; ++l) dx2.C[l] = wpart.as<float>() + (size_t)l * B * C;
         small_b(dx2, B, C, C, L * C, C, C, 0, 0, 0);
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, wpart.as<float>(), de2.as<float>(), L, B, C, C, 1LL, (long long)C, 0LL);
     } else for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
-        const float* df = dfilm.as<float>() + (size_t)l * C;
-        small(df, e2.as<float>(), G(q + "weight"), C, C, B, L * C, C, C, 1, 0, 0, nullptr);            // dWp[o][i] = sum_b dfilm[b][o] e2[b][i]
-        small(df, P(q + "weight"), de2.as<float>(), B, C, C, L * C, C, C, 0, 0, 1, nullptr);           // de2[b][i] += sum_o dfilm[b][o] Wp[o][i]
-        hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);   // dbp = sum_b dfilm[b]
+        small(dfilm.as<float>() + (size_t)l * C, P(q + "weight"), de2.as<float>(), B, C, C, L * C, C, C, 0, 0, 1, nullptr);
     }
     small(de2.as<float>(), e1.as<float>(), G("denoise_fn.mlp.2.weight"), C, 4 * C, B, C, 4 * C, 4 * C, 1, 0, 0, nullptr);
     hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, de2.as<float>(), G("denoise_fn.mlp.2.bias"), B, C, C, B);
@@ -986,8 +1030,11 @@ int dsvc_trainer::step(const dsvc_train_args* ta, float* loss_out, hipStream_t s
         hipLaunchKernelGGL(k_embed_bwd, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, dcond.as<float>(), ta->pitch,
                            ta->mel2ph, G("fs2.pitch_embed.weight"), B, T, H, Tp, cfg.pitch_vocab);
     }
-    if (loss_scale != 1.0f) hipLaunchKernelGGL(k_scale_inplace, dim3(ew), dim3(256), 0, st, grads, (size_t)total, 1.0f / loss_scale);
+    unscale_range("denoise_fn.input_projection.weight", "denoise_fn.mlp.2.bias");
+    unscale_range("fs2.pitch_embed.weight", "fs2.pitch_embed.weight");
     if (loss_out) DSVC_HIP(hipMemcpyAsync(loss_out, loss.p, 4, hipMemcpyDeviceToDevice, st));
+    next_layer = -1;
+  }
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
@@ -1046,6 +1093,23 @@ int dsvc_trainer_set_schedule(dsvc_trainer* t, const float* sqrt_ac, const float
     t->n_spec = n_spec;
     t->cfg.timesteps = K;
     return DSVC_OK;
+}
+
+int dsvc_trainer_step_begin(dsvc_trainer* t, const dsvc_train_args* a, void* stream) {
+    if (!t || !a) return fail(DSVC_EINVAL, "null argument");
+    if (!t->params || !t->grads || !t->sa.p) return fail(DSVC_ESTATE, "trainer: bind the parameter buffers and set the schedule first");
+    if (a->B < 1 || a->T < 1 || !a->mel || !a->cond || !a->t || (a->T * t->cfg.mel_bins) % 4) return fail(DSVC_EINVAL, "trainer: bad step arguments");
+    return t->run(dsvc_trainer::PH_BEGIN, 0, 0, a, nullptr, (hipStream_t)stream);
+}
+
+int dsvc_trainer_step_layers(dsvc_trainer* t, int32_t l_hi, int32_t l_lo, void* stream) {
+    if (!t) return fail(DSVC_EINVAL, "null argument");
+    return t->run(dsvc_trainer::PH_LAYERS, l_hi, l_lo, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int dsvc_trainer_step_end(dsvc_trainer* t, float* loss_out, void* stream) {
+    if (!t) return fail(DSVC_EINVAL, "null argument");
+    return t->run(dsvc_trainer::PH_END, 0, 0, nullptr, loss_out, (hipStream_t)stream);
 }
 
 int dsvc_trainer_step(dsvc_trainer* t, const dsvc_train_args* a, float* loss_out, void* stream) {

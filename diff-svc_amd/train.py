@@ -2,8 +2,10 @@
 ``GaussianDiffusion.forward(infer=False)`` -> ``p_losses`` (network/diff/diffusion.py:200-225,237-241) with the gradients of
 every ``denoise_fn.*`` parameter and of ``fs2.pitch_embed.weight``, gradient-norm clipping (utils/pl_utils.py:1081-1084),
 AdamW and the StepLR schedule (training/task/SVC_task.py:60-66,116-125), and data-parallel training as the reference does it
-(utils/pl_utils.py:179-221: one process per GPU, gradients averaged over ranks) -- here one all-reduce of the flat gradient
-buffer per step through ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI; ``gloo`` in the CPU tests).
+(utils/pl_utils.py:179-221: one process per GPU, gradients averaged over ranks) through ``torch.distributed`` (backend ``nccl`` = RCCL
+over xGMI; ``gloo`` in the CPU tests): the flat gradient buffer is all-reduced in BUCKETS -- the tail, groups of residual layers from the
+top down, the head -- each launched as soon as ``dsvc_trainer_step_begin / _layers / _end`` has made its slice final, so the exchange of
+layers 19..15 runs on RCCL's stream under the backward pass of layers 14..0 (what the reference's DDP reducer does, pl_utils.py:187-221).
 
 Parameters and gradients are two flat fp32 device tensors owned by this object; the C ABI (include/dsvc.h, dsvc_trainer_*)
 reads / writes them in place, ``state_dict()`` exposes the reference's key names and shapes, so a checkpoint written from it
@@ -43,7 +45,7 @@ class TrainerHandle:
         lo, hi = spec_min.detach().cpu().float().reshape(-1).contiguous(), spec_max.detach().cpu().float().reshape(-1).contiguous()
         check(lib().dsvc_trainer_set_schedule(self._h, ptr(a), ptr(b), a.numel(), ptr(lo), ptr(hi), lo.numel()))
 
-    def step(self, mel, cond, t, pitch=None, mel2ph=None, seed=0, first_clip=0, clip_ids=None, loss_out=None):
+    def _args(self, mel, cond, t, pitch, mel2ph, seed, first_clip, clip_ids):
         B, T, M = mel.shape
         i32 = lambda x: x.to(torch.int32).contiguous() if x is not None else None
         mel, cond = mel.contiguous().float(), cond.contiguous().float()
@@ -58,8 +60,26 @@ class TrainerHandle:
         a = _lib.TrainArgs(B, T, mel.data_ptr(), cond.data_ptr(), t.data_ptr(), pitch.data_ptr() if pitch is not None else None,
                            mel2ph.data_ptr() if mel2ph is not None else None, seed, first_clip,
                            clip_ids.data_ptr() if clip_ids is not None else None)
+        return a, (mel, cond, t, pitch, mel2ph, clip_ids)            # the tensors stay referenced while the step is enqueued
+
+    def step(self, mel, cond, t, pitch=None, mel2ph=None, seed=0, first_clip=0, clip_ids=None, loss_out=None):
+        a, keep = self._args(mel, cond, t, pitch, mel2ph, seed, first_clip, clip_ids)
         loss = loss_out if loss_out is not None else torch.empty(1, device=mel.device, dtype=torch.float32)
         check(lib().dsvc_trainer_step(self._h, ctypes.byref(a), ptr(loss), stream_ptr()))
+        return loss
+
+    # the same step in phases (include/dsvc.h): after each call a contiguous slice of the gradient buffer is final
+    def step_begin(self, mel, cond, t, pitch=None, mel2ph=None, seed=0, first_clip=0, clip_ids=None):
+        a, self._inflight = self._args(mel, cond, t, pitch, mel2ph, seed, first_clip, clip_ids)
+        check(lib().dsvc_trainer_step_begin(self._h, ctypes.byref(a), stream_ptr()))
+
+    def step_layers(self, l_hi, l_lo):
+        check(lib().dsvc_trainer_step_layers(self._h, int(l_hi), int(l_lo), stream_ptr()))
+
+    def step_end(self, loss_out=None):
+        loss = loss_out if loss_out is not None else torch.empty(1, device=self._inflight[0].device, dtype=torch.float32)
+        check(lib().dsvc_trainer_step_end(self._h, ptr(loss), stream_ptr()))
+        self._inflight = None
         return loss
 
     def __del__(self):
@@ -69,6 +89,23 @@ class TrainerHandle:
                 self._h = ctypes.c_void_p(0)
         except Exception:
             pass
+
+
+def gradient_buckets(layout, n_layers, layers_per_bucket=5):
+    """The order in which the phased step makes the flat gradient buffer final, as (phase, l_hi, l_lo, [(offset, numel), ...]):
+    ('begin', -, -, tail slice), ('layers', hi, lo, slice) from the top layer down, ('end', -, -, head slice + pitch embedding).
+    The slices partition [0, n_floats) (tests/test_host.py)."""
+    off = {name: (o, n) for name, o, n in layout}
+    span = lambda first, last: (off[first][0], off[last][0] + off[last][1] - off[first][0])
+    out = [("begin", 0, 0, [span("denoise_fn.skip_projection.weight", "denoise_fn.output_projection.bias")])]
+    hi = n_layers
+    while hi > 0:
+        lo = max(0, hi - layers_per_bucket)
+        out.append(("layers", hi, lo, [span("denoise_fn.residual_layers.%d.dilated_conv.weight" % lo,
+                                            "denoise_fn.residual_layers.%d.output_projection.bias" % (hi - 1))]))
+        hi = lo
+    out.append(("end", 0, 0, [span("denoise_fn.input_projection.weight", "denoise_fn.mlp.2.bias"), off["fs2.pitch_embed.weight"]]))
+    return out
 
 
 def allreduce_mean_(flat, group=None):
@@ -140,21 +177,57 @@ class DiffusionTrainerHip:
         return self.h.step(mels, cond, t, pitch=ret["pitch_pred"].squeeze(-1), mel2ph=mel2ph, seed=seed, first_clip=first_clip, clip_ids=clip_ids)
 
     @torch.no_grad()
-    def train_step(self, hubert, mel2ph, f0, mels, t=None, seed=None, first_clip=0, clip_ids=None):
-        """One optimisation step: forward + backward, all-reduce (mean) of the gradients over the ranks, gradient-norm clip, AdamW."""
+    def forward_backward_overlapped(self, hubert, mel2ph, f0, mels, t, seed=0, first_clip=0, clip_ids=None, layers_per_bucket=5):
+        """forward_backward + the gradient all-reduce (mean), bucket by bucket under the backward pass: every bucket's all-reduce is
+        launched asynchronously (RCCL's own stream, ordered after the kernels that made the slice final) and waited for at the end.
+        ``self.grads`` holds the averaged gradients on return."""
+        import torch.distributed as dist
+        ret = self.fs2(hubert, mel2ph, None, None, f0.clone(), None, None, infer=False)
+        cond = ret["decoder_inp"].transpose(1, 2).contiguous()
+        world = dist.get_world_size(self.group)
+        works, loss = [], None
+        for phase, hi, lo, slices in gradient_buckets(self.h.layout, int(self.hp["residual_layers"]), layers_per_bucket):
+            if phase == "begin":
+                self.h.step_begin(mels, cond, t, pitch=ret["pitch_pred"].squeeze(-1), mel2ph=mel2ph, seed=seed, first_clip=first_clip, clip_ids=clip_ids)
+            elif phase == "layers":
+                self.h.step_layers(hi, lo)
+            else:
+                loss = self.h.step_end()
+            for o, n in slices:
+                works.append(dist.all_reduce(self.grads[o:o + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        if world > 1:
+            self.grads.mul_(1.0 / world)
+        return loss
+
+    @torch.no_grad()
+    def train_step(self, hubert, mel2ph, f0, mels, t=None, seed=None, first_clip=0, clip_ids=None, overlap=None):
+        """One optimisation step: forward + backward, all-reduce (mean) of the gradients over the ranks, gradient-norm clip, AdamW.
+        overlap: all-reduce bucket by bucket under the backward pass (default: whenever a process group with more than one rank is up)."""
+        import torch.distributed as dist
         B = mels.shape[0]
         if t is None:
             t = torch.randint(0, int(self.hp.get("K_step", self.hp["timesteps"])), (B,), device=mels.device)       # train_pipeline.py:233
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        loss = self.forward_backward(hubert, mel2ph, f0, mels, t, seed=seed, first_clip=first_clip, clip_ids=clip_ids)
-        self.optimizer_step()
+        ddp = dist.is_available() and dist.is_initialized()
+        if overlap is None:
+            overlap = ddp and dist.get_world_size(self.group) > 1
+        if overlap and ddp:
+            loss = self.forward_backward_overlapped(hubert, mel2ph, f0, mels, t, seed=seed, first_clip=first_clip, clip_ids=clip_ids)
+            self.optimizer_step(reduced=True)
+        else:
+            loss = self.forward_backward(hubert, mel2ph, f0, mels, t, seed=seed, first_clip=first_clip, clip_ids=clip_ids)
+            self.optimizer_step()
         return loss
 
     @torch.no_grad()
-    def optimizer_step(self):
-        """What follows the backward pass: all-reduce (mean) of ``self.grads`` over the ranks, clip_grad_norm_, AdamW at the StepLR rate."""
-        allreduce_mean_(self.grads, self.group)
+    def optimizer_step(self, reduced=False):
+        """What follows the backward pass: all-reduce (mean) of ``self.grads`` over the ranks (unless the overlapped backward pass has done
+        it already), clip_grad_norm_, AdamW at the StepLR rate."""
+        if not reduced:
+            allreduce_mean_(self.grads, self.group)
         lr = self.lr()                                       # step k (0-based) runs at lr0 * 0.5 ** (max(k - 1, 0) // decay_steps)
         self.global_step += 1
         hp, n = self.hp, self.h.n_floats

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DSVC_ABI_VERSION 5
+#define DSVC_ABI_VERSION 6
 
 enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM = 4 };
 
@@ -323,6 +323,19 @@ int dsvc_trainer_set_schedule(dsvc_trainer* t, const float* sqrt_alphas_cumprod,
                               const float* spec_min, const float* spec_max, int32_t n_spec);
 /* forward + backward of one batch: grads <- d loss / d params (overwritten), *loss_out (device float, may be NULL) <- the loss */
 int dsvc_trainer_step(dsvc_trainer* t, const dsvc_train_args* a, float* loss_out, void* stream);
+/* The same step in three phases, for a data-parallel host that all-reduces finished gradient slices while the backward pass of the
+ * earlier layers still runs (what the reference's DDP reducer does bucket by bucket, utils/pl_utils.py:187-221):
+ *   begin              inputs, forward, loss, backward of the tail.  Final afterwards: the contiguous slice
+ *                      [denoise_fn.skip_projection.weight .. denoise_fn.output_projection.bias]
+ *   layers(l_hi, l_lo) backward of residual layers l_hi-1 ... l_lo (top down; the first call has l_hi = residual_layers, each later call
+ *                      continues where the previous one stopped).  Final afterwards: the contiguous slice
+ *                      [denoise_fn.residual_layers.<l_lo>.dilated_conv.weight .. denoise_fn.residual_layers.<l_hi-1>.output_projection.bias]
+ *   end                input projection, step-embedding MLP, pitch embedding; *loss_out.  Final afterwards: everything
+ *                      ([denoise_fn.input_projection.weight .. denoise_fn.mlp.2.bias] and fs2.pitch_embed.weight were the missing slices).
+ * dsvc_trainer_step == begin; layers(residual_layers, 0); end.  All three enqueue on `stream` and return. */
+int dsvc_trainer_step_begin(dsvc_trainer* t, const dsvc_train_args* a, void* stream);
+int dsvc_trainer_step_layers(dsvc_trainer* t, int32_t l_hi, int32_t l_lo, void* stream);
+int dsvc_trainer_step_end(dsvc_trainer* t, float* loss_out, void* stream);
 /* torch.optim.AdamW update of a flat buffer.  The gradient is multiplied by *grad_scale_dev (device, e.g. the clip coefficient)
  * when that pointer is not NULL, else by grad_scale. */
 int dsvc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,

@@ -24,8 +24,8 @@ def _batch(hp, clips, T, n_units, seed):
 @pytest.mark.parametrize("arch,loss_type", [("tiny", "l2"), ("tiny", "l1"), ("44k", "l2")])
 def test_train_step_loss_and_gradients_vs_autograd(arch, loss_type):
     """Forward + backward: the loss and EVERY gradient tensor (43 for the tiny architecture, 171 for the 44.1 kHz one, plus the
-    pitch embedding reached through cond).  All contractions run at split-fp16 (fp32-class) precision: per-tensor relative L2
-    error <= 1e-3 of autograd's, worst printed."""
+    pitch embedding reached through cond).  All contractions run at split-fp16 (fp32-class) precision and the backward pass is
+    loss-scaled into fp16's normal range: per-tensor relative L2 error <= 5e-5 of autograd's (measured 4e-6 ... 1e-5), worst printed."""
     from diffsvc_amd.train import DiffusionTrainerHip
     hp = dict(synth.tiny_hparams(K=50) if arch == "tiny" else synth.HPARAMS_44K, diff_loss_type=loss_type)
     sd = synth.acoustic_state(hp, 3)
@@ -50,7 +50,7 @@ def test_train_step_loss_and_gradients_vs_autograd(arch, loss_type):
         if err > worst:
             worst, worst_name = err, name
     print("train step %s %s: loss %.6f (ref %.6f), worst gradient rel-L2 err %.2e (%s)" % (arch, loss_type, loss.item(), ref_loss.item(), worst, worst_name))
-    assert worst < 1e-3, (worst, worst_name)
+    assert worst < 5e-5, (worst, worst_name)
 
 
 def test_optimizer_step_matches_torch_adamw_with_grad_clip():
@@ -162,8 +162,70 @@ def test_train_step_vs_real_reference_golden(case):
             worst, worst_name = err, k
     print("train step %s vs the real reference: loss %.6f (ref %.6f), worst gradient rel-L2 err %.2e (%s), worst |norm| err %.2e"
           % (case, loss.item(), ref_loss, worst, worst_name, worst_norm))
-    # l2: smooth loss -> the split-fp16 (fp32-class) bar of 1e-3 per tensor.  l1: d|r|/d eps = sign(r) is discontinuous, so the 1e-6-class
-    # difference between two correct forward passes flips the sign of the ~1e-6 of the elements whose residual sits that close to zero,
-    # each flip changing an entry by 2: a relative L2 error of ~2.5e-3 at the 44.1 kHz size (5.0e-3 allowed) while every NORM agrees to 1e-4
-    tol = 5e-3 if case.endswith("l1") else 1e-3
-    assert worst < tol and worst_norm < 1e-3, (worst, worst_name, worst_norm)
+    # measured 4e-6 (l2) / 1e-5 (l1) since the backward pass is loss-scaled (d loss / d eps ~ 1e-6 used to sit in fp16's subnormal range, where
+    # its hi + lo split kept 4 bits: 8e-4 / 2.5e-3 then)
+    assert worst < 5e-5 and worst_norm < 1e-5, (worst, worst_name, worst_norm)
+
+
+def test_phased_step_equals_the_monolithic_step():
+    """dsvc_trainer_step_begin / _layers / _end (the phases a data-parallel host interleaves with bucketed all-reduces) against
+    dsvc_trainer_step on the same batch: same loss, same gradients (bias gradients are float atomics: compared to 1e-6 relative), and a
+    wrong walking order is refused."""
+    from diffsvc_amd.train import DiffusionTrainerHip, gradient_buckets
+    hp = dict(synth.HPARAMS_44K, diff_loss_type="l2")
+    sd = synth.acoustic_state(hp, 3)
+    clips, T, n_units, seed = [4, 9, 11], 64, 37, 6
+    hub, m2p, f0, mels, t = (v.cuda() for v in _batch(hp, clips, T, n_units, seed))
+    ids = torch.tensor(clips, dtype=torch.int32, device="cuda")
+    tr = DiffusionTrainerHip(hp, sd)
+    loss_a = tr.forward_backward(hub, m2p, f0, mels, t, seed=seed, clip_ids=ids).item()
+    ga = tr.grads.clone()
+    ret = tr.fs2(hub, m2p, None, None, f0.clone(), None, None, infer=False)
+    cond = ret["decoder_inp"].transpose(1, 2).contiguous()
+    tr.grads.fill_(float("nan"))
+    covered = torch.zeros_like(tr.grads, dtype=torch.bool)
+    loss_b = None
+    for phase, hi, lo, slices in gradient_buckets(tr.h.layout, hp["residual_layers"], 7):
+        if phase == "begin":
+            tr.h.step_begin(mels, cond, t, pitch=ret["pitch_pred"].squeeze(-1), mel2ph=m2p, seed=seed, clip_ids=ids)
+            with pytest.raises(RuntimeError):
+                tr.h.step_layers(3, 0)                         # layers are walked from the top down
+        elif phase == "layers":
+            tr.h.step_layers(hi, lo)
+        else:
+            loss_b = tr.h.step_end().item()
+        torch.cuda.synchronize()
+        for o, n in slices:                                    # the slice the phase declares final IS final: it never changes afterwards
+            assert not covered[o:o + n].any()
+            covered[o:o + n] = True
+            d = (tr.grads[o:o + n] - ga[o:o + n]).norm().item() / max(ga[o:o + n].norm().item(), 1e-30)
+            assert d < 1e-6, (phase, hi, lo, d)
+    assert covered.all() and loss_a == loss_b
+    with pytest.raises(RuntimeError):
+        tr.h.step_layers(hp["residual_layers"], 0)             # no step in flight
+
+
+def test_overlapped_allreduce_step_under_a_process_group():
+    """train_step(overlap=True): the bucketed asynchronous all-reduces (RCCL, one rank: the sums are identities) interleaved with the phased
+    backward pass leave the same parameters as the plain step."""
+    import torch.distributed as dist
+    from diffsvc_amd.train import DiffusionTrainerHip
+    hp = dict(synth.tiny_hparams(K=50), diff_loss_type="l2", lr=1e-3)
+    sd = synth.acoustic_state(hp, 3)
+    hub, m2p, f0, mels, t = (v.cuda() for v in _batch(hp, [0, 1, 2], 40, 23, 5))
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    try:
+        a, b = DiffusionTrainerHip(hp, sd), DiffusionTrainerHip(hp, sd)
+        for step in range(3):
+            la = a.train_step(hub, m2p, f0, mels, t=t, seed=7 + step, overlap=False)
+            lb = b.train_step(hub, m2p, f0, mels, t=t, seed=7 + step, overlap=True)
+            assert abs(la.item() - lb.item()) <= 1e-6 * abs(la.item())
+        torch.cuda.synchronize()
+        d = (a.params - b.params).abs().max().item()
+        print("overlapped vs plain training step, 3 steps: max |param diff| %.2e" % d)
+        assert d < 1e-6
+    finally:
+        if own:
+            dist.destroy_process_group()

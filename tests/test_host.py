@@ -374,3 +374,34 @@ def test_shard_clips_by_length_balances_and_is_deterministic():
             assert [lens[i] for i in p] == sorted((lens[i] for i in p), reverse=True)
     even = shard_clips_by_length([861] * 256, 8)
     assert all(len(p) == 32 for p in even) and sorted(even[3]) == shard_clips(256, 3, 8)
+
+
+def test_gradient_buckets_partition_the_flat_gradient_buffer():
+    """diffsvc_amd.train.gradient_buckets: the slices the phased training step declares final (tail, groups of residual layers from the top
+    down, head + pitch embedding) cover the flat buffer exactly once, in the order the C side finishes them."""
+    from diffsvc_amd import synth
+    from diffsvc_amd.train import gradient_buckets
+    hp = synth.HPARAMS_44K
+    M, H, C, L = hp["audio_num_mel_bins"], hp["hidden_size"], hp["residual_channels"], hp["residual_layers"]
+    names = [("denoise_fn.input_projection.weight", C * M), ("denoise_fn.input_projection.bias", C), ("denoise_fn.mlp.0.weight", 4 * C * C),
+             ("denoise_fn.mlp.0.bias", 4 * C), ("denoise_fn.mlp.2.weight", 4 * C * C), ("denoise_fn.mlp.2.bias", C)]
+    for l in range(L):
+        q = "denoise_fn.residual_layers.%d." % l
+        names += [(q + "dilated_conv.weight", 2 * C * C * 3), (q + "dilated_conv.bias", 2 * C), (q + "diffusion_projection.weight", C * C),
+                  (q + "diffusion_projection.bias", C), (q + "conditioner_projection.weight", 2 * C * H), (q + "conditioner_projection.bias", 2 * C),
+                  (q + "output_projection.weight", 2 * C * C), (q + "output_projection.bias", 2 * C)]
+    names += [("denoise_fn.skip_projection.weight", C * C), ("denoise_fn.skip_projection.bias", C), ("denoise_fn.output_projection.weight", M * C),
+              ("denoise_fn.output_projection.bias", M), ("fs2.pitch_embed.weight", 300 * H)]
+    layout, off = [], 0
+    for n, k in names:
+        layout.append((n, off, k)); off += k
+    for per in (1, 5, 7, 20, 64):
+        buckets = gradient_buckets(layout, L, per)
+        assert buckets[0][0] == "begin" and buckets[-1][0] == "end"
+        layer_calls = [(hi, lo) for ph, hi, lo, _ in buckets if ph == "layers"]
+        assert layer_calls[0][0] == L and layer_calls[-1][1] == 0 and all(a[1] == b[0] for a, b in zip(layer_calls, layer_calls[1:]))
+        cover = np.zeros(off, dtype=np.int32)
+        for _, _, _, slices in buckets:
+            for o, n in slices:
+                cover[o:o + n] += 1
+        assert (cover == 1).all(), per
