@@ -200,7 +200,7 @@ def test_phased_step_equals_the_monolithic_step():
             covered[o:o + n] = True
             d = (tr.grads[o:o + n] - ga[o:o + n]).norm().item() / max(ga[o:o + n].norm().item(), 1e-30)
             assert d < 1e-6, (phase, hi, lo, d)
-    assert covered.all() and loss_a == loss_b
+    assert covered.all() and abs(loss_a - loss_b) <= 1e-6 * abs(loss_a)      # (the loss is a float-atomic sum of block partials)
     with pytest.raises(RuntimeError):
         tr.h.step_layers(hp["residual_layers"], 0)             # no step in flight
 
