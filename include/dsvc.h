@@ -36,10 +36,11 @@ enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM
  *            into the residual stream and the skip sum): 6.7e-4 ... 9.7e-4 on single clips, 1.14e-3 on one clip of a batch of 32
  *            (over the bar): round 2's DDPM default, no longer shipped.
  *   F16_W2 : w = w_hi + w_lo, x fp16                   2 MFMAs              (6.2e-4 ... 8.8e-4 mel after 1000 steps over 27 goldens;
- *            2.3e-4 on conditioned checkpoints).  The shipped DDPM precision.
+ *            2.3e-4 on conditioned checkpoints).  What the Python drop-in's "auto" runs batched DDPM at (>= 6000 frames per call).
  *   F16_X3 : w = w_hi + w_lo, x = x_hi + x_lo          3 MFMAs              (fp32-class, ~1e-5) on the conv_gemm engine
  *   F16_X3T: the same operand scheme on the tgemm engine (activation rows hold [x_hi | x_lo] planes; the weight stream is F16_W2's):
- *            the fp32-class scheme at the speed class of the small-batch tgemm kernels.                                       */
+ *            the fp32-class scheme at the speed class of the small-batch tgemm kernels (3.3e-5 ... 4.9e-5 mel after 1000 steps on 21
+ *            goldens, +14 ... 20 % over F16_W2 up to six 10 s clips, 1.5 ... 1.9x beyond).  "auto": DDPM calls under 6000 frames, PLMS, forward(). */
 enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2, DSVC_PREC_F16_MIX = 3, DSVC_PREC_F16_X3T = 4 };
 
 int dsvc_abi_version(void);
