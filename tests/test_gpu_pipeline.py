@@ -22,9 +22,10 @@ def tiny_pipeline(K=30, precision="f16_x3"):
     return SvcPipeline(hp, sd, vs, h, precision=precision, vocoder_precision="f16_x3"), hp, h, sd, vs
 
 
+@pytest.mark.parametrize("precision", ["f16_x3", "auto"])          # auto: what ships (f16_x3t at this size, the tgemm engine)
 @pytest.mark.parametrize("speedup", [1, 10])
-def test_pipeline_end_to_end_vs_oracle(speedup):
-    pipe, hp, h, sd, vs = tiny_pipeline()
+def test_pipeline_end_to_end_vs_oracle(speedup, precision):
+    pipe, hp, h, sd, vs = tiny_pipeline(precision=precision)
     T, n_units, clips, seed = 40, 23, [0, 1], 11
     hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
     wav, mel = pipe.infer(hub.cuda(), m2p.cuda(), f0.cuda(), speedup=speedup, seed=seed, first_clip=0, return_mel=True)
@@ -65,7 +66,8 @@ def test_denoiser_module_seam():
     assert (out2.cpu() - 2 * ref).abs().max().item() < 6e-4
 
 
-def test_sampler_module_use_gt_mel_start():
+@pytest.mark.parametrize("precision", ["f16_x3", "auto"])
+def test_sampler_module_use_gt_mel_start(precision):
     """use_gt_mel / add_noise_step (diffusion.py:255-261): the chain starts from q_sample(norm_spec(ref_mel), t-1); norm_spec,
     q_sample and the noise draw run inside the C ABI (dsvc_sample_args.ref_mel)."""
     from diffsvc_amd.denoiser import DiffNetHip
@@ -73,7 +75,7 @@ def test_sampler_module_use_gt_mel_start():
     hp = synth.tiny_hparams(K=50)
     sd = synth.acoustic_state(hp, 3)
     M = hp["audio_num_mel_bins"]
-    model = GaussianDiffusionHip(None, M, DiffNetHip(M, hparams=hp, precision="f16_x3"), timesteps=50, K_step=50,
+    model = GaussianDiffusionHip(None, M, DiffNetHip(M, hparams=hp, precision=precision), timesteps=50, K_step=50,
                                  loss_type="l2", spec_min=hp["spec_min"], spec_max=hp["spec_max"], hparams=hp)
     model.load_state_dict(sd, strict=True)
     model.cuda()
@@ -242,13 +244,14 @@ def _ragged_inputs(hp, clips, lens, n_units_of, T):
     return hub, m2p, f0, per
 
 
+@pytest.mark.parametrize("precision", ["f16_x3", "auto"])
 @pytest.mark.parametrize("speedup", [1, 10])
-def test_ragged_batch_equals_per_clip_reference_runs(speedup):
+def test_ragged_batch_equals_per_clip_reference_runs(speedup, precision):
     """Variable-length clips in one padded batch (Svc.after_infer, infer_tool.py:177-191): the reference processes every clip
     ALONE at its own length, so the batch must reproduce those runs -- trailing padded frames act as the convs' zero padding
     inside the sampler, all-zero mel frames are dropped and f0 is cut with the same mask before the vocoder.  Checked against
     the oracle run per clip at the clip's own length: mel (1e-3) and PCM end to end (1e-4 RMS)."""
-    pipe, hp, h, sd, vs = tiny_pipeline(K=30)
+    pipe, hp, h, sd, vs = tiny_pipeline(K=30, precision=precision)
     clips, lens, T, seed = [4, 1, 7, 2], [40, 33, 40, 21], 40, 19
     n_units_of = lambda l: max(2, (l * 23) // 40)
     hub, m2p, f0, per = _ragged_inputs(hp, clips, lens, n_units_of, T)
