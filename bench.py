@@ -85,6 +85,13 @@ def dominant_kernel_roofline(handle, B, precision):
                 "avg_launch_us": us, "frames_per_launch": frames, "traffic": None, "algorithmic_bytes": nbytes,
                 "mfma_tflops": tf, "mfma_frac": tf / PEAK_TFLOPS_F16}
         tfile = {32: "layer_traffic_b32.json"}.get(B)
+    # `achieved` / `mfma_tflops` count ALGORITHMIC flops (one multiply-add per product); the split-operand schemes issue 2 (hi + lo weights) or 3
+    # (+ split activations) MFMAs per product, so the matrix pipe itself is that many times busier
+    mpp = 3 if precision in ("f16_x3t", "f16_x3") else (2 if precision == "f16_w2" else 1)
+    alg_tf = roof["achieved"] if roof["bound"] == "mfma" else roof["mfma_tflops"]
+    roof["mfma_per_product"] = mpp
+    roof["pipe_tflops"] = alg_tf * mpp
+    roof["pipe_frac"] = alg_tf * mpp / PEAK_TFLOPS_F16
     if tfile:
         roof["traffic"], roof["traffic_source"] = load_traffic(tfile, precision)
     return roof
@@ -386,6 +393,7 @@ def main():
                 tf_ = r_["achieved"] if r_["bound"] == "mfma" else r_.get("mfma_tflops")
                 if tf_:
                     r_["frac_of_sustained"] = tf_ / sustained["cold"]["tflops"]       # MFMA side, against what the part holds on real data
+                    r_["pipe_frac_of_sustained"] = r_["pipe_tflops"] / sustained["cold"]["tflops"]
                 if r_["bound"] == "hbm":
                     r_["frac_of_stream_copy"] = r_["achieved"] / 6290.0               # against the 6.29 TB/s a float4 copy reaches (MI355X_MICROARCH.md)
             if FAST_SIDE and precb != FAST_SIDE:
