@@ -215,7 +215,11 @@ def test_overlapped_allreduce_step_under_a_process_group():
     hub, m2p, f0, mels, t = (v.cuda() for v in _batch(hp, [0, 1, 2], 40, 23, 5))
     own = not dist.is_initialized()
     if own:
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     try:
         a, b = DiffusionTrainerHip(hp, sd), DiffusionTrainerHip(hp, sd)
         for step in range(3):
