@@ -10,7 +10,7 @@
 //   forward   y = conv_dil(x + film) + W_c cond + b ;  g = sigmoid(y_a) tanh(y_b) ;  [r; s] = W_o g + b ;  x' = (x + r)/sqrt2 ; skip += s
 //             (sigma, tau, g and every layer's x are kept: ~1.3 GB for the 64 x 128-frame batch)
 //   backward  dO = [dx/sqrt2 ; dskip] ;  dg = W_o^T dO ;  dy = dg (tau sigma(1-sigma) ; sigma(1-tau^2)) ;  dx = dx/sqrt2 + convT(dy) ;
-//             dcond += W_c^T dy ;  weight gradients dW[o][k] = sum_n A[n][o] B[n][k] on channel-major fp16 hi|lo planes of both
+//             (the conditioner's data gradient is never formed: k_bin_sums) ;  weight gradients dW[o][k] = sum_n A[n][o] B[n][k] on channel-major fp16 hi|lo planes of both
 //             operands (wgrad.h: k_split_t + wgrad_nt_kernel; the contraction index is the frame index).
 //   loss scaling: d loss / d eps is ~1/(B M T) ~ 1e-6, inside fp16's SUBNORMAL range where a hi + lo split keeps 4 bits; the backward
 //             pass is linear in it, so it runs on deps * 2^k (k chosen from 1/(B M T): operands in fp16's normal range) and the flat
@@ -428,19 +428,58 @@ __global__ void k_mish_bwd(const float* __restrict__ x, const float* __restrict_
     dx[i] = dy[i] * (th + v * (1.0f - th * th) * sg);
 }
 
-// d pitch_embed[pitch[b,t]] += dcond[row] on frames with mel2ph > 0  (fs2.py:229-237: decoder_inp = (gather + embed) * nonpadding)
-__global__ void k_embed_bwd(const float* __restrict__ dcond, const int* __restrict__ pitch, const int* __restrict__ mel2ph,
-                            float* __restrict__ demb, int B, int T, int H, int stride, int vocab) {
-    const size_t n = (size_t)B * T * H;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int h = (int)(i % H);
-        const size_t bt = i / H;
-        const int t = (int)(bt % T), b = (int)(bt / T);
-        if (mel2ph && mel2ph[bt] <= 0) continue;
-        const int p = pitch[bt];
-        if (p <= 0 || p >= vocab) continue;                  // padding_idx 0 receives no gradient (nn.Embedding padding_idx)
-        atomicAdd(demb + (size_t)p * H + h, dcond[((size_t)b * stride + t) * H + h]);
+// ---- pitch-embedding gradient without the conditioner data gradient --------------------------------------------------------------------
+// cond = (gather(hubert) + pitch_embed[pitch]) * (mel2ph > 0) (fs2.py:229-237) reaches the loss only through the layers' conditioner
+// projections, and pitch_embed is the only trained tensor behind it:
+//     d pitch_embed[p][h] = sum_frames(pitch = p, mel2ph > 0) sum_l sum_o W_c,l[o][h] dy_l[frame][o]
+//                         = sum_l sum_o W_c,l[o][h] S_l[p][o],      S_l[p][o] = sum_frames(pitch = p, mel2ph > 0) dy_l[frame][o]
+// so instead of dcond += W_c,l^T dy_l over ~8 700 rows per layer (20 GEMMs, 8 % of the step) the frames are sorted by pitch bin once per step,
+// every layer adds its dy rows up per bin (one read of dy), and ONE [vocab x 2C] x [2C x H] product per layer closes it.  Bin 0 is the
+// embedding's padding_idx and receives no gradient (nn.Embedding).
+__device__ __forceinline__ bool bin_ok(const int* __restrict__ pitch, const int* __restrict__ mel2ph, int i, int vocab, int& p) {
+    p = pitch[i];
+    return p > 0 && p < vocab && !(mel2ph && mel2ph[i] <= 0);
+}
+__global__ void k_bin_count(const int* __restrict__ pitch, const int* __restrict__ mel2ph, int n, int vocab, int* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int p;
+    if (i < n && bin_ok(pitch, mel2ph, i, vocab, p)) atomicAdd(count + p, 1);
+}
+// one thread: cursor[p] = first slot of bin p in `order`; segments of at most seg_len frames: segs[s] = (bin, first slot, length)
+__global__ void k_bin_scan(const int* __restrict__ count, int vocab, int* __restrict__ cursor, int* __restrict__ segs, int* __restrict__ n_segs, int seg_len) {
+    if (blockIdx.x || threadIdx.x) return;
+    int pos = 0, ns = 0;
+    for (int p = 0; p < vocab; ++p) {
+        cursor[p] = pos;
+        for (int o = 0; o < count[p]; o += seg_len) {
+            const int len = count[p] - o < seg_len ? count[p] - o : seg_len;
+            segs[3 * ns] = p; segs[3 * ns + 1] = pos + o; segs[3 * ns + 2] = len;
+            ++ns;
+        }
+        pos += count[p];
     }
+    *n_segs = ns;
+}
+__global__ void k_bin_scatter(const int* __restrict__ pitch, const int* __restrict__ mel2ph, int n, int vocab, int* __restrict__ cursor, int* __restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int p;
+    if (i < n && bin_ok(pitch, mel2ph, i, vocab, p)) order[atomicAdd(cursor + p, 1)] = i;
+}
+// S[bin][c] += sum over the segment's frames of src[row(frame)][c]; grid (max segments, ceil(C / 256)), 64 threads x 4 columns
+__global__ __launch_bounds__(64) void k_bin_sums(const float* __restrict__ src, int ld, const int* __restrict__ order, const int* __restrict__ segs,
+                                                 const int* __restrict__ n_segs, int T, int stride, float* __restrict__ S, int C) {
+    if ((int)blockIdx.x >= *n_segs) return;
+    const int bin = segs[3 * blockIdx.x], first = segs[3 * blockIdx.x + 1], len = segs[3 * blockIdx.x + 2];
+    const int c = blockIdx.y * 256 + threadIdx.x * 4;
+    if (c >= C) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < len; ++i) {
+        const int bt = order[first + i], b = bt / T, t = bt - b * T;
+        const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)b * stride + t) * ld + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* d = S + (size_t)bin * C + c;
+    atomicAdd(d, s.x); atomicAdd(d + 1, s.y); atomicAdd(d + 2, s.z); atomicAdd(d + 3, s.w);
 }
 
 __global__ void k_iota(int* p, int base, int n) {
@@ -523,12 +562,13 @@ struct dsvc_trainer {
     float loss_scale = 1.0f;                                        // 2^k the backward pass is scaled by (see the header)
     DevBuf xt, xs, sig, tau, g, skip, ypre, s2pre, eps, deps, condT, tstep, clipid, iotaB;
     DevBuf e0, e1pre, e1, e2, filmB, dfilm, de2, de1, de1pre;
-    DevBuf dx, dxin, dO, dy, ds2pre, dcond, dh0, loss;
+    DevBuf dx, dxin, dO, dy, ds2pre, dh0, loss;
+    DevBuf bin_count, bin_cursor, bin_segs, bin_nsegs, bin_order, bin_S;     // frames sorted by pitch bin; S_l[vocab][2C] per layer
     DevBuf AT, BT;                                 // dY^T and X^T as channel-major fp16 hi|lo planes: [2][a_rows | b_rows][ldT]
     APlanes condP, dyP;                            // fragment-tiled fp16 hi|lo planes of cond and of a layer's dy (pgemm.h operands)
     int rows_p = 0;                                // nr rounded up to the 256-row tile
     WPlanes wp_call;                               // every layer's conditioner projection, stacked: [L * 2C][H]
-    std::vector<WPlanes> wp_dT, wp_cT;
+    std::vector<WPlanes> wp_dT;
     std::vector<Packed> w_d, w_o, w_oT;
     DevBuf wpart;                                  // frame-slice partial tiles of one weight-gradient GEMM
     // per-step repacked weights
@@ -538,13 +578,12 @@ struct dsvc_trainer {
 
     ~dsvc_trainer() {
         for (DevBuf* b : {&sa, &sb, &spec_min, &spec_max, &xt, &xs, &sig, &tau, &g, &skip, &ypre, &s2pre, &eps, &deps, &condT, &tstep,
-                          &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre, &dcond,
-                          &dh0, &loss, &AT, &BT, &wpart, &gatemap})
+                          &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre,
+                          &dh0, &loss, &AT, &BT, &wpart, &gatemap, &bin_count, &bin_cursor, &bin_segs, &bin_nsegs, &bin_order, &bin_S})
             b->release();
         for (APlanes* a : {&condP, &dyP}) a->buf.release();
         wp_call.w.release();
-        for (auto* v : {&wp_dT, &wp_cT})
-            for (auto& p : *v) p.w.release();
+        for (auto& p : wp_dT) p.w.release();
         auto rel = [](Packed& p) { p.w.release(); };
         for (auto* v : {&w_d, &w_o, &w_oT})
             for (auto& p : *v) rel(p);
@@ -676,7 +715,7 @@ int dsvc_trainer::repack(hipStream_t st) {
     // tile shapes); the transposed conv, the conditioner data gradient and ALL layers' conditioner projections as one stacked operand run on
     // pgemm.h (99 / 60 / 489 us against 110 / 65 / 20 x 32).  pgemm operands: weights as fragment-tiled fp16 hi|lo planes, rows = output channels.
     const int c2p = round_up(2 * C, 128);
-    w_d.resize(L); w_o.resize(L); w_oT.resize(L); wp_dT.resize(L); wp_cT.resize(L);
+    w_d.resize(L); w_o.resize(L); w_oT.resize(L); wp_dT.resize(L);
     for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
         DSVC_TRY(pack(w_d[l], P(q + "dilated_conv.weight"), gm, 2 * C, 3, C, 2 * C, (long long)C * 3, 3, 1, 0, 1.0f, st));
@@ -685,7 +724,6 @@ int dsvc_trainer::repack(hipStream_t st) {
         DSVC_TRY(pack(w_oT[l], P(q + "output_projection.weight"), nullptr, C, 1, 2 * C, C, 1, C, 0, 0, 1.0f, st));
         // the conditioner projections of all layers in the gates' paired gate | filter row order, stacked
         DSVC_TRY(wplanes(wp_call, l * c2p, L * c2p, P(q + "conditioner_projection.weight"), gm, 2 * C, 1, H, H, 1, 0, 0, 1.0f, st));
-        DSVC_TRY(wplanes(wp_cT[l], 0, H, P(q + "conditioner_projection.weight"), nullptr, H, 1, 2 * C, 1, H, 0, 0, 1.0f, st));
         // transposed conv: dxin[c] = sum_tap sum_o W_d[o][c][2 - tap] * dy[row + (tap-1)*d][o]
         DSVC_TRY(wplanes(wp_dT[l], 0, C, P(q + "dilated_conv.weight"), nullptr, C, 3, 2 * C, 3, (long long)C * 3, 1, 1, 1.0f, st));
     }
@@ -715,7 +753,12 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     DSVC_TRY(z(filmB, (size_t)B * L * C * 4)); DSVC_TRY(z(dfilm, (size_t)B * L * C * 4)); DSVC_TRY(z(de2, (size_t)B * C * 4));
     DSVC_TRY(z(de1, (size_t)B * 4 * C * 4)); DSVC_TRY(z(de1pre, (size_t)B * 4 * C * 4));
     DSVC_TRY(z(dx, r * C * 4)); DSVC_TRY(z(dxin, r * C * 4)); DSVC_TRY(z(dO, r * 2 * C * 4)); DSVC_TRY(z(dy, r * 2 * C * 4));
-    DSVC_TRY(z(ds2pre, r * C * 4)); DSVC_TRY(z(dcond, r * H * 4)); DSVC_TRY(z(dh0, r * C * 4)); DSVC_TRY(z(loss, 16));
+    DSVC_TRY(z(ds2pre, r * C * 4)); DSVC_TRY(z(dh0, r * C * 4)); DSVC_TRY(z(loss, 16));
+    {   // pitch-bin bookkeeping (k_bin_*): at most ceil(B T / 32) + vocab segments of <= 32 frames
+        const int V = cfg.pitch_vocab, max_segs = ceil_div(B * T, 32) + V;
+        DSVC_TRY(z(bin_count, (size_t)V * 4)); DSVC_TRY(z(bin_cursor, (size_t)V * 4)); DSVC_TRY(z(bin_segs, (size_t)max_segs * 12));
+        DSVC_TRY(z(bin_nsegs, 16)); DSVC_TRY(z(bin_order, (size_t)B * T * 4)); DSVC_TRY(z(bin_S, (size_t)L * V * 2 * C * 4));
+    }
     rows_p = round_up(nr, 256);
     DSVC_TRY(aplanes(condP, round_up(H, 32), st)); DSVC_TRY(aplanes(dyP, 2 * C, st));
     // weight-gradient operands (wgrad.h): frames contiguous, zero beyond the data rows and in the channel padding
@@ -932,6 +975,14 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
     hipLaunchKernelGGL(k_copy_cols, dim3(ew), dim3(256), 0, st, dx.as<float>(), dO.as<float>(), nr, C, 2 * C, 0, 0.0f);   // ... so the residual half of dO starts at 0
     // cond^T planes once (weight gradients of every conditioner projection): the last segment of the layers' k axis, which nothing else writes
     DSVC_TRY(split_t(false, 3 * cp128, condT.as<float>(), H, H, nullptr, 0, 0, st));
+    if (ta->pitch) {   // frames by pitch bin, once per step (the pitch-embedding gradient: k_bin_sums per layer, one product at the end)
+        const int V = cfg.pitch_vocab, n = B * T;
+        DSVC_HIP(hipMemsetAsync(bin_count.p, 0, (size_t)V * 4, st));
+        DSVC_HIP(hipMemsetAsync(bin_S.p, 0, (size_t)L * V * 2 * C * 4, st));
+        hipLaunchKernelGGL(k_bin_count, dim3(ceil_div(n, 256)), dim3(256), 0, st, ta->pitch, ta->mel2ph, n, V, bin_count.as<int>());
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(64), 0, st, bin_count.as<int>(), V, bin_cursor.as<int>(), bin_segs.as<int>(), bin_nsegs.as<int>(), 32);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(ceil_div(n, 256)), dim3(256), 0, st, ta->pitch, ta->mel2ph, n, V, bin_cursor.as<int>(), bin_order.as<int>());
+    }
     unscale_range("denoise_fn.skip_projection.weight", "denoise_fn.output_projection.bias");      // final: the tail's four tensors
     next_layer = L;
   }
@@ -963,10 +1014,10 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             // (one launch over [taps | cond] is 33 tiles at C = 384: one more than an XCD has CUs)
             DSVC_TRY(wgrad_nt(2 * C, hp128, 3 * cp128, seg1(G(q + "conditioner_projection.weight"), H, H), 1.0f, st));
         }
-        {   // dcond += W_c^T dy
-            EpBwd::Args e{dcond.as<float>(), H, H, nullptr, 0, 1.0f, l == L - 1 ? 0 : 1, ri};
-            DSVC_TRY(pg<EpBwd>(dyP, wp_cT[l], 0, H, 1, 1, e, st));
-        }
+        if (ta->pitch)     // S_l[bin] = sum of this layer's dy rows per pitch bin (instead of dcond += W_c^T dy: see k_bin_sums)
+            hipLaunchKernelGGL(k_bin_sums, dim3(ceil_div(B * T, 32) + cfg.pitch_vocab, ceil_div(2 * C, 256)), dim3(64), 0, st, dy.as<float>(), 2 * C,
+                               bin_order.as<int>(), bin_segs.as<int>(), bin_nsegs.as<int>(), T, Tp,
+                               bin_S.as<float>() + (size_t)l * cfg.pitch_vocab * 2 * C, 2 * C);
         {   // dxin = convT(dy)
             EpBwd::Args e{dxin.as<float>(), C, C, nullptr, 0, 1.0f, 0, ri};
             DSVC_TRY(pg<EpBwd>(dyP, wp_dT[l], 0, C, 3, d, e, st));
@@ -1025,10 +1076,19 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
     small(de1pre.as<float>(), e0.as<float>(), G("denoise_fn.mlp.0.weight"), 4 * C, C, B, 4 * C, C, C, 1, 0, 0, nullptr);
     hipLaunchKernelGGL(k_colsum, dim3(ceil_div(4 * C, 256), 1), dim3(256), 0, st, de1pre.as<float>(), G("denoise_fn.mlp.0.bias"), B, 4 * C, 4 * C, B);
     // ---- pitch embedding (through cond) ----
-    if (ta->pitch) {
-        const size_t n = (size_t)B * T * H;
-        hipLaunchKernelGGL(k_embed_bwd, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, dcond.as<float>(), ta->pitch,
-                           ta->mel2ph, G("fs2.pitch_embed.weight"), B, T, H, Tp, cfg.pitch_vocab);
+    if (ta->pitch) {   // d pitch_embed[p][h] = sum_l sum_o S_l[p][o] W_c,l[o][h]: per-layer partials into the idle scratch, then a fixed-order sum
+        const int V = cfg.pitch_vocab;
+        if (L > 32 || (size_t)L * V * H * 4 > wpart.bytes) return fail(DSVC_EINVAL, "trainer: %d layers x %d pitch bins exceed the scratch", L, V);
+        SmallBatch pe{};
+        pe.n = L;
+        for (int l = 0; l < L; ++l) {
+            pe.A[l] = bin_S.as<float>() + (size_t)l * V * 2 * C;
+            pe.B[l] = P("denoise_fn.residual_layers." + std::to_string(l) + ".conditioner_projection.weight");
+            pe.C[l] = wpart.as<float>() + (size_t)l * V * H;
+        }
+        small_b(pe, V, H, 2 * C, 2 * C, H, H, 0, 0, 0);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(ceil_div(V * H, 256)), dim3(256), 0, st, wpart.as<float>(), G("fs2.pitch_embed.weight"), L, V, H, H, 1LL,
+                           (long long)H, 0LL);
     }
     unscale_range("denoise_fn.input_projection.weight", "denoise_fn.mlp.2.bias");
     unscale_range("fs2.pitch_embed.weight", "fs2.pitch_embed.weight");
