@@ -36,27 +36,42 @@ int launch(const ConvGemmArgs& a, const typename Epi::Args& e, hipStream_t st) {
 // weights -> conv_gemm fragment layout [ctile][tap][k16][plane 2][lane][8] on the device.
 //   W(col, tap, ci) = src[colmap(col) * s_col + ci * s_ci + tap_of(tap) * s_tap] * scale,  0 outside (cout, cin)
 //   flip: tap_of(tap) = taps-1-tap (transposed conv).  colmap: optional packed-column -> source-column permutation (-1 = zero).
-__global__ void k_pack_w(const float* __restrict__ src, const int* __restrict__ colmap, _Float16* __restrict__ dst, int n_ctiles,
-                         int taps, int cin_pad, int cout, int cin, long long s_col, long long s_ci, long long s_tap, int flip, float scale) {
-    const int nk16 = cin_pad >> 4;
-    const long long total = (long long)n_ctiles * taps * nk16 * 512;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+struct PackDesc {
+    const float* src; const int* colmap; _Float16* dst;
+    int n_ctiles, taps, cin_pad, cout, cin;
+    long long s_col, s_ci, s_tap;
+    int flip; float scale;
+};
+__device__ __forceinline__ void pack_w_body(const PackDesc& d, long long first, long long step) {
+    const int nk16 = d.cin_pad >> 4;
+    const long long total = (long long)d.n_ctiles * d.taps * nk16 * 512;
+    for (long long idx = first; idx < total; idx += step) {
         long long r = idx;
         const int e = (int)(r & 7), l = (int)((r >> 3) & 63);
         r >>= 9;
         const int k = (int)(r % nk16); r /= nk16;
-        const int tap = (int)(r % taps);
-        const int ct = (int)(r / taps);
+        const int tap = (int)(r % d.taps);
+        const int ct = (int)(r / d.taps);
         int col = ct * 32 + (l & 31);
         const int ci = k * 16 + 8 * (l >> 5) + e;
-        if (colmap) col = colmap[col];
+        if (d.colmap) col = d.colmap[col];
         float w = 0.f;
-        if (col >= 0 && col < cout && ci < cin) w = src[(long long)col * s_col + (long long)ci * s_ci + (long long)(flip ? taps - 1 - tap : tap) * s_tap] * scale;
+        if (col >= 0 && col < d.cout && ci < d.cin)
+            w = d.src[(long long)col * d.s_col + (long long)ci * d.s_ci + (long long)(d.flip ? d.taps - 1 - tap : tap) * d.s_tap] * d.scale;
         const _Float16 hi = (_Float16)w;
-        _Float16* f = dst + ((((size_t)ct * taps + tap) * nk16 + k) * 2) * 512 + l * 8 + e;
+        _Float16* f = d.dst + ((((size_t)ct * d.taps + tap) * nk16 + k) * 2) * 512 + l * 8 + e;
         f[0] = hi;
         f[512] = (_Float16)(w - (float)hi);
     }
+}
+__global__ void k_pack_w(const float* __restrict__ src, const int* __restrict__ colmap, _Float16* __restrict__ dst, int n_ctiles,
+                         int taps, int cin_pad, int cout, int cin, long long s_col, long long s_ci, long long s_tap, int flip, float scale) {
+    const PackDesc d{src, colmap, dst, n_ctiles, taps, cin_pad, cout, cin, s_col, s_ci, s_tap, flip, scale};
+    pack_w_body(d, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+// many weight tensors in one launch (a training step re-packs ~65 of them: 5 us each as separate launches): blockIdx.y = descriptor
+__global__ void k_pack_w_batch(const PackDesc* __restrict__ descs) {
+    pack_w_body(descs[blockIdx.y], (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 }
 
 }  // namespace

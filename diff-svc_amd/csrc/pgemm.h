@@ -144,29 +144,38 @@ int pgemm_launch(const PGemmArgs& a, const typename Epi::Args& e, hipStream_t st
 // ---- operand planes -------------------------------------------------------------------------------------------------------------
 // weights:  dst[plane][row][tap * K_pad + ci] = src[rowmap(row) * s_row + ci * s_ci + tap_of(tap) * s_tap] * scale   (0 outside n_rows / cin);
 // rowmap: optional packed-row -> source-row permutation; flip: tap_of(tap) = taps - 1 - tap (transposed conv).  One thread per 8 k.
-__global__ __launch_bounds__(256) void k_wplanes(const float* __restrict__ src, const int* __restrict__ rowmap, _Float16* __restrict__ dst, long long plane_halfs,
-                                                 int rows_pad, int n_rows, int taps, int K_pad, int cin, long long s_row, long long s_ci, long long s_tap,
-                                                 int flip, float scale) {
-    const int ldb = taps * K_pad;
-    const long long total = (long long)rows_pad * (ldb >> 3);
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+struct WPlaneDesc {
+    const float* src; const int* rowmap; _Float16* dst; long long plane_halfs;
+    int rows_pad, n_rows, taps, K_pad, cin;
+    long long s_row, s_ci, s_tap;
+    int flip; float scale;
+};
+__device__ __forceinline__ void wplanes_body(const WPlaneDesc& d, long long first, long long step) {
+    const int ldb = d.taps * d.K_pad;
+    const long long total = (long long)d.rows_pad * (ldb >> 3);
+    for (long long idx = first; idx < total; idx += step) {
         const int row = (int)(idx / (ldb >> 3));
         const int k8 = (int)(idx - (long long)row * (ldb >> 3)) << 3;
-        const int tap = k8 / K_pad, ci0 = k8 - tap * K_pad;
-        const int srow = row < n_rows ? (rowmap ? rowmap[row] : row) : -1;
+        const int tap = k8 / d.K_pad, ci0 = k8 - tap * d.K_pad;
+        const int srow = row < d.n_rows ? (d.rowmap ? d.rowmap[row] : row) : -1;
         half8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ci = ci0 + e;
             float w = 0.f;
-            if (srow >= 0 && ci < cin) w = src[(long long)srow * s_row + (long long)ci * s_ci + (long long)(flip ? taps - 1 - tap : tap) * s_tap] * scale;
+            if (srow >= 0 && ci < d.cin)
+                w = d.src[(long long)srow * d.s_row + (long long)ci * d.s_ci + (long long)(d.flip ? d.taps - 1 - tap : tap) * d.s_tap] * d.scale;
             hi[e] = (_Float16)w;
             lo[e] = (_Float16)(w - (float)hi[e]);
         }
-        _Float16* p = dst + pl_off(row, k8, ldb);
+        _Float16* p = d.dst + pl_off(row, k8, ldb);
         *reinterpret_cast<half8*>(p) = hi;
-        *reinterpret_cast<half8*>(p + plane_halfs) = lo;
+        *reinterpret_cast<half8*>(p + d.plane_halfs) = lo;
     }
+}
+// many weight tensors in one launch: blockIdx.y = descriptor
+__global__ __launch_bounds__(256) void k_wplanes_batch(const WPlaneDesc* __restrict__ descs) {
+    wplanes_body(descs[blockIdx.y], (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 }
 
 // activations (dst = base of the tiled planes, data row r = tiled row r + 64):  dst[plane][row][c] = valid(row) ? src[row][c] + add[clip][c] : 0   for c < C (% 8 == 0); one thread per 8 channels

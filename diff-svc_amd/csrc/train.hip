@@ -579,7 +579,7 @@ struct dsvc_trainer {
     ~dsvc_trainer() {
         for (DevBuf* b : {&sa, &sb, &spec_min, &spec_max, &xt, &xs, &sig, &tau, &g, &skip, &ypre, &s2pre, &eps, &deps, &condT, &tstep,
                           &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre,
-                          &dh0, &loss, &AT, &BT, &wpart, &gatemap, &bin_count, &bin_cursor, &bin_segs, &bin_nsegs, &bin_order, &bin_S})
+                          &dh0, &loss, &AT, &BT, &wpart, &gatemap, &pack_dev, &wplane_dev, &bin_count, &bin_cursor, &bin_segs, &bin_nsegs, &bin_order, &bin_S})
             b->release();
         for (APlanes* a : {&condP, &dyP}) a->buf.release();
         wp_call.w.release();
@@ -599,6 +599,11 @@ struct dsvc_trainer {
     int pack(Packed& pk, const float* src, const int* colmap, int cout_pad, int taps, int cin, int cout, long long s_col, long long s_ci,
              long long s_tap, int flip, float scale, hipStream_t st);
     int repack(hipStream_t st);
+    std::vector<PackDesc> pack_q;                  // the weight re-packs of a step, queued by pack() / wplanes() and launched together
+    std::vector<WPlaneDesc> wplane_q;
+    DevBuf pack_dev, wplane_dev;
+    std::vector<char> pack_cached, wplane_cached;
+    int flush_packs(hipStream_t st);
     int wplanes(WPlanes& wp, int row0, int rows_total, const float* src, const int* rowmap, int n_rows, int taps, int cin, long long s_row, long long s_ci,
                 long long s_tap, int flip, float scale, hipStream_t st);
     int aplanes(APlanes& ap, int ld, hipStream_t st);
@@ -647,10 +652,30 @@ int dsvc_trainer::pack(Packed& pk, const float* src, const int* colmap, int cout
     pk.cin_pad = round_up(cin, 16);
     const size_t halfs = packed_halfs(pk.n_ctiles, taps, pk.cin_pad, 2);
     DSVC_TRY(pk.w.alloc(halfs * 2));
-    const long long total_el = (long long)halfs / 2;
-    const int blocks = (int)((total_el + 255) / 256 < 8192 ? (total_el + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_pack_w, dim3(blocks), dim3(256), 0, st, src, colmap, pk.w.as<_Float16>(), pk.n_ctiles, taps, pk.cin_pad, cout, cin,
-                       s_col, s_ci, s_tap, flip, scale);
+    (void)st;                                                    // queued: repack() launches every descriptor of the step at once
+    pack_q.push_back(PackDesc{src, colmap, pk.w.as<_Float16>(), pk.n_ctiles, taps, pk.cin_pad, cout, cin, s_col, s_ci, s_tap, flip, scale});
+    return DSVC_OK;
+}
+
+// the queued weight re-packs of a step as two launches; the descriptor tables only change when a buffer was (re)allocated
+int dsvc_trainer::flush_packs(hipStream_t st) {
+    auto upload = [&](DevBuf& dev, std::vector<char>& cached, const void* host, size_t bytes) -> int {
+        if (cached.size() != bytes || memcmp(cached.data(), host, bytes) != 0) {
+            DSVC_HIP(hipStreamSynchronize(st));                  // a launch reading the old table may still be in flight
+            DSVC_TRY(dev.alloc(bytes));
+            DSVC_HIP(hipMemcpy(dev.p, host, bytes, hipMemcpyHostToDevice));
+            cached.assign((const char*)host, (const char*)host + bytes);
+        }
+        return DSVC_OK;
+    };
+    if (!pack_q.empty()) {
+        DSVC_TRY(upload(pack_dev, pack_cached, pack_q.data(), pack_q.size() * sizeof(PackDesc)));
+        hipLaunchKernelGGL(k_pack_w_batch, dim3(96, (unsigned)pack_q.size()), dim3(256), 0, st, pack_dev.as<PackDesc>());
+    }
+    if (!wplane_q.empty()) {
+        DSVC_TRY(upload(wplane_dev, wplane_cached, wplane_q.data(), wplane_q.size() * sizeof(WPlaneDesc)));
+        hipLaunchKernelGGL(k_wplanes_batch, dim3(96, (unsigned)wplane_q.size()), dim3(256), 0, st, wplane_dev.as<WPlaneDesc>());
+    }
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
@@ -662,11 +687,9 @@ int dsvc_trainer::wplanes(WPlanes& wp, int row0, int rows_total, const float* sr
     const int ldb = taps * wp.K_pad;
     DSVC_TRY(wp.w.alloc((size_t)2 * wp.rows_pad * ldb * 2));
     const int rows_here = round_up(n_rows, 128) < wp.rows_pad - row0 ? round_up(n_rows, 128) : wp.rows_pad - row0;
-    const long long total = (long long)rows_here * (ldb / 8);
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_wplanes, dim3(blocks), dim3(256), 0, st, src, rowmap, wp.w.as<_Float16>() + (size_t)row0 * ldb, wp.plane(), rows_here, n_rows, taps,
-                       wp.K_pad, cin, s_row, s_ci, s_tap, flip, scale);
-    DSVC_HIP(hipGetLastError());
+    (void)st;
+    wplane_q.push_back(WPlaneDesc{src, rowmap, wp.w.as<_Float16>() + (size_t)row0 * ldb, wp.plane(), rows_here, n_rows, taps, wp.K_pad, cin, s_row, s_ci,
+                                  s_tap, flip, scale});
     return DSVC_OK;
 }
 
@@ -701,6 +724,7 @@ int dsvc_trainer::pg(const APlanes& ap, const WPlanes& wp, int b_row0, int n_col
 
 int dsvc_trainer::repack(hipStream_t st) {
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
+    pack_q.clear(); wplane_q.clear();
     const float isl = 1.0f / sqrtf((float)L);
     const int* gm = gatemap.as<int>();
     // forward (natural [O][I][taps] sources)
@@ -727,7 +751,7 @@ int dsvc_trainer::repack(hipStream_t st) {
         // transposed conv: dxin[c] = sum_tap sum_o W_d[o][c][2 - tap] * dy[row + (tap-1)*d][o]
         DSVC_TRY(wplanes(wp_dT[l], 0, C, P(q + "dilated_conv.weight"), nullptr, C, 3, 2 * C, 3, (long long)C * 3, 1, 1, 1.0f, st));
     }
-    return DSVC_OK;
+    return flush_packs(st);
 }
 
 // The workspace layout depends on (B, T): clips sit Tp rows apart with ZERO gap rows (the convs' padding, and rows the weight-gradient
@@ -795,7 +819,7 @@ int dsvc_trainer::split_t(bool a_side, int row0, const float* src, int ld_src, i
     const int nrows = a_side ? a_rows : b_rows;
     if (row0 < 0 || row0 + (dil > 0 ? 2 * cp128 : 0) + C > nrows || dil > 64) return fail(DSVC_EINVAL, "split_t: rows [%d, %d) outside the %d-row operand planes", row0, row0 + C, nrows);
     const long long plane = (long long)nrows * ldT;
-    hipLaunchKernelGGL(k_split_t, dim3(ldT / 64, ceil_div(C, 32)), dim3(256), 0, st, src, ld_src, buf.as<_Float16>() + (size_t)row0 * ldT, plane, ldT, C,
+    hipLaunchKernelGGL(k_split_t, dim3(ldT / 64, ceil_div(C, 64)), dim3(256), 0, st, src, ld_src, buf.as<_Float16>() + (size_t)row0 * ldT, plane, ldT, C,
                        add, add_stride, SplitRows{Tp, wsT, wsB}, dil > 0 ? 3 : 1, dil, (long long)cp128 * ldT, 1.0f, dil > 0 ? nullptr : colsum,
                        rowp && dil == 0 ? rowp->base() : nullptr, rowp ? rowp->plane : 0, rowp ? rowp->ld : 0);
     DSVC_HIP(hipGetLastError());
@@ -827,7 +851,7 @@ int dsvc_trainer::wgrad_nt(int O, int K_pad, int b_row0, const WgradSegs& segs, 
     }
     hipLaunchKernelGGL(wgrad_nt_kernel, dim3(tiles * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, a);
     DSVC_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_wgrad_nt_reduce, dim3(ceil_div(K_pad, 256), O), dim3(256), 0, st, wpart.as<float>(), S, O_pad, K_pad, O, segs, scale);
+    hipLaunchKernelGGL(k_wgrad_nt_reduce, dim3(ceil_div(K_pad, 1024), O), dim3(256), 0, st, wpart.as<float>(), S, O_pad, K_pad, O, segs, scale);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }

@@ -36,71 +36,82 @@ __host__ __device__ __forceinline__ size_t pl_off(int row, int k, int K) {
 //              t + (j - 1) * dil of the SAME clip, or the conv's zero padding when that leaves the clip.
 // colsum (n_taps = 1): colsum[c] += sum_m of the values written (a bias gradient: dY is read here anyway).
 // rowp (n_taps = 1): the values once more as frame-major tiled planes with the clips' gap rows (dY as the A operand of pgemm.h's data gradients).
-// Columns past the last real frame are written as zeros.  grid (n_out / 64, ceil(C / 32)), 256 threads; n_out % 64 == 0, dil <= 64; channels >= C
-// of a padded plane are left as they are (callers ignore them).
+// Columns past the last real frame are written as zeros.  256 threads; n_out % 64 == 0, dil <= 64; channels >= C of a padded plane are left as
+// they are (callers ignore them).
 struct SplitRows { int clip_stride, clip_len, n_clips; };
 
-// dst = the planes' base + first_row * ldT (first_row % 32 == 0); tap_halfs = tap row offset * ldT
+// dst = the planes' base + first_row * ldT (first_row % 32 == 0); tap_halfs = tap row offset * ldT.  A block handles 64 frames x 64 channels:
+// 16-byte loads along the channels (256 B per row), 16-byte stores along the frames.  grid (n_out / 64, ceil(C / 64)); C % 4 == 0.
 __global__ __launch_bounds__(256) void k_split_t(const float* __restrict__ src, int ld_src, _Float16* __restrict__ dst, long long plane_halfs,
                                                  int ldT, int C, const float* __restrict__ add, int add_stride, SplitRows ri, int n_taps, int dil,
                                                  long long tap_halfs, float scale, float* __restrict__ colsum, _Float16* __restrict__ rowp,
                                                  long long rowp_plane, int rowp_ld) {
-    __shared__ float tile[64 + 128][33];
-    const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    __shared__ float tile[64 + 128][68];
+    const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int halo = n_taps == 3 ? dil : 0;
     const int n_real = ri.n_clips * ri.clip_len;
-    for (int i = ty; i < 64 + 2 * halo; i += 8) {
-        const int m = n0 - halo + i, c = c0 + tx;
-        float v = 0.f;
-        if (m >= 0 && m < n_real && c < C) {
-            const int clip = m / ri.clip_len, t = m - clip * ri.clip_len;
-            v = (src[((size_t)clip * ri.clip_stride + t) * ld_src + c] + (add ? add[(size_t)clip * add_stride + c] : 0.f)) * scale;
+    {
+        const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, c = c0 + 4 * tx;
+        for (int i = ty; i < 64 + 2 * halo; i += 16) {
+            const int m = n0 - halo + i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m >= 0 && m < n_real && c < C) {
+                const int clip = m / ri.clip_len, t = m - clip * ri.clip_len;
+                v = *reinterpret_cast<const float4*>(src + ((size_t)clip * ri.clip_stride + t) * ld_src + c);
+                if (add) {
+                    const float4 f = *reinterpret_cast<const float4*>(add + (size_t)clip * add_stride + c);
+                    v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
+                }
+                v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            }
+            *reinterpret_cast<float4*>(&tile[i][4 * tx]) = v;
         }
-        tile[i][tx] = v;
     }
     __syncthreads();
-    if (colsum && threadIdx.x < 32 && c0 + tx < C) {          // the bias gradient of the layer dY belongs to: column sums of this tile (n_taps == 1)
+    if (colsum && threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {          // the bias gradient of the layer dY belongs to: column sums of this tile (n_taps == 1)
         float sum = 0.f;
 #pragma unroll 8
-        for (int i = 0; i < 64; ++i) sum += tile[i][tx];
-        atomicAdd(colsum + c0 + tx, sum);
+        for (int i = 0; i < 64; ++i) sum += tile[i][threadIdx.x];
+        atomicAdd(colsum + c0 + threadIdx.x, sum);
     }
     if (rowp) {          // the same values as FRAME-major tiled planes (a pgemm.h A operand: row = clip * clip_stride + t + 64 guard rows, k = channel)
-        const int tn = threadIdx.x & 63, cg = threadIdx.x >> 6;          // frame n0 + tn, channels c0 + 8 cg .. + 7
-        const int m = n0 + tn;
-        if (m < n_real && c0 + cg * 8 < C) {
+        const int tn = threadIdx.x & 63, m = n0 + tn;
+        if (m < n_real) {
             const int clip = m / ri.clip_len, t = m - clip * ri.clip_len;
-            half8 hi, lo;
+            for (int cg = threadIdx.x >> 6; cg < 8; cg += 4) {              // channels c0 + 8 cg .. + 7
+                if (c0 + cg * 8 >= C) break;
+                half8 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = tile[tn][cg * 8 + e];
-                hi[e] = (_Float16)v;
-                lo[e] = (_Float16)(v - (float)hi[e]);
+                for (int e = 0; e < 8; ++e) {
+                    const float v = tile[tn][cg * 8 + e];
+                    hi[e] = (_Float16)v;
+                    lo[e] = (_Float16)(v - (float)hi[e]);
+                }
+                _Float16* p = rowp + pl_off(clip * ri.clip_stride + t + 64, c0 + cg * 8, rowp_ld);
+                *reinterpret_cast<half8*>(p) = hi;
+                *reinterpret_cast<half8*>(p + rowp_plane) = lo;
             }
-            _Float16* p = rowp + pl_off(clip * ri.clip_stride + t + 64, c0 + cg * 8, rowp_ld);
-            *reinterpret_cast<half8*>(p) = hi;
-            *reinterpret_cast<half8*>(p + rowp_plane) = lo;
         }
     }
-    // write: thread = (channel c0 + cw, frames n0 + 8 * g .. + 7) -> one 16-byte store per plane into the fragment-tiled layout
-    const int cw = threadIdx.x & 31, g8 = threadIdx.x >> 5;
+    // write: thread = (channel c0 + cw, frames n0 + 8 g .. + 7) -> one 16-byte store per plane into the fragment-tiled layout
+    const int cw = threadIdx.x & 63;
     if (c0 + cw < C) {
-        for (int j = 0; j < n_taps; ++j) {
-            half8 hi, lo;
+        for (int g8 = threadIdx.x >> 6; g8 < 8; g8 += 4)
+            for (int j = 0; j < n_taps; ++j) {
+                half8 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int tn = g8 * 8 + e, m = n0 + tn, t = m % ri.clip_len;
-                const int ts = t + (j - (n_taps >> 1)) * halo;           // the tap's source frame inside the clip
-                const bool ok = m < n_real && ts >= 0 && ts < ri.clip_len;
-                const float v = ok ? tile[tn + j * halo][cw] : 0.f;
-                hi[e] = (_Float16)v;
-                lo[e] = (_Float16)(v - (float)hi[e]);
+                for (int e = 0; e < 8; ++e) {
+                    const int tn = g8 * 8 + e, m = n0 + tn, t = m % ri.clip_len;
+                    const int ts = t + (j - (n_taps >> 1)) * halo;           // the tap's source frame inside the clip
+                    const bool ok = m < n_real && ts >= 0 && ts < ri.clip_len;
+                    const float v = ok ? tile[tn + j * halo][cw] : 0.f;
+                    hi[e] = (_Float16)v;
+                    lo[e] = (_Float16)(v - (float)hi[e]);
+                }
+                _Float16* p = dst + (size_t)j * tap_halfs + pl_off(c0 + cw, n0 + g8 * 8, ldT);
+                *reinterpret_cast<half8*>(p) = hi;
+                *reinterpret_cast<half8*>(p + plane_halfs) = lo;
             }
-            _Float16* p = dst + (size_t)j * tap_halfs + pl_off(c0 + cw, n0 + g8 * 8, ldT);
-            *reinterpret_cast<half8*>(p) = hi;
-            *reinterpret_cast<half8*>(p + plane_halfs) = lo;
-        }
     }
 }
 
@@ -225,7 +236,7 @@ struct WgradSegs { WgradSeg s[4]; int n; };
 
 __global__ __launch_bounds__(256) void k_wgrad_nt_reduce(const float* __restrict__ part, int n_slices, int O_pad, int K_pad, int n_o, WgradSegs segs,
                                                          float scale) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = (blockIdx.x * 256 + threadIdx.x) * 4;           // four adjacent columns per thread (segments begin at multiples of 128, lengths % 4 == 0)
     const int o = blockIdx.y;
     if (k >= K_pad || o >= n_o) return;
     int si = -1;
@@ -233,12 +244,19 @@ __global__ __launch_bounds__(256) void k_wgrad_nt_reduce(const float* __restrict
     for (int s = 0; s < 4; ++s)
         if (s < segs.n && k >= segs.s[s].k_begin && k < segs.s[s].k_begin + segs.s[s].k_len) si = s;
     if (si < 0) return;
-    float v = 0.f;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t slice = (size_t)O_pad * K_pad;
     const float* p = part + (size_t)o * K_pad + k;
-    for (int z = 0; z < n_slices; ++z) v += p[z * slice];
-    const WgradSeg& sg = segs.s[si];
-    sg.dst[(long long)o * sg.stride_o + (long long)(k - sg.k_begin) * sg.stride_k + sg.off] = v * scale;
+    for (int z = 0; z < n_slices; ++z) {
+        const float4 x = *reinterpret_cast<const float4*>(p + z * slice);
+        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    }
+    float* dptr = nullptr; int kb = 0; long long so = 0, sk = 0, off = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s == si) { dptr = segs.s[s].dst; kb = segs.s[s].k_begin; so = segs.s[s].stride_o; sk = segs.s[s].stride_k; off = segs.s[s].off; }
+    float* d = dptr + (long long)o * so + (long long)(k - kb) * sk + off;
+    d[0] = v.x * scale; d[sk] = v.y * scale; d[2 * sk] = v.z * scale; d[3 * sk] = v.w * scale;
 }
 
 }  // namespace dsvc
