@@ -24,43 +24,48 @@ struct PGemmArgs {
     long long a_plane, b_plane; // halfs between the hi and the lo plane
     int lda, ldb;               // halfs per row (% 8 == 0)
     int n_rows;                 // rows with data (the epilogue skips the rest)
-    int row_blocks, col_blocks; // 256-row / 128-column tiles
+    int row_blocks, col_blocks; // (64 WR)-row / 128-column tiles
     int K, taps, dil;           // reduction channels per tap (% 32 == 0), taps (1 or 3), dilation
 };
 
-template <class Epi>
-__global__ void __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// WR = waves along the rows: 4 -> a 256 x 128 tile, 8 waves, three 48 KB stages (one workgroup per CU); 2 -> a 128 x 128 tile, 4 waves, three
+// 32 KB stages (narrow outputs over ~8 700 rows: 256-row tiles would leave 60 % of the CUs without a workgroup)
+template <class Epi, int WR>
+__global__ void __launch_bounds__(128 * WR, WR == 4 ? 2 : 4) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pgemm_kernel(const PGemmArgs a, const typename Epi::Args ea) {
+    constexpr int NWAVES = 2 * WR, A_PIECES = 8 * WR, PIECES = A_PIECES + 16, PER_WAVE = PIECES / NWAVES;     // 48 / 8 = 6, 32 / 4 = 8
+    constexpr int STAGE_BYTES = PIECES * 1024;
+    constexpr int STAGES = WR == 4 ? 3 : 2;                  // WR = 2: 2 x 32 KB, so that two workgroups (8 waves) share a CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef const half8 __attribute__((address_space(3))) * lds_frag_ptr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wo = wave >> 1, wk = wave & 1;                 // this wave's 64 x 64 corner of the 256 x 128 tile
+    const int wo = wave >> 1, wk = wave & 1;                 // this wave's 64 x 64 corner of the tile
     // workgroup i runs on XCD i % 8: the column blocks of one row block share that row block's A pieces through ONE L2
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int rb = xcd + 8 * (j / a.col_blocks), cb = j % a.col_blocks;
     if (rb >= a.row_blocks) return;
-    const int m0 = rb * 256, n0 = cb * 128;
+    const int m0 = rb * (64 * WR), n0 = cb * 128;
     const int kst = a.K >> 5;                                // stages per tap
     const int stages = a.taps * kst;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
     const int bkp = a.ldb >> 4;                                // B pieces per 32-row block
     auto dma = [&](int s) {
-        char* dst = smem + (s % WG_STAGES) * WG_STAGE_BYTES;
+        char* dst = smem + (s % STAGES) * STAGE_BYTES;
         const int tap = s / kst, kk = (s - tap * kst) << 5;
         // a conv tap shifts the A rows: lane l's row of the piece (two contiguous runs in the tiled plane unless the shift is 0)
         const int arow = m0 + 64 + (tap - (a.taps >> 1)) * a.dil + (lane & 31);
         const int bk0 = tap * a.K + kk;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int pc = wave + 8 * i;                       // piece 0..31: A (tile r, plane p, k-step q), 32..47: B
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int pc = wave + NWAVES * i;                  // piece 0 .. A_PIECES-1: A (tile r, plane p, k-step q), then 16 of B
             const _Float16* src;
-            if (i < 4) {
+            if (i < A_PIECES / NWAVES) {
                 const int r = pc >> 2, p = (pc >> 1) & 1, q = pc & 1;
                 src = a.a + (long long)p * a.a_plane + pl_off(arow + r * 32, kk + q * 16 + 8 * (lane >> 5), a.lda);
             } else {
-                const int t = pc - 32, c = t >> 2, p = (t >> 1) & 1, q = t & 1;
+                const int t = pc - A_PIECES, c = t >> 2, p = (t >> 1) & 1, q = t & 1;
                 src = a.b + (long long)p * a.b_plane + ((long long)((n0 >> 5) + c) * bkp + ((bk0 >> 4) + q)) * 512 + lane * 8;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -77,15 +82,16 @@ pgemm_kernel(const PGemmArgs a, const typename Epi::Args ea) {
             for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
 
     dma(0);
-    if (stages > 1) dma(1);
+    if (STAGES == 3 && stages > 1) dma(1);
     for (int s = 0; s < stages; ++s) {
-        // vmcnt retires in order and a wave's only vector-memory traffic in the loop is its 6 DMA pieces per stage (wgrad.h)
-        if (s + 1 < stages) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // vmcnt retires in order and a wave's only vector-memory traffic in the loop is its PER_WAVE DMA pieces per stage (wgrad.h): with
+        // three buffers stage s + 1 may stay in flight, with two nothing else has been issued yet
+        if (STAGES == 3 && s + 1 < stages) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 2 < stages) dma(s + 2);
-        const unsigned buf = lds0 + (unsigned)(s % WG_STAGES) * WG_STAGE_BYTES + (unsigned)lane * 16u;
+        if (s + STAGES - 1 < stages) dma(s + STAGES - 1);
+        const unsigned buf = lds0 + (unsigned)(s % STAGES) * STAGE_BYTES + (unsigned)lane * 16u;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             half8 fa[2][2], fb[2][2];
@@ -94,7 +100,7 @@ pgemm_kernel(const PGemmArgs a, const typename Epi::Args ea) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     fa[i][p] = *(lds_frag_ptr)(size_t)(buf + (unsigned)((((2 * wo + i) * 2 + p) * 2 + q) * 1024));
-                    fb[i][p] = *(lds_frag_ptr)(size_t)(buf + (unsigned)((32 + ((2 * wk + i) * 2 + p) * 2 + q) * 1024));
+                    fb[i][p] = *(lds_frag_ptr)(size_t)(buf + (unsigned)((A_PIECES + ((2 * wk + i) * 2 + p) * 2 + q) * 1024));
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -126,19 +132,32 @@ pgemm_kernel(const PGemmArgs a, const typename Epi::Args ea) {
         }
 }
 
-template <class Epi>
-int pgemm_launch(const PGemmArgs& a, const typename Epi::Args& e, hipStream_t st) {
-    if (a.K % 32 || a.lda % 8 || a.ldb % 8 || (a.taps != 1 && a.taps != 3) || a.row_blocks < 1 || a.col_blocks < 1)
-        return fail(DSVC_EINVAL, "pgemm: K %d, lda %d, ldb %d, taps %d", a.K, a.lda, a.ldb, a.taps);
+template <class Epi, int WR>
+int pgemm_launch_wr(const PGemmArgs& a, const typename Epi::Args& e, hipStream_t st) {
+    constexpr int smem = (WR == 4 ? 3 : 2) * (8 * WR + 16) * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        DSVC_HIP(hipFuncSetAttribute((const void*)pgemm_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_STAGES * WG_STAGE_BYTES));
+        DSVC_HIP(hipFuncSetAttribute((const void*)pgemm_kernel<Epi, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     const int grid = 8 * ((a.row_blocks + 7) / 8) * a.col_blocks;
-    hipLaunchKernelGGL(pgemm_kernel<Epi>, dim3(grid), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, a, e);
+    hipLaunchKernelGGL((pgemm_kernel<Epi, WR>), dim3(grid), dim3(128 * WR), smem, st, a, e);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
+}
+
+// rows_pad: the A planes' data rows rounded up to 256; the tile height is chosen so that the launch has >= ~200 workgroups when it can
+template <class Epi>
+int pgemm_launch(PGemmArgs a, int rows_pad, int n_cols, const typename Epi::Args& e, hipStream_t st) {
+    if (a.K % 32 || a.lda % 16 || a.ldb % 16 || (a.taps != 1 && a.taps != 3) || rows_pad % 256 || n_cols < 1)
+        return fail(DSVC_EINVAL, "pgemm: K %d, lda %d, ldb %d, taps %d, rows %d", a.K, a.lda, a.ldb, a.taps, rows_pad);
+    a.col_blocks = (n_cols + 127) / 128;
+    if ((rows_pad / 256) * a.col_blocks < 160) {
+        a.row_blocks = rows_pad / 128;
+        return pgemm_launch_wr<Epi, 2>(a, e, st);
+    }
+    a.row_blocks = rows_pad / 256;
+    return pgemm_launch_wr<Epi, 4>(a, e, st);
 }
 
 // ---- operand planes -------------------------------------------------------------------------------------------------------------

@@ -565,11 +565,11 @@ struct dsvc_trainer {
     DevBuf dx, dxin, dO, dy, ds2pre, dh0, loss;
     DevBuf bin_count, bin_cursor, bin_segs, bin_nsegs, bin_order, bin_S;     // frames sorted by pitch bin; S_l[vocab][2C] per layer
     DevBuf AT, BT;                                 // dY^T and X^T as channel-major fp16 hi|lo planes: [2][a_rows | b_rows][ldT]
-    APlanes condP, dyP;                            // fragment-tiled fp16 hi|lo planes of cond and of a layer's dy (pgemm.h operands)
+    APlanes condP, dyP, dOP;                       // fragment-tiled fp16 hi|lo planes of cond and of a layer's dy / dO (pgemm.h operands)
     int rows_p = 0;                                // nr rounded up to the 256-row tile
     WPlanes wp_call;                               // every layer's conditioner projection, stacked: [L * 2C][H]
-    std::vector<WPlanes> wp_dT;
-    std::vector<Packed> w_d, w_o, w_oT;
+    std::vector<WPlanes> wp_dT, wp_oT;
+    std::vector<Packed> w_d, w_o;
     DevBuf wpart;                                  // frame-slice partial tiles of one weight-gradient GEMM
     // per-step repacked weights
     Packed w_in, w_skip, w_fin, w_finT, w_skipT;
@@ -581,11 +581,12 @@ struct dsvc_trainer {
                           &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre,
                           &dh0, &loss, &AT, &BT, &wpart, &gatemap, &pack_dev, &wplane_dev, &bin_count, &bin_cursor, &bin_segs, &bin_nsegs, &bin_order, &bin_S})
             b->release();
-        for (APlanes* a : {&condP, &dyP}) a->buf.release();
+        for (APlanes* a : {&condP, &dyP, &dOP}) a->buf.release();
         wp_call.w.release();
-        for (auto& p : wp_dT) p.w.release();
+        for (auto* v : {&wp_dT, &wp_oT})
+            for (auto& p : *v) p.w.release();
         auto rel = [](Packed& p) { p.w.release(); };
-        for (auto* v : {&w_d, &w_o, &w_oT})
+        for (auto* v : {&w_d, &w_o})
             for (auto& p : *v) rel(p);
         rel(w_in); rel(w_skip); rel(w_fin); rel(w_finT); rel(w_skipT);
     }
@@ -717,9 +718,9 @@ int dsvc_trainer::pg(const APlanes& ap, const WPlanes& wp, int b_row0, int n_col
     PGemmArgs a{};
     a.a = ap.base(); a.a_plane = ap.plane; a.lda = ap.ld;
     a.b = wp.w.as<_Float16>() + (size_t)b_row0 * wp.taps * wp.K_pad; a.b_plane = wp.plane(); a.ldb = wp.taps * wp.K_pad;
-    a.n_rows = nr; a.row_blocks = rows_p / 256; a.col_blocks = round_up(n_cols, 128) / 128;
+    a.n_rows = nr;
     a.K = wp.K_pad; a.taps = taps; a.dil = dil;
-    return pgemm_launch<Epi>(a, e, st);
+    return pgemm_launch<Epi>(a, rows_p, n_cols, e, st);
 }
 
 int dsvc_trainer::repack(hipStream_t st) {
@@ -734,18 +735,18 @@ int dsvc_trainer::repack(hipStream_t st) {
     // transposed (data gradients): W^T(col = input channel, ci = output channel) = W[ci][col]
     DSVC_TRY(pack(w_finT, P("denoise_fn.output_projection.weight"), nullptr, C, 1, M, C, 1, C, 0, 0, 1.0f, st));
     DSVC_TRY(pack(w_skipT, P("denoise_fn.skip_projection.weight"), nullptr, C, 1, C, C, 1, C, 0, 0, isl, st));
-    // Which engine runs which layer GEMM was measured (profiles/r3u_kernel_stats_train.csv against r3p): the gate conv, the output projection and
-    // dg = W_o^T dO stay on conv_gemm (79 / 60 / 80 us against 88 / 80 / 81 on pgemm.h -- both engines pull ~8 TB/s through the L2s at these
-    // tile shapes); the transposed conv, the conditioner data gradient and ALL layers' conditioner projections as one stacked operand run on
-    // pgemm.h (99 / 60 / 489 us against 110 / 65 / 20 x 32).  pgemm operands: weights as fragment-tiled fp16 hi|lo planes, rows = output channels.
+    // Which engine runs which layer GEMM was measured (profiles/r3u, r3G, r3H_kernel_stats_train.csv against r3p): the gate conv and the output
+    // projection stay on conv_gemm (79 / 60 us against 88 / 80 on pgemm.h -- both engines pull ~8 TB/s through the L2s at these tile shapes);
+    // the transposed conv, dg = W_o^T dO (128-row tiles: 86 / 64 us against 110 / 89) and ALL layers' conditioner projections as one stacked
+    // operand (490 us against 20 x 32) run on pgemm.h.  pgemm operands: weights as fragment-tiled fp16 hi|lo planes, rows = output channels.
     const int c2p = round_up(2 * C, 128);
-    w_d.resize(L); w_o.resize(L); w_oT.resize(L); wp_dT.resize(L);
+    w_d.resize(L); w_o.resize(L); wp_oT.resize(L); wp_dT.resize(L);
     for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
         DSVC_TRY(pack(w_d[l], P(q + "dilated_conv.weight"), gm, 2 * C, 3, C, 2 * C, (long long)C * 3, 3, 1, 0, 1.0f, st));
         DSVC_TRY(pack(w_o[l], P(q + "output_projection.weight"), nullptr, 2 * C, 1, C, 2 * C, C, 1, 0, 0, 1.0f, st));
-        // transposed (data gradients): W^T(col = input channel, ci = output channel) = W[ci][col]
-        DSVC_TRY(pack(w_oT[l], P(q + "output_projection.weight"), nullptr, C, 1, 2 * C, C, 1, C, 0, 0, 1.0f, st));
+        // transposed (data gradients): W^T(row = input channel, k = output channel) = W[k][row]
+        DSVC_TRY(wplanes(wp_oT[l], 0, C, P(q + "output_projection.weight"), nullptr, C, 1, 2 * C, 1, C, 0, 0, 1.0f, st));
         // the conditioner projections of all layers in the gates' paired gate | filter row order, stacked
         DSVC_TRY(wplanes(wp_call, l * c2p, L * c2p, P(q + "conditioner_projection.weight"), gm, 2 * C, 1, H, H, 1, 0, 0, 1.0f, st));
         // transposed conv: dxin[c] = sum_tap sum_o W_d[o][c][2 - tap] * dy[row + (tap-1)*d][o]
@@ -784,7 +785,7 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
         DSVC_TRY(z(bin_nsegs, 16)); DSVC_TRY(z(bin_order, (size_t)B * T * 4)); DSVC_TRY(z(bin_S, (size_t)L * V * 2 * C * 4));
     }
     rows_p = round_up(nr, 256);
-    DSVC_TRY(aplanes(condP, round_up(H, 32), st)); DSVC_TRY(aplanes(dyP, 2 * C, st));
+    DSVC_TRY(aplanes(condP, round_up(H, 32), st)); DSVC_TRY(aplanes(dyP, 2 * C, st)); DSVC_TRY(aplanes(dOP, 2 * C, st));
     // weight-gradient operands (wgrad.h): frames contiguous, zero beyond the data rows and in the channel padding
     ldT = round_up(B * T, 128);                                  // real frames only (no gap rows); whole 32-frame stages, 64-frame split tiles
     cp128 = round_up(C, 128); hp128 = round_up(H, 128);
@@ -1017,13 +1018,12 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
         const int d = 1 << (l % cfg.dilation_cycle);
         const float* xl = xs.as<float>() + (size_t)l * slab;
         const float* gl = g.as<float>() + (size_t)l * slab;
-        DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias")));
+        DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias"), &dOP));   // + dO as pgemm planes
         DSVC_TRY(split_t(false, 0, gl, C, C, nullptr, 0, 0, st));
         DSVC_TRY(wgrad_nt(2 * C, cp128, 0, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
         {   // dg = W_o^T dO -> dy (fp32 for the weight-gradient planes, fp16 hi|lo planes for the two data gradients below)
-            ConvGemmArgs a = base(dO.as<float>(), 2 * C, 2 * C, w_oT[l], 1);
             EpGateBwd::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(), C, ri};
-            DSVC_TRY(launch<EpGateBwd>(a, e, st));
+            DSVC_TRY(pg<EpGateBwd>(dOP, wp_oT[l], 0, C, 1, 1, e, st));
         }
         // dW_d[o][c][tap] = sum_n dy[n][o] (x^l + film)[n + (tap-1) d][c]  and  dW_c[o][h] = sum_n dy[n][o] cond[n][h]  share dy^T: ONE
         // contraction over the k axis [tap 0 | tap 1 | tap 2 | cond]
