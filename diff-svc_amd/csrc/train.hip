@@ -514,11 +514,22 @@ __global__ void k_sqsum(const float* __restrict__ g, size_t n, float* __restrict
         if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(out, red[0]);
-}
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];            // per-block partials, summed in a fixed order by k_clip_coef: every rank of a
+}                                                               // data-parallel job must derive the SAME coefficient from the same gradients
 
-// clip coefficient of torch.nn.utils.clip_grad_norm_: min(1, max_norm / (norm + 1e-6))
-__global__ void k_clip_coef(const float* __restrict__ sq, float max_norm, float* __restrict__ coef) {
+// clip coefficient of torch.nn.utils.clip_grad_norm_: min(1, max_norm / (norm + 1e-6)); one block of 256 threads
+__global__ void k_clip_coef(const float* __restrict__ part, int n_part, float* __restrict__ sq, float max_norm, float* __restrict__ coef) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x) return;
+    *sq = red[0];
     const float nrm = sqrtf(*sq);
     const float c = max_norm / (nrm + 1e-6f);
     *coef = c < 1.0f ? c : 1.0f;
@@ -1218,11 +1229,14 @@ int dsvc_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
 int dsvc_grad_clip_coef(const float* grads, int64_t n, float max_norm, float* sqnorm_dev, float* coef_dev, void* stream) {
     if (!grads || !sqnorm_dev || !coef_dev || n < 0) return fail(DSVC_EINVAL, "bad argument");
     hipStream_t st = (hipStream_t)stream;
-    DSVC_HIP(hipMemsetAsync(sqnorm_dev, 0, 4, st));
-    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_sqsum, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, grads, (size_t)n, sqnorm_dev);
-    hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(1), 0, st, sqnorm_dev, max_norm, coef_dev);
+    int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (blocks < 1) blocks = 1;
+    float* part = nullptr;                                       // stream-ordered scratch for the per-block partial sums
+    DSVC_HIP(hipMallocAsync((void**)&part, (size_t)blocks * 4, st));
+    hipLaunchKernelGGL(k_sqsum, dim3(blocks), dim3(256), 0, st, grads, (size_t)n, part);
+    hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(256), 0, st, part, blocks, sqnorm_dev, max_norm, coef_dev);
     DSVC_HIP(hipGetLastError());
+    DSVC_HIP(hipFreeAsync(part, st));
     return DSVC_OK;
 }
 

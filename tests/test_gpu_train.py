@@ -236,3 +236,54 @@ def test_overlapped_allreduce_step_under_a_process_group():
     finally:
         if own:
             dist.destroy_process_group()
+
+
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from diffsvc_amd.train import DiffusionTrainerHip
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        hp = dict(synth.tiny_hparams(K=50), diff_loss_type="l2", lr=1e-3)
+        sd = synth.acoustic_state(hp, 3)
+        tr = DiffusionTrainerHip(hp, sd)
+        hub, m2p, f0, mels, t = (v.cuda() for v in _batch(hp, [2 * rank, 2 * rank + 1], 40, 23, 5 + rank))
+        tr.train_step(hub, m2p, f0, mels, t=t, seed=7, first_clip=2 * rank)           # world > 1: the overlapped, bucketed path
+        torch.cuda.synchronize()
+        out[rank] = tr.params.cpu()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_step_averages_the_gradients_bucket_by_bucket():
+    """Data-parallel training as the reference runs it (one process per rank, gradients averaged): two ranks (sharing this GPU, gloo) step on
+    different batches through train_step's overlapped bucketed all-reduce; both must end with the parameters a single process gets from the
+    averaged gradients of the two batches."""
+    import socket
+    import torch.multiprocessing as mp
+    from diffsvc_amd.train import DiffusionTrainerHip
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    hp = dict(synth.tiny_hparams(K=50), diff_loss_type="l2", lr=1e-3)
+    sd = synth.acoustic_state(hp, 3)
+    tr = DiffusionTrainerHip(hp, sd)
+    g = []
+    for rank in range(2):
+        hub, m2p, f0, mels, t = (v.cuda() for v in _batch(hp, [2 * rank, 2 * rank + 1], 40, 23, 5 + rank))
+        tr.forward_backward(hub, m2p, f0, mels, t, seed=7, first_clip=2 * rank)
+        g.append(tr.grads.clone())
+    tr.grads.copy_((g[0] + g[1]) * 0.5)
+    tr.optimizer_step(reduced=True)
+    torch.cuda.synchronize()
+    d01 = (out[0] - out[1]).abs().max().item()
+    dref = (out[0] - tr.params.cpu()).abs().max().item()
+    print("two-rank training step: max |param diff| rank 0 vs rank 1 %.2e, vs the single-process average %.2e" % (d01, dref))
+    assert d01 == 0.0 and dref < 5e-5
