@@ -51,6 +51,12 @@ def test_hubert_units_lengths_vs_oracle(hubert, n):
     assert err < UNIT_TOL, err
     again = hb.units(torch.from_numpy(wav).cuda())[0].cpu()         # a shorter call after a longer one must not see stale workspace rows
     assert torch.equal(again, u)
+    if n <= 24001:                                                  # and a third call at the same length reads its own samples
+        wav2 = synth.speech_like_wav(8, n)
+        u2 = hb.units(torch.from_numpy(wav2).cuda())[0].cpu()
+        with torch.no_grad():
+            ref2 = O.hubert_units(sd, torch.from_numpy(wav2)[None, None])[0]
+        assert (u2 - ref2).abs().max().item() < UNIT_TOL and not torch.equal(u2, u)
 
 
 def test_hubertencoder_plugin_contract(tmp_path, hubert):
