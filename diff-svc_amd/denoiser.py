@@ -22,8 +22,9 @@ output 1x1; ``"f16_x3"`` splits the activations as well (3 MFMAs, fp32-class).  
 * PLMS/PNDM, whose Adams-Bashforth extrapolation amplifies a single evaluation's rounding: ``f16_x3t`` (7e-6 on the 50-iteration golden
   at T=861; 26 ms per 10 s clip).  With fp16 activations even exact weights leave that chain at (8.2 +- 1.2)e-4 over ten (clip, noise)
   pairs, one of them at 1.08e-3 (profiles/r2w_precision_spread.txt).
-Inference only: there is no autograd through the HIP kernels, so
-``infer=False`` training keeps using the reference module.
+``forward`` is inference only (no autograd through a single evaluation); training goes through the sampler module's ``infer=False`` branch
+(``GaussianDiffusionHip.forward``: loss and gradients of every parameter of this module from ``dsvc_trainer_step``) or through
+``diffsvc_amd.train.DiffusionTrainerHip``.
 """
 import math
 

@@ -6,6 +6,12 @@ returning the same ``ret`` dict.  ``infer=True`` runs the whole sampling loop (D
 ``p_sample_plms``, selected by ``hparams['pndm_speedup']`` exactly like diffusion.py:269-278) inside
 libdsvc_hip.so.  The schedule used at inference is whatever the loaded checkpoint carries.
 
+``infer=False`` is the training branch (diffusion.py:237-241 -> training/train_pipeline.py:222-238): ``ret['diff_loss']`` is a scalar that
+carries a gradient -- ``dsvc_trainer_step`` behind a ``torch.autograd.Function`` -- so the reference's own loop (``total_loss.backward()``,
+``torch.optim.AdamW.step()``, training/task/SVC_task.py:109-125) trains through the drop-in unchanged: ``backward()`` fills ``.grad`` of every
+``denoise_fn.*`` parameter and of ``fs2.pitch_embed.weight``.  (``diffsvc_amd.train.DiffusionTrainerHip`` is the same step on flat buffers with
+the clip + AdamW kernels and the bucketed all-reduce: faster, no per-step gather / scatter of 32 M floats.)
+
 Random numbers: the reference draws torch.randn on the device; here x_T and the per-step z come from a
 Philox4x32-10 stream keyed by ``seed`` (a fresh seed is drawn from torch's default generator per call, so
 ``torch.manual_seed`` still makes runs reproducible).
@@ -32,6 +38,26 @@ def _cosine_beta_schedule(timesteps, s=0.008):
     ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
     ac = ac / ac[0]
     return np.clip(1 - (ac[1:] / ac[:-1]), a_min=0, a_max=0.999)
+
+
+class _DiffLoss(torch.autograd.Function):
+    """p_losses (diffusion.py:207-225) with its backward pass: forward gathers the module's parameters into the trainer's flat buffer and runs
+    dsvc_trainer_step (loss AND gradients in one pass over the kernels); backward hands the stored gradients out, scaled by the incoming one."""
+
+    @staticmethod
+    def forward(ctx, owner, step_args, *params):
+        h, flat_p, flat_g = owner._trainer(params[0].device)
+        with torch.no_grad():
+            for (name, off, n), p in zip(h.layout, params):
+                flat_p[off:off + n].copy_(p.detach().reshape(-1))
+        loss = h.step(*step_args[:3], pitch=step_args[3], mel2ph=step_args[4], seed=step_args[5])
+        ctx.layout, ctx.shapes = h.layout, [p.shape for p in params]
+        ctx.grads = flat_g.clone()                       # the flat gradient buffer is overwritten by the next forward
+        return loss.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + tuple((ctx.grads[off:off + n] * g).view(shape) for (name, off, n), shape in zip(ctx.layout, ctx.shapes))
 
 
 class GaussianDiffusionHip(nn.Module):
@@ -74,6 +100,36 @@ class GaussianDiffusionHip(nn.Module):
         self.register_buffer("spec_min", torch.FloatTensor(spec_min)[None, None, :kb])
         self.register_buffer("spec_max", torch.FloatTensor(spec_max)[None, None, :kb])
         self._samplers = {}            # 'ddpm' / 'plms' -> (SamplerHandle, key): the two loops may run at different precisions
+        self._train = None             # (TrainerHandle, flat params, flat grads, schedule key): the infer=False branch
+
+    def _trainer(self, device):
+        from .train import TrainerHandle
+        key = tuple((b.data_ptr(), b._version) for b in (self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, self.spec_min, self.spec_max))
+        if self._train is None or self._train[3] != key or self._train[1].device != device:
+            h = TrainerHandle(self.hp, self.loss_type, self.fs2.pitch_embed.weight.shape[0])
+            flat_p = torch.zeros(h.n_floats, device=device, dtype=torch.float32)
+            flat_g = torch.zeros(h.n_floats, device=device, dtype=torch.float32)
+            h.bind(flat_p, flat_g)
+            h.set_schedule(self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, self.spec_min, self.spec_max)
+            self._train = (h, flat_p, flat_g, key)
+        return self._train[:3]
+
+    def _p_losses(self, ret, ref_mels, mel2ph, t=None, seed=None):
+        """ret['diff_loss'] of the training branch (Batch2Loss.module4: t ~ randint(0, K_step), noise ~ N(0, 1) -- here the Philox stream of
+        ``seed``, drawn from torch's generator like t)."""
+        if ref_mels is None or not ref_mels.is_cuda:
+            raise RuntimeError("diffsvc_amd: training needs ref_mels on the HIP device; there is no CPU path")
+        B = ref_mels.shape[0]
+        if t is None:
+            t = torch.randint(0, self.K_step, (B,), device=ref_mels.device)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        named = dict(self.named_parameters())
+        h = self._trainer(ref_mels.device)[0]
+        params = [named[name] for name, _, _ in h.layout]
+        cond = ret["decoder_inp"].detach().transpose(1, 2).contiguous()
+        pitch = ret["pitch_pred"].detach().squeeze(-1) if "pitch_pred" in ret else None
+        return _DiffLoss.apply(self, (ref_mels.detach(), cond, t, pitch, mel2ph, seed), *params)
 
     def _handle(self, use="ddpm", speedup=1, frames=None):
         den = self.denoise_fn.handle(use, speedup, frames)
@@ -91,12 +147,16 @@ class GaussianDiffusionHip(nn.Module):
 
     def forward(self, hubert, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None, infer=False,
                 **kwargs):
+        if not infer:      # training branch: the pitch embedding's gradient comes from dsvc_trainer_step, not from an autograd graph over fs2
+            with torch.no_grad():
+                ret = self.fs2(hubert, mel2ph, spk_embed, None, f0, uv, energy, skip_decoder=True, infer=False)
+            ret.pop("cond_bht", None)
+            ret["diff_loss"] = self._p_losses(ret, ref_mels, mel2ph, t=kwargs.get("t"), seed=kwargs.get("seed"))
+            return ret
         ret = self.fs2(hubert, mel2ph, spk_embed, None, f0, uv, energy, skip_decoder=True, infer=infer)
         cond = ret.pop("cond_bht", None)                     # the device builder emits the [B, H, T] layout alongside (one launch)
         if cond is None:
             cond = ret["decoder_inp"].transpose(1, 2).contiguous()
-        if not infer:
-            raise NotImplementedError("training (p_losses, diffusion.py:207-225) stays on the reference autograd path")
         hp = self.hp
         seed = kwargs.get("seed")
         if seed is None:

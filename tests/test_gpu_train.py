@@ -287,3 +287,42 @@ def test_two_rank_training_step_averages_the_gradients_bucket_by_bucket():
     dref = (out[0] - tr.params.cpu()).abs().max().item()
     print("two-rank training step: max |param diff| rank 0 vs rank 1 %.2e, vs the single-process average %.2e" % (d01, dref))
     assert d01 == 0.0 and dref < 5e-5
+
+
+def test_reference_style_training_loop_through_the_drop_in_module():
+    """GaussianDiffusionHip.forward(infer=False) as the reference's task drives its model (training/task/SVC_task.py:68-125): ret['diff_loss']
+    carries a gradient, loss.backward() fills .grad of every denoise_fn.* parameter and of fs2.pitch_embed.weight, torch.optim.AdamW steps.
+    The gradients equal DiffusionTrainerHip's (same kernels) and a step changes the loss."""
+    from diffsvc_amd.denoiser import DiffNetHip
+    from diffsvc_amd.sampler import GaussianDiffusionHip
+    from diffsvc_amd.train import DiffusionTrainerHip
+    hp = dict(synth.tiny_hparams(K=50), diff_loss_type="l2")
+    sd = synth.acoustic_state(hp, 3)
+    M = hp["audio_num_mel_bins"]
+    model = GaussianDiffusionHip(None, M, DiffNetHip(M, hparams=hp), timesteps=50, K_step=50, loss_type="l2", spec_min=hp["spec_min"],
+                                 spec_max=hp["spec_max"], hparams=hp)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    hub, m2p, f0, mels, t = (v.cuda() for v in _batch(hp, [0, 1, 2], 40, 23, 5))
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    ret = model(hub, mel2ph=m2p, ref_mels=mels, f0=f0.clone(), infer=False, t=t, seed=7)
+    loss = ret["diff_loss"]
+    assert loss.requires_grad and loss.dim() == 0
+    opt.zero_grad()
+    (2.0 * loss).backward()                                   # a scaled loss: the incoming gradient multiplies through
+    tr = DiffusionTrainerHip(hp, sd)
+    ref_loss = tr.forward_backward(hub, m2p, f0.clone(), mels, t, seed=7)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-6 * abs(ref_loss.item())
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for name, off, n in tr.h.layout:
+        g = named[name].grad
+        assert g is not None, name
+        r = 2.0 * tr.view(tr.grads, name)
+        worst = max(worst, (g - r).norm().item() / max(r.norm().item(), 1e-30))
+    assert worst < 1e-6, worst
+    opt.step()
+    with torch.no_grad():
+        loss2 = model(hub, mel2ph=m2p, ref_mels=mels, f0=f0.clone(), infer=False, t=t, seed=7)["diff_loss"]
+    print("reference-style loop: loss %.4f -> %.4f after one AdamW step; worst gradient difference vs the trainer %.1e" % (loss.item(), loss2.item(), worst))
+    assert loss2.item() < loss.item()
