@@ -47,9 +47,8 @@ class _DiffLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, step_args, *params):
         h, flat_p, flat_g = owner._trainer(params[0].device)
-        with torch.no_grad():
-            for (name, off, n), p in zip(h.layout, params):
-                flat_p[off:off + n].copy_(p.detach().reshape(-1))
+        with torch.no_grad():                            # one fused multi-tensor copy instead of 172 launches
+            torch._foreach_copy_([flat_p[off:off + n].view(p.shape) for (name, off, n), p in zip(h.layout, params)], [p.detach() for p in params])
         loss = h.step(*step_args[:3], pitch=step_args[3], mel2ph=step_args[4], seed=step_args[5])
         ctx.layout, ctx.shapes = h.layout, [p.shape for p in params]
         ctx.grads = flat_g.clone()                       # the flat gradient buffer is overwritten by the next forward
@@ -57,7 +56,8 @@ class _DiffLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (None, None) + tuple((ctx.grads[off:off + n] * g).view(shape) for (name, off, n), shape in zip(ctx.layout, ctx.shapes))
+        scaled = ctx.grads * g
+        return (None, None) + tuple(scaled[off:off + n].view(shape) for (name, off, n), shape in zip(ctx.layout, ctx.shapes))
 
 
 class GaussianDiffusionHip(nn.Module):
