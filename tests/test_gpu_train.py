@@ -326,3 +326,33 @@ def test_reference_style_training_loop_through_the_drop_in_module():
         loss2 = model(hub, mel2ph=m2p, ref_mels=mels, f0=f0.clone(), infer=False, t=t, seed=7)["diff_loss"]
     print("reference-style loop: loss %.4f -> %.4f after one AdamW step; worst gradient difference vs the trainer %.1e" % (loss.item(), loss2.item(), worst))
     assert loss2.item() < loss.item()
+
+
+def test_train_step_at_the_benchmarked_batch_equals_the_mean_of_its_sub_batches():
+    """BASELINE configs[4] as bench.py times it: 64 clips x 128 frames on the 44.1 kHz architecture (8 704 rows: the many-row conv tilings, the
+    sliced weight-gradient GEMMs with XCD-local slices, the 128-row pgemm tiles, 2^14 loss scale).  The loss is a mean over equal-sized clips, so
+    the step on the whole batch must equal the average of the steps on its four 16-clip quarters -- which run on the small-batch tilings (fewer
+    slices, other tile shapes): a size-independent consistency check of every gradient tensor at the benchmarked size."""
+    from diffsvc_amd.train import DiffusionTrainerHip
+    hp = dict(synth.HPARAMS_44K, diff_loss_type="l2")
+    sd = synth.acoustic_state(hp, 3)
+    clips, T, n_units, seed = list(range(64)), 128, 74, 9
+    hub, m2p, f0, mels, t = (v.cuda() for v in _batch(hp, clips, T, n_units, seed))
+    ids = torch.tensor(clips, dtype=torch.int32, device="cuda")
+    tr = DiffusionTrainerHip(hp, sd)
+    loss_full = tr.forward_backward(hub, m2p, f0.clone(), mels, t, seed=seed, clip_ids=ids).item()
+    g_full = tr.grads.clone()
+    g_avg, loss_avg = torch.zeros_like(g_full), 0.0
+    for q in range(4):
+        sl = slice(16 * q, 16 * q + 16)
+        loss_avg += tr.forward_backward(hub[sl], m2p[sl], f0[sl].clone(), mels[sl], t[sl], seed=seed, clip_ids=ids[sl]).item() / 4
+        g_avg += tr.grads / 4
+    assert abs(loss_full - loss_avg) <= 5e-6 * abs(loss_full), (loss_full, loss_avg)      # (float-atomic sums of block partials)
+    worst, worst_name = 0.0, None
+    for name, off, n in tr.h.layout:
+        a, b = g_full[off:off + n], g_avg[off:off + n]
+        err = (a - b).norm().item() / max(b.norm().item(), 1e-30)
+        if err > worst:
+            worst, worst_name = err, name
+    print("train step 64 x 128 vs the mean of its four quarters: loss %.6f / %.6f, worst gradient rel-L2 difference %.2e (%s)" % (loss_full, loss_avg, worst, worst_name))
+    assert torch.isfinite(g_full).all() and worst < 2e-5, (worst, worst_name)
