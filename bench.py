@@ -176,15 +176,12 @@ def cpu_baseline(hp, sd, vs, h, budget_s=20.0):
 
 
 def train_batch(hp, B, T, rank, device):
-    """Synthetic training batch of BASELINE configs[4]: B clips x T mel frames (content units, alignment, f0, target mels)."""
+    """Synthetic training batch of BASELINE configs[4]: B clips x T mel frames (content units, alignment, f0, target mels).  It is
+    synth.train_batch_kat -- on rank 0 at 64 x 128 exactly the batch the real reference's forward(infer=False) + backward() was run on for
+    tests/golden/train_grads_bench.npz (oracle/make_golden.py::TRAIN_CASES_BENCH), so the timed step is the step that has a parity number."""
     n_units = max(2, T * N_UNITS // T_FRAMES)
-    hub, m2p, f0 = [], [], []
-    for c in range(B):
-        a, b, c_, _ = synth.clip_inputs(rank * B + c, T=T, n_units=n_units, H=hp["hidden_size"])
-        hub.append(a); m2p.append(b); f0.append(c_)
-    g = np.random.Generator(np.random.PCG64(77 + rank))
-    mels = (g.standard_normal((B, T, hp["audio_num_mel_bins"])) * 0.7 - 2.5).astype(np.float32)
-    return tuple(torch.from_numpy(np.stack(v)).to(device) for v in (hub, m2p, f0)) + (torch.from_numpy(mels).to(device),)
+    hub, m2p, f0, mels, _ = synth.train_batch_kat(hp, range(rank * B, rank * B + B), T, n_units, 77 + rank)
+    return tuple(torch.from_numpy(v).to(device) for v in (hub, m2p, f0, mels))
 
 
 def time_train_steps(hp, sd, B, T, steps, warmup, rank, device, sync):

@@ -217,8 +217,21 @@ SPREAD_COND = (("ca", (1.5, 0.07), (0, 1)),                            # the PLM
                ("cb", (1.2, 0.15), (0, 1, 2, 3)))                      # twice the random-network share: 0.6 % of the mel on the clamp
 
 
-def spread_names():
+# Round 4: EVERY clip of two per-GPU shares of BASELINE configs[3] (clips 0..31 and 32..63 of the 256-clip job, seed 2026) has a golden, so
+# that tests/test_gpu_headline.py::test_batch_of_32_* checks all 64 clips of two batches and fits the tail of the error distribution on 64
+# samples instead of 12.  Clips 0 and 1 are the two rows of e2e_44k_T861_k1000; SPREAD_CLIPS were minted in round 3.
+SHARE_CLIPS = tuple(c for c in range(64) if c not in (0, 1) and c not in SPREAD_CLIPS)
+
+
+def share_golden(clip):
+    """(golden name, row) of clip `clip` (seed 2026, random-init checkpoint) of the 64-clip double share."""
+    return ("e2e_44k_T861_k1000", clip) if clip in (0, 1) else ("e2e_44k_T861_k1000_s2026_c%d" % clip, 0)
+
+
+def spread_names(share=False):
     out = [("e2e_44k_T861_k1000_s2026_c%d" % c, c, SPREAD_SEED, None) for c in SPREAD_CLIPS]
+    if share:
+        return [("e2e_44k_T861_k1000_s2026_c%d" % c, c, SPREAD_SEED, None) for c in SHARE_CLIPS]
     out.append(("e2e_44k_T861_k1000_c9", 9, 1009, None))               # the shipped round-2 precision's worst (clip, noise) pair
     for tag, cond, clips in SPREAD_COND:
         out += [("e2e_44k_T861_k1000_%s_c%d" % (tag, c), c, SPREAD_SEED, cond) for c in clips]
@@ -228,7 +241,7 @@ def spread_names():
 def golden_headline_spread(only=None):
     """17 more single-clip runs of the benchmarked configuration through the REAL reference (~80 s each on 8 cores); skips files that
     exist, so an interrupted run resumes."""
-    for name, clip, seed, cond in spread_names():
+    for name, clip, seed, cond in spread_names() + spread_names(share=True):
         if only and name not in only:
             continue
         if os.path.exists(os.path.join(OUT, name + ".npz")) and "--force" not in sys.argv:
@@ -249,7 +262,13 @@ TRAIN_CASES = (  # name, arch, loss, clips, T, n_units, seed  (the batches of te
     ("44k_l2", "44k", "l2", (4, 9), 64, 37, 6), ("44k_l1", "44k", "l1", (4, 9), 64, 37, 6))
 
 
-def golden_train():
+# Round 4: BASELINE configs[4] AT THE BENCHMARKED SIZE -- exactly the batch bench.py --train times on rank 0 (bench.train_batch: clips 0..63,
+# 128 frames, 74 content units, PCG64(77)): 8 704 rows, where the many-row conv tilings, the XCD-sliced weight gradients, the 128-row pgemm
+# tiles and the 2^14 loss scale are in play.  Its own file (the 44.1 kHz lattice of all 171 tensors is ~5 MB).
+TRAIN_CASES_BENCH = (("bench64x128_l2", "44k", "l2", tuple(range(64)), 128, 74, 77),)
+
+
+def golden_train(cases=TRAIN_CASES, fname="train_grads"):
     """Training parity pin (BASELINE configs[4]): the REAL GaussianDiffusion.forward(infer=False) ->
     Batch2Loss.module4 -> p_losses (diffusion.py:207-241, train_pipeline.py:222-238) with torch autograd, on the batches of
     tests/test_gpu_train.py.  The two random draws of the training forward are injected: ``torch.randint`` (the diffusion steps t,
@@ -257,7 +276,7 @@ def golden_train():
     Stored: the loss, the L2 norm of every parameter gradient, and the gradients themselves (tiny architecture: all of them;
     44.1 kHz: small tensors whole, large ones on the lattice of synth.train_grad_slices)."""
     out = {}
-    for name, arch, loss_type, clips, T, n_units, seed in TRAIN_CASES:
+    for name, arch, loss_type, clips, T, n_units, seed in cases:
         hp = dict(synth.tiny_hparams(K=50) if arch == "tiny" else synth.HPARAMS_44K, diff_loss_type=loss_type)
         sd = synth.acoustic_state(hp, 3)
         model = build_reference_model(hp, sd)
@@ -298,7 +317,7 @@ def golden_train():
         out[name + "/names"] = np.array(names)
         out[name + "/norms"] = np.array(norms, dtype=np.float64)
         print("train", name, "loss %.6f, %d gradient tensors, |g| %.4f" % (loss.item(), len(names), float(np.sqrt((np.array(norms) ** 2).sum()))))
-    np.savez_compressed(os.path.join(OUT, "train_grads.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname + ".npz"), **out)
 
 
 def golden_melspec(name, sr, n_fft, win, hop, n_mels, fmin, fmax, n_samples):
@@ -368,6 +387,8 @@ def main():
         return golden_headline_spread()
     if "--train-only" in sys.argv:
         return golden_train()
+    if "--train-bench" in sys.argv:
+        return golden_train(TRAIN_CASES_BENCH, "train_grads_bench")
     if "--plms-only" in sys.argv:
         return golden_plms_conditioned()
     if "--hifigan-only" in sys.argv:
@@ -398,6 +419,7 @@ def main():
     golden_headline_extra()
     golden_headline_spread()
     golden_train()
+    golden_train(TRAIN_CASES_BENCH, "train_grads_bench")
     golden_slicer()
     golden_slicer_demo_input()
     golden_schedule()

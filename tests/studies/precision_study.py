@@ -44,6 +44,50 @@ def dither_variants(w, K, seed=0):
 def r16(x):
     return x.half().float()
 
+# ---- round 4: the w_lo * x correction on the block-scaled 6-bit matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4) ----
+E2M3 = np.array([m / 8 for m in range(8)] + [(1 + m / 8) * 2 ** e for e in range(3) for m in range(8)], dtype=np.float64)     # fp6: 0 .. 7.5
+E3M2 = np.array([m / 16 for m in range(4)] + [(1 + m / 4) * 2.0 ** (e - 3) for e in range(1, 8) for m in range(4)], dtype=np.float64)  # bf6: 0 .. 28
+
+def grid_floor_ceil(u, grid):
+    """(largest grid value <= |u|, smallest >= |u|) with the sign restored; saturating at the grid's end."""
+    a = np.minimum(np.abs(u), grid[-1])
+    i = np.searchsorted(grid, a, side="right") - 1
+    lo = grid[i]; hi = grid[np.minimum(i + 1, len(grid) - 1)]
+    hi = np.where(lo == a, lo, hi)
+    return np.sign(u) * lo, np.sign(u) * hi      # (towards zero, away from zero)
+
+def q_nearest(u, grid):
+    lo, hi = grid_floor_ceil(u, grid)
+    return np.where(np.abs(u - lo) <= np.abs(hi - u), lo, hi)
+
+def lo6_variants(w, K, grid, block=32, seed=0, blockscale=True):
+    """K 6-bit roundings of w_lo = w - fp16(w) ([O, I, taps]): per (output row, tap, 32 input channels) block a power-of-two scale that
+    maps the block's largest magnitude just inside the grid, element values rounded towards / away from zero by stratified thresholds
+    (the K copies average to w_lo to 1/K of a grid step)."""
+    w = w.numpy().astype(np.float64)
+    wl = w - w.astype(np.float16).astype(np.float64)
+    O_, I, taps = wl.shape
+    b = wl.transpose(0, 2, 1).reshape(O_, taps, I // block, block)
+    amax = np.abs(b).max(-1, keepdims=True) if blockscale else np.full((O_, taps, I // block, 1), np.abs(b).max())
+    e = np.ceil(np.log2(np.maximum(amax, 1e-30) / grid[-1]))
+    sc = 2.0 ** e
+    u = b / sc
+    lo, hi = grid_floor_ceil(u, grid)
+    span = hi - lo
+    frac = np.where(span != 0, (u - lo) / np.where(span != 0, span, 1), 0.0)
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    phase = rng.random(u.shape) if K > 1 else np.zeros_like(u)
+    out = []
+    for k in range(K):
+        th = ((k + 0.5) / K + phase) % 1.0 if K > 1 else 0.5
+        q = np.where(frac > th, hi, lo) * sc
+        out.append(torch.from_numpy(q.reshape(O_, taps, I).transpose(0, 2, 1).astype(np.float32).copy()))
+    return out
+
+def x6(x, grid, scale):
+    """activations for the 6-bit product: nearest on the grid after division by `scale` (saturating), as v_cvt_scalef32_pk32_*_f16 does"""
+    return torch.from_numpy((q_nearest(x.numpy().astype(np.float64) / scale, grid) * scale).astype(np.float32))
+
 class Net:
     def __init__(self, sd, hp, scheme):
         self.sd, self.hp, self.scheme = sd, hp, scheme
@@ -60,12 +104,23 @@ class Net:
         self.wd, self.wo = [], []
         for l in range(self.L):
             wd, wo = sd[p % (l, "dilated_conv.weight")], sd[p % (l, "output_projection.weight")]
-            if scheme == "f32" or scheme == "w2":
+            if scheme.startswith("w6"):            # w6[b|f]<K>[xb|xf][s<scale>]: gate = fp16(w) x + lo6_k x6; output projection exact (w2)
+                self.wd.append([r16(wd)]); self.wo.append([wo])
+            elif scheme == "f32" or scheme == "w2":
                 self.wd.append([wd]); self.wo.append([wo])
             elif scheme == "f16":
                 self.wd.append([r16(wd)]); self.wo.append([r16(wo)])
             else:
                 self.wd.append(dither_variants(wd, self.K, 2 * l)); self.wo.append(dither_variants(wo, self.K, 2 * l + 1))
+        self.lo6 = None
+        if scheme.startswith("w6"):
+            import re
+            m = re.match(r"w6([bf])(\d+)(x[bf])?(s\d+)?(g)?$", scheme)
+            wgrid = E3M2 if m.group(1) == "b" else E2M3
+            self.K = int(m.group(2))
+            self.xgrid = E2M3 if m.group(3) == "xf" else E3M2
+            self.xscale = float(m.group(4)[1:]) if m.group(4) else 4.0
+            self.lo6 = [lo6_variants(sd[p % (l, "dilated_conv.weight")], self.K, wgrid, seed=l, blockscale=not m.group(5)) for l in range(self.L)]
         self.order = list(range(self.K))
         if self.K > 1:      # bit-reversed visiting order: consecutive steps use far-apart thresholds
             bits = int(math.log2(self.K))
@@ -88,7 +143,10 @@ class Net:
             q = lambda s: p("residual_layers.%d.%s" % (l, s))
             d = 2 ** (l % self.cyc)
             film = F.linear(emb, q("diffusion_projection.weight"), q("diffusion_projection.bias"))[:, :, None]
-            y = F.conv1d(act(x + film), self.wd[l][k % len(self.wd[l])], q("dilated_conv.bias"), padding=d, dilation=d) + cproj[l]
+            xin = act(x + film)
+            y = F.conv1d(xin, self.wd[l][k % len(self.wd[l])], q("dilated_conv.bias"), padding=d, dilation=d) + cproj[l]
+            if self.lo6 is not None:
+                y = y + F.conv1d(x6(xin, self.xgrid, self.xscale), self.lo6[l][k], None, padding=d, dilation=d)
             z = torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
             o = F.conv1d(act(z), self.wo[l][k % len(self.wo[l])], q("output_projection.bias"))
             x = (x + o[:, :C]) / math.sqrt(2.0)

@@ -129,17 +129,20 @@ def test_train_step_rejects_bad_arguments():
         tr.h.step(mels.cuda(), torch.zeros(1, 31, 40, device="cuda"), t.cuda())     # wrong hidden size
 
 
-@pytest.mark.parametrize("case", ["tiny_l2", "tiny_l1", "44k_l2", "44k_l1"])
+@pytest.mark.parametrize("case", ["tiny_l2", "tiny_l1", "44k_l2", "44k_l1", "bench64x128_l2"])
 def test_train_step_vs_real_reference_golden(case):
     """The HIP training step against the REAL reference's p_losses + autograd (tests/golden/train_grads.npz, minted by
     oracle/make_golden.py::golden_train from GaussianDiffusion.forward(infer=False) with t and the Philox noise injected): loss,
     the L2 norm of every gradient tensor, and the stored gradient values (tiny: all; 44.1 kHz: the small tensors whole, the large ones
-    on a stride-8 lattice).  Nothing of the oracle restatement is in this comparison."""
+    on a stride-8 lattice).  Nothing of the oracle restatement is in this comparison.
+    bench64x128_l2 (round 4, tests/golden/train_grads_bench.npz) is BASELINE configs[4] AT THE BENCHMARKED SIZE: exactly the batch
+    `bench.py --train` times on rank 0 (64 clips x 128 frames = 8 704 rows: the many-row conv tilings, the XCD-sliced weight gradients, the
+    128-row pgemm tiles, the 2^14 loss scale) through the real reference's forward(infer=False) + backward()."""
     from diffsvc_amd.train import DiffusionTrainerHip
-    from make_golden import TRAIN_CASES
+    from make_golden import TRAIN_CASES, TRAIN_CASES_BENCH
     from util import load_golden
-    g = load_golden("train_grads")
-    name, arch, loss_type, clips, T, n_units, seed = next(c for c in TRAIN_CASES if c[0] == case)
+    g = load_golden("train_grads_bench" if case.startswith("bench") else "train_grads")
+    name, arch, loss_type, clips, T, n_units, seed = next(c for c in TRAIN_CASES + TRAIN_CASES_BENCH if c[0] == case)
     hp = dict(synth.tiny_hparams(K=50) if arch == "tiny" else synth.HPARAMS_44K, diff_loss_type=loss_type)
     sd = synth.acoustic_state(hp, 3)
     hub, m2p, f0, mels, t = (torch.from_numpy(v).cuda() for v in synth.train_batch_kat(hp, clips, T, n_units, seed))

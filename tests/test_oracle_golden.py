@@ -175,17 +175,17 @@ def test_pitch_extractor_matches_reference():
 
 
 
-@pytest.mark.parametrize("case", ["tiny_l2", "tiny_l1", "44k_l2", "44k_l1"])
+@pytest.mark.parametrize("case", ["tiny_l2", "tiny_l1", "44k_l2", "44k_l1", "bench64x128_l2"])
 def test_training_loss_and_gradients_match_the_real_p_losses(case):
     """The training oracle (O.train_loss_and_grads: q_sample -> DiffNet -> l1 / l2, torch autograd) against the REAL
     GaussianDiffusion.forward(infer=False) -> Batch2Loss.module4 -> p_losses + loss.backward() (diffusion.py:207-241,
     train_pipeline.py:222-238), minted with the diffusion steps and the Philox training noise injected (tests/golden/train_grads.npz,
     oracle/make_golden.py::golden_train): the loss, the L2 norm of every one of the 43 / 171 gradient tensors, and the stored gradient
     values (tiny: every element; 44.1 kHz: small tensors whole -- input / output / skip projections, biases, fs2.pitch_embed -- the large
-    ones on a stride-8 lattice)."""
-    from make_golden import TRAIN_CASES
-    g = load_golden("train_grads")
-    name, arch, loss_type, clips, T, n_units, seed = next(c for c in TRAIN_CASES if c[0] == case)
+    ones on a stride-8 lattice).  bench64x128_l2: the batch `bench.py --train` times (tests/golden/train_grads_bench.npz)."""
+    from make_golden import TRAIN_CASES, TRAIN_CASES_BENCH
+    g = load_golden("train_grads_bench" if case.startswith("bench") else "train_grads")
+    name, arch, loss_type, clips, T, n_units, seed = next(c for c in TRAIN_CASES + TRAIN_CASES_BENCH if c[0] == case)
     hp = dict(synth.tiny_hparams(K=50) if arch == "tiny" else synth.HPARAMS_44K, diff_loss_type=loss_type)
     sd = synth.acoustic_state(hp, 3)
     hub, m2p, f0, mels, t = (torch.from_numpy(v) for v in synth.train_batch_kat(hp, clips, T, n_units, seed))
