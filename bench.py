@@ -175,6 +175,37 @@ def cpu_baseline(hp, sd, vs, h, budget_s=20.0):
                       % (n, per_step, t_voc)}
 
 
+def spawn_ranks(n):
+    """Re-run this command line as n ranks on this node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n (rendezvous on
+    127.0.0.1, a free port).  Returns the launcher's exit code; rank 0 of the child job prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def comm_info(dist, world, share_device):
+    """What moved the bytes between the ranks: backend, world size and (RCCL) library version -- on the JSON line of every N > 1 run."""
+    if world <= 1 or dist is None:
+        return None
+    info = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+    if info["backend"] == "nccl":
+        try:
+            info["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            info["library"] = "RCCL (torch.distributed 'nccl' on ROCm), xGMI peer-to-peer"
+        except Exception as ex:
+            info["version"] = repr(ex)[:80]
+    elif share_device:
+        info["note"] = "launch-contract test mode (DSVC_BENCH_SHARE_DEVICE=1): every rank on cuda:0, gloo on the host"
+    return info
+
+
 def train_batch(hp, B, T, rank, device):
     """Synthetic training batch of BASELINE configs[4]: B clips x T mel frames (content units, alignment, f0, target mels).  It is
     synth.train_batch_kat -- on rank 0 at 64 x 128 exactly the batch the real reference's forward(infer=False) + backward() was run on for
@@ -227,23 +258,52 @@ def main():
                     help="launch the sampler steps eagerly (rocprofv3 --pmc segfaults on hipGraph replays on this stack)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU under torch.distributed.run, as the reference's
+        # trainer spawns its DDP workers, utils/pl_utils.py:483-485) instead of silently measuring one GPU
+        sys.exit(spawn_ranks(args.gpus))
     SHARE_DEVICE = os.environ.get("DSVC_BENCH_SHARE_DEVICE") == "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to print a line whose n_gpus would not be what was "
+              "asked for" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    DRY = os.environ.get("DSVC_BENCH_DRY") == "1"          # launch-contract test WITHOUT a GPU (tests/test_host.py): spawn, rendezvous, clocks, JSON line
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if SHARE_DEVICE:        # launch-contract test on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL
+        if SHARE_DEVICE or DRY: # launch-contract test on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL
             local_rank = 0
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world)
+    if DRY:
+        # no hot path, no number: every rank sleeps its "steps" between the same barriers, the MAX over the ranks is taken the same way,
+        # and rank 0 prints a line that says what it is
+        import time as _t
+        if world > 1:
+            dist.barrier()
+        t0 = _t.perf_counter()
+        for _ in range(args.steps):
+            _t.sleep(0.01 * (1 + rank))
+        if world > 1:
+            dist.barrier()
+        el = torch.tensor([_t.perf_counter() - t0])
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "dry run of the launch contract (no GPU work)", "value": None, "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": float(el.item()) / max(args.steps, 1) * 1e3, "dry_run": True,
+                              "scaling": "weak", "rccl": comm_info(dist, world, True), "train": bool(args.train)}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a HIP device: the product path has no CPU fallback"
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     pcm16 = args.pcm16 or os.environ.get("DSVC_BENCH_PCM16") == "1"
@@ -274,7 +334,7 @@ def main():
                               "config": {"workload": "BASELINE configs[4]: training step on a 64 x 128-frame mel batch per GPU, gradient all-reduce (mean) "
                                                      "of 32 M fp32 over the ranks", "clips_per_gpu": Bt, "mel_frames": Tt, "loss": hp["diff_loss_type"],
                                          "parallelism": "data-parallel x%d" % world},
-                              "final_loss": loss}))
+                              "rccl": comm_info(dist, world, SHARE_DEVICE), "final_loss": loss}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -337,6 +397,7 @@ def main():
                        "weights": "random-init (synthetic checkpoint, seeds 0/1)", "parallelism": "utterance-sharded x%d, gather of PCM" % world,
                        "gather": "int16 PCM" if pcm16 else "fp32 PCM"},
             "finite_output": ok,
+            "rccl": comm_info(dist, world, SHARE_DEVICE),
             "roofline": roof,
         }
         if os.environ.get("DSVC_BENCH_PCM_STATS") == "1":       # test hook: per-clip moments of the gathered PCM of the last step

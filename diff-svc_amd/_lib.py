@@ -11,12 +11,13 @@ LIB_PATH = os.path.join(HERE, "libdsvc_hip.so")
 PREC_F16, PREC_F16_W2, PREC_F16_X3 = 0, 1, 2
 PREC_F16_MIX = 3
 PREC_F16_X3T = 4
+PREC_F16_W6 = 5
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3, "f16_x3t": PREC_F16_X3T}
 ABI_VERSION = 6
 
 
 def parse_precision(p):
-    """'f16' | 'f16_w2' | 'f16_x3' | 'f16_x3t' (f16_x3's operand scheme on the tgemm engine) | 'f16_dN' (fp16 operands, N time-dithered weight roundings) | 'f16_mN' (the same for the dilated
+    """'f16' | 'f16_w2' | 'f16_x3' | 'f16_x3t' (f16_x3's operand scheme on the tgemm engine) | 'f16_w6' / 'f16_w6dN' (f16_w2 with fp6 w_lo codes, N dithered roundings, default 64) | 'f16_dN' (fp16 operands, N time-dithered weight roundings) | 'f16_mN' (the same for the dilated
     conv, exact hi+lo weights for the output 1x1) -> (enum, variants)."""
     if isinstance(p, (tuple, list)):
         return int(p[0]), int(p[1])
@@ -28,6 +29,10 @@ def parse_precision(p):
         return PREC_F16, int(p[5:])
     if p.startswith("f16_m") and p[5:].isdigit() and int(p[5:]) >= 1:
         return PREC_F16_MIX, int(p[5:])
+    if p == "f16_w6":                                    # f16_w2 with the w_lo * x correction of the dilated conv on the 6-bit matrix instruction
+        return PREC_F16_W6, 64                           # (fused layer kernel; w_lo as 64 time-dithered fp6 roundings)
+    if p.startswith("f16_w6d") and p[7:].isdigit() and int(p[7:]) >= 1:
+        return PREC_F16_W6, int(p[7:])
     raise ValueError("precision must be one of %s, 'f16_dN' or 'f16_mN'" % sorted(PRECISIONS))
 
 c_f32p = ctypes.POINTER(ctypes.c_float)

@@ -119,6 +119,55 @@ int tpack(TPacked& tp, const std::vector<float>& src, int O, int I, int taps, in
     return upload(tp.bias, bias, (size_t)nbias * 4);
 }
 
+// fp6 codes of a conv's w_lo plane (DSVC_PREC_F16_W6, tgemm.h: k_tpack6); rows, row scales and the overall scale as for the fp16 planes
+struct TPacked6 {
+    DevBuf codes;   // [variant][m_tile][tap][cin_pad / 64][1536 B]
+    int n_variants = 1, e6 = 0;
+    size_t variant_dwords = 0;
+};
+
+template <class FR>
+int tpack6(TPacked6& tp, const std::vector<float>& src, int O, int I, int taps, int m_tiles, int n_variants, float scale, unsigned salt,
+           FR&& rowmap, const std::vector<float>* rowscale) {
+    const int cin_pad = round_up(I, 128);
+    if ((size_t)O * I * taps != src.size()) return fail(DSVC_EINVAL, "tpack6: weight tensor has %zu elements, expected %zu", src.size(), (size_t)O * I * taps);
+    std::vector<int> rm(m_tiles * 32);
+    float amax = 0.f;
+    for (int r = 0; r < m_tiles * 32; ++r) {
+        rm[r] = rowmap(r);
+        if (rm[r] >= O) return fail(DSVC_EINVAL, "tpack6: row map out of range");
+        if (rm[r] < 0) continue;
+        const float rs = rowscale ? (*rowscale)[r] : 1.0f;
+        const float* wrow = src.data() + (size_t)rm[r] * I * taps;
+        for (int i = 0; i < I * taps; ++i) {
+            const float w = wrow[i] * scale * rs;                  // the same two roundings as the packing kernels
+            const float wl = fabsf(w - (float)(_Float16)w);
+            if (wl > amax) amax = wl;
+        }
+    }
+    // one power-of-two scale per conv: the largest |w_lo| lands inside the E2M3 grid (<= 7.5)
+    int e6 = -60;
+    if (amax > 0.f) { e6 = (int)ceilf(log2f(amax / 7.5f)); if (ldexpf(7.5f, e6) < amax) ++e6; }
+    if (e6 < -100 || e6 > 20) return fail(DSVC_EINVAL, "tpack6: w_lo scale 2^%d out of range", e6);
+    tp.e6 = e6; tp.n_variants = n_variants;
+    tp.variant_dwords = (size_t)m_tiles * taps * (cin_pad / 64) * (TFRAG6_BYTES / 4);
+    DevBuf dsrc, drm, drs;
+    DSVC_TRY(upload(dsrc, src.data(), src.size() * 4));
+    DSVC_TRY(upload(drm, rm.data(), rm.size() * 4));
+    if (rowscale) {
+        if ((int)rowscale->size() != m_tiles * 32) return fail(DSVC_EINVAL, "tpack6: row scale table has the wrong size");
+        DSVC_TRY(upload(drs, rowscale->data(), rowscale->size() * 4));
+    }
+    DSVC_TRY(tp.codes.alloc(tp.variant_dwords * n_variants * 4));
+    const long long total = (long long)m_tiles * taps * (cin_pad / 64) * 64 * n_variants;
+    const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    hipLaunchKernelGGL(k_tpack6, dim3(blocks), dim3(256), 0, 0, dsrc.as<float>(), drm.as<int>(), rowscale ? drs.as<float>() : nullptr,
+                       tp.codes.as<unsigned>(), I, taps, cin_pad, m_tiles, n_variants, scale, ldexpf(1.0f, -e6), salt);
+    DSVC_HIP(hipGetLastError());
+    DSVC_HIP(hipDeviceSynchronize());
+    return DSVC_OK;
+}
+
 // tiling choice of the tgemm path: 128-frame tiles x 8 waves when the batch fills the chip, otherwise 32-frame tiles
 // x 4 waves with the output-channel passes spread over blockIdx.y
 template <class Epi, int NW, int NA = 1>
@@ -190,6 +239,7 @@ struct dsvc_denoiser {
     int NA = 1;                       // activation planes of the two big contractions: 2 = split [hi | lo] rows (DSVC_PREC_F16_X3T)
     int Cp = 0, Mp = 0, guard = 8;
     TPacked in_t, skip_t, fin_t;
+    std::vector<TPacked6> dil6_t;     // DSVC_PREC_F16_W6: fp6 codes of the dilated convs' w_lo planes
     TPacked skipall_t;                // deferred skip path (tskip.h): W_sp W_out,l[C:2C] / sqrt(L) for all layers as one [C x L*C] operand
     DevBuf gall;                      // fp16 gate outputs of all layers [L][rows_alloc][Cp]: written by the fused layer kernels, read by tskip
     std::vector<TPacked> dil_t, out_t;
@@ -210,6 +260,7 @@ struct dsvc_denoiser {
                                  // Measured at 32 clips (profiles/r3e_*): layer kernel 132 -> 123 us and 14 % fewer HBM bytes, but the skip
                                  // halves' MFMAs, which hide under the layer's memory-bound output phase, then cost 342 us per step as their
                                  // own kernel: the step time is unchanged (+-1 %).  Built, parity-tested, not the default.
+    int dbg_w6_off = 0;          // 1: a DSVC_PREC_F16_W6 handle runs its fused layers with the fp16 lo plane (= f16_w2): the A/B partner of the 6-bit product
     int dbg_two_launch = 0;      // 1: run a residual layer as its two tgemm launches even where the fused kernel is the choice (bit-equality
                                  // test); -1: the fused kernel wherever it is SUPPORTED (>= 48 tiles), not only where it is faster (>= 120)
     int* step_err = nullptr;     // host-mapped sticky flag: a dsvc_denoiser_forward call saw a diffusion step outside [0, max_steps)
@@ -380,7 +431,8 @@ int dsvc_denoiser::finalize_t() {
     int max_dil = 1;
     for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     guard = round_up(max_dil, 8);
-    const int planes = (cfg.precision == DSVC_PREC_F16_W2 || cfg.precision == DSVC_PREC_F16_X3T) ? 2 : 1;
+    const bool w6 = cfg.precision == DSVC_PREC_F16_W6;
+    const int planes = (cfg.precision == DSVC_PREC_F16_W2 || cfg.precision == DSVC_PREC_F16_X3T || w6) ? 2 : 1;
     const int nvar = (planes == 1 && cfg.weight_variants > 1) ? cfg.weight_variants : 1;       // (F16 and F16_MIX)
 #define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
     {
@@ -394,6 +446,7 @@ int dsvc_denoiser::finalize_t() {
     // 1000-step chain robustly under the 1e-3 bar (profiles/r2w_precision_spread.txt)
     const bool out_w2 = cfg.precision == DSVC_PREC_F16_MIX;
     dil_t.resize(L); out_t.resize(L);
+    if (w6) dil6_t.resize(L);
     for (int l = 0; l < L; ++l) {
         const std::string q = "residual_layers." + std::to_string(l) + ".";
         GET(wd, q + "dilated_conv.weight", 2 * C * C * 3);
@@ -405,6 +458,10 @@ int dsvc_denoiser::finalize_t() {
         DSVC_TRY(tpack(dil_t[l], *wd, 2 * C, C, 3, C / 16, planes, nvar, 1.0f, 1000u + 2 * l, false,
                        [&](int r) { const int mt = r >> 5, i = r & 31; return (i >> 4) * C + mt * 16 + trow_to_ch8(i & 15); },
                        bo->data(), 1, &gsc));
+        // F16_W6: the same rows' w_lo plane once more as time-dithered fp6 codes for the fused layer kernel's 6-bit product (the fp16 lo plane
+        // above serves the two-launch tilings of smaller batches, which compute f16_w2)
+        if (w6) DSVC_TRY(tpack6(dil6_t[l], *wd, 2 * C, C, 3, C / 16, cfg.weight_variants > 1 ? cfg.weight_variants : 1, 1.0f, 2000u + l,
+                                [&](int r) { const int mt = r >> 5, i = r & 31; return (i >> 4) * C + mt * 16 + trow_to_ch8(i & 15); }, &gsc));
         // output 1x1: tiles 0..C/32-1 residual half (conv channels 0..C-1), then the skip half (C..2C-1)
         DSVC_TRY(tpack(out_t[l], *wo, 2 * C, C, 1, 2 * C / 32, out_w2 ? 2 : planes, out_w2 ? 1 : nvar, 1.0f, 1001u + 2 * l, false,
                        [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, bo->data(), 2 * C));
@@ -692,6 +749,17 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
 #else
     constexpr int pf = 0;
 #endif
+    if (cfg.precision == DSVC_PREC_F16_W6 && !defer && dbg_w6_off == 0) {
+        const TPacked6& t6 = dil6_t[l];
+        TLayerW6 w6{t6.codes.as<unsigned>(), (long long)t6.variant_dwords, t6.e6, t6.n_variants};
+        TGemmArgs ga6 = ga;
+        ga6.n_variants = 1;
+        if (host_step >= 0 && t6.n_variants > 1 && step.per_clip == 0) {      // variant known at launch: pass it by value
+            w6.codes += (size_t)(host_step % t6.n_variants) * t6.variant_dwords;
+            w6.n_variants = 1;
+        }
+        return tlayer_launch<2>(ga6, cp, oa, oe, C, rows_alloc, 0, st, nullptr, 0, &w6);
+    }
     if (dil_t[l].planes == 1 && out_t[l].planes == 2) return tlayer_launch<1, 2>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl, layer_prio);      // F16_MIX
     return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl, layer_prio) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl, layer_prio);
 }
@@ -807,8 +875,8 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
     // The captured segment is one period of the dither schedule (64 steps for f16_d64) replayed from a period-aligned step, so
     // every kernel node knows its weight variant at capture time and passes it by value: the alternative -- a scalar load of the
     // step in front of every kernel's weight stream -- costs ~0.4 us x 43 kernels per step in the single-clip regime.
-    const int nvar = (den->tpath && (den->cfg.precision == DSVC_PREC_F16 || den->cfg.precision == DSVC_PREC_F16_MIX) && den->cfg.weight_variants > 1)
-                         ? den->cfg.weight_variants : 1;
+    const int nvar = (den->tpath && (den->cfg.precision == DSVC_PREC_F16 || den->cfg.precision == DSVC_PREC_F16_MIX || den->cfg.precision == DSVC_PREC_F16_W6)
+                      && den->cfg.weight_variants > 1) ? den->cfg.weight_variants : 1;
     const int UNROLL = (nvar > 1 && nvar <= 64) ? nvar : 10;
     const bool aligned = UNROLL == nvar && nvar > 1;
     if (a->use_graph && n >= 2 * UNROLL) {
@@ -923,7 +991,7 @@ int dsvc_abi_version(void) { return DSVC_ABI_VERSION; }
 
 int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out) {
     if (!cfg || !out) return fail(DSVC_EINVAL, "null argument");
-    if (cfg->precision < DSVC_PREC_F16 || cfg->precision > DSVC_PREC_F16_X3T) return fail(DSVC_EINVAL, "unknown precision %d", cfg->precision);
+    if (cfg->precision < DSVC_PREC_F16 || cfg->precision > DSVC_PREC_F16_W6) return fail(DSVC_EINVAL, "unknown precision %d", cfg->precision);
     int ndev = 0;
     DSVC_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(DSVC_EHIP, "no HIP device visible");
@@ -1059,6 +1127,7 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     const std::string k(key);
     if (k == "stop_after_layers") d->dbg_stop_after = value;
     else if (k == "two_launch_layer") d->dbg_two_launch = value > 0 ? 1 : (value < 0 ? -1 : 0);
+    else if (k == "w6_off") d->dbg_w6_off = value ? 1 : 0;
     else if (k == "layer_prio") d->layer_prio = value;
     else if (k == "defer_skip") {
         d->defer_skip = value != 0;

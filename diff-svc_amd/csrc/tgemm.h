@@ -582,6 +582,88 @@ __global__ void k_tpack(const float* __restrict__ src, const int* __restrict__ r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4 (DSVC_PREC_F16_W6): the w_lo plane as 6-bit floats for v_mfma_scale_f32_32x32x64_f8f6f4.
+//   The correction term w_lo * x of the exact-weight scheme (w = fp16(w) + w_lo, |w_lo| <= ulp/2) needs ~4 significant bits, not 11: it is
+//   2^-12 of the product.  One K = 64 block-scaled MFMA on fp6 (E2M3) weights x bf6 (E3M2) activations replaces four fp16 MFMAs at a quarter
+//   of their issue time (tools/micro/mx_probe.hip: 20 ns against 4 x 21 ns per SIMD).  Layout [variant][m_tile][tap][k64 group][1536 B]:
+//   a fragment is [lane 64][16 B] followed by [lane 64][8 B] -- the 24 bytes (32 codes, little-endian bit stream) of lane l = (row l & 31,
+//   half h = l >> 5) split so that both loads of a wave are contiguous.  Code m = 8 kk + e of the lane is input channel
+//   64 q + 16 kk + 8 h + e: exactly the element order of the lane's four fp16 activation fragments kk = 0..3, which the kernel converts with
+//   ONE v_cvt_scalef32_pk32_bf6_f16.  All codes of a layer share the power-of-two scale 2^e6 (w_lo is uniform in +-ulp/2, not heavy-tailed:
+//   per-block scales measured 2.9 % against 4.6 % relative rms error of w_lo, i.e. 6e-6 against 9.5e-6 of w -- plain fp16 rounding is 2.1e-4),
+//   and the rounding to the fp6 grid is time-dithered like k_tpack's (towards / away from zero by a stratified per-element threshold; the
+//   n variants average to w_lo to 1/n of a grid step), so what is left of the systematic weight error is below the fp16 activation rounding
+//   by two orders of magnitude (tests/studies/precision_study.py: w6f64).
+// ---------------------------------------------------------------------------------------------
+constexpr int TFRAG6_BYTES = 1536;
+
+// magnitude grid of E2M3: index i (= the code without its sign bit) -> value
+__host__ __device__ inline float tg_e2m3_value(int i) {
+    const int e = i >> 3, m = i & 7;
+    return e == 0 ? (float)m * 0.125f : (float)(8 + m) * 0.125f * (float)(1 << (e - 1));
+}
+
+// largest grid index whose value is <= a (0 <= a; saturates at 31 = 7.5)
+__host__ __device__ inline int tg_e2m3_floor(float a) {
+    if (a >= 7.5f) return 31;
+    if (a < 2.0f) return (int)(a * 8.0f);                 // subnormals and [1, 2): step 1/8, indices 0 .. 15
+    if (a < 4.0f) return 16 + (int)((a - 2.0f) * 4.0f);
+    return 24 + (int)((a - 4.0f) * 2.0f);
+}
+
+__global__ void k_tpack6(const float* __restrict__ src, const int* __restrict__ rowmap, const float* __restrict__ rowscale,
+                         unsigned* __restrict__ dst, int I, int taps, int cin_pad, int m_tiles, int n_variants, float scale, float inv6,
+                         unsigned salt) {
+    const int nq = cin_pad >> 6;
+    const long long per_variant = (long long)m_tiles * taps * nq * 64;         // lanes of one variant
+    const long long total = per_variant * n_variants;
+    int bits = 0;
+    while ((1 << bits) < n_variants) ++bits;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(idx / per_variant);
+        long long r = idx - (long long)v * per_variant;
+        const int l = (int)(r & 63);
+        r >>= 6;
+        const int q = (int)(r % nq); r /= nq;
+        const int tap = (int)(r % taps);
+        const int mt = (int)(r / taps);
+        const int row = mt * 32 + (l & 31), h = l >> 5;
+        const int o = rowmap[row];
+        int vr = 0;
+        for (int b = 0; b < bits; ++b) vr |= ((v >> b) & 1) << (bits - 1 - b);
+        if (vr >= n_variants) vr = v;
+        unsigned long long acc = 0;
+        int nbits = 0, word = 0;
+        unsigned out[6];
+        for (int m = 0; m < 32; ++m) {
+            const int ci = 64 * q + 16 * (m >> 3) + 8 * h + (m & 7);
+            const float w = (o >= 0 && ci < I) ? src[((size_t)o * I + ci) * taps + tap] * scale * (rowscale ? rowscale[row] : 1.0f) : 0.f;
+            const float wl = w - (float)(_Float16)w;
+            const float u = wl * inv6, a = fabsf(u);
+            int i0 = tg_e2m3_floor(a);
+            if (i0 < 31) {
+                const float lo = tg_e2m3_value(i0), hi = tg_e2m3_value(i0 + 1);
+                const float frac = (a - lo) / (hi - lo);
+                float th = 0.5f;
+                if (n_variants > 1) {
+                    const uint32_t hh = tg_hash32(((uint32_t)row * 0x9E3779B1u) ^ ((uint32_t)(tap * cin_pad + ci) * 0x85EBCA77u) ^ salt);
+                    th = ((float)vr + 0.5f) / (float)n_variants + (float)(hh >> 8) * (1.0f / 16777216.0f);
+                    if (th >= 1.0f) th -= 1.0f;
+                }
+                if (frac > th) ++i0;
+            }
+            const unsigned code = (unsigned)i0 | (u < 0.f ? 32u : 0u);
+            acc |= (unsigned long long)code << nbits;
+            nbits += 6;
+            if (nbits >= 32) { out[word++] = (unsigned)acc; acc >>= 32; nbits -= 32; }
+        }
+        unsigned* f = dst + ((size_t)v * per_variant / 64 + ((size_t)mt * taps + tap) * nq + q) * (TFRAG6_BYTES / 4);
+        f[l * 4 + 0] = out[0]; f[l * 4 + 1] = out[1]; f[l * 4 + 2] = out[2]; f[l * 4 + 3] = out[3];
+        f[256 + l * 2 + 0] = out[4]; f[256 + l * 2 + 1] = out[5];
+    }
+}
+
 inline size_t tpacked_halfs(int m_tiles, int taps, int cin_pad, int planes, int n_variants) {
     return (size_t)n_variants * m_tiles * taps * (cin_pad / 16) * planes * TFRAG_HALFS;
 }

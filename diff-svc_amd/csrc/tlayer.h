@@ -39,6 +39,11 @@ struct TLayerArgs {
     int n_variants;             // > 1: variant = (*step_ptr - step_off) mod n_variants is resolved in the kernel; the sampler passes
     const int* step_ptr;        //      the variant by value (gw / ow already offset, n_variants = 1)
     int step_off;
+    // W6 (DSVC_PREC_F16_W6): the gate's w_lo plane as fp6 codes (tgemm.h: k_tpack6), one 1536-B fragment per (m_tile, tap, 64 input channels);
+    // gw then holds hi | lo fp16 planes of which only the hi fragments are streamed
+    const unsigned* gw6;
+    long long g6var;            // dwords between dither variants of gw6
+    int sc6;                    // E8M0 scale bytes of the 6-bit product: weights (2^e6) | activations (xscale) << 8
 #ifdef DSVC_PROFILING
     unsigned long long* stamps; // profiling build: 16 s_memrealtime stamps per wave of the LAST launch (tools/gpu_layer_stamps.py)
 #endif
@@ -101,6 +106,68 @@ __device__ __forceinline__ void tl_load_group(half8 (&ring)[KG * NW], const _Flo
     for (int u = 0; u < KG * NW; ++u) ring[u] = *reinterpret_cast<const half8*>(p + u * TFRAG_HALFS);
 }
 
+typedef int v6i_t __attribute__((ext_vector_type(6)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half16_t __attribute__((ext_vector_type(16)));
+typedef _Float16 half32_t __attribute__((ext_vector_type(32)));
+constexpr float TL_X6_SCALE = 4.0f;        // activations of the 6-bit product are converted as bf6(x / 4): saturation at |x| = 112, rel. rms error 5.7 %
+constexpr int TL_X6_E8M0 = 129;            // 2^2
+
+// W6: one group = 64 input channels of one tap against 4 N-tiles, N-tile by N-tile: four fp16 MFMAs on the hi fragments, then the lane's four
+// B fragments (k = 16 kk + 8 h + e: exactly the order k_tpack6 packs the weight codes in) are converted to bf6 by ONE instruction and one
+// K = 64 block-scaled MFMA adds w_lo * x.  The next N-tile's four fragments are read while the current one computes.
+__device__ __forceinline__ void tl_compute_group_w6(const half8 (&hi)[4], const v6i_t& lo, f32x16 (&acc)[4], unsigned base0, unsigned nt_stride,
+                                                    unsigned xs, int sc_w) {
+    typedef const half8 __attribute__((address_space(3))) * lds_frag_ptr;
+    unsigned base[4];
+    base[0] = base0;
+#pragma unroll
+    for (int nt = 1; nt < 4; ++nt) base[nt] = base[nt - 1] + nt_stride;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(base[nt]));
+    const v8i_t a6 = __builtin_shufflevector(lo, lo, 0, 1, 2, 3, 4, 5, -1, -1);
+    half8 b[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) b[0][kk] = *(lds_frag_ptr)(size_t)(base[0] + (((unsigned)kk << 5) ^ xs));
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        if (nt + 1 < 4) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) b[(nt + 1) & 1][kk] = *(lds_frag_ptr)(size_t)(base[nt + 1] + (((unsigned)kk << 5) ^ xs));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi[kk], b[nt & 1][kk], acc[nt], 0, 0, 0);
+        const half16_t v01 = __builtin_shufflevector(b[nt & 1][0], b[nt & 1][1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        const half16_t v23 = __builtin_shufflevector(b[nt & 1][2], b[nt & 1][3], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        const half32_t v = __builtin_shufflevector(v01, v23, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25,
+                                                   26, 27, 28, 29, 30, 31);
+        const v6i_t q = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(v, TL_X6_SCALE);
+        const v8i_t b6 = __builtin_shufflevector(q, q, 0, 1, 2, 3, 4, 5, -1, -1);
+        acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a6, b6, acc[nt], 2 /* A: fp6 E2M3 */, 3 /* B: bf6 E3M2 */, 0, sc_w, 0, TL_X6_E8M0);
+    }
+    // pin the software pipeline (left alone, the scheduler re-uses one fragment tuple for two N-tiles and waits lgkmcnt(0) behind every read):
+    // N-tile 0's four reads, then one read of N-tile nt+1 behind each fp16 MFMA of N-tile nt, the conversion, the 6-bit MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (nt + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+}
+
+// hi fragments of one W6 group (the hi | lo fp16 planes are interleaved per k16 step: every second KiB) + its fp6 fragment
+__device__ __forceinline__ void tl_load_group_w6(half8 (&hi)[8], v6i_t& lo, const _Float16* p, const unsigned* p6, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) hi[kk] = *reinterpret_cast<const half8*>(p + (2 * kk) * TFRAG_HALFS + lane * 8);
+    const int4 a = *reinterpret_cast<const int4*>(p6 + lane * 4);
+    const int2 c = *reinterpret_cast<const int2*>(p6 + 256 + lane * 2);
+    lo = v6i_t{a.x, a.y, a.z, a.w, c.x, c.y};
+}
+
 // NB = C / 128 = gate passes = output passes (8 waves x 16 g-channels, 8 waves x 32 output rows of 2C): 2 (C = 256) or 3 (C = 384).
 // PF: prefetch the output projection's first accumulator init (residual stream) already under the LAST gate pass's main loop
 // (64 more live VGPRs there) instead of right after it.
@@ -111,11 +178,12 @@ __device__ __forceinline__ void tl_load_group(half8 (&ring)[KG * NW], const _Flo
 // written to HBM as well (fp16, 768 B per frame) and ONE K = L*C contraction per evaluation (tskip.h) produces relu(skip_projection(sum of
 // the skips) / sqrt(L)) from all layers' g with pre-composed weights.  The layer then moves 8.5 KB per frame instead of 10.8 (no fp32 skip
 // read-modify-write), and on a part whose matrix and HBM phases do not overlap (profiles/r3c_overlap.txt) bytes are time.
-template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0, int PRIOV = 0>
+template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0, int PRIOV = 0, int W6 = 0>
 __global__ void __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
 tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiResSkip::Args oe) {
     constexpr int KG2 = KG * NW / NW2;
     static_assert(KG2 * NW2 == KG * NW && KG2 >= 1, "both phases use the same eight ring registers");
+    static_assert(!W6 || (KG == 4 && NW == 2 && NW2 == 2 && !DEFER), "W6: hi | lo fp16 planes packed, 64 input channels per group");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -157,6 +225,8 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     // wave-uniform weight bases (SGPRs); the lane's 16-byte slot inside a fragment is added where a ring is loaded
     const _Float16* gw = ga.gw + (long long)variant * ga.gvar;
     const _Float16* ow = ga.ow + (long long)variant * ga.ovar;
+    const unsigned* gw6 = W6 ? ga.gw6 + (long long)variant * ga.g6var : nullptr;
+    const int sc_w6 = ga.sc6 & 255;
     const int lane8 = lane * 8;
     const int gpt = (ga.cin >> 4) / KG;                   // gate: groups per tap
     const int G1 = 3 * gpt;                               // gate: groups per output tile
@@ -179,10 +249,28 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const TEpiGate::Args ge{cproj, nullptr, ga.cin, ga.cin};
     f32x16 acc[4], nxt[4];
     half8 ringA[KG * NW], ringB[KG * NW];
+    v6i_t lo6A, lo6B;                                     // W6: the fp6 fragment of the group in ringA / ringB (whose first four entries hold its hi fragments)
     half8 gmid[4];                                        // the middle gate pass's g block share (NB == 3)
 
+    // gate-phase operand stream and group product in their two forms (fp16 planes | W6: hi fragments + fp6 codes)
+    auto gload = [&](half8 (&ring)[KG * NW], v6i_t& lo6, int mt_, int g_) {
+        if constexpr (W6) tl_load_group_w6(ring, lo6, gw + (long long)mt_ * tile1 + (long long)g_ * GROUP_HALFS, gw6 + ((size_t)mt_ * G1 + g_) * (TFRAG6_BYTES / 4), lane);
+        else tl_load_group<KG, NW>(ring, gw + (long long)mt_ * tile1 + (long long)g_ * GROUP_HALFS + lane8);
+    };
+    const unsigned nt_stride_x0 = 32u * (unsigned)row_bytes;
+    auto gcompute = [&](const half8 (&ring)[KG * NW], const v6i_t& lo6, int g_) {
+        const int tap = g_ / gpt, kb = (g_ - tap * gpt) * KG;
+        const int rr = halo + (tap - 1) * ga.dil + (lane & 31);
+        const unsigned b0 = lds0 + (unsigned)rr * (unsigned)row_bytes, xs = (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5);
+        if constexpr (W6) {
+            const half8 (&hi)[4] = reinterpret_cast<const half8 (&)[4]>(ring);
+            tl_compute_group_w6(hi, lo6, acc, b0, nt_stride_x0, xs, sc_w6);
+        } else {
+            tl_compute_group<KG, NW>(ring, acc, b0, nt_stride_x0, xs);
+        }
+    };
     // first operands in flight before the barrier
-    tl_load_group<KG, NW>(ringA, gw + (long long)tile_of(0) * tile1 + lane8);
+    gload(ringA, lo6A, tile_of(0), 0);
     gepi.init(ge, tile_of(0), row0, lane, acc);
     TL_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -190,12 +278,10 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     __syncthreads();
     TL_STAMP(3);
 
-    const unsigned nt_stride_x = 32u * (unsigned)row_bytes;
     // =========================== phase 1: gate passes ===========================
 #pragma unroll
     for (int pi = 0; pi < NB; ++pi) {
         const int mt = tile_of(pi);
-        const _Float16* wp = gw + (long long)mt * tile1;
         const bool last = pi == NB - 1;
         const int mt_n = last ? (DEFER ? wave : tile_of(0)) : tile_of(pi + 1);          // last gate pass: the next "tile" is output pass 0
         bool nxt_issued = false;
@@ -207,34 +293,19 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
         prio_pass(pi + 1);
         for (; g + 1 < G1; g += 2) {
             prio_group(g >> 1);
-            tl_load_group<KG, NW>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
+            gload(ringB, lo6B, mt, g + 1);
             if (g == g_issue && (!last || PF)) { issue_next_init(); nxt_issued = true; }
             __builtin_amdgcn_sched_barrier(0);
-            {
-                const int tap = g / gpt, kb = (g - tap * gpt) * KG;
-                const int rr = halo + (tap - 1) * ga.dil + (lane & 31);
-                tl_compute_group<KG, NW>(ringA, acc, lds0 + (unsigned)rr * (unsigned)row_bytes, nt_stride_x,
-                                         (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5));
-            }
+            gcompute(ringA, lo6A, g);
             const int gn = g + 2 < G1 ? g + 2 : G1 - 1;
-            tl_load_group<KG, NW>(ringA, wp + (long long)gn * GROUP_HALFS + lane8);
+            gload(ringA, lo6A, mt, gn);
             __builtin_amdgcn_sched_barrier(0);
-            {
-                const int g1 = g + 1, tap = g1 / gpt, kb = (g1 - tap * gpt) * KG;
-                const int rr = halo + (tap - 1) * ga.dil + (lane & 31);
-                tl_compute_group<KG, NW>(ringB, acc, lds0 + (unsigned)rr * (unsigned)row_bytes, nt_stride_x,
-                                         (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5));
-            }
+            gcompute(ringB, lo6B, g + 1);
         }
-        if (g < G1) {
-            const int tap = g / gpt, kb = (g - tap * gpt) * KG;
-            const int rr = halo + (tap - 1) * ga.dil + (lane & 31);
-            tl_compute_group<KG, NW>(ringA, acc, lds0 + (unsigned)rr * (unsigned)row_bytes, nt_stride_x,
-                                     (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5));
-        }
+        if (g < G1) gcompute(ringA, lo6A, g);
         TL_STAMP(4 + pi);                                  // (4, 5, 6: end of a gate pass's main loop)
         // the next tile's weight stream starts before this tile's epilogue
-        if (!last) tl_load_group<KG, NW>(ringA, gw + (long long)mt_n * tile1 + lane8);
+        if (!last) gload(ringA, lo6A, mt_n, 0);
         else tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
         if (!nxt_issued && (!last || PF)) issue_next_init();
         // ---- gate epilogue: g = sigmoid * tanh -> fp16 (TEpiGate::finish, kept on chip) ----
@@ -385,9 +456,9 @@ inline bool tlayer_supported(int C, int cin_pad, int dil, int n_rows) {
     return C == cin_pad && (C == 256 || C == 384) && n_rows % TL_TN == 0 && tlayer_smem(dil, cin_pad) <= 160 * 1024;
 }
 
-template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0, int PRIOV = 0>
+template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0, int PRIOV = 0, int W6 = 0>
 inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiResSkip::Args& oe, int n_rows, hipStream_t stream) {
-    auto kern = tlayer_kernel<NB, KG, NW, PF, NW2, DEFER, PRIOV>;
+    auto kern = tlayer_kernel<NB, KG, NW, PF, NW2, DEFER, PRIOV, W6>;
     const size_t smem = tlayer_smem(ga.dil, ga.cin);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {
@@ -400,9 +471,17 @@ inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiR
 }
 
 // gate weights `g` (taps 3, m_tiles C/16) + output-projection weights `o` (taps 1, m_tiles 2C/32) of ONE layer, as tgemm would get them
+// w6 (DSVC_PREC_F16_W6): fp6 codes of the gate's w_lo plane (k_tpack6) for the block-scaled 6-bit product; e6 = their common exponent
+struct TLayerW6 {
+    const unsigned* codes = nullptr;     // the variant to use (already offset when the caller knows the step), or variant 0 with n_variants > 1
+    long long variant_dwords = 0;
+    int e6 = 0;
+    int n_variants = 1;                  // > 1: resolved in the kernel from *step_ptr
+};
+
 template <int NW, int NW2 = NW>
 inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs& o, const TEpiResSkip::Args& oe, int C, int n_rows,
-                         int prefetch, hipStream_t stream, _Float16* gall = nullptr, int priov = 0) {
+                         int prefetch, hipStream_t stream, _Float16* gall = nullptr, int priov = 0, const TLayerW6* w6 = nullptr) {
     constexpr int KG = NW == 2 ? 4 : 8;
     if (g.taps != 3 || o.taps != 1 || g.m_tiles != C / 16 || o.m_tiles != 2 * C / 32 || g.cin != C || o.cin != C)
         return fail(DSVC_EINVAL, "tlayer: unexpected layer geometry");
@@ -420,6 +499,16 @@ inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs
         if (n_rows / TL_TN <= 4096) { a.stamps = tl_stamp_buffer(); tl_stamp_groups() = n_rows / TL_TN; }
     }
 #endif
+    if constexpr (NW == 2 && NW2 == 2) {
+        if (w6 && w6->codes) {                            // hi fragments of g's two planes + fp6 codes: 16 fp16 + 4 six-bit MFMAs per group instead of 32
+            a.gw6 = w6->codes; a.g6var = w6->variant_dwords; a.sc6 = (127 + w6->e6) | (TL_X6_E8M0 << 8);
+            a.n_variants = w6->n_variants;
+            a.gvar = 0; a.ovar = 0;                       // (the dither variants are those of the fp6 plane; n_variants / step_ptr select among them)
+            if (gall) return fail(DSVC_EINVAL, "tlayer: the deferred skip form is not built for f16_w6");
+            if (C == 384) return tlayer_launch_t<3, KG, NW, 0, NW2, 0, 0, 1>(a, cproj, oe, n_rows, stream);
+            return tlayer_launch_t<2, KG, NW, 0, NW2, 0, 0, 1>(a, cproj, oe, n_rows, stream);
+        }
+    }
     if (gall) {                                           // skip-deferred form: g also goes to HBM, residual half of the 1x1 only
         a.gall = gall;
         if (C == 384) return tlayer_launch_t<3, KG, NW, 0, NW2, 1>(a, cproj, oe, n_rows, stream);

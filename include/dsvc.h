@@ -40,8 +40,13 @@ enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM
  *   F16_X3 : w = w_hi + w_lo, x = x_hi + x_lo          3 MFMAs              (fp32-class, ~1e-5) on the conv_gemm engine
  *   F16_X3T: the same operand scheme on the tgemm engine (activation rows hold [x_hi | x_lo] planes; the weight stream is F16_W2's):
  *            the fp32-class scheme at the speed class of the small-batch tgemm kernels (3.3e-5 ... 4.9e-5 mel after 1000 steps on 21
- *            goldens, +14 ... 20 % over F16_W2 up to six 10 s clips, 1.5 ... 1.9x beyond).  "auto": DDPM calls under 6000 frames, PLMS, forward(). */
-enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2, DSVC_PREC_F16_MIX = 3, DSVC_PREC_F16_X3T = 4 };
+ *            goldens, +14 ... 20 % over F16_W2 up to six 10 s clips, 1.5 ... 1.9x beyond).  "auto": DDPM calls under 6000 frames, PLMS, forward().
+ *   F16_W6 : F16_W2 whose w_lo * x correction of the dilated conv runs on the block-scaled 6-bit matrix instruction in the fused layer kernel
+ *            (round 4): w_lo as time-dithered fp6 (E2M3) codes (weight_variants roundings, one power-of-two scale per conv), x converted to
+ *            bf6 (E3M2) in registers -- 16 fp16 + 4 six-bit MFMAs per 64 input channels instead of 32 fp16 ones.  The correction is 2^-12 of
+ *            the product, so 4 significant bits carry it: the error class is F16_W2's (fp16 activation rounding).  Batches too small for the
+ *            fused layer kernel run F16_W2 itself (the handle keeps the fp16 lo plane as well). */
+enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2, DSVC_PREC_F16_MIX = 3, DSVC_PREC_F16_X3T = 4, DSVC_PREC_F16_W6 = 5 };
 
 int dsvc_abi_version(void);
 const char* dsvc_last_error(void);
@@ -66,7 +71,7 @@ typedef struct {
     int32_t dilation_cycle;  /* dilation_cycle_length                             (net.py:94)  */
     int32_t max_steps;       /* number of integer diffusion steps to tabulate (timesteps)      */
     int32_t precision;       /* DSVC_PREC_* for the two big per-layer contractions              */
-    int32_t weight_variants; /* DSVC_PREC_F16 / F16_MIX: number of dithered weight roundings (<= 1: nearest) */
+    int32_t weight_variants; /* DSVC_PREC_F16 / F16_MIX / F16_W6: number of dithered weight roundings (<= 1: nearest) */
 } dsvc_denoiser_cfg;
 
 int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out);

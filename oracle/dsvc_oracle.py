@@ -171,7 +171,7 @@ def step_embedding(sd, t, prefix="denoise_fn."):
     scale = math.log(10000) / (half - 1)
     freqs = torch.exp(torch.arange(half) * -scale)
     ang = t[:, None] * freqs[None, :]
-    emb = torch.cat((ang.sin(), ang.cos()), dim=-1)
+    emb = torch.cat((ang.sin(), ang.cos()), dim=-1).to(sd[prefix + "mlp.0.weight"].dtype)      # (a float64 state dict evaluates the net in fp64)
     h = F.linear(emb, sd[prefix + "mlp.0.weight"], sd[prefix + "mlp.0.bias"])
     return F.linear(mish(h), sd[prefix + "mlp.2.weight"], sd[prefix + "mlp.2.bias"])
 

@@ -320,6 +320,36 @@ def golden_train(cases=TRAIN_CASES, fname="train_grads"):
     np.savez_compressed(os.path.join(OUT, fname + ".npz"), **out)
 
 
+def golden_train_bench_f64():
+    """The benchmarked training batch once more in FLOAT64 (the oracle's restatement, which tests/test_oracle_golden.py pins to the real
+    reference at 2e-5, evaluated with a float64 state dict): the yardstick for the fp32 rounding of the reference ITSELF.  At 8 192 frames the
+    conditioner-projection weight gradients are sums with heavy cancellation -- the real reference's fp32 autograd sits 2.2e-4 ... 2.7e-4 from
+    this evaluation on those 20 tensors (asserted below), so a comparison with the fp32 golden alone cannot ask for 5e-5 there;
+    tests/test_gpu_train.py holds the HIP step to the fp64 values instead.  Same lattice as train_grads_bench.npz."""
+    (name, arch, loss_type, clips, T, n_units, seed), = TRAIN_CASES_BENCH
+    hp = dict(synth.HPARAMS_44K, diff_loss_type=loss_type)
+    sd = synth.acoustic_state(hp, 3)
+    hub, m2p, f0, mels, t = (torch.from_numpy(v) for v in synth.train_batch_kat(hp, clips, T, n_units, seed))
+    noise = O.ddpm_noise_ref_layout(seed, list(clips), 0, T, hp["audio_num_mel_bins"], O.PURPOSE_TRAIN_NOISE)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    loss, grads = O.train_loss_and_grads(sd64, hub.double(), m2p, f0.double(), mels.double(), t, noise.double(), hp)
+    g32 = np.load(os.path.join(OUT, "train_grads_bench.npz"))
+    out = {name + "/loss": np.float64(loss.item())}
+    worst = {}
+    for k in (str(n) for n in g32[name + "/names"]):
+        part = grads[k][synth.train_grad_slices(tuple(grads[k].shape))]
+        out[name + "/grad/" + k] = part.numpy().copy()
+        ref = torch.from_numpy(g32[name + "/grad/" + k]).double()
+        if part.norm().item() > 0:
+            kind = k.split(".")[-2] if "residual_layers" in k else k
+            worst[kind] = max(worst.get(kind, 0.0), (part - ref).norm().item() / part.norm().item())
+    print("train f64: loss %.9f (fp32 reference %.9f); the fp32 reference's relative L2 distance from the fp64 values, worst per tensor kind:" % (loss.item(), float(g32[name + "/loss"])))
+    for kind, e in sorted(worst.items(), key=lambda kv: -kv[1]):
+        print("   %-40s %.2e" % (kind, e))
+    assert 1e-4 < worst["conditioner_projection"] < 5e-4
+    np.savez_compressed(os.path.join(OUT, "train_grads_bench_f64.npz"), **out)
+
+
 def golden_melspec(name, sr, n_fft, win, hop, n_mels, fmin, fmax, n_samples):
     """STFT.get_mel of the REAL reference (nvSTFT.py:72-104).  Two shims are unavoidable on this image:
     librosa's mel filterbank is replaced by the oracle's restatement (librosa is not installed), and
@@ -388,7 +418,10 @@ def main():
     if "--train-only" in sys.argv:
         return golden_train()
     if "--train-bench" in sys.argv:
-        return golden_train(TRAIN_CASES_BENCH, "train_grads_bench")
+        golden_train(TRAIN_CASES_BENCH, "train_grads_bench")
+        return golden_train_bench_f64()
+    if "--train-bench-f64" in sys.argv:
+        return golden_train_bench_f64()
     if "--plms-only" in sys.argv:
         return golden_plms_conditioned()
     if "--hifigan-only" in sys.argv:
@@ -420,6 +453,7 @@ def main():
     golden_headline_spread()
     golden_train()
     golden_train(TRAIN_CASES_BENCH, "train_grads_bench")
+    golden_train_bench_f64()
     golden_slicer()
     golden_slicer_demo_input()
     golden_schedule()

@@ -143,12 +143,19 @@ class Net:
             q = lambda s: p("residual_layers.%d.%s" % (l, s))
             d = 2 ** (l % self.cyc)
             film = F.linear(emb, q("diffusion_projection.weight"), q("diffusion_projection.bias"))[:, :, None]
-            xin = act(x + film)
+            which = os.environ.get("STUDY_ACT", "xg")          # which of the two big contractions see fp16-rounded activations
+            act_x = act if "x" in which else (lambda v: v)
+            act_g = act if "g" in which else (lambda v: v)
+            if "G6" in which:                                   # g = fp16(g) + bf6((g - fp16(g)) * 2^11) * 2^-11: the output 1x1 with a 6-bit g_lo correction
+                act_g = lambda v: r16(v) + x6((v - r16(v)) * 2048.0, E3M2, 1.0 / 16) / 2048.0
+            if "X6" in which:
+                act_x = lambda v: r16(v) + x6((v - r16(v)) * 2048.0, E3M2, 1.0) / 2048.0
+            xin = act_x(x + film)
             y = F.conv1d(xin, self.wd[l][k % len(self.wd[l])], q("dilated_conv.bias"), padding=d, dilation=d) + cproj[l]
             if self.lo6 is not None:
                 y = y + F.conv1d(x6(xin, self.xgrid, self.xscale), self.lo6[l][k], None, padding=d, dilation=d)
             z = torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
-            o = F.conv1d(act(z), self.wo[l][k % len(self.wo[l])], q("output_projection.bias"))
+            o = F.conv1d(act_g(z), self.wo[l][k % len(self.wo[l])], q("output_projection.bias"))
             x = (x + o[:, :C]) / math.sqrt(2.0)
             skip = skip + o[:, C:]
         s = F.relu(F.conv1d(a_skip(skip), p("skip_projection.weight") / math.sqrt(self.L), p("skip_projection.bias")))   # fp16(skip), 1/sqrt(L) in the weights
@@ -170,7 +177,7 @@ def main():
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     schemes = sys.argv[3:] or ["f32", "f16", "w2", "dither2", "dither4", "dither8", "dither16"]
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("STUDY_THREADS", "8")))
     hp = dict(synth.HPARAMS_44K)
     sd = synth.acoustic_state(hp, 0)
     clips, seed = [0], 2024

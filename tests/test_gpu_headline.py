@@ -15,7 +15,7 @@ import torch
 
 from diffsvc_amd import synth
 import dsvc_oracle as O
-from util import clip_batch, golden_state, load_golden, oracle_sample
+from util import GOLD, clip_batch, golden_state, load_golden, oracle_sample
 
 pytestmark = pytest.mark.gpu
 
@@ -338,45 +338,67 @@ def test_spread_of_single_clip_chains_vs_reference(which):
         assert worst < MEL_BAR, errs
 
 
-@pytest.mark.parametrize("which", ["shipped", "f16_m64", "f16_w2", "f16_x3t"])
-@pytest.mark.parametrize("ckpt", ["random", "ca", "cb"])
+def gumbel_fit(maxima):
+    """Method-of-moments Gumbel fit of per-clip maximum errors: (mu, beta, P(one clip > 1e-3), P(a 256-clip job holds a clip > 1e-3))."""
+    import math
+    v = np.asarray(maxima, dtype=np.float64)
+    beta = v.std(ddof=1) * math.sqrt(6.0) / math.pi
+    mu = v.mean() - 0.5772156649 * beta
+    p1 = 1.0 - math.exp(-math.exp(-(MEL_BAR - mu) / beta))
+    return mu, beta, p1, 1.0 - (1.0 - p1) ** 256
+
+
+@pytest.mark.parametrize("which", ["shipped", "f16_m64", "f16_w2", "f16_w6", "f16_x3t"])
+@pytest.mark.parametrize("ckpt", ["random", "random2", "ca", "cb"])
 def test_batch_of_32_full_chain_every_clip_with_a_golden(ckpt, which):
     """The per-GPU share of BASELINE configs[3] -- what bench.py's `batched.value` times: 32 clips x T=861 in ONE batch (28 672 rows,
-    the fused layer kernel tlayer_kernel<3, .>), 1000 steps, at the shipped precision.  Clips 0..31 with seed 2026: EVERY clip of
-    the batch that has a real-reference golden is checked (12 on the random-init checkpoint, 2 + 4 on the two conditioned ones).  The
-    other operand schemes are measured beside the shipped one."""
+    the fused layer kernel tlayer_kernel<3, .>), 1000 steps, at the shipped precision, seed 2026.  Round 4: EVERY clip of TWO shares has a
+    real-reference golden -- "random" = clips 0..31 (rank 0's share of the 256-clip job), "random2" = clips 32..63 (rank 1's) on the random-init
+    checkpoint, 32 of 32 checked each -- plus 2 + 4 clips on the two conditioned checkpoints.  The shipped precision must stay <= 9.0e-4 on all of
+    them; the Gumbel fit of the per-clip maxima (the numbers bench.py's `batched.p_over_bar_per_256_clips` quotes) is printed.  The other operand
+    schemes are measured beside the shipped one."""
     precision = _shipped(batched=True) if which == "shipped" else which
     if which != "shipped" and precision == _shipped(batched=True):
         pytest.skip("is the shipped precision")
     from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
-    from make_golden import SPREAD_CLIPS, SPREAD_COND, SPREAD_SEED
+    from make_golden import SPREAD_COND, SPREAD_SEED, share_golden
     hp = dict(synth.HPARAMS_44K)
-    cond_par = None if ckpt == "random" else dict((t, c) for t, c, _ in SPREAD_COND)[ckpt]
-    have = {0: ("e2e_44k_T861_k1000", 0), 1: ("e2e_44k_T861_k1000", 1)} if ckpt == "random" else {}
-    if ckpt == "random":
-        have.update({c: ("e2e_44k_T861_k1000_s2026_c%d" % c, 0) for c in SPREAD_CLIPS})
+    random_init = ckpt.startswith("random")
+    first = 32 if ckpt == "random2" else 0
+    cond_par = None if random_init else dict((t, c) for t, c, _ in SPREAD_COND)[ckpt]
+    if random_init:
+        have = {c: share_golden(c) for c in range(first, first + 32)}
+        if os.environ.get("DSVC_PARTIAL_GOLDENS") == "1":   # (while oracle/make_golden.py --headline-spread is still minting: check what exists)
+            have = {c: v for c, v in have.items() if os.path.exists(os.path.join(GOLD, v[0] + ".npz"))}
     else:
-        have.update({c: ("e2e_44k_T861_k1000_%s_c%d" % (ckpt, c), 0) for c in dict((t, cl) for t, _, cl in SPREAD_COND)[ckpt]})
+        have = {c: ("e2e_44k_T861_k1000_%s_c%d" % (ckpt, c), 0) for c in dict((t, cl) for t, _, cl in SPREAD_COND)[ckpt]}
     sd = synth.acoustic_state_conditioned(hp, 0, *cond_par) if cond_par else synth.acoustic_state(hp, 0)
     den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=precision, prefix="denoise_fn.")
     smp = SamplerHandle(den, sd)
-    clips = list(range(32))
+    clips = list(range(first, first + 32))
     hub, m2p, f0 = clip_batch(hp, clips, 861, 500)
     cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
-    mel = smp.sample(cond.transpose(1, 2).contiguous().cuda(), 1000, mel2ph=m2p.cuda(), seed=SPREAD_SEED, first_clip=0, use_graph=True).cpu()
+    mel = smp.sample(cond.transpose(1, 2).contiguous().cuda(), 1000, mel2ph=m2p.cuda(), seed=SPREAD_SEED, first_clip=first, use_graph=True).cpu()
     assert torch.isfinite(mel).all()
     errs = []
     for c, (name, row) in sorted(have.items()):
         g = load_golden(name)
         assert int(g["seed"]) == SPREAD_SEED and int(g["clips"][row]) == c
-        errs.append((c, (mel[c] - torch.from_numpy(g["mel_out"][row])).abs().max().item()))
-    print("batch of 32 (%s checkpoint, %s %s): mel max-abs err per golden clip %s" % (ckpt, which, precision, ["%d: %.2e" % e for e in errs]))
+        errs.append((c, (mel[c - first] - torch.from_numpy(g["mel_out"][row])).abs().max().item()))
+    if random_init and os.environ.get("DSVC_PARTIAL_GOLDENS") != "1":
+        assert len(errs) == 32                              # every clip of the share
+    worst = max(e[1] for e in errs)
+    print("batch of 32 (%s checkpoint, %s %s): worst %.2e; mel max-abs err per golden clip %s" % (ckpt, which, precision, worst, ["%d: %.2e" % e for e in errs]))
+    if random_init and precision != "f16_x3t":
+        mu, beta, p1, p256 = gumbel_fit([e[1] for e in errs])
+        print("batch of 32 (%s, %s %s): Gumbel fit of the 32 per-clip maxima mu %.3e beta %.3e -> P(clip > 1e-3) %.2e, P(a 256-clip job holds one) %.2f"
+              % (ckpt, which, precision, mu, beta, p1, p256))
     if which == "shipped":
-        assert max(e[1] for e in errs) <= SHIP_BAR, errs
-    elif precision == "f16_w2":
-        assert max(e[1] for e in errs) < MEL_BAR, errs
+        assert worst <= SHIP_BAR, errs
+    elif precision in ("f16_w2", "f16_w6"):
+        assert worst < MEL_BAR, errs
     elif precision == "f16_x3t":          # bench.py's `fp32_class.batched_value`: the 64-frame two-launch tiling of the split-activation scheme
-        assert max(e[1] for e in errs) < 1e-4, errs
+        assert worst < 1e-4, errs
 
 
 @pytest.mark.parametrize("precision", ["f16_w2", "f16_m64"])

@@ -176,7 +176,7 @@ def test_full_size_vocoder_properties():
     assert (short[0, :n] - wav[0, :n]).abs().max().item() < 1e-5
 
 
-def _run_bench(nproc, clips_per_gpu, extra_env=None, share_device=True):
+def _run_bench(nproc, clips_per_gpu, extra_env=None, share_device=True, self_spawn=False):
     import json, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DSVC_BENCH_PCM_STATS="1", **(extra_env or {}))
@@ -185,12 +185,14 @@ def _run_bench(nproc, clips_per_gpu, extra_env=None, share_device=True):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this host driver
     tail = [os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "1", "--warmup", "1", "--ddpm-steps", "20",
             "--clips-per-gpu", str(clips_per_gpu), "--no-cpu-baseline", "--no-batched"]
-    if nproc > 1:
+    if nproc > 1 and not self_spawn:
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + tail
     else:
         cmd = [sys.executable] + tail
+    if self_spawn:
+        env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -207,6 +209,11 @@ def test_bench_launch_contract_two_ranks_share_the_device():
     d = _run_bench(2, 2)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["finite_output"] and d["value"] > 0
     assert d["config"]["parallelism"].startswith("utterance-sharded x2") and d["config"]["clips_per_gpu"] == 2
+    assert d["rccl"]["world_size"] == 2
+    # round 4: the same job as plain `python bench.py --gpus 2` -- no launcher: bench.py spawns its ranks itself -- gives the same PCM
+    d2 = _run_bench(2, 2, self_spawn=True)
+    assert d2["n_gpus"] == 2 and d2["rccl"]["world_size"] == 2
+    assert [s[:1] + [round(v, 6) for v in s[1:]] for s in d2["pcm_stats"]] == [s[:1] + [round(v, 6) for v in s[1:]] for s in d["pcm_stats"]]
     one = _run_bench(1, 4)
     assert [s[0] for s in d["pcm_stats"]] == [0, 1, 2, 3] == [s[0] for s in one["pcm_stats"]]
     for a, b in zip(d["pcm_stats"], one["pcm_stats"]):

@@ -405,3 +405,25 @@ def test_gradient_buckets_partition_the_flat_gradient_buffer():
             for o, n in slices:
                 cover[o:o + n] += 1
         assert (cover == 1).all(), per
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_bench_spawns_its_own_ranks_and_refuses_a_mismatched_world(train):
+    """`python bench.py --gpus 2` with NO launcher around it must run two ranks (round 3 it silently measured one GPU and printed n_gpus: 1):
+    bench.py re-executes itself under torch.distributed.run, as the reference spawns its DDP workers (utils/pl_utils.py:483-485).  Exercised
+    without a GPU through the dry-run mode (DSVC_BENCH_DRY=1: rendezvous over gloo, the barrier-bracketed clock, max over ranks, one JSON line
+    from rank 0 -- no hot path, value null).  A launcher that started another world size than --gpus asks for is refused with exit code 2."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DSVC_BENCH_DRY"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"] + (["--train"] if train else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] and d["train"] == train and d["rccl"]["world_size"] == 2 and d["rccl"]["backend"] == "gloo"
+    assert d["ms_per_step"] >= 19.0                          # the slower rank's clock (rank 1 sleeps 20 ms per step), not rank 0's
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=60, cwd=root, env=dict(env, WORLD_SIZE="3", RANK="0"))
+    assert bad.returncode == 2 and "WORLD_SIZE=3" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]

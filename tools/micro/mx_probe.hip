@@ -76,6 +76,34 @@ __global__ void k_mx(const v8i* __restrict__ a, const v8i* __restrict__ b, const
     d[l] = c;
 }
 
+template <int FA, int FB>
+__global__ void k_mx2(const v8i* __restrict__ a, const v8i* __restrict__ b, const int* __restrict__ sa, const int* __restrict__ sb, f32x16* __restrict__ d) {
+    const int l = threadIdx.x;
+    f32x16 c;
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[l], b[l], c, FA, FB, 0, sa[l], 0, sb[l]);
+    d[l] = c;
+}
+
+// D: the sequence the layer kernel would run: four fp16 B fragments of a lane (k = 16 kk + 8 (lane >> 5) + e) -> ONE pk32 conversion to bf6 ->
+// K = 64 product with fp6 weight codes (A), uniform E8M0 scales
+__global__ void k_inreg(const int* __restrict__ a6, const half8* __restrict__ hb, f32x16* __restrict__ d, float xscale, int sa, int sb) {
+    const int l = threadIdx.x;
+    half32 v;
+    for (int kk = 0; kk < 4; ++kk) {
+        const half8 f = hb[kk * 64 + l];
+        for (int e = 0; e < 8; ++e) v[8 * kk + e] = f[e];
+    }
+    const v6i q = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(v, xscale);
+    v6i w;                                              // (sizeof(v6i) is 32, not 24: index the packed stream by hand)
+    for (int i = 0; i < 6; ++i) w[i] = a6[l * 6 + i];
+    const v8i A = __builtin_shufflevector(w, w, 0, 1, 2, 3, 4, 5, -1, -1), B = __builtin_shufflevector(q, q, 0, 1, 2, 3, 4, 5, -1, -1);
+    f32x16 c;
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 2, 3, 0, sa, 0, sb);
+    d[l] = c;
+}
+
 // ---------------- C: rates ----------------
 // MODE 0: 32 f16 MFMAs per group.  1: 16 f16 + 4 fp8.  2: 16 f16 + 4 fp8 + 64 cvt.  3: 16 f16 + 4 bf6.  4: 16 f16 + 4 bf6 + 4 pk32 cvt.
 // 5: 4 fp8 only.  6: 4 bf6 only.  7: 16 f16 only.
@@ -247,6 +275,84 @@ int main() {
             printf("B fmt %d %s scales: max|D| %.4g   H1 (own-lane scale) err %.3g   H2 (lanes 0..31 scale) err %.3g\n", fmt, trial ? "random" : "unit", mag, e1, e2);
             CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dsa)); CK(hipFree(dsb)); CK(hipFree(dd));
         }
+    }
+    // ---- B2: mixed formats (which of cbsz / blgp is the first operand's?) ----
+    for (int order = 0; order < 2; ++order) {
+        std::vector<unsigned> a(64 * 8), b(64 * 8);
+        std::vector<int> sa(64), sb(64);
+        unsigned x = 4242u;
+        auto rnd = [&]() { x = x * 1664525u + 1013904223u; return x >> 8; };
+        for (auto& w : a) w = rnd() | (rnd() << 24);
+        for (auto& w : b) w = rnd() | (rnd() << 24);
+        for (int l = 0; l < 64; ++l) { sa[l] = 120 + (int)(rnd() % 12); sb[l] = 124 + (int)(rnd() % 6); }
+        v8i *da, *db; int *dsa, *dsb; f32x16* dd;
+        CK(hipMalloc(&da, 64 * 32)); CK(hipMalloc(&db, 64 * 32)); CK(hipMalloc(&dsa, 256)); CK(hipMalloc(&dsb, 256)); CK(hipMalloc(&dd, 64 * 64));
+        CK(hipMemcpy(da, a.data(), 64 * 32, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), 64 * 32, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dsa, sa.data(), 256, hipMemcpyHostToDevice)); CK(hipMemcpy(dsb, sb.data(), 256, hipMemcpyHostToDevice));
+        if (order == 0) hipLaunchKernelGGL((k_mx2<2, 3>), dim3(1), dim3(64), 0, 0, da, db, dsa, dsb, dd);
+        else hipLaunchKernelGGL((k_mx2<3, 2>), dim3(1), dim3(64), 0, 0, da, db, dsa, dsb, dd);
+        std::vector<float> hd(64 * 16);
+        CK(hipMemcpy(hd.data(), dd, 64 * 64, hipMemcpyDeviceToHost));
+        for (int hyp = 0; hyp < 2; ++hyp) {                 // hyp 0: cbsz is the FIRST operand's format; 1: the second's
+            const int fa = (order == 0) == (hyp == 0) ? 2 : 3, fb = 5 - fa;
+            double err = 0, mag = 0;
+            for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 16; ++r) {
+                    const int j = l & 31, i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                    double s1 = 0;
+                    for (int h = 0; h < 2; ++h) {
+                        double p = 0;
+                        for (int m = 0; m < 32; ++m) {
+                            const unsigned ca = get6(&a[(i + 32 * h) * 8], m), cb = get6(&b[(j + 32 * h) * 8], m);
+                            p += (double)(fa == 2 ? dec_e2m3(ca) : dec_e3m2(ca)) * (double)(fb == 2 ? dec_e2m3(cb) : dec_e3m2(cb));
+                        }
+                        s1 += p * ldexp(1.0, sa[i + 32 * h] - 127) * ldexp(1.0, sb[j + 32 * h] - 127);
+                    }
+                    err = fmax(err, fabs(hd[l * 16 + r] - s1)); mag = fmax(mag, fabs(s1));
+                }
+            printf("B2 builtin(cbsz=%d, blgp=%d), hypothesis '%s': max|D| %.4g err %.3g\n", order == 0 ? 2 : 3, order == 0 ? 3 : 2,
+                   hyp == 0 ? "cbsz = format of operand 1" : "cbsz = format of operand 2", mag, err);
+        }
+        CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dsa)); CK(hipFree(dsb)); CK(hipFree(dd));
+    }
+    // ---- D: fp16 fragments -> pk32 bf6 -> product with fp6 codes ----
+    {
+        std::vector<unsigned> a(64 * 6);
+        std::vector<_Float16> hb(4 * 64 * 8);
+        unsigned x = 99u;
+        auto rnd = [&]() { x = x * 1664525u + 1013904223u; return x >> 8; };
+        for (auto& w : a) w = rnd() | (rnd() << 24);
+        for (auto& v : hb) v = (_Float16)(((int)(rnd() % 4001) - 2000) / 250.0f);       // [-8, 8]
+        const float xscale = 4.0f; const int sa = 127 - 20, sb = 129;
+        int* da; half8* dh; f32x16* dd;
+        CK(hipMalloc(&da, 64 * 24)); CK(hipMalloc(&dh, hb.size() * 2)); CK(hipMalloc(&dd, 64 * 64));
+        CK(hipMemcpy(da, a.data(), 64 * 24, hipMemcpyHostToDevice)); CK(hipMemcpy(dh, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_inreg, dim3(1), dim3(64), 0, 0, da, dh, dd, xscale, sa, sb);
+        std::vector<float> hd(64 * 16);
+        CK(hipMemcpy(hd.data(), dd, 64 * 64, hipMemcpyDeviceToHost));
+        // host: bf6 nearest (ties to even) of x / xscale, saturating at 28
+        auto q_bf6 = [&](float v) {
+            float best = 0; double bd = 1e30; int bc = 0;
+            for (int c = 0; c < 32; ++c) { const double g = dec_e3m2(c), dd_ = fabs(fabs((double)v) - g); if (dd_ < bd || (dd_ == bd && !(c & 1) && (bc & 1))) { bd = dd_; best = (float)g; bc = c; } }
+            return v < 0 ? -best : best;
+        };
+        double err = 0, mag = 0, exact_err = 0;
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 16; ++r) {
+                const int j = l & 31, i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                double s = 0, se = 0;
+                for (int h = 0; h < 2; ++h)
+                    for (int kk = 0; kk < 4; ++kk)
+                        for (int e = 0; e < 8; ++e) {
+                            const double wv = dec_e2m3(get6(&a[(i + 32 * h) * 6], 8 * kk + e)) * ldexp(1.0, sa - 127);
+                            const float xv = (float)hb[(kk * 64 + j + 32 * h) * 8 + e];
+                            s += wv * (double)q_bf6(xv / xscale) * ldexp(1.0, sb - 127);
+                            se += wv * (double)xv;
+                        }
+                err = fmax(err, fabs(hd[l * 16 + r] - s)); exact_err = fmax(exact_err, fabs(hd[l * 16 + r] - se)); mag = fmax(mag, fabs(se));
+            }
+        printf("D in-register fp16 -> bf6 -> fp6 x bf6 product: max|D| %.4g   err vs emulation %.3g   err vs unquantised x %.3g\n", mag, err, exact_err);
+        CK(hipFree(da)); CK(hipFree(dh)); CK(hipFree(dd));
     }
     // ---- C ----
     {
