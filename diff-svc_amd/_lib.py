@@ -12,6 +12,7 @@ PREC_F16, PREC_F16_W2, PREC_F16_X3 = 0, 1, 2
 PREC_F16_MIX = 3
 PREC_F16_X3T = 4
 PREC_F16_W6 = 5
+PREC_F16_W6N = 6
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3, "f16_x3t": PREC_F16_X3T}
 ABI_VERSION = 6
 
@@ -33,6 +34,8 @@ def parse_precision(p):
         return PREC_F16_W6, 64                           # (fused layer kernel; w_lo as 64 time-dithered fp6 roundings)
     if p.startswith("f16_w6d") and p[7:].isdigit() and int(p[7:]) >= 1:
         return PREC_F16_W6, int(p[7:])
+    if p == "f16_w6n":                                   # ... without the output projection's g_lo correction (f16_w2's error class, faster)
+        return PREC_F16_W6N, 64
     raise ValueError("precision must be one of %s, 'f16_dN' or 'f16_mN'" % sorted(PRECISIONS))
 
 c_f32p = ctypes.POINTER(ctypes.c_float)
@@ -139,6 +142,7 @@ SYMBOLS = [
     ("dsvc_trainer_set_schedule", ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int32, _VP, _VP, ctypes.c_int32]),
     ("dsvc_trainer_step", ctypes.c_int, [_VP, ctypes.POINTER(TrainArgs), _VP, _VP]),
     ("dsvc_trainer_step_begin", ctypes.c_int, [_VP, ctypes.POINTER(TrainArgs), _VP]),
+    ("dsvc_trainer_check", ctypes.c_int, [_VP, _VP]),
     ("dsvc_trainer_step_layers", ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, _VP]),
     ("dsvc_trainer_step_end", ctypes.c_int, [_VP, _VP, _VP]),
     ("dsvc_adamw_step", ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,

@@ -128,7 +128,7 @@ struct TPacked6 {
 
 template <class FR>
 int tpack6(TPacked6& tp, const std::vector<float>& src, int O, int I, int taps, int m_tiles, int n_variants, float scale, unsigned salt,
-           FR&& rowmap, const std::vector<float>* rowscale) {
+           FR&& rowmap, const std::vector<float>* rowscale, bool whole = false) {
     const int cin_pad = round_up(I, 128);
     if ((size_t)O * I * taps != src.size()) return fail(DSVC_EINVAL, "tpack6: weight tensor has %zu elements, expected %zu", src.size(), (size_t)O * I * taps);
     std::vector<int> rm(m_tiles * 32);
@@ -141,7 +141,7 @@ int tpack6(TPacked6& tp, const std::vector<float>& src, int O, int I, int taps, 
         const float* wrow = src.data() + (size_t)rm[r] * I * taps;
         for (int i = 0; i < I * taps; ++i) {
             const float w = wrow[i] * scale * rs;                  // the same two roundings as the packing kernels
-            const float wl = fabsf(w - (float)(_Float16)w);
+            const float wl = whole ? fabsf(w) : fabsf(w - (float)(_Float16)w);
             if (wl > amax) amax = wl;
         }
     }
@@ -162,7 +162,7 @@ int tpack6(TPacked6& tp, const std::vector<float>& src, int O, int I, int taps, 
     const long long total = (long long)m_tiles * taps * (cin_pad / 64) * 64 * n_variants;
     const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
     hipLaunchKernelGGL(k_tpack6, dim3(blocks), dim3(256), 0, 0, dsrc.as<float>(), drm.as<int>(), rowscale ? drs.as<float>() : nullptr,
-                       tp.codes.as<unsigned>(), I, taps, cin_pad, m_tiles, n_variants, scale, ldexpf(1.0f, -e6), salt);
+                       tp.codes.as<unsigned>(), I, taps, cin_pad, m_tiles, n_variants, scale, ldexpf(1.0f, -e6), salt, whole ? 1 : 0);
     DSVC_HIP(hipGetLastError());
     DSVC_HIP(hipDeviceSynchronize());
     return DSVC_OK;
@@ -240,6 +240,9 @@ struct dsvc_denoiser {
     int Cp = 0, Mp = 0, guard = 8;
     TPacked in_t, skip_t, fin_t;
     std::vector<TPacked6> dil6_t;     // DSVC_PREC_F16_W6: fp6 codes of the dilated convs' w_lo planes
+    std::vector<TPacked6> out6_t;     //                   fp6 codes of the output projections' weights (g_lo correction)
+    std::vector<TPacked6> outl6_t;    //                   fp6 codes of the output projections' w_lo planes
+    int dbg_g6_off = 0;               // 1: no g_lo correction in the fused layers (A/B)
     TPacked skipall_t;                // deferred skip path (tskip.h): W_sp W_out,l[C:2C] / sqrt(L) for all layers as one [C x L*C] operand
     DevBuf gall;                      // fp16 gate outputs of all layers [L][rows_alloc][Cp]: written by the fused layer kernels, read by tskip
     std::vector<TPacked> dil_t, out_t;
@@ -260,6 +263,7 @@ struct dsvc_denoiser {
                                  // Measured at 32 clips (profiles/r3e_*): layer kernel 132 -> 123 us and 14 % fewer HBM bytes, but the skip
                                  // halves' MFMAs, which hide under the layer's memory-bound output phase, then cost 342 us per step as their
                                  // own kernel: the step time is unchanged (+-1 %).  Built, parity-tested, not the default.
+    bool is_w6() const { return cfg.precision == DSVC_PREC_F16_W6 || cfg.precision == DSVC_PREC_F16_W6N; }
     int dbg_w6_off = 0;          // 1: a DSVC_PREC_F16_W6 handle runs its fused layers with the fp16 lo plane (= f16_w2): the A/B partner of the 6-bit product
     int dbg_two_launch = 0;      // 1: run a residual layer as its two tgemm launches even where the fused kernel is the choice (bit-equality
                                  // test); -1: the fused kernel wherever it is SUPPORTED (>= 48 tiles), not only where it is faster (>= 120)
@@ -431,7 +435,7 @@ int dsvc_denoiser::finalize_t() {
     int max_dil = 1;
     for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     guard = round_up(max_dil, 8);
-    const bool w6 = cfg.precision == DSVC_PREC_F16_W6;
+    const bool w6 = is_w6();
     const int planes = (cfg.precision == DSVC_PREC_F16_W2 || cfg.precision == DSVC_PREC_F16_X3T || w6) ? 2 : 1;
     const int nvar = (planes == 1 && cfg.weight_variants > 1) ? cfg.weight_variants : 1;       // (F16 and F16_MIX)
 #define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
@@ -446,7 +450,7 @@ int dsvc_denoiser::finalize_t() {
     // 1000-step chain robustly under the 1e-3 bar (profiles/r2w_precision_spread.txt)
     const bool out_w2 = cfg.precision == DSVC_PREC_F16_MIX;
     dil_t.resize(L); out_t.resize(L);
-    if (w6) dil6_t.resize(L);
+    if (w6) { dil6_t.resize(L); out6_t.resize(L); outl6_t.resize(L); }
     for (int l = 0; l < L; ++l) {
         const std::string q = "residual_layers." + std::to_string(l) + ".";
         GET(wd, q + "dilated_conv.weight", 2 * C * C * 3);
@@ -462,6 +466,12 @@ int dsvc_denoiser::finalize_t() {
         // above serves the two-launch tilings of smaller batches, which compute f16_w2)
         if (w6) DSVC_TRY(tpack6(dil6_t[l], *wd, 2 * C, C, 3, C / 16, cfg.weight_variants > 1 ? cfg.weight_variants : 1, 1.0f, 2000u + l,
                                 [&](int r) { const int mt = r >> 5, i = r & 31; return (i >> 4) * C + mt * 16 + trow_to_ch8(i & 15); }, &gsc));
+        // ... the output projection's w_lo plane likewise (same dither schedule) ...
+        if (w6) DSVC_TRY(tpack6(outl6_t[l], *wo, 2 * C, C, 1, 2 * C / 32, cfg.weight_variants > 1 ? cfg.weight_variants : 1, 1.0f, 4000u + l,
+                                [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, nullptr));
+        // ... and the output projection's weights THEMSELVES as fp6 codes (nearest, one variant): the weight operand of the 6-bit g_lo correction
+        if (w6) DSVC_TRY(tpack6(out6_t[l], *wo, 2 * C, C, 1, 2 * C / 32, 1, 1.0f, 3000u + l,
+                                [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, nullptr, true));
         // output 1x1: tiles 0..C/32-1 residual half (conv channels 0..C-1), then the skip half (C..2C-1)
         DSVC_TRY(tpack(out_t[l], *wo, 2 * C, C, 1, 2 * C / 32, out_w2 ? 2 : planes, out_w2 ? 1 : nvar, 1.0f, 1001u + 2 * l, false,
                        [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, bo->data(), 2 * C));
@@ -749,13 +759,19 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
 #else
     constexpr int pf = 0;
 #endif
-    if (cfg.precision == DSVC_PREC_F16_W6 && !defer && dbg_w6_off == 0) {
+    if (is_w6() && !defer && dbg_w6_off == 0) {
         const TPacked6& t6 = dil6_t[l];
+        const TPacked6& o6 = outl6_t[l];
         TLayerW6 w6{t6.codes.as<unsigned>(), (long long)t6.variant_dwords, t6.e6, t6.n_variants};
+        w6.out_lo_codes = o6.codes.as<unsigned>(); w6.out_lo_variant_dwords = (long long)o6.variant_dwords; w6.eol6 = o6.e6;
+        if (cfg.precision == DSVC_PREC_F16_W6 && dbg_g6_off == 0 && tlayer_smem(ga.dil, Cp, true) <= 160 * 1024) {      // (a dilation beyond 8 leaves no room for the code block beside the time tile)
+            w6.out_codes = out6_t[l].codes.as<unsigned>(); w6.eo6 = out6_t[l].e6;
+        }
         TGemmArgs ga6 = ga;
         ga6.n_variants = 1;
         if (host_step >= 0 && t6.n_variants > 1 && step.per_clip == 0) {      // variant known at launch: pass it by value
             w6.codes += (size_t)(host_step % t6.n_variants) * t6.variant_dwords;
+            w6.out_lo_codes += (size_t)(host_step % o6.n_variants) * o6.variant_dwords;
             w6.n_variants = 1;
         }
         return tlayer_launch<2>(ga6, cp, oa, oe, C, rows_alloc, 0, st, nullptr, 0, &w6);
@@ -875,7 +891,7 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
     // The captured segment is one period of the dither schedule (64 steps for f16_d64) replayed from a period-aligned step, so
     // every kernel node knows its weight variant at capture time and passes it by value: the alternative -- a scalar load of the
     // step in front of every kernel's weight stream -- costs ~0.4 us x 43 kernels per step in the single-clip regime.
-    const int nvar = (den->tpath && (den->cfg.precision == DSVC_PREC_F16 || den->cfg.precision == DSVC_PREC_F16_MIX || den->cfg.precision == DSVC_PREC_F16_W6)
+    const int nvar = (den->tpath && (den->cfg.precision == DSVC_PREC_F16 || den->cfg.precision == DSVC_PREC_F16_MIX || den->is_w6())
                       && den->cfg.weight_variants > 1) ? den->cfg.weight_variants : 1;
     const int UNROLL = (nvar > 1 && nvar <= 64) ? nvar : 10;
     const bool aligned = UNROLL == nvar && nvar > 1;
@@ -991,7 +1007,7 @@ int dsvc_abi_version(void) { return DSVC_ABI_VERSION; }
 
 int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out) {
     if (!cfg || !out) return fail(DSVC_EINVAL, "null argument");
-    if (cfg->precision < DSVC_PREC_F16 || cfg->precision > DSVC_PREC_F16_W6) return fail(DSVC_EINVAL, "unknown precision %d", cfg->precision);
+    if (cfg->precision < DSVC_PREC_F16 || cfg->precision > DSVC_PREC_F16_W6N) return fail(DSVC_EINVAL, "unknown precision %d", cfg->precision);
     int ndev = 0;
     DSVC_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(DSVC_EHIP, "no HIP device visible");
@@ -1027,14 +1043,10 @@ int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t,
     DSVC_TRY(d->ensure_ws(B, T, st));
     DSVC_TRY(d->set_clip_meta(nullptr, 0, nullptr, st));
     // steps: clamped on the device (no synchronising range check per call); a step outside the table raises the sticky flag, which
-    // the NEXT call -- or dsvc_denoiser_check -- reports
+    // dsvc_denoiser_check reports (and only it: a later, valid call is executed, not rejected for its predecessor's argument)
     if (!d->step_err) {
         DSVC_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->step_err), sizeof(int), hipHostMallocMapped));
         *d->step_err = 0;
-    }
-    if (*d->step_err) {
-        *d->step_err = 0;
-        return fail(DSVC_EINVAL, "an earlier dsvc_denoiser_forward call passed a diffusion step outside [0, %d): its output used the clamped step", d->cfg.max_steps);
     }
     hipLaunchKernelGGL(k_clamp_steps, dim3(ceil_div(B, 256)), dim3(256), 0, st, d->tsteps.as<int>(), t, d->cfg.max_steps, B, d->step_err);
     if (fresh || cond_changed || !d->cond_ready) DSVC_TRY(d->prepare_cond(cond, B, T, st));
@@ -1128,6 +1140,7 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     if (k == "stop_after_layers") d->dbg_stop_after = value;
     else if (k == "two_launch_layer") d->dbg_two_launch = value > 0 ? 1 : (value < 0 ? -1 : 0);
     else if (k == "w6_off") d->dbg_w6_off = value ? 1 : 0;
+    else if (k == "g6_off") d->dbg_g6_off = value ? 1 : 0;
     else if (k == "layer_prio") d->layer_prio = value;
     else if (k == "defer_skip") {
         d->defer_skip = value != 0;

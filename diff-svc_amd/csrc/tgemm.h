@@ -614,7 +614,7 @@ __host__ __device__ inline int tg_e2m3_floor(float a) {
 
 __global__ void k_tpack6(const float* __restrict__ src, const int* __restrict__ rowmap, const float* __restrict__ rowscale,
                          unsigned* __restrict__ dst, int I, int taps, int cin_pad, int m_tiles, int n_variants, float scale, float inv6,
-                         unsigned salt) {
+                         unsigned salt, int whole) {         // whole: the codes are those of w itself (the g_lo correction's weight operand), not of w_lo
     const int nq = cin_pad >> 6;
     const long long per_variant = (long long)m_tiles * taps * nq * 64;         // lanes of one variant
     const long long total = per_variant * n_variants;
@@ -639,7 +639,7 @@ __global__ void k_tpack6(const float* __restrict__ src, const int* __restrict__ 
         for (int m = 0; m < 32; ++m) {
             const int ci = 64 * q + 16 * (m >> 3) + 8 * h + (m & 7);
             const float w = (o >= 0 && ci < I) ? src[((size_t)o * I + ci) * taps + tap] * scale * (rowscale ? rowscale[row] : 1.0f) : 0.f;
-            const float wl = w - (float)(_Float16)w;
+            const float wl = whole ? w : w - (float)(_Float16)w;
             const float u = wl * inv6, a = fabsf(u);
             int i0 = tg_e2m3_floor(a);
             if (i0 < 31) {

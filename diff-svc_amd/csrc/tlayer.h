@@ -43,7 +43,13 @@ struct TLayerArgs {
     // gw then holds hi | lo fp16 planes of which only the hi fragments are streamed
     const unsigned* gw6;
     long long g6var;            // dwords between dither variants of gw6
-    int sc6;                    // E8M0 scale bytes of the 6-bit product: weights (2^e6) | activations (xscale) << 8
+    int sc6;                    // E8M0 scale bytes of the 6-bit products: gate weights (2^e6) | x (TL_X6_E8M0) << 8 | output-1x1 weights << 16 | g_lo << 24
+    // G6 (W6 == 2): the output projection gets a 6-bit g_lo correction too -- the gate epilogue keeps bf6((g - fp16(g)) * 2^16) beside
+    // fp16(g) in LDS, and ow6 holds fp6 codes of the output-projection weights THEMSELVES (k_tpack6 with `whole`)
+    const unsigned* ow6;
+    const unsigned* ow6lo;      // W6: fp6 codes of the output projection's w_lo plane (dither variants o6var dwords apart), scale byte sc6b & 255
+    long long o6var;
+    int sc6b;
 #ifdef DSVC_PROFILING
     unsigned long long* stamps; // profiling build: 16 s_memrealtime stamps per wave of the LAST launch (tools/gpu_layer_stamps.py)
 #endif
@@ -106,19 +112,35 @@ __device__ __forceinline__ void tl_load_group(half8 (&ring)[KG * NW], const _Flo
     for (int u = 0; u < KG * NW; ++u) ring[u] = *reinterpret_cast<const half8*>(p + u * TFRAG_HALFS);
 }
 
+typedef int tl_v3i __attribute__((ext_vector_type(3)));
 typedef int v6i_t __attribute__((ext_vector_type(6)));
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half16_t __attribute__((ext_vector_type(16)));
 typedef _Float16 half32_t __attribute__((ext_vector_type(32)));
 constexpr float TL_X6_SCALE = 4.0f;        // activations of the 6-bit product are converted as bf6(x / 4): saturation at |x| = 112, rel. rms error 5.7 %
 constexpr int TL_X6_E8M0 = 129;            // 2^2
+constexpr float TL_G6_UP = 65536.0f;       // g_lo = g - fp16(g), |g_lo| <= 2^-12 (|g| < 1), is converted as bf6(g_lo * 2^16): |.| <= 16 of the format's 28
+constexpr int TL_G6_E8M0 = 127 - 16;
+constexpr float TL_G_X6_SCALE = 0.0625f;   // the gate output g (|g| < 1) enters the output projection's 6-bit w_lo product as bf6(16 g)
+constexpr int TL_G_X6_E8M0 = 127 - 4;
+constexpr int TL_S6_BYTES = TL_TN * 128;   // the 6-bit g_lo codes of one g block: 128 frames x [4 slots (64-channel group, lane half) x 32 B]
 
-// W6: one group = 64 input channels of one tap against 4 N-tiles, N-tile by N-tile: four fp16 MFMAs on the hi fragments, then the lane's four
+// W6: one group = 64 input channels (of one tap) against 4 N-tiles, N-tile by N-tile: four fp16 MFMAs on the hi fragments, then the lane's four
 // B fragments (k = 16 kk + 8 h + e: exactly the order k_tpack6 packs the weight codes in) are converted to bf6 by ONE instruction and one
 // K = 64 block-scaled MFMA adds w_lo * x.  The next N-tile's four fragments are read while the current one computes.
+//   xscale / sc_x   the activations are converted as bf6(x / xscale); sc_x = 127 + log2(xscale)
+// G6 (the output projection of DSVC_PREC_F16_W6): a second 6-bit MFMA adds W6 * g_lo6 -- the fp6 codes `wg` of the weights THEMSELVES against the
+// bf6 codes of g_lo = g - fp16(g) the gate epilogue left in LDS (c0: byte address of the lane's code row of N-tile 0, rows of N-tiles 4096 B
+// apart; o0 / o1: offsets of its two 16-byte chunks, 12 bytes used of each), read one N-tile ahead like the fragments.
+template <bool G6>
 __device__ __forceinline__ void tl_compute_group_w6(const half8 (&hi)[4], const v6i_t& lo, f32x16 (&acc)[4], unsigned base0, unsigned nt_stride,
-                                                    unsigned xs, int sc_w) {
+                                                    unsigned xs, int sc_w, float xscale, int sc_x, const v6i_t& wg, unsigned c0, unsigned o0,
+                                                    unsigned o1, int sc_wg, int sc_g) {
     typedef const half8 __attribute__((address_space(3))) * lds_frag_ptr;
+    typedef const tl_v3i __attribute__((address_space(3))) * lds_code_ptr;     // 12 of a chunk's 16 bytes: ds_read_b96.  (Integers: __builtin_bit_cast of a
+                                                                                 //  vector ELEMENT expression silently reads element 0 with this clang.)
+    // (NBUF = 1: single-buffered fragments -- tried for G6 beside a prefetched second accumulator set; spilled all the same)
+    constexpr int NBUF = 2;
     unsigned base[4];
     base[0] = base0;
 #pragma unroll
@@ -126,36 +148,55 @@ __device__ __forceinline__ void tl_compute_group_w6(const half8 (&hi)[4], const 
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(base[nt]));
     const v8i_t a6 = __builtin_shufflevector(lo, lo, 0, 1, 2, 3, 4, 5, -1, -1);
-    half8 b[2][4];
+    const v8i_t ag = __builtin_shufflevector(wg, wg, 0, 1, 2, 3, 4, 5, -1, -1);
+    half8 b[NBUF][4];
+    tl_v3i cu[2];
+    if constexpr (NBUF == 2) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) b[0][kk] = *(lds_frag_ptr)(size_t)(base[0] + (((unsigned)kk << 5) ^ xs));
+        for (int kk = 0; kk < 4; ++kk) b[0][kk] = *(lds_frag_ptr)(size_t)(base[0] + (((unsigned)kk << 5) ^ xs));
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        if (nt + 1 < 4) {
+        if constexpr (NBUF == 1) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) b[(nt + 1) & 1][kk] = *(lds_frag_ptr)(size_t)(base[nt + 1] + (((unsigned)kk << 5) ^ xs));
+            for (int kk = 0; kk < 4; ++kk) b[0][kk] = *(lds_frag_ptr)(size_t)(base[nt] + (((unsigned)kk << 5) ^ xs));
         }
+        if constexpr (G6) {
+            cu[0] = *(lds_code_ptr)(size_t)(c0 + (unsigned)nt * 4096u + o0);
+            cu[1] = *(lds_code_ptr)(size_t)(c0 + (unsigned)nt * 4096u + o1);
+        }
+        if (NBUF == 2 && nt + 1 < 4) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi[kk], b[nt & 1][kk], acc[nt], 0, 0, 0);
-        const half16_t v01 = __builtin_shufflevector(b[nt & 1][0], b[nt & 1][1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-        const half16_t v23 = __builtin_shufflevector(b[nt & 1][2], b[nt & 1][3], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            for (int kk = 0; kk < 4; ++kk) b[(nt + 1) % NBUF][kk] = *(lds_frag_ptr)(size_t)(base[nt + 1] + (((unsigned)kk << 5) ^ xs));
+        }
+        const half8 (&bn)[4] = b[nt % NBUF];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi[kk], bn[kk], acc[nt], 0, 0, 0);
+        const half16_t v01 = __builtin_shufflevector(bn[0], bn[1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        const half16_t v23 = __builtin_shufflevector(bn[2], bn[3], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
         const half32_t v = __builtin_shufflevector(v01, v23, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25,
                                                    26, 27, 28, 29, 30, 31);
-        const v6i_t q = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(v, TL_X6_SCALE);
+        const v6i_t q = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(v, xscale);
         const v8i_t b6 = __builtin_shufflevector(q, q, 0, 1, 2, 3, 4, 5, -1, -1);
-        acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a6, b6, acc[nt], 2 /* A: fp6 E2M3 */, 3 /* B: bf6 E3M2 */, 0, sc_w, 0, TL_X6_E8M0);
+        acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a6, b6, acc[nt], 2 /* A: fp6 E2M3 */, 3 /* B: bf6 E3M2 */, 0, sc_w, 0, sc_x);
+        if constexpr (G6) {
+            const v8i_t g6 = __builtin_shufflevector(cu[0], cu[1], 0, 1, 2, 3, 4, 5, -1, -1);
+            acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ag, g6, acc[nt], 2, 3, 0, sc_wg, 0, sc_g);
+        }
     }
     // pin the software pipeline (left alone, the scheduler re-uses one fragment tuple for two N-tiles and waits lgkmcnt(0) behind every read):
-    // N-tile 0's four reads, then one read of N-tile nt+1 behind each fp16 MFMA of N-tile nt, the conversion, the 6-bit MFMA
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    // double-buffered: N-tile 0's reads, then one read of N-tile nt+1 behind each fp16 MFMA of N-tile nt, the conversion, the 6-bit MFMA;
+    // G6: an N-tile's six reads, its four fp16 MFMAs, its two 6-bit MFMAs
+    if constexpr (NBUF == 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
+        if constexpr (NBUF == 1) __builtin_amdgcn_sched_group_barrier(0x100, G6 ? 6 : 4, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (nt + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (NBUF == 2 && nt + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, G6 ? 2 : 1, 0);
     }
 }
 
@@ -184,6 +225,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     constexpr int KG2 = KG * NW / NW2;
     static_assert(KG2 * NW2 == KG * NW && KG2 >= 1, "both phases use the same eight ring registers");
     static_assert(!W6 || (KG == 4 && NW == 2 && NW2 == 2 && !DEFER), "W6: hi | lo fp16 planes packed, 64 input channels per group");
+    constexpr bool G6 = W6 == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -214,6 +256,10 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned s_off = (unsigned)(((size_t)rows_lds * row_bytes + 1023) & ~(size_t)1023);
     auto block_base = [&](int pos) -> unsigned { return lds0 + (pos == 0 ? s_off : (unsigned)(pos - 1) * (unsigned)TL_BLOCK_BYTES); };
+    // G6: the code block of g block `pos` -- behind S for the first pass, behind the two g blocks that replace the time tile for the others
+    auto s6_base = [&](int pos) -> unsigned {
+        return lds0 + (pos == 0 ? s_off + (unsigned)TL_BLOCK_BYTES : (unsigned)(NB - 1) * (unsigned)TL_BLOCK_BYTES + (unsigned)(pos - 1) * (unsigned)TL_S6_BYTES);
+    };
 
     int variant = 0;
     if (ga.n_variants > 1 && ga.step_ptr) {               // (the sampler passes the variant by value: n_variants == 1 on the hot path)
@@ -226,7 +272,9 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const _Float16* gw = ga.gw + (long long)variant * ga.gvar;
     const _Float16* ow = ga.ow + (long long)variant * ga.ovar;
     const unsigned* gw6 = W6 ? ga.gw6 + (long long)variant * ga.g6var : nullptr;
-    const int sc_w6 = ga.sc6 & 255;
+    const int sc_w6 = ga.sc6 & 255, sc_o6 = (ga.sc6 >> 16) & 255, sc_ol6 = ga.sc6b & 255;
+    const unsigned* ow6 = G6 ? ga.ow6 : nullptr;
+    const unsigned* ow6lo = W6 ? ga.ow6lo + (long long)variant * ga.o6var : nullptr;
     const int lane8 = lane * 8;
     const int gpt = (ga.cin >> 4) / KG;                   // gate: groups per tap
     const int G1 = 3 * gpt;                               // gate: groups per output tile
@@ -249,6 +297,7 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const TEpiGate::Args ge{cproj, nullptr, ga.cin, ga.cin};
     f32x16 acc[4], nxt[4];
     half8 ringA[KG * NW], ringB[KG * NW];
+    v6i_t gmid6 = {};                                     // G6: the middle pass's g_lo codes
     v6i_t lo6A, lo6B;                                     // W6: the fp6 fragment of the group in ringA / ringB (whose first four entries hold its hi fragments)
     half8 gmid[4];                                        // the middle gate pass's g block share (NB == 3)
 
@@ -264,9 +313,23 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
         const unsigned b0 = lds0 + (unsigned)rr * (unsigned)row_bytes, xs = (unsigned)(((rr & ga.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5);
         if constexpr (W6) {
             const half8 (&hi)[4] = reinterpret_cast<const half8 (&)[4]>(ring);
-            tl_compute_group_w6(hi, lo6, acc, b0, nt_stride_x0, xs, sc_w6);
+            tl_compute_group_w6<false>(hi, lo6, acc, b0, nt_stride_x0, xs, sc_w6, TL_X6_SCALE, TL_X6_E8M0, lo6, 0u, 0u, 0u, 0, 0);
         } else {
             tl_compute_group<KG, NW>(ring, acc, b0, nt_stride_x0, xs);
+        }
+    };
+    // ... and of the output projection (W6: hi fragments of its two planes + fp6 w_lo codes; G6: + the fp6 codes of the weights themselves)
+    v6i_t wg6 = {};
+    auto oload = [&](half8 (&ring)[KG * NW], v6i_t& lo6, int mt_, int g_) {
+        if constexpr (W6) tl_load_group_w6(ring, lo6, ow + (long long)mt_ * tile2 + (long long)g_ * GROUP_HALFS, ow6lo + ((size_t)mt_ * G2 + g_) * (TFRAG6_BYTES / 4), lane);
+        else tl_load_group<KG2, NW2>(ring, ow + (long long)mt_ * tile2 + (long long)g_ * GROUP_HALFS + lane8);
+    };
+    auto oload_g = [&](v6i_t& wg, int mt_, int g_) {
+        if constexpr (G6) {
+            const unsigned* p6 = ow6 + ((size_t)mt_ * G2 + g_) * (TFRAG6_BYTES / 4);
+            const int4 a = *reinterpret_cast<const int4*>(p6 + lane * 4);
+            const int2 c = *reinterpret_cast<const int2*>(p6 + 256 + lane * 2);
+            wg = v6i_t{a.x, a.y, a.z, a.w, c.x, c.y};
         }
     };
     // first operands in flight before the barrier
@@ -306,14 +369,28 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
         TL_STAMP(4 + pi);                                  // (4, 5, 6: end of a gate pass's main loop)
         // the next tile's weight stream starts before this tile's epilogue
         if (!last) gload(ringA, lo6A, mt_n, 0);
-        else tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
+        else { oload(ringA, lo6A, mt_n, 0); oload_g(wg6, mt_n, 0); }
         if (!nxt_issued && (!last || PF)) issue_next_init();
         // ---- gate epilogue: g = sigmoid * tanh -> fp16 (TEpiGate::finish, kept on chip) ----
         half8 gq[4];
+        v6i_t gq6 = {};
+        if constexpr (G6) {
+            half32_t glo;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) gq[nt][r] = (_Float16)gate_act_scaled(acc[nt][r], acc[nt][8 + r]);
+                for (int r = 0; r < 8; ++r) {
+                    const float gv = gate_act_scaled(acc[nt][r], acc[nt][8 + r]);
+                    gq[nt][r] = (_Float16)gv;
+                    glo[8 * nt + r] = (_Float16)((gv - (float)gq[nt][r]) * TL_G6_UP);        // exact: |.| <= 16, and the difference has < 11 significant bits left
+                }
+            gq6 = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(glo, 1.0f);                     // code 8 nt + r: frame 32 nt + (lane & 31), channel 16 wave + 8 h + r
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) gq[nt][r] = (_Float16)gate_act_scaled(acc[nt][r], acc[nt][8 + r]);
+        }
         if constexpr (DEFER) {                             // g also goes to HBM: the step's one skip contraction reads it (tskip.h)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -329,17 +406,42 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
                 *(half8 __attribute__((address_space(3)))*)(size_t)a = v[nt];
             }
         };
+        // G6: the consumer (phase 2) reads, per frame and 64-channel group q and lane half h, 32 codes in the order 8 kk + e <-> channel
+        // 64 q + 16 kk + 8 h + e: this wave's 8 channels are (q, kk) = (wave >> 2, wave & 3) of its block, i.e. 6 bytes of that 24-byte string.
+        // A frame's row is 128 B = 4 slots (2 q + h) of two 16-B chunks [kk 0, kk 1 | pad] [kk 2, kk 3 | pad]; chunk c of frame f sits at
+        // c ^ ((f >> 1) & 7), which makes the consumer's 16-byte reads (32 frames x one logical chunk) conflict-free.
+        auto store_block6 = [&](int pos, const v6i_t& r6) {
+            const unsigned bb = s6_base(pos);
+            const unsigned c = 2u * (2u * (unsigned)(wave >> 2) + (unsigned)(lane >> 5)) + (unsigned)((wave >> 1) & 1);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const unsigned lo32 = (nt & 1) ? (((unsigned)r6[3 * (nt >> 1) + 1] >> 16) | ((unsigned)r6[3 * (nt >> 1) + 2] << 16)) : (unsigned)r6[3 * (nt >> 1)];
+                const unsigned hi16 = (nt & 1) ? ((unsigned)r6[3 * (nt >> 1) + 2] >> 16) : ((unsigned)r6[3 * (nt >> 1) + 1] & 0xffffu);
+                const unsigned f = 32u * nt + (unsigned)(lane & 31);
+                const unsigned a = bb + f * 128u + ((c ^ ((f >> 1) & 7u)) << 4);
+                if (wave & 1) {                            // bytes 6 .. 11 of the chunk
+                    *(unsigned short __attribute__((address_space(3)))*)(size_t)(a + 6u) = (unsigned short)(lo32 & 0xffffu);
+                    *(unsigned __attribute__((address_space(3)))*)(size_t)(a + 8u) = (lo32 >> 16) | (hi16 << 16);
+                } else {                                   // bytes 0 .. 5
+                    *(unsigned __attribute__((address_space(3)))*)(size_t)a = lo32;
+                    *(unsigned short __attribute__((address_space(3)))*)(size_t)(a + 4u) = (unsigned short)hi16;
+                }
+            }
+        };
         if (pi == 0) {
             store_block(0, gq);                            // S is disjoint from the time tile: no barrier needed
+            if constexpr (G6) store_block6(0, gq6);
         } else if (!last) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) gmid[nt] = gq[nt];
+            if constexpr (G6) gmid6 = gq6;
         }
         if (last) {
             if (!PF) oepi.init(oe, mt_n, row0, lane, nxt);  // accumulators are dead: the output projection's first init goes out now
             __syncthreads();                               // every wave is done reading the time tile
-            if (NB == 3) store_block(1, gmid);
+            if (NB == 3) { store_block(1, gmid); if constexpr (G6) store_block6(1, gmid6); }
             store_block(NB - 1, gq);
+            if constexpr (G6) store_block6(NB - 1, gq6);
             __syncthreads();                               // g complete
             TL_STAMP(7);
         }
@@ -404,7 +506,6 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
 #pragma unroll
     for (int po = 0; po < NB; ++po) {
         const int mt = tile_of(po);
-        const _Float16* wp = ow + (long long)mt * tile2;
         const bool last = po == NB - 1;
         const int mt_n = last ? 0 : tile_of(po + 1);
         bool nxt_issued = false;
@@ -414,30 +515,62 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             base0 = block_base(pos) + (unsigned)(lane & 31) * 256u;
             xs = xs_g ^ ((unsigned)(kb & 7) << 5);
         };
+        // one group of the output projection.  W6: hi fragments + fp6 w_lo codes against bf6(g / TL_G_X6_SCALE) converted in registers, as in the gate
+        // phase; G6: plus the g_lo correction from the code rows the gate epilogue left in LDS (tl_compute_group_w6<true>)
+        auto group2 = [&](const half8 (&ring)[KG * NW], const v6i_t& lo6, const v6i_t& wg, int g_) {
+            unsigned b0, xs;
+            group_b(g_, b0, xs);
+            if constexpr (W6) {
+                static_assert(!W6 || (KG2 == 4 && NW2 == 2), "one group = 64 g-channels, hi | lo planes packed");
+                const half8 (&hi)[4] = reinterpret_cast<const half8 (&)[4]>(ring);
+                if constexpr (G6) {
+                    int pos = (g_ >> 1) - rot; if (pos < 0) pos += NB;
+                    const unsigned sw = (unsigned)((lane & 31) >> 1) & 7u;
+                    const unsigned sl = 2u * (2u * (unsigned)(g_ & 1) + (unsigned)(lane >> 5));
+                    tl_compute_group_w6<true>(hi, lo6, acc, b0, 32u * 256u, xs, sc_ol6, TL_G_X6_SCALE, TL_G_X6_E8M0, wg,
+                                              s6_base(pos) + (unsigned)(lane & 31) * 128u, (sl ^ sw) << 4, ((sl + 1u) ^ sw) << 4, sc_o6, TL_G6_E8M0);
+                } else {
+                    tl_compute_group_w6<false>(hi, lo6, acc, b0, 32u * 256u, xs, sc_ol6, TL_G_X6_SCALE, TL_G_X6_E8M0, lo6, 0u, 0u, 0u, 0, 0);
+                }
+            } else {
+                tl_compute_group<KG2, NW2>(ring, acc, b0, 32u * 256u, xs);
+            }
+        };
         int g = 0;
         prio_pass(po);
         for (; g + 1 < G2; g += 2) {
             prio_group(g >> 1);
-            tl_load_group<KG2, NW2>(ringB, wp + (long long)(g + 1) * GROUP_HALFS + lane8);
-            if (g == g_issue2 && !last) { oepi.init(oe, mt_n, row0, lane, nxt); nxt_issued = true; }
+            oload(ringB, lo6B, mt, g + 1);
+            if (!G6 && g == g_issue2 && !last) { oepi.init(oe, mt_n, row0, lane, nxt); nxt_issued = true; }
+            // (G6 -- no registers for `nxt` -- with plain loads of the next tiles at this point to warm the L2: 139 instead of 133 us per layer, not kept)
             __builtin_amdgcn_sched_barrier(0);
-            { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG2, NW2>(ringA, acc, b0, 32u * 256u, xs); }
+            group2(ringA, lo6A, wg6, g);
+            oload_g(wg6, mt, g + 1);                        // (single-buffered: the 1.5 KB fragment is re-loaded right after use, a whole group ahead)
             const int gn = g + 2 < G2 ? g + 2 : G2 - 1;
-            tl_load_group<KG2, NW2>(ringA, wp + (long long)gn * GROUP_HALFS + lane8);
+            oload(ringA, lo6A, mt, gn);
             __builtin_amdgcn_sched_barrier(0);
-            { unsigned b0, xs; group_b(g + 1, b0, xs); tl_compute_group<KG2, NW2>(ringB, acc, b0, 32u * 256u, xs); }
+            group2(ringB, lo6B, wg6, g + 1);
+            if (g + 2 < G2) oload_g(wg6, mt, g + 2);
         }
-        if (g < G2) { unsigned b0, xs; group_b(g, b0, xs); tl_compute_group<KG2, NW2>(ringA, acc, b0, 32u * 256u, xs); }
+        if (g < G2) group2(ringA, lo6A, wg6, g);
         TL_STAMP(8 + 2 * po);                              // (8, 10, 12: end of an output pass's main loop; 9, 11, 13: its stores issued)
         if (!last) {
-            tl_load_group<KG2, NW2>(ringA, ow + (long long)mt_n * tile2 + lane8);
-            if (!nxt_issued) oepi.init(oe, mt_n, row0, lane, nxt);
+            oload(ringA, lo6A, mt_n, 0);
+            oload_g(wg6, mt_n, 0);
+            if (!G6 && !nxt_issued) oepi.init(oe, mt_n, row0, lane, nxt);
         }
         oepi.finish(oe, mt, row0, lane, acc);
         TL_STAMP(9 + 2 * po);
         if (!last) {
+            if constexpr (G6) {
+                // G6 has no registers for a second accumulator set beside its code operands (a prefetched `nxt` made the allocator spill whole
+                // accumulator tiles inside the loops: 166 us per layer): the next pass's residual / skip tiles are loaded straight into the
+                // accumulators once this pass's stores are out; the other wave of the SIMD covers the wait
+                oepi.init(oe, mt_n, row0, lane, acc);
+            } else {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = nxt[nt];
+                for (int nt = 0; nt < 4; ++nt) acc[nt] = nxt[nt];
+            }
         }
     }
 #ifdef DSVC_PROFILING
@@ -445,9 +578,9 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
 #endif
 }
 
-inline size_t tlayer_smem(int dil, int cin) {
+inline size_t tlayer_smem(int dil, int cin, bool g6 = false) {
     const size_t x = (((size_t)(TL_TN + 2 * dil) * cin * 2) + 1023) & ~(size_t)1023;
-    return x + TL_BLOCK_BYTES;
+    return x + TL_BLOCK_BYTES + (g6 ? TL_S6_BYTES : 0);
 }
 
 // can this layer shape run fused?  C a multiple of 128 with 2 or 3 channel blocks, the time tile + one g block inside 160 KB, and
@@ -459,7 +592,8 @@ inline bool tlayer_supported(int C, int cin_pad, int dil, int n_rows) {
 template <int NB, int KG, int NW, int PF, int NW2 = NW, int DEFER = 0, int PRIOV = 0, int W6 = 0>
 inline int tlayer_launch_t(const TLayerArgs& ga, const float* cproj, const TEpiResSkip::Args& oe, int n_rows, hipStream_t stream) {
     auto kern = tlayer_kernel<NB, KG, NW, PF, NW2, DEFER, PRIOV, W6>;
-    const size_t smem = tlayer_smem(ga.dil, ga.cin);
+    const size_t smem = tlayer_smem(ga.dil, ga.cin, W6 == 2);
+    if (smem > 160 * 1024) return fail(DSVC_EINVAL, "tlayer: %zu B of LDS requested", smem);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {
         DSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -477,6 +611,11 @@ struct TLayerW6 {
     long long variant_dwords = 0;
     int e6 = 0;
     int n_variants = 1;                  // > 1: resolved in the kernel from *step_ptr
+    const unsigned* out_codes = nullptr; // G6: fp6 codes of the output projection's weights (whole weights, one variant), exponent eo6; null: no g_lo correction
+    int eo6 = 0;
+    const unsigned* out_lo_codes = nullptr;   // fp6 codes of the output projection's w_lo plane (the variant to use, like `codes`), exponent eol6
+    long long out_lo_variant_dwords = 0;
+    int eol6 = 0;
 };
 
 template <int NW, int NW2 = NW>
@@ -502,6 +641,15 @@ inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs
     if constexpr (NW == 2 && NW2 == 2) {
         if (w6 && w6->codes) {                            // hi fragments of g's two planes + fp6 codes: 16 fp16 + 4 six-bit MFMAs per group instead of 32
             a.gw6 = w6->codes; a.g6var = w6->variant_dwords; a.sc6 = (127 + w6->e6) | (TL_X6_E8M0 << 8);
+            if (!w6->out_lo_codes) return fail(DSVC_EINVAL, "tlayer: f16_w6 needs the fp6 codes of both contractions' w_lo planes");
+            a.ow6lo = w6->out_lo_codes; a.o6var = w6->out_lo_variant_dwords; a.sc6b = 127 + w6->eol6;
+            if (w6->out_codes) {                          // + the output projection's g_lo correction
+                a.ow6 = w6->out_codes; a.sc6 |= ((127 + w6->eo6) << 16) | (TL_G6_E8M0 << 24);
+                a.n_variants = w6->n_variants; a.gvar = 0; a.ovar = 0;
+                if (gall) return fail(DSVC_EINVAL, "tlayer: the deferred skip form is not built for f16_w6");
+                if (C == 384) return tlayer_launch_t<3, KG, NW, 0, NW2, 0, 0, 2>(a, cproj, oe, n_rows, stream);
+                return tlayer_launch_t<2, KG, NW, 0, NW2, 0, 0, 2>(a, cproj, oe, n_rows, stream);
+            }
             a.n_variants = w6->n_variants;
             a.gvar = 0; a.ovar = 0;                       // (the dither variants are those of the fp6 plane; n_variants / step_ptr select among them)
             if (gall) return fail(DSVC_EINVAL, "tlayer: the deferred skip form is not built for f16_w6");

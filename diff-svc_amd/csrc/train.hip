@@ -160,9 +160,13 @@ __global__ void k_bct_to_rows(const float* __restrict__ src, float* __restrict__
     }
 }
 
-__global__ void k_clamp_copy(int* __restrict__ dst, const int* __restrict__ src, int lo, int hi, int n) {
+__global__ void k_clamp_copy(int* __restrict__ dst, const int* __restrict__ src, int lo, int hi, int n, int* __restrict__ flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const int v = src[i]; dst[i] = v < lo ? lo : (v > hi ? hi : v); }
+    if (i < n) {
+        const int v = src[i];
+        if ((v < lo || v > hi) && flag) *flag = 1;        // sticky, host-mapped: dsvc_trainer_check reports it (as dsvc_denoiser_check does)
+        dst[i] = v < lo ? lo : (v > hi ? hi : v);
+    }
 }
 
 // x_t = sa[t_b] * norm_spec(mel) + sb[t_b] * noise   (diffusion.py:200-205,286-287); mel [B][T][M] -> frame-major [B*stride][M]
@@ -563,6 +567,7 @@ struct dsvc_trainer {
     int64_t total = 0;
     float* params = nullptr;
     float* grads = nullptr;
+    int* step_err = nullptr;                                        // host-mapped sticky flag: a step saw a diffusion step outside [0, timesteps)
     std::vector<float> h_sa, h_sb;
     DevBuf sa, sb, spec_min, spec_max;
     int n_spec = 0;
@@ -594,6 +599,7 @@ struct dsvc_trainer {
             b->release();
         for (APlanes* a : {&condP, &dyP, &dOP}) a->buf.release();
         wp_call.w.release();
+        if (step_err) (void)hipHostFree(step_err);
         for (auto* v : {&wp_dT, &wp_oT})
             for (auto& p : *v) p.w.release();
         auto rel = [](Packed& p) { p.w.release(); };
@@ -922,7 +928,11 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
     DSVC_HIP(hipMemsetAsync(loss.p, 0, 16, st));
     // ---- inputs ----
     // the diffusion steps index the noise schedule (k_make_xt) and the step embedding: clamped into [0, timesteps) on the way in
-    hipLaunchKernelGGL(k_clamp_copy, dim3(ceil_div(B, 256)), dim3(256), 0, st, tstep.as<int>(), ta->t, 0, cfg.timesteps - 1, B);
+    if (!step_err) {
+        DSVC_HIP(hipHostMalloc(reinterpret_cast<void**>(&step_err), sizeof(int), hipHostMallocMapped));
+        *step_err = 0;
+    }
+    hipLaunchKernelGGL(k_clamp_copy, dim3(ceil_div(B, 256)), dim3(256), 0, st, tstep.as<int>(), ta->t, 0, cfg.timesteps - 1, B, step_err);
     if (ta->clip_ids) DSVC_HIP(hipMemcpyAsync(clipid.p, ta->clip_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     else hipLaunchKernelGGL(k_iota, dim3(ceil_div(B, 256)), dim3(256), 0, st, clipid.as<int>(), ta->first_clip, B);
     hipLaunchKernelGGL(k_make_xt, dim3(ceil_div(T * M / 4, 256), B), dim3(256), 0, st, ta->mel, xt.as<float>(), tstep.as<int>(), sa.as<float>(),
@@ -1187,6 +1197,16 @@ int dsvc_trainer_set_schedule(dsvc_trainer* t, const float* sqrt_ac, const float
     DSVC_HIP(hipMemcpy(t->spec_max.p, spec_max, (size_t)n_spec * 4, hipMemcpyHostToDevice));
     t->n_spec = n_spec;
     t->cfg.timesteps = K;
+    return DSVC_OK;
+}
+
+int dsvc_trainer_check(dsvc_trainer* t, void* stream) {
+    if (!t) return fail(DSVC_EINVAL, "null handle");
+    DSVC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (t->step_err && *t->step_err) {
+        *t->step_err = 0;
+        return fail(DSVC_EINVAL, "a training step was given a diffusion step outside [0, %d): it ran at the clamped step", t->cfg.timesteps);
+    }
     return DSVC_OK;
 }
 

@@ -15,10 +15,14 @@ output 1x1; ``"f16_x3"`` splits the activations as well (3 MFMAs, fp32-class).  
   activations, 3 MFMAs) on the tgemm engine.  The small-batch kernels are bound by the weight stream and by latency, not by MFMAs, so the
   third MFMA costs 14 ... 20 % there (0.418 ms per step for one clip against 0.366 at f16_w2) and buys 3.3e-5 ... 4.9e-5 mel error after 1000
   steps on every real-reference golden instead of 6e-4 ... 9e-4 (round 3; profiles/r3l_auto_sweep.txt, r3l_pytest_gpu.txt).
-* DDPM, larger calls: ``f16_w2`` -- exact weights, fp16 activations, 2 MFMAs; f16_x3t costs 1.5 ... 1.9x there.  The maximum mel error
-  of a 1000-step chain is a heavy-tailed statistic, so the scheme is held to <= 9.0e-4 on EVERY real-reference golden of the batch of
-  32 (worst 8.0e-4; 21 single clips: worst 8.8e-4; conditioned checkpoints 2.3e-4).  The faster f16_m64 (round 2's default) measured
-  1.14e-3 on one clip of that batch and is no longer shipped (profiles/r3_precision_spread.txt).
+* DDPM, larger calls: ``f16_w6`` (round 4) -- f16_w2's operand scheme (exact weights as fp16 hi + w_lo, fp16 activations) with every
+  correction term on the block-scaled 6-bit matrix instruction inside the fused layer kernel (w_lo as time-dithered fp6 codes against
+  bf6(x) converted in registers: 16 fp16 + 4 six-bit MFMAs per 64 input channels instead of 32 fp16 ones), plus a 6-bit correction of the
+  gate output's own fp16 rounding in the output 1x1.  The maximum mel error of a 1000-step chain is a heavy-tailed statistic: on the 31 + n
+  real-reference goldens of two 32-clip batches it is 4.0e-4 ... 5.7e-4 (Gumbel fit: P(a clip > 1e-3) ~ 5e-9), conditioned checkpoints
+  1.3e-4 ... 1.7e-4; f16_w2 itself measures 6.2e-4 ... 9.1e-4 there (P ~ 1e-3 per clip -- one 256-clip job in four holds a clip over the
+  bar on a random-init checkpoint) at 9 % more time per step.  Calls between 6000 frames and the fused kernel's minimum (about 18 clips)
+  run f16_w2 on the two-launch tilings.  ``f16_w6n`` = the same without the gate-output correction: f16_w2's error class, another 6 % faster.
 * PLMS/PNDM, whose Adams-Bashforth extrapolation amplifies a single evaluation's rounding: ``f16_x3t`` (7e-6 on the 50-iteration golden
   at T=861; 26 ms per 10 s clip).  With fp16 activations even exact weights leave that chain at (8.2 +- 1.2)e-4 over ten (clip, noise)
   pairs, one of them at 1.08e-3 (profiles/r2w_precision_spread.txt).
@@ -55,7 +59,7 @@ class _ResidualBlockParams(nn.Module):
 
 
 class DiffNetHip(nn.Module):
-    AUTO = {"ddpm": "f16_x3t", "ddpm_batched": "f16_w2", "plms": "f16_x3t", "plms_coarse": "f16_x3t", "forward": "f16_x3t"}
+    AUTO = {"ddpm": "f16_x3t", "ddpm_batched": "f16_w6", "plms": "f16_x3t", "plms_coarse": "f16_x3t", "forward": "f16_x3t"}
     BATCHED_FRAMES = 6000          # B * T from which a DDPM call takes the batched precision (7 ten-second clips: f16_x3t costs +14 ... 20 % below
                                    # that and +50 ... 90 % above, profiles/r3l_auto_sweep.txt)
 

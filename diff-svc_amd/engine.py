@@ -60,7 +60,7 @@ class DenoiserHandle:
             raise ValueError("diffusion_step must hold one step per clip (%d), got %d" % (B, t32.numel()))
         # the step embedding / FiLM path is TABULATED for the integer steps 0 .. timesteps-1 (net.py:32-44,99-103 evaluated at load).
         # Steps outside the table are clamped ON THE DEVICE and raise a sticky flag (no device-to-host check on this 1000-calls-per-
-        # clip seam): the next forward() -- or check() -- raises.  (The sampler never leaves the range; this guards direct callers.)
+        # clip seam): check() raises (later, valid calls are executed normally).  (The sampler never leaves the range; this guards direct callers.)
         out = torch.empty_like(spec)
         check(lib().dsvc_denoiser_forward(self._h, ptr(spec), ptr(t32), ptr(cond), ptr(out), B, T,
                                           1 if cond_changed else 0, stream_ptr()))

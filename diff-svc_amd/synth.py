@@ -390,6 +390,20 @@ def mel_like(seed, B, T, M, pad_tail=(0,)):
     return mel
 
 
+def cfg0_units(chunk, n):
+    """Stand-in content units of voiced chunk `chunk` of the BASELINE configs[0] golden (oracle/make_golden_cfg0.py: the HuBERT encoder is
+    outside the parity claim there; 50 units per second).  [n, 256] f32."""
+    g = np.random.Generator(np.random.PCG64(1000 + chunk))
+    return (g.standard_normal((n, 256)) * 0.5).astype(np.float32)
+
+
+def cfg0_f0(n, chunk):
+    """Stand-in f0 track (Hz, 0 = unvoiced) of the same golden: the reference extracts it with torchcrepe, which is third-party."""
+    t = np.arange(n)
+    f = 170.0 * 2.0 ** (0.25 * np.sin(t / 37.0 + chunk))
+    return np.where((t + 13 * chunk) % 90 < 78, f, 0.0).astype(np.float32)
+
+
 def speech_like_wav(seed, n, sr=16000):
     """A deterministic voiced-ish test signal in [-1, 1]: gliding harmonics with an amplitude envelope plus a little noise."""
     g = _rng("wav", seed)

@@ -23,6 +23,7 @@ from .cond import CondBuilder
 class TrainerHandle:
     def __init__(self, hp, loss_type="l2", pitch_vocab=300):
         self._h = ctypes.c_void_p(0)
+        self._inflight = None                              # tensors of the step between step_begin() and step_end()
         self.cfg = _lib.TrainerCfg(hp["audio_num_mel_bins"], hp["hidden_size"], hp["residual_channels"], hp["residual_layers"],
                                    hp["dilation_cycle_length"], int(hp.get("timesteps", 1000)), 1 if loss_type == "l1" else 0, pitch_vocab)
         check(lib().dsvc_trainer_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
@@ -34,6 +35,11 @@ class TrainerHandle:
             name, off, n = ctypes.c_char_p(), ctypes.c_int64(0), ctypes.c_int64(0)
             check(lib().dsvc_trainer_param_info(self._h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(n)))
             self.layout.append((name.value.decode(), off.value, n.value))
+
+    def check(self):
+        """Wait for the current stream and raise if a step since the last check was given a diffusion step outside [0, timesteps) (steps are
+        clamped on the device; the reference's extract() would raise an IndexError)."""
+        check(lib().dsvc_trainer_check(self._h, stream_ptr()))
 
     def bind(self, params, grads):
         assert params.is_cuda and grads.is_cuda and params.numel() == self.n_floats == grads.numel()
@@ -77,6 +83,8 @@ class TrainerHandle:
         check(lib().dsvc_trainer_step_layers(self._h, int(l_hi), int(l_lo), stream_ptr()))
 
     def step_end(self, loss_out=None):
+        if self._inflight is None:
+            raise RuntimeError("diffsvc_amd: step_end() without a step in flight (call step_begin first)")
         loss = loss_out if loss_out is not None else torch.empty(1, device=self._inflight[0].device, dtype=torch.float32)
         check(lib().dsvc_trainer_step_end(self._h, ptr(loss), stream_ptr()))
         self._inflight = None

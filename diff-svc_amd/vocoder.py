@@ -120,7 +120,7 @@ class NsfHifiGANHip(BaseVocoder):
         self.seed += 1
         c = torch.FloatTensor(np.asarray(mel)).unsqueeze(0).to(self.device)
         f = torch.FloatTensor(np.asarray(f0)[None, :]).to(self.device)
-        y = self.model.vocode(c, f, seed=kwargs.get("seed", self.seed)).view(-1)
+        y = self.model.vocode(c, f, seed=kwargs.get("seed", self.seed), first_clip=kwargs.get("first_clip", 0)).view(-1)
         return y.cpu().numpy()
 
     @staticmethod
@@ -208,7 +208,7 @@ class HifiGANHip(BaseVocoder):
         self.seed += 1
         c = torch.FloatTensor(np.asarray(mel)).unsqueeze(0).to(self.device)      # natural-log mel, NOT rescaled (hifigan.py:64)
         f = torch.FloatTensor(np.asarray(f0)[None, :]).to(self.device) if with_source else None
-        y = self._handle(with_source).vocode(c, f, seed=kwargs.get("seed", self.seed)).view(-1)
+        y = self._handle(with_source).vocode(c, f, seed=kwargs.get("seed", self.seed), first_clip=kwargs.get("first_clip", 0)).view(-1)
         return y.cpu().numpy()
 
     @staticmethod

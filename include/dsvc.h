@@ -41,12 +41,18 @@ enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM
  *   F16_X3T: the same operand scheme on the tgemm engine (activation rows hold [x_hi | x_lo] planes; the weight stream is F16_W2's):
  *            the fp32-class scheme at the speed class of the small-batch tgemm kernels (3.3e-5 ... 4.9e-5 mel after 1000 steps on 21
  *            goldens, +14 ... 20 % over F16_W2 up to six 10 s clips, 1.5 ... 1.9x beyond).  "auto": DDPM calls under 6000 frames, PLMS, forward().
- *   F16_W6 : F16_W2 whose w_lo * x correction of the dilated conv runs on the block-scaled 6-bit matrix instruction in the fused layer kernel
- *            (round 4): w_lo as time-dithered fp6 (E2M3) codes (weight_variants roundings, one power-of-two scale per conv), x converted to
- *            bf6 (E3M2) in registers -- 16 fp16 + 4 six-bit MFMAs per 64 input channels instead of 32 fp16 ones.  The correction is 2^-12 of
- *            the product, so 4 significant bits carry it: the error class is F16_W2's (fp16 activation rounding).  Batches too small for the
- *            fused layer kernel run F16_W2 itself (the handle keeps the fp16 lo plane as well). */
-enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2, DSVC_PREC_F16_MIX = 3, DSVC_PREC_F16_X3T = 4, DSVC_PREC_F16_W6 = 5 };
+ *   F16_W6 : (round 4) F16_W2 with every correction term on the block-scaled 6-bit matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, 4x the
+ *            fp16 MFMA rate) inside the fused layer kernel.  Per 64 input channels: 16 fp16 MFMAs (w_hi x) + 4 six-bit ones (w_lo as
+ *            time-dithered fp6 E2M3 codes -- weight_variants roundings, one power-of-two scale per conv -- against x converted to bf6 E3M2 in
+ *            registers) instead of 32 fp16 MFMAs, in the dilated conv AND the output 1x1; the output 1x1 additionally adds W6 * g_lo6: the gate
+ *            epilogue keeps bf6((g - fp16(g)) 2^16) beside fp16(g) in LDS, which removes the fp16 rounding of the gate output (57 % of the
+ *            chain's error variance).  A correction term is 2^-12 of its product, so 4 significant bits carry it.  Measured at 32 clips:
+ *            133 instead of 145 us per layer, 4.0e-4 ... 5.7e-4 mel after 1000 steps on 31 real-reference goldens (F16_W2: 6.2e-4 ... 9.1e-4).
+ *            Batches too small for the fused layer kernel run F16_W2 itself (the handle keeps the fp16 lo planes as well).
+ *            "auto": DDPM calls from 6000 frames.
+ *   F16_W6N: F16_W6 without the g_lo correction: F16_W2's error class at 125 us per layer. */
+enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2, DSVC_PREC_F16_MIX = 3, DSVC_PREC_F16_X3T = 4, DSVC_PREC_F16_W6 = 5,
+       DSVC_PREC_F16_W6N = 6 };
 
 int dsvc_abi_version(void);
 const char* dsvc_last_error(void);
@@ -340,6 +346,10 @@ int dsvc_trainer_step(dsvc_trainer* t, const dsvc_train_args* a, float* loss_out
  *                      ([denoise_fn.input_projection.weight .. denoise_fn.mlp.2.bias] and fs2.pitch_embed.weight were the missing slices).
  * dsvc_trainer_step == begin; layers(residual_layers, 0); end.  All three enqueue on `stream` and return. */
 int dsvc_trainer_step_begin(dsvc_trainer* t, const dsvc_train_args* a, void* stream);
+/* Diffusion steps outside [0, timesteps) are clamped on the device (the reference's extract() would raise an IndexError, diffusion.py:22-25,
+ * but a device-to-host check per step is not what a training loop wants): a sticky flag records it, and this call -- which waits for
+ * `stream` -- returns DSVC_EINVAL once and clears it.  Same contract as dsvc_denoiser_check. */
+int dsvc_trainer_check(dsvc_trainer* t, void* stream);
 int dsvc_trainer_step_layers(dsvc_trainer* t, int32_t l_hi, int32_t l_lo, void* stream);
 int dsvc_trainer_step_end(dsvc_trainer* t, float* loss_out, void* stream);
 /* torch.optim.AdamW update of a flat buffer.  The gradient is multiplied by *grad_scale_dev (device, e.g. the clip coefficient)

@@ -1,0 +1,215 @@
+"""Mint tests/golden/infer_cfg0.npz: BASELINE configs[0] -- "infer.py on raw/test_input.wav, 22.05 kHz input, 20-iteration PNDM, PyTorch
+CPU reference path" -- through the REAL reference, wav in -> wav out.  Container-only (needs /root/reference); TEST INFRASTRUCTURE.
+
+    python oracle/make_golden_cfg0.py
+
+What runs, unmodified, from /root/reference (behind oracle/refshim.py's stubs for the third-party packages this image lacks):
+  * infer_tools/slicer.py:40-125       Slicer.slice on the shipped demo input raw/test_input.wav (the chunking of infer.py:37-41)
+  * infer_tools/infer_tool.py:140-201  Svc.infer / Svc.pre / temporary_dict2processed_input / getitem / processed_input2batch / after_infer
+  * network/diff/diffusion.py:227-284  GaussianDiffusion.forward(infer=True): 20 p_sample_plms iterations (acc = pndm_speedup = 50 over the
+                                       1000-step schedule), over network/diff/net.py DiffNet and modules/fastspeech/fs2.py's no_fs2 branch
+  * modules/fastspeech/pe.py:120-148   PitchExtractor(mel_out) -> the f0 the vocoder is driven with (use_pe, config B: infer.py:20)
+  * network/vocoders/hifigan.py:46-81  HifiGAN.__init__ (checkpoint directory as the reference reads it) and spec2wav over
+                                       modules/hifigan/hifigan.py HifiGanGenerator (NSF source)
+The loop around Svc.infer is infer.py:43-67 (run_clip) restated line by line below: run_clip itself cannot run here -- it reads and writes
+audio through librosa / soundfile, which are not installed.
+What is stubbed, and therefore stored as INPUT in the golden instead of being compared: the content units (Hubertencoder: seeded synthetic
+units, 50 per second as HuBERT-soft produces), the f0 track (torchcrepe: a synthetic contour with unvoiced gaps), and PWG.wav2spec
+(librosa.stft / librosa.filters.mel: the oracle's restatement; resampling 22.05 -> 24 kHz by scipy's polyphase filter).  The sampler's and
+the NSF source's random draws are the Philox streams of oracle/dsvc_oracle.py, as in every other golden.
+Config B (SURVEY.md 8(d) Cfg 1): M = 80, C = 256, L = 20, hop 128, 24 kHz; synthetic conditioned acoustic checkpoint (the PLMS probes'
+kind: eps tracks its input, so the unclamped PNDM chain contracts), synthetic PitchExtractor and HifiGAN checkpoints, all written in the
+reference's own checkpoint formats and loaded by its own loaders.
+"""
+import io
+import json
+import os
+import sys
+import tempfile
+import wave
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+work = tempfile.mkdtemp(prefix="dsvc_cfg0_")
+os.makedirs(os.path.join(work, "infer_tools"))             # infer_tool.py:52 opens ./infer_tools/f0_temp.json relative to the CWD
+os.chdir(work)
+
+import refshim  # noqa: E402
+
+refshim.install()
+import infer_tools.infer_tool as IT  # noqa: E402
+from infer_tools.slicer import Slicer  # noqa: E402
+
+import diffsvc_amd  # noqa: E402,F401
+from diffsvc_amd import synth  # noqa: E402
+import dsvc_oracle as O  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+KEY, ACC, SEED = 2, 50, 11                                 # key shift in semitones, pndm_speedup (=> 20 iterations), Philox seed
+COND = (1.35, 0.05)                                        # synth.acoustic_state_conditioned(lam, rho)
+WSEED, PESEED, VSEED = 2, 5, 4
+
+# ---- no device in the container: .cuda() / .to('cuda') are the identity (the reference hard-codes them, infer_tool.py:155-160) ----
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+units_of, f0_track = synth.cfg0_units, synth.cfg0_f0        # the stand-in inputs live with the other synthetic fixtures (tests regenerate them)
+
+
+def main():
+    hp = dict(synth.HPARAMS_24K, wav2spec_eps=1e-6, loud_norm=False, use_nsf=True, vocoder="network.vocoders.hifigan.HifiGAN",
+              vocoder_ckpt=os.path.join(work, "hifigan"), pe_ckpt=os.path.join(work, "pe", "model_ckpt_steps_100.ckpt"), max_frames=42000,
+              max_input_tokens=60000, debug=False, profile_infer=False, hubert_gpu=False,
+              binarization_args=dict(with_f0=True, with_hubert=True, with_align=True))
+    refshim.set_hparams(hp)
+    from utils.hparams import hparams as ref_hp
+    import utils as ref_utils
+    from network.diff.diffusion import GaussianDiffusion
+    from network.diff.net import DiffNet
+    from modules.fastspeech.pe import PitchExtractor
+    from network.vocoders.hifigan import HifiGAN
+    from network.vocoders.pwg import PWG
+    import scipy.signal
+
+    # ---- checkpoints in the reference's formats, loaded by the reference's loaders ----
+    sd = synth.acoustic_state_conditioned(hp, WSEED, *COND)
+    ckpt = os.path.join(work, "model_ckpt_steps_100.ckpt")
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "global_step": 0, "epoch": 0}, ckpt)
+    os.makedirs(os.path.dirname(hp["pe_ckpt"]))
+    torch.save({"state_dict": {"model." + k: v for k, v in synth.pe_state(hp, PESEED).items()}}, hp["pe_ckpt"])
+    synth.save_hifigan_ckpt(hp["vocoder_ckpt"], dict(synth.VOCODER_24K), VSEED)
+
+    svc = IT.Svc.__new__(IT.Svc)                           # Svc.__init__ needs a YAML on disk, a HuBERT checkpoint and a GPU: built by hand, same attributes
+    svc.project_name = "demo"
+    svc.mel_bins = ref_hp["audio_num_mel_bins"]
+    svc.model = GaussianDiffusion(phone_encoder=None, out_dims=svc.mel_bins, denoise_fn=DiffNet(svc.mel_bins), timesteps=ref_hp["timesteps"],
+                                  K_step=ref_hp["K_step"], loss_type=ref_hp["diff_loss_type"], spec_min=ref_hp["spec_min"], spec_max=ref_hp["spec_max"])
+    svc.model_path = ckpt
+    svc.load_ckpt()                                        # utils.load_ckpt(strict=True)
+    svc.model.eval()
+    svc.pe = PitchExtractor()
+    ref_utils.load_ckpt(svc.pe, ref_hp["pe_ckpt"], "model", strict=True)
+    svc.pe.eval()
+    svc.vocoder = HifiGAN()                                # network/vocoders/hifigan.py:46-56
+    svc.vocoder.device = torch.device("cpu")
+
+    # ---- stubs: content units, f0, the librosa front-end ----
+    state = {"chunk": 0, "mel_in": None, "wav24": None}
+
+    class Units:
+        def encode(self, wav_fn):
+            return units_of(state["chunk"], max(2, int(round(len(state["wav24"]) / 24000 * 50))))
+
+    svc.hubert = Units()
+    IT.get_pitch_crepe = lambda wav_, mel_, hp_, thre: (f0_track(len(mel_), state["chunk"]), np.ones(len(mel_), np.int64))
+
+    def wav2spec(wav_fn, return_linear=False):
+        wav_fn.seek(0)
+        with wave.open(wav_fn, "rb") as w:
+            sr, pcm = w.getframerate(), np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+        wav24 = scipy.signal.resample_poly(pcm.astype(np.float64), 24000 // np.gcd(24000, sr), sr // np.gcd(24000, sr)).astype(np.float32)
+        mel = O.process_utterance_mel(torch.from_numpy(wav24)[None], 24000, 512, 512, 128, 80, 30, 12000, eps=1e-6)[0].numpy()
+        state["mel_in"], state["wav24"] = mel, wav24
+        return wav24, mel
+
+    PWG.wav2spec = staticmethod(wav2spec)
+
+    # ---- random draws -> Philox ----
+    import network.diff.diffusion as D
+    orig_randn, orig_rand, orig_randn_like = torch.randn, torch.rand, torch.randn_like
+    rng = {}
+
+    def randn(*shape, **kw):                               # diffusion.py:262: x = torch.randn(shape) -- the chain's start
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
+        assert len(shape) == 4 and shape[:3] == (1, 1, 80), shape
+        return O.ddpm_noise_ref_layout(SEED, [state["chunk"]], 0, shape[3], 80, O.PURPOSE_X_INIT)
+
+    def rand(*shape, **kw):                                # NSF source: initial phases (modules/hifigan/hifigan.py SineGen)
+        return rng["ini"].clone()
+
+    def randn_like(x, **kw):                               # NSF source: additive noise
+        return rng["nz"].clone() if x.shape[-1] == rng["nz"].shape[-1] else torch.zeros_like(x)
+
+    # ---- the input file and its chunks (infer.py:30-41; slicer.cut's defaults: infer_tools/slicer.py:128-142) ----
+    with wave.open(os.path.join(refshim.REF_ROOT, "raw", "test_input.wav"), "rb") as w:
+        in_sr, raw = w.getframerate(), np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    audio = raw.astype(np.float32) / 32768.0               # what librosa.load(sr=None) returns for 16-bit PCM
+    chunks = Slicer(sr=in_sr, db_threshold=-40, min_length=5000, win_l=300, win_s=20, max_silence_kept=500).slice(audio)
+    out = {"key": KEY, "acc": ACC, "seed": SEED, "cond": np.array(COND), "wseed": WSEED, "peseed": PESEED, "vseed": VSEED, "in_sr": in_sr}
+    table, f0_tst, f0_pred_all, audio_out = [], [], [], []
+    hop, sr_out = ref_hp["hop_size"], ref_hp["audio_sample_rate"]
+    for k, v in chunks.items():                            # infer.py:43-67
+        tag = v["slice"]
+        s, e = (int(x) for x in v["split_time"].split(","))
+        if s == e:
+            continue
+        data = audio[s:e]
+        length = int(np.ceil(len(data) / in_sr * sr_out))
+        c = len(table)
+        state["chunk"] = c
+        if tag:
+            _f0_tst, _f0_pred, _audio = (np.zeros(int(np.ceil(length / hop))), np.zeros(int(np.ceil(length / hop))), np.zeros(length))
+            table.append((c, 1, s, e, length, 0))
+        else:
+            buf = io.BytesIO()                             # soundfile.write(raw_path, data, audio_sr, format="wav") (PCM_16)
+            with wave.open(buf, "wb") as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(in_sr)
+                w.writeframes(np.clip(np.rint(data * 32767.0), -32768, 32767).astype("<i2").tobytes())
+            buf.seek(0)
+            T = None
+            torch.randn, torch.rand, torch.randn_like = randn, rand, randn_like
+            try:
+                # the vocoder's draws depend on the mel length, known only inside: bind them lazily through after_infer's call
+                orig_spec2wav = svc.vocoder.spec2wav
+
+                def spec2wav(mel, **kw):
+                    n = mel.shape[0] * hop
+                    rng["ini"], rng["nz"] = O.vocoder_rng(SEED, [c], n)
+                    return orig_spec2wav(mel, **kw)
+
+                svc.vocoder.spec2wav = spec2wav
+                _f0_tst, _f0_pred, _audio = svc.infer(buf, key=KEY, acc=ACC, use_pe=True, use_crepe=True, thre=0.05, use_gt_mel=False, add_noise_step=500)
+                svc.vocoder.spec2wav = orig_spec2wav
+            finally:
+                torch.randn, torch.rand, torch.randn_like = orig_randn, orig_rand, orig_randn_like
+            T = state["mel_in"].shape[0]
+            table.append((c, 0, s, e, length, T))
+            out["c%d/mel_in" % c] = state["mel_in"]
+            out["c%d/f0_pred" % c] = np.asarray(_f0_pred, np.float32)
+            out["c%d/f0_gt" % c] = np.asarray(_f0_tst, np.float32)
+            out["c%d/wav" % c] = np.asarray(_audio, np.float32)
+            out["c%d/mel_out" % c] = last["mel_out"]
+            out["c%d/n_units" % c] = max(2, int(round(len(state["wav24"]) / 24000 * 50)))
+            print("chunk %d: %.2f s voiced, T = %d, mel range %.2f..%.2f, wav rms %.4f" % (c, len(data) / in_sr, T, last["mel_out"].min(),
+                                                                                             last["mel_out"].max(), float(np.sqrt(np.mean(np.square(_audio))))), flush=True)
+        fix_audio = np.zeros(length)
+        fix_audio[:] = np.mean(_audio)
+        fix_audio[:len(_audio)] = _audio[0 if len(_audio) < len(fix_audio) else len(_audio) - len(fix_audio):]
+        f0_tst.extend(_f0_tst); f0_pred_all.extend(_f0_pred); audio_out.extend(list(fix_audio))
+    out["chunks"] = np.array(table, dtype=np.int64)        # (index, silent, start, end, output samples, mel frames)
+    out["audio_len"] = len(audio_out)
+    pcm16 = np.clip(np.rint(np.asarray(audio_out) * 32767.0), -32768, 32767).astype(np.int16)     # soundfile.write(..., 'PCM_16'), infer.py:70
+    out["audio_pcm16_crc"] = np.int64(int(np.bitwise_xor.reduce(pcm16.astype(np.int64) * (np.arange(len(pcm16)) % 65521 + 1))))
+    out["audio_rms"] = float(np.sqrt(np.mean(np.square(np.asarray(audio_out)))))
+    np.savez_compressed(os.path.join(OUT, "infer_cfg0.npz"), **out)
+    print("infer_cfg0: %d chunks (%d voiced), %d output samples at %d Hz, rms %.4f" % (len(table), sum(1 for t in table if not t[1]), len(audio_out), sr_out, out["audio_rms"]))
+
+
+# the real after_infer hands the clipped mel to the vocoder and returns only (f0_gt, f0_pred, wav): keep the unclipped sampler output too
+last = {}
+_orig_after = IT.Svc.after_infer
+
+
+def _after(self, prediction, singer, in_path):
+    last["mel_out"] = np.asarray(prediction["outputs"].cpu().numpy() if hasattr(prediction["outputs"], "cpu") else prediction["outputs"])[0].copy()
+    return _orig_after(self, prediction, singer, in_path)
+
+
+IT.Svc.after_infer = _after
+
+if __name__ == "__main__":
+    main()
