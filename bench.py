@@ -34,7 +34,12 @@ N_UNITS = 500
 FLOP_PER_FRAME_DILATED = 2 * 384 * 768 * 3        # the k=3 dilated conv of one residual layer
 FLOP_PER_FRAME_OUTPROJ = 2 * 384 * 768            # ... and its 1x1 output projection (residual + skip halves)
 PEAK_TFLOPS_F16 = 2500.0                           # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
-FAST_SIDE = "f16_m64"                              # the faster operand scheme reported beside the shipped one (see `faster_scheme`)
+FAST_SIDE = "f16_w6n"                              # the faster operand scheme reported beside the shipped one (see `faster_scheme`)
+# Per-clip maximum mel error of the shipped batched precision (f16_w6) over the 64 real-reference goldens of two 32-clip batches
+# (tests/test_gpu_headline.py::test_batch_of_32_full_chain_every_clip_with_a_golden[random|random2-shipped], profiles/r4*_b32_goldens.txt):
+# Gumbel fit (mu, beta) of the 64 maxima -> P(a clip exceeds the 1e-3 bar) and P(a 256-clip job holds such a clip)
+B32_ERROR_FIT = {"precision": "f16_w6", "clips": 64, "worst": 5.97e-4, "gumbel_mu": 4.67e-4, "gumbel_beta": 3.3e-5,
+                 "source": "profiles/r4_b32_goldens.txt"}
 PEAK_HBM_GBS = 8000.0                              # HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
 # algorithmic HBM bytes per frame of one residual layer, C = 384, fp16 operands / fp32 residual + skip + cproj:
 #   gate kernel alone : xh in 768*(1 + 2d/128 averaged over d = 1,2,4,8 -> 1.06) + cproj 3072 + g out 768
@@ -74,9 +79,12 @@ def dominant_kernel_roofline(handle, B, precision):
                                      + (2 if precision in ("f16_w2", "f16_x3t") else 1) * WEIGHT_BYTES_GATE}
         tfile = {1: "gate_traffic.json", 32: "gate_traffic_b32.json"}.get(B)
     else:
-        out_planes = 2 if (precision.startswith("f16_m") or precision == "f16_w2") else 1
-        gate_planes = 2 if precision == "f16_w2" else 1
-        nbytes = BYTES_PER_FRAME_LAYER * frames + gate_planes * WEIGHT_BYTES_GATE + out_planes * WEIGHT_BYTES_OUT
+        w6 = precision in ("f16_w6", "f16_w6n")
+        # f16_w6: one fp16 plane + the w_lo plane as 6-bit codes (0.375 of a plane) per contraction; the g_lo correction streams the output
+        # projection's weights once more as codes
+        out_planes = (1.375 + (0.375 if precision == "f16_w6" else 0.0)) if w6 else (2 if (precision.startswith("f16_m") or precision == "f16_w2") else 1)
+        gate_planes = 1.375 if w6 else (2 if precision == "f16_w2" else 1)
+        nbytes = int(BYTES_PER_FRAME_LAYER * frames + gate_planes * WEIGHT_BYTES_GATE + out_planes * WEIGHT_BYTES_OUT)
         ach = nbytes / (us * 1e-6) / 1e9
         tf = (FLOP_PER_FRAME_DILATED + FLOP_PER_FRAME_OUTPROJ) * frames / (us * 1e-6) / 1e12
         roof = {"bound": "hbm", "kernel": "tlayer_kernel (one residual layer in one launch: dilated conv + cond projection + gate -> g in LDS -> "
@@ -87,7 +95,9 @@ def dominant_kernel_roofline(handle, B, precision):
         tfile = {32: "layer_traffic_b32.json"}.get(B)
     # `achieved` / `mfma_tflops` count ALGORITHMIC flops (one multiply-add per product); the split-operand schemes issue 2 (hi + lo weights) or 3
     # (+ split activations) MFMAs per product, so the matrix pipe itself is that many times busier
-    mpp = 3 if precision in ("f16_x3t", "f16_x3") else (2 if precision == "f16_w2" else 1)
+    # (f16_w6: a 6-bit K = 64 MFMA takes a quarter of the four fp16 MFMAs it replaces -- 1.25 units per product, 1.5 in the output 1x1 with the
+    #  g_lo correction: 1.3125 over a layer's flops)
+    mpp = 3 if precision in ("f16_x3t", "f16_x3") else (2 if precision == "f16_w2" else (1.3125 if precision == "f16_w6" else (1.25 if precision == "f16_w6n" else 1)))
     alg_tf = roof["achieved"] if roof["bound"] == "mfma" else roof["mfma_tflops"]
     roof["mfma_per_product"] = mpp
     roof["pipe_tflops"] = alg_tf * mpp
@@ -243,9 +253,10 @@ def main():
     ap.add_argument("--speedup", type=int, default=1, help="pndm_speedup (>1 = PLMS); the headline config is 1")
     ap.add_argument("--precision", default="auto",
                     help="auto (default: what DiffNetHip.precision_for picks by sampler and call size -- f16_x3t, fp32-class, for DDPM under 6000 "
-                         "frames, PLMS and forward(); f16_w2 for batched DDPM: the precisions tests/test_gpu_headline.py holds to <= 9.0e-4 of the "
+                         "frames, PLMS and forward(); f16_w6 for batched DDPM: the precisions tests/test_gpu_headline.py holds to <= 9.0e-4 of the "
                          "1e-3 mel bar on every real-reference golden of the benchmarked sizes), f16_x3t (hi+lo weights and split activations on "
-                         "the tgemm engine), f16_w2 (exact hi+lo weights, fp16 activations), f16_mN / f16_dN (N time-dithered single-plane weight "
+                         "the tgemm engine), f16_w6 (hi + 6-bit lo weight products, 6-bit correction of the gate output; f16_w6n without it), "
+                         "f16_w2 (exact hi+lo weights, fp16 activations), f16_mN / f16_dN (N time-dithered single-plane weight "
                          "roundings; m: exact output 1x1), f16_x3 (the split scheme on the older conv_gemm engine), f16")
     ap.add_argument("--pcm16", action="store_true",
                     help="gather the PCM as the 16-bit integers the reference writes (infer.py:70) instead of fp32: half the bytes on xGMI")
@@ -442,6 +453,11 @@ def main():
             result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
                                  "clips_per_gpu": Bb, "precision": precb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
                                  "s_per_batch": tb, "roofline": broof}
+            if precb == B32_ERROR_FIT["precision"]:
+                import math
+                p1 = 1.0 - math.exp(-math.exp(-(1e-3 - B32_ERROR_FIT["gumbel_mu"]) / B32_ERROR_FIT["gumbel_beta"]))
+                result["batched"]["mel_error_vs_reference"] = dict(B32_ERROR_FIT, bar=1e-3, p_clip_over_bar=p1,
+                                                                   p_over_bar_per_256_clips=1.0 - (1.0 - p1) ** 256)
             # the sustained MFMA rate again, on the chip as the batched run leaves it (hot, clocks settled)
             sustained["after_batched"] = probe_mfma()
             sustained.update(operands="random fp16, register-resident v_mfma_f32_32x32x16_f16 loop, 2 waves/SIMD, every CU",
@@ -455,19 +471,21 @@ def main():
                 if r_["bound"] == "hbm":
                     r_["frac_of_stream_copy"] = r_["achieved"] / 6290.0               # against the 6.29 TB/s a float4 copy reaches (MI355X_MICROARCH.md)
             if FAST_SIDE and precb != FAST_SIDE:
-                # the faster operand schemes beside the shipped ones: f16_w2 for the single clip (auto runs it at the fp32-class
-                # f16_x3t), f16_m64 for both (not held to the <= 9.0e-4 bar on every golden: 1.14e-3 on one clip of the batch of 32)
+                # other operand schemes beside the shipped ones: f16_w2 -- round 3's batched default, and what a single clip runs
+                # at when the fp32-class f16_x3t is not asked for -- and f16_w6n (f16_w6 without the gate-output correction: f16_w2's error class)
                 fs = {"unit": "audio-sec/wall-sec"}
-                for scheme, with_batch in (("f16_w2", False), (FAST_SIDE, True)):
+                for scheme, with_single, with_batch in (("f16_w2", True, True), (FAST_SIDE, False, True)):
                     if scheme == prec:
                         continue
                     try:
                         pf = SvcPipeline(hp, sd, vs, h, precision=scheme, vocoder_precision="f16_x3")
-                        pf.infer(hub, m2p, f0, seed=3, clip_ids=clip_ids)
-                        torch.cuda.synchronize(); t1 = time.perf_counter()
-                        pf.infer(hub, m2p, f0, seed=4, clip_ids=clip_ids)
-                        torch.cuda.synchronize(); t1 = time.perf_counter() - t1
-                        fs[scheme] = {"value": CLIP_SECONDS / t1}
+                        fs[scheme] = {}
+                        if with_single:
+                            pf.infer(hub, m2p, f0, seed=3, clip_ids=clip_ids)
+                            torch.cuda.synchronize(); t1 = time.perf_counter()
+                            pf.infer(hub, m2p, f0, seed=4, clip_ids=clip_ids)
+                            torch.cuda.synchronize(); t1 = time.perf_counter() - t1
+                            fs[scheme]["value"] = CLIP_SECONDS / t1
                         if with_batch:
                             pf.model.hp = dict(hp, K_step=30); pf.model.K_step = 30
                             pf.infer(hb, mb, fb, seed=1)
@@ -479,8 +497,9 @@ def main():
                         del pf
                     except Exception as ex:
                         fs[scheme] = {"error": repr(ex)[:200]}
-                fs["note"] = ("not the shipped precisions: f16_w2 is what batches run at (<= 9.0e-4 on every golden) but a single clip gets the "
-                              "fp32-class f16_x3t; f16_m64 is over the 9.0e-4 ship bar on some real-reference goldens")
+                fs["note"] = ("not the shipped precisions: f16_w2 (round 3's batched default: 6.2e-4 ... 9.1e-4 on the goldens, one 256-clip job in four "
+                              "holds a clip over 1e-3 on the random-init probe) and f16_w6n (the shipped f16_w6 without the 6-bit correction of the gate "
+                              "output: f16_w2's error class); a single clip gets the fp32-class f16_x3t")
                 result["faster_scheme"] = fs
         if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched:
             # the stages either side of the sampler, one 10 s clip each (informational; `value` above is cond -> PCM on the device)

@@ -14,7 +14,7 @@ PREC_F16_X3T = 4
 PREC_F16_W6 = 5
 PREC_F16_W6N = 6
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3, "f16_x3t": PREC_F16_X3T}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def parse_precision(p):

@@ -80,6 +80,7 @@ class CondBuilder(nn.Module):
         nn.init.constant_(self.pitch_embed.weight[self.padding_idx], 0)
         self._extras = {}          # checkpointed-but-unused fs2.* tensors (mel_out, pitch_predictor, ...)
         self._thr_dev = None       # (device, thresholds) of the device pitch path
+        self._oob = None           # sticky device flag: a device-path call saw mel2ph outside [0, N] (check_alignment)
 
     # accept (and round-trip) the fs2.* tensors of the branches that are disabled by no_fs2 / use_pe=False
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
@@ -95,6 +96,15 @@ class CondBuilder(nn.Module):
         super()._save_to_state_dict(destination, prefix, keep_vars)
         for k, v in self._extras.items():
             destination[prefix + k] = v
+
+    def check_alignment(self):
+        """Raise IndexError if any device-path call since the last check was given a mel2ph entry outside [0, number of content units] -- what
+        torch.gather raises immediately in the reference (fs2.py:100-102); here such frames silently got zero content.  Synchronises."""
+        if self._oob is not None:
+            bad, self._oob = bool(self._oob.item()), None
+            if bad:
+                raise IndexError("diffsvc_amd: mel2ph holds an index outside [0, hubert frames] (the reference's torch.gather raises here); "
+                                 "those frames were built from the zero pad row")
 
     def _pitch_device(self, f0, mel2ph, uv):
         """f0_denorm and the coarse bin on the device (csrc/cond.hip): no host round trip, no synchronisation."""
@@ -136,6 +146,10 @@ class CondBuilder(nn.Module):
         coarse = torch.empty(B, T, device=dev, dtype=torch.int64)
         check(lib().dsvc_cond_build(ptr(hub), ptr(m2p), ptr(x), ptr(uv_t) if uv_t is not None else ctypes.c_void_p(0), ptr(thr), thr.numel(),
                                     ptr(emb), B, N, T, H, ptr(dec), ptr(cond), ptr(f0_denorm), ptr(coarse), stream_ptr()))
+        # the reference's torch.gather (fs2.py:100-102) raises on an alignment index outside [0, N]; the kernel reads the zero pad row instead
+        # (memory-safe).  A sticky DEVICE flag keeps the difference visible without a synchronisation on this path: check_alignment() reports it.
+        oob = ((m2p < 0) | (m2p > N)).any()
+        self._oob = oob if self._oob is None or self._oob.device != dev else (self._oob | oob)
         if x is not f0:
             f0.copy_(x)                                                        # the reference mutates its argument (fs2.py:231)
         return dec, cond, f0_denorm, coarse
@@ -175,8 +189,10 @@ class CondBuilder(nn.Module):
         dev = hubert.device
         if hp.get("pitch_norm", "log") != "log":
             raise NotImplementedError("pitch_norm must be 'log'")
-        if hubert.is_cuda:                                   # (no autograd through it: the drop-ins are inference modules, the trainer
-            dec, cond, f0_denorm, coarse = self._build_device(hubert, mel2ph, f0, uv)      # differentiates the embedding by hand)
+        if hubert.is_cuda:
+            # NOT differentiable: the tensors below carry no autograd graph even with grad enabled (the drop-ins are inference modules; the
+            # training branch, GaussianDiffusionHip.forward(infer=False), gets d pitch_embed from dsvc_trainer_step, not from a graph over this)
+            dec, cond, f0_denorm, coarse = self._build_device(hubert, mel2ph, f0, uv)
             ret.update(f0_denorm=f0_denorm, pitch_pred=coarse.unsqueeze(-1), decoder_inp=dec, cond_bht=cond)
             return ret
         padded = F.pad(hubert, [0, 0, 1, 0])

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/dsvc.h"
+#include "../../include/dsvc_debug.h"
 #include "diffnet_t.h"
 #include "tlayer.h"
 #include "tskip.h"

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/dsvc.h"
+#include "../../include/dsvc_debug.h"
 #include "common.h"
 
 using namespace dsvc;

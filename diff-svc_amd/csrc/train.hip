@@ -160,6 +160,19 @@ __global__ void k_bct_to_rows(const float* __restrict__ src, float* __restrict__
     }
 }
 
+// Zero the rows of a [slabs][rows][ld] fp32 buffer that the step never writes: the gap rows t in [T, Tp) of every clip (the convs' zero padding and
+// the separation between clips) and the tail rows [B * Tp, rows).  After a change of (B, T) they hold the previous layout's activations; every
+// other row is rewritten by the step itself, so this replaces a memset of the whole workspace (1.9 GB at the 64 x 128 batch: a max_tokens loader,
+// training/task/tts.py:60-88, changes the shape every step).  One thread per float4; ld % 4 == 0.
+__global__ void k_zero_gap_rows(float* __restrict__ buf, long long slab_floats, int ld, int B, int Tp, int T, int rows) {
+    const int gap = Tp - T, n_gap = B * gap, n_rows = n_gap + (rows - B * Tp), q_per_row = ld >> 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n_rows * q_per_row) return;
+    const int ri = (int)(i / q_per_row), q = (int)(i - (long long)ri * q_per_row);
+    const int row = ri < n_gap ? (ri / gap) * Tp + T + ri % gap : B * Tp + (ri - n_gap);
+    reinterpret_cast<float4*>(buf + (size_t)blockIdx.y * slab_floats + (size_t)row * ld)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __global__ void k_clamp_copy(int* __restrict__ dst, const int* __restrict__ src, int lo, int hi, int n, int* __restrict__ flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -787,8 +800,20 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     rows = round_up(nr, 128);                   // the contraction length of the weight-gradient GEMMs: a multiple of the staged chunk
     const size_t r = (size_t)rows;
     auto z = [&](DevBuf& b, size_t bytes) -> int { DSVC_TRY(b.alloc(bytes)); DSVC_HIP(hipMemsetAsync(b.p, 0, bytes, st)); return DSVC_OK; };
-    DSVC_TRY(z(xt, r * M * 4)); DSVC_TRY(z(xs, r * C * 4 * (L + 1))); DSVC_TRY(z(sig, r * C * 4 * L)); DSVC_TRY(z(tau, r * C * 4 * L));
-    DSVC_TRY(z(g, r * C * 4 * L)); DSVC_TRY(z(skip, r * C * 4)); DSVC_TRY(z(ypre, r * (size_t)L * round_up(2 * C, 128) * 4)); DSVC_TRY(z(s2pre, r * C * 4));
+    // the five per-layer activation stores are 95 % of the workspace: when their allocation is re-used under a new (B, T), only the rows the
+    // step itself never writes are zeroed (k_zero_gap_rows); a fresh allocation is cleared whole
+    auto zg = [&](DevBuf& b, int ld, int slabs) -> int {
+        const size_t bytes = r * (size_t)ld * 4 * slabs;
+        const bool reused = b.p && bytes <= b.bytes;
+        DSVC_TRY(b.alloc(bytes));
+        if (!reused) { DSVC_HIP(hipMemsetAsync(b.p, 0, bytes, st)); return DSVC_OK; }
+        const long long quads = (long long)(B * (Tp - T) + (rows - nr)) * (ld / 4);
+        if (quads > 0) hipLaunchKernelGGL(k_zero_gap_rows, dim3((unsigned)ceil_div((int)quads, 256), slabs), dim3(256), 0, st, b.as<float>(), (long long)r * ld, ld, B, Tp, T, rows);
+        DSVC_HIP(hipGetLastError());
+        return DSVC_OK;
+    };
+    DSVC_TRY(z(xt, r * M * 4)); DSVC_TRY(zg(xs, C, L + 1)); DSVC_TRY(zg(sig, C, L)); DSVC_TRY(zg(tau, C, L));
+    DSVC_TRY(zg(g, C, L)); DSVC_TRY(z(skip, r * C * 4)); DSVC_TRY(zg(ypre, round_up(2 * C, 128), L)); DSVC_TRY(z(s2pre, r * C * 4));
     DSVC_TRY(z(eps, r * M * 4)); DSVC_TRY(z(deps, r * M * 4)); DSVC_TRY(z(condT, r * H * 4));
     DSVC_TRY(z(tstep, (size_t)B * 4)); DSVC_TRY(z(clipid, (size_t)B * 4)); DSVC_TRY(z(iotaB, (size_t)B * 4));
     DSVC_TRY(z(e0, (size_t)B * C * 4)); DSVC_TRY(z(e1pre, (size_t)B * 4 * C * 4)); DSVC_TRY(z(e1, (size_t)B * 4 * C * 4)); DSVC_TRY(z(e2, (size_t)B * C * 4));

@@ -42,7 +42,10 @@ def _cosine_beta_schedule(timesteps, s=0.008):
 
 class _DiffLoss(torch.autograd.Function):
     """p_losses (diffusion.py:207-225) with its backward pass: forward gathers the module's parameters into the trainer's flat buffer and runs
-    dsvc_trainer_step (loss AND gradients in one pass over the kernels); backward hands the stored gradients out, scaled by the incoming one."""
+    dsvc_trainer_step (loss AND gradients in one pass over the kernels); backward hands the stored gradients out, scaled by the incoming one.
+    NOTE: the gradients returned by backward are views of ONE flat buffer (128 MB at the 44.1 kHz architecture): after ``loss.backward()`` the
+    ``.grad`` of the denoiser's parameters may share that storage (AccumulateGrad adopts the incoming tensor when ``.grad`` is None).  Harmless
+    for torch.optim and clip_grad_norm_, which treat every ``.grad`` independently; clone before mutating one ``.grad`` through another's base."""
 
     @staticmethod
     def forward(ctx, owner, step_args, *params):
@@ -101,10 +104,13 @@ class GaussianDiffusionHip(nn.Module):
         self.register_buffer("spec_max", torch.FloatTensor(spec_max)[None, None, :kb])
         self._samplers = {}            # 'ddpm' / 'plms' -> (SamplerHandle, key): the two loops may run at different precisions
         self._train = None             # (TrainerHandle, flat params, flat grads, schedule key): the infer=False branch
+        self._train_params = None      # (that handle, the module's parameters in its flat layout's order)
 
     def _trainer(self, device):
         from .train import TrainerHandle
         key = tuple((b.data_ptr(), b._version) for b in (self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, self.spec_min, self.spec_max))
+        key += (self.loss_type,) + tuple(self.hp.get(k) for k in ("residual_layers", "residual_channels", "dilation_cycle_length", "hidden_size",
+                                                                  "audio_num_mel_bins", "timesteps"))      # a changed loss / architecture rebuilds it
         if self._train is None or self._train[3] != key or self._train[1].device != device:
             h = TrainerHandle(self.hp, self.loss_type, self.fs2.pitch_embed.weight.shape[0])
             flat_p = torch.zeros(h.n_floats, device=device, dtype=torch.float32)
@@ -124,9 +130,11 @@ class GaussianDiffusionHip(nn.Module):
             t = torch.randint(0, self.K_step, (B,), device=ref_mels.device)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        named = dict(self.named_parameters())
         h = self._trainer(ref_mels.device)[0]
-        params = [named[name] for name, _, _ in h.layout]
+        if self._train_params is None or self._train_params[0] is not h:      # the ordered parameter list lives and dies with the trainer handle
+            named = dict(self.named_parameters())
+            self._train_params = (h, [named[name] for name, _, _ in h.layout])
+        params = self._train_params[1]
         cond = ret["decoder_inp"].detach().transpose(1, 2).contiguous()
         pitch = ret["pitch_pred"].detach().squeeze(-1) if "pitch_pred" in ret else None
         return _DiffLoss.apply(self, (ref_mels.detach(), cond, t, pitch, mel2ph, seed), *params)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DSVC_ABI_VERSION 6
+#define DSVC_ABI_VERSION 7
 
 enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM = 4 };
 
@@ -56,12 +56,6 @@ enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2, DSVC_PREC_
 
 int dsvc_abi_version(void);
 const char* dsvc_last_error(void);
-/* measurement aid for bench.py: the dense fp16 MFMA rate (TFLOP/s) and shader clock (GHz) this chip sustains right now on a
- * register-resident loop with random (1) or zero (0) operands -- the rate a roofline fraction can actually approach. */
-int dsvc_probe_mfma(int32_t random_data, float* tflops, float* clock_ghz, void* stream);
-/* the same probe in detail: out4 = { TFLOP/s over the kernel's wall time (HIP events), TFLOP/s over the 4 ms in-kernel window every wave
- * issues MFMAs for, mean shader clock over all waves [GHz], lowest clock any wave saw [GHz] } */
-int dsvc_probe_mfma_detail(int32_t random_data, float* out4, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Denoiser -- replaces network/diff/net.py:86-135 (class DiffNet), selected through the DIFF_DECODERS
@@ -95,22 +89,10 @@ void dsvc_denoiser_destroy(dsvc_denoiser* d);
 int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t, const float* cond,
                           float* out, int32_t B, int32_t T, int32_t cond_changed, void* stream);
 
-/* debugging aid for the parity tests: copy an internal frame-major buffer ("xres", "g", "skip", "s2", "eps",
- * "condT", "cproj", "film", "xin", "xh") to a device pointer as fp32; rows/ld receive its logical shape. */
-int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, int64_t numel, int32_t* rows, int32_t* ld);
-
 /* dsvc_denoiser_forward clamps diffusion steps outside [0, max_steps) on the device (the step embedding is tabulated for the integer
  * steps of the schedule, net.py:32-44,99-103) and raises a sticky flag instead of synchronising on every call of the 1000-calls-per-clip
  * denoiser seam; the flag is reported by the NEXT dsvc_denoiser_forward call, or by this function, which first waits for `stream`. */
 int dsvc_denoiser_check(dsvc_denoiser* d, void* stream);
-
-/* test support (explicit handle state; the library reads no environment variable): "stop_after_layers" = n >= 0 makes an evaluation
- * return after n residual layers so that dsvc_denoiser_debug_buffer taps layer n-1 (-1 = off); "two_launch_layer" = 1 runs a residual
- * layer as its two tgemm launches even where the fused layer kernel is the automatic choice, -1 runs the fused kernel wherever it is
- * supported (>= 48 frame tiles) and not only where it is faster (>= 120 tiles), 0 = automatic (bit-equality test of the two forms); "defer_skip" != 0 makes
- * the fused layer kernels write the gate output to HBM and leave the skip halves of all layers to ONE contraction per evaluation with
- * pre-composed skip-projection weights (csrc/tskip.h: 14 % fewer HBM bytes per layer, measured time-neutral; default off). */
-int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampler -- replaces GaussianDiffusion.forward(infer=True) from the initial x to mel_out
@@ -152,14 +134,6 @@ typedef struct {
 } dsvc_sample_args;
 
 int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream);
-
-/* per-kernel timing for bench.py's roofline: average duration in microseconds of the dominant kernel at this batch size,
- * measured with HIP events on the launch stream over back-to-back launches of all layers (a different dither variant per round:
- * weights as cold as in the real chain), and the number of frames (rows) one launch processed.
- * kind (may be NULL) receives which kernel that is: 0 = the gate kernel (dilated conv + conditioner projection + gate: small
- * batches run a layer as two launches), 1 = the fused residual-layer kernel (gate GEMM + output projection: the throughput tiling). */
-int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters,
-                                     float* avg_us, int64_t* rows, int32_t* kind, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Vocoder -- replaces modules/nsf_hifigan/models.py:325-387 (Generator.forward) + :14-30 (load_model),

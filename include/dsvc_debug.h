@@ -1,0 +1,48 @@
+/* dsvc_debug.h -- measurement and test-support entry points of libdsvc_hip.so.
+ *
+ * NOT part of the product surface (include/dsvc.h is): nothing here replaces an interface of the reference.  bench.py's roofline fields and
+ * the parity tests' per-layer taps go through these; a host that only wants the drop-in never includes this file.  The functions live in
+ * the same shared library (the tests need them on the very kernels that ship), behind the same error convention (int codes,
+ * dsvc_last_error). */
+#ifndef DSVC_DEBUG_H
+#define DSVC_DEBUG_H
+
+#include "dsvc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* measurement aid for bench.py: the dense fp16 MFMA rate (TFLOP/s) and shader clock (GHz) this chip sustains right now on a
+ * register-resident loop with random (1) or zero (0) operands -- the rate a roofline fraction can actually approach. */
+int dsvc_probe_mfma(int32_t random_data, float* tflops, float* clock_ghz, void* stream);
+/* the same probe in detail: out4 = { TFLOP/s over the kernel's wall time (HIP events), TFLOP/s over the 4 ms in-kernel window every wave
+ * issues MFMAs for, mean shader clock over all waves [GHz], lowest clock any wave saw [GHz] } */
+int dsvc_probe_mfma_detail(int32_t random_data, float* out4, void* stream);
+
+/* debugging aid for the parity tests: copy an internal frame-major buffer ("xres", "g", "skip", "s2", "eps",
+ * "condT", "cproj", "film", "xin", "xh") to a device pointer as fp32; rows/ld receive its logical shape. */
+int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, int64_t numel, int32_t* rows, int32_t* ld);
+
+/* test support (explicit handle state; the library reads no environment variable): "stop_after_layers" = n >= 0 makes an evaluation
+ * return after n residual layers so that dsvc_denoiser_debug_buffer taps layer n-1 (-1 = off); "two_launch_layer" = 1 runs a residual
+ * layer as its two tgemm launches even where the fused layer kernel is the automatic choice, -1 runs the fused kernel wherever it is
+ * supported (>= 48 frame tiles) and not only where it is faster (>= 120 tiles), 0 = automatic (bit-equality test of the two forms); "w6_off" /
+ * "g6_off" = 1 make a DSVC_PREC_F16_W6 handle run its fused layers with the fp16 lo planes (= F16_W2) / without the gate-output correction
+ * (= F16_W6N): the A/B partners of the 6-bit products on one set of packed weights; "defer_skip" != 0 makes
+ * the fused layer kernels write the gate output to HBM and leave the skip halves of all layers to ONE contraction per evaluation with
+ * pre-composed skip-projection weights (csrc/tskip.h: 14 % fewer HBM bytes per layer, measured time-neutral; default off). */
+int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
+
+/* per-kernel timing for bench.py's roofline: average duration in microseconds of the dominant kernel at this batch size,
+ * measured with HIP events on the launch stream over back-to-back launches of all layers (a different dither variant per round:
+ * weights as cold as in the real chain), and the number of frames (rows) one launch processed.
+ * kind (may be NULL) receives which kernel that is: 0 = the gate kernel (dilated conv + conditioner projection + gate: small
+ * batches run a layer as two launches), 1 = the fused residual-layer kernel (gate GEMM + output projection: the throughput tiling). */
+int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters,
+                                     float* avg_us, int64_t* rows, int32_t* kind, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -423,3 +423,15 @@ def test_cond_builder_device_pitch_path_equals_host_path():
     r = cbd(hub[:1, :, :].cuda(), mel2ph=torch.ones(1, 2 * n, dtype=torch.long).cuda(), f0=probe.cuda())
     assert (r["pitch_pred"][0, :n, 0].cpu() == torch.arange(2, n + 2)).all()
     assert (r["pitch_pred"][0, n:, 0].cpu() == torch.arange(1, n + 1)).all()
+    # an alignment index past the content frames: the reference's torch.gather raises (fs2.py:100-102); the one-launch device path stays
+    # memory-safe (zero pad row) and keeps a sticky flag that check_alignment() turns into the same IndexError, once
+    cbd.check_alignment()
+    bad = m2p.clone(); bad[0, 5] = hub.shape[1] + 3
+    out_bad = cbd(hub.cuda(), mel2ph=bad.cuda(), f0=f0.clone().cuda())
+    assert (out_bad["decoder_inp"][0, 5] == 0).all()
+    cbd(hub.cuda(), mel2ph=m2p.cuda(), f0=f0.clone().cuda())                   # a later valid call does not clear it
+    with pytest.raises(IndexError, match="mel2ph holds an index outside"):
+        cbd.check_alignment()
+    cbd.check_alignment()
+    with pytest.raises((IndexError, RuntimeError)):
+        cb(hub, mel2ph=bad, f0=f0.clone())                                     # the host path IS torch.gather
