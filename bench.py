@@ -63,6 +63,43 @@ def probe_mfma():
     return {"tflops": o[1], "tflops_wall": o[0], "clock_ghz": o[2], "clock_ghz_min_cu": o[3]}
 
 
+def latency_floor(precision, measured_us):
+    """What bounds the single-clip gate kernel is latency, not the 2.5 PF/s roof: 1.5 GFLOP per launch on 224 workgroups.  A stated floor
+    for ONE launch inside the replayed graph, from the measured constants of this part (tools/micro/launch_floor.hip,
+    profiles/r02h_stamps.txt, MI355X_MICROARCH.md):
+      boundary   1.75 us  a graph node of an empty kernel (launch_floor.hip)
+      tile DMA   the workgroup's (32 + 2 d) x row time tile through the CU's 64 B/clk vector-memory path + one L2 round trip (~0.3 us)
+      stream     the 9 waves of a workgroup pull 3 output tiles x 72 k-steps x planes x 1 KiB of weight fragments through the same 64 B/clk
+                 path (every wave streams its own weights: nothing is shared in LDS)
+      matrix     per SIMD: 9 waves / 4 SIMDs x 24 k-steps x (MFMAs per product) x 32 cycles -- overlaps the stream, the larger of the two counts
+      tail       split-K reduction through LDS + gate epilogue + store drain, ~0.5 us (stamps)
+    at the 2.4 GHz the chip holds in this regime (the matrix pipe is mostly idle)."""
+    clk = 2.4e3                                   # cycles per us
+    planes = 2 if precision in ("f16_w2", "f16_x3t") else 1
+    mpp = 3 if precision == "f16_x3t" else planes
+    row_bytes = 384 * 2 * (2 if precision == "f16_x3t" else 1)
+    dma = (32 + 2 * 3.75) * row_bytes / 64.0 / clk + 0.3            # mean dilation of the 1, 2, 4, 8 cycle
+    stream = 3 * 72 * planes * 1024 / 64.0 / clk
+    matrix = (9 / 4.0) * 24 * mpp * 32 / clk
+    floor = 1.75 + dma + max(stream, matrix) + 0.5
+    return {"latency_floor_us": floor, "latency_floor_parts_us": {"boundary": 1.75, "tile_dma": dma, "weight_stream": stream, "matrix": matrix, "tail": 0.5},
+            "frac_of_latency_floor": floor / measured_us}
+
+
+def train_step_flops(hp, frames):
+    """Algorithmic FLOPs (one multiply-add = 2) of one training step over `frames` valid mel frames: per residual layer the forward (dilated
+    conv, conditioner projection, output 1x1), the data gradients (transposed conv, d gate) and the three weight gradients; the conditioner's
+    data gradient is never formed.  Tail: input / skip / output projections, forward + data + weight gradients."""
+    C, H, M, L = hp["residual_channels"], hp["hidden_size"], hp["audio_num_mel_bins"], hp["residual_layers"]
+    conv, outp, cond = 2 * C * 2 * C * 3, 2 * C * 2 * C, 2 * H * 2 * C
+    per_layer = (conv + cond + outp) + (conv + outp) + (conv + cond + outp)
+    tail = 3 * 2 * (M * C + C * C + C * M)
+    return (per_layer * L + tail) * frames
+
+
+VOCODER_FLOP_PER_FRAME = 649.5e6                   # NSF-HiFiGAN generator, 44.1 kHz config (DESIGN.md 4.3): 512 output samples per mel frame
+
+
 def dominant_kernel_roofline(handle, B, precision):
     """HIP-event timing of the dominant kernel at this batch size (dsvc_sampler_profile_gate_kernel) against its roofline.
     Small batches run a layer as two launches and the gate kernel dominates (MFMA-shaped: 1.77 MFLOP per frame); the throughput
@@ -78,6 +115,8 @@ def dominant_kernel_roofline(handle, B, precision):
                 "algorithmic_bytes": ((814 * 2 + 3072 + 768 * 2) if precision == "f16_x3t" else BYTES_PER_FRAME_GATE) * frames
                                      + (2 if precision in ("f16_w2", "f16_x3t") else 1) * WEIGHT_BYTES_GATE}
         tfile = {1: "gate_traffic.json", 32: "gate_traffic_b32.json"}.get(B)
+        if B == 1:
+            roof.update(latency_floor(precision, us))
     else:
         w6 = precision in ("f16_w6", "f16_w6n")
         # f16_w6: one fp16 plane + the w_lo plane as 6-bit codes (0.375 of a plane) per contraction; the g_lo correction streams the output
@@ -514,6 +553,11 @@ def main():
                 mel1 = (torch.randn(1, T_FRAMES, hp["audio_num_mel_bins"], device=dev) * 0.5 - 2.5).clamp(hp["mel_vmin"], hp["mel_vmax"])
                 f01 = torch.full((1, T_FRAMES), 220.0, device=dev)
                 stages["vocoder_ms"] = timed(lambda: pipe.vocoder.vocode(mel1, f01, seed=1))
+                vtf = VOCODER_FLOP_PER_FRAME * T_FRAMES / (stages["vocoder_ms"] * 1e-3) / 1e12
+                stages["vocoder_roofline"] = {"bound": "mfma", "algorithmic_gflop_per_clip": VOCODER_FLOP_PER_FRAME * T_FRAMES / 1e9, "achieved": vtf,
+                                              "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": vtf / PEAK_TFLOPS_F16, "mfma_per_product": 3,
+                                              "pipe_frac": 3 * vtf / PEAK_TFLOPS_F16,
+                                              "scope": "the whole generator for one 10 s clip (29 launches), split fp16 operands (f16_x3)"}
                 # what the reference's host glue adds around the device path (infer_tool.py:174,200: mel / f0 to numpy, PCM to numpy)
                 stages["host_round_trip_ms"] = timed(lambda: (mel1.cpu().numpy(), f01.cpu().numpy(), wav[:1].cpu().numpy()))
                 from diffsvc_amd.hubert import HubertSoftHip
@@ -557,9 +601,15 @@ def main():
             try:
                 torch.cuda.empty_cache()
                 ms_t, loss_t = time_train_steps(hp, sd, 64, 128, 5, 2, 0, dev, torch.cuda.synchronize)
+                tfl = train_step_flops(hp, 64 * 128) / (ms_t * 1e-3) / 1e12
                 result["train_step"] = {"workload": "BASELINE configs[4]: diffusion loss fwd+bwd + AdamW on a 64 x 128-frame mel batch, 1 GPU",
                                         "ms_per_step": ms_t, "value": 64 * 128 / (ms_t * 1e-3), "unit": "frames/s", "final_loss": loss_t,
-                                        "precision": "split fp16 operands (fp32-class), fp32 master weights"}
+                                        "precision": "split fp16 operands (fp32-class), fp32 master weights",
+                                        "roofline": {"bound": "mfma", "scope": "whole step (forward + backward + clip + AdamW), not one kernel: the largest "
+                                                     "kernel, pgemm_kernel<EpBwd>, is 22 % of it (profiles/)",
+                                                     "algorithmic_tflop_per_step": train_step_flops(hp, 64 * 128) / 1e12, "achieved": tfl,
+                                                     "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": tfl / PEAK_TFLOPS_F16, "mfma_per_product": 3,
+                                                     "pipe_frac": 3 * tfl / PEAK_TFLOPS_F16}}
             except Exception as ex:                                           # never lose the inference line to the extra measurement
                 result["train_step"] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline and world == 1:

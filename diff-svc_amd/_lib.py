@@ -62,7 +62,8 @@ class VocoderCfg(ctypes.Structure):
                 ("upsample_rates", ctypes.c_int32 * 8), ("upsample_kernel_sizes", ctypes.c_int32 * 8),
                 ("n_kernels", ctypes.c_int32), ("resblock_kernel_sizes", ctypes.c_int32 * 4),
                 ("resblock_dilations", (ctypes.c_int32 * 3) * 4), ("harmonics", ctypes.c_int32),
-                ("precision", ctypes.c_int32), ("mel_scale", ctypes.c_float), ("use_source", ctypes.c_int32)]
+                ("precision", ctypes.c_int32), ("mel_scale", ctypes.c_float), ("use_source", ctypes.c_int32),
+                ("resblock", ctypes.c_int32), ("n_dilations", ctypes.c_int32)]
 
 
 class MelspecCfg(ctypes.Structure):

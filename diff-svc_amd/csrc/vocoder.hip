@@ -667,6 +667,9 @@ struct dsvc_vocoder {
 int dsvc_vocoder::finalize() {
     const int nu = cfg.n_ups, nk = cfg.n_kernels, ch0 = cfg.upsample_initial_channel, M = cfg.num_mels;
     if (nu < 1 || nu > 8 || nk < 1 || nk > 4) return fail(DSVC_EINVAL, "vocoder: bad stage / kernel counts");
+    const bool rb2_type = cfg.resblock == 2;
+    const int ndil = cfg.n_dilations > 0 ? cfg.n_dilations : 3;
+    if (cfg.resblock < 0 || cfg.resblock > 2 || ndil > 3 || (!rb2_type && ndil != 3)) return fail(DSVC_EINVAL, "vocoder: resblock %d with %d dilations", cfg.resblock, ndil);
     if (M % 16) return fail(DSVC_EINVAL, "vocoder: num_mels must be a multiple of 16");
     dim = cfg.harmonics + 1;
     if (dim > 12) return fail(DSVC_EINVAL, "vocoder: at most 11 harmonics");
@@ -718,14 +721,23 @@ int dsvc_vocoder::finalize() {
             if (!nw || !nb) return DSVC_ESTATE;
             DSVC_TRY(upload(nc_w[i], nw->data(), nw->size() * 4)); DSVC_TRY(upload(nc_b[i], nb->data(), nb->size() * 4));
         }
-        // resblocks (ResBlock1, models.py:33-64)
+        // resblocks (ResBlock1, models.py:33-64: conv pairs; ResBlock2, models.py:73-91: one conv per residual step)
         for (int j = 0; j < nk; ++j) {
             const int rk = cfg.resblock_kernel_sizes[j];
             if (!(rk & 1)) return fail(DSVC_EINVAL, "vocoder: even resblock kernel size");
-            for (int m = 0; m < 3; ++m) {
+            for (int m = 0; m < ndil; ++m) {
                 const int d = cfg.resblock_dilations[j][m];
                 const std::string base = "resblocks." + std::to_string(i * nk + j) + ".";
                 const size_t idx = ((size_t)i * nk + j) * 3 + m;
+                const int halo = (rk / 2) * d;
+                if (ceil_div(halo, rate) > need_gap) need_gap = ceil_div(halo, rate);
+                if (rb2_type) {
+                    DSVC_TRY(folded(base + "convs." + std::to_string(m), (size_t)cout * cout * rk, cout, w));
+                    const std::vector<float>* b1 = plain(base + "convs." + std::to_string(m) + ".bias", cout);
+                    if (!b1) return DSVC_ESTATE;
+                    DSVC_TRY(pack_conv(rb1[idx], cout, rk, cout, d, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b1->data(), cout));
+                    continue;
+                }
                 DSVC_TRY(folded(base + "convs1." + std::to_string(m), (size_t)cout * cout * rk, cout, w));
                 const std::vector<float>* b1 = plain(base + "convs1." + std::to_string(m) + ".bias", cout);
                 if (!b1) return DSVC_ESTATE;
@@ -744,8 +756,6 @@ int dsvc_vocoder::finalize() {
                 if (!b2) return DSVC_ESTATE;
                 DSVC_TRY(pack_conv(rb2[idx], cout, rk, cout, 1, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b2->data(), cout));
                 if (narrow) DSVC_TRY(pack_f32(rb2_f32[idx]));
-                const int halo = (rk / 2) * d;
-                if (ceil_div(halo, rate) > need_gap) need_gap = ceil_div(halo, rate);
             }
         }
         if (ceil_div(reach, rate / u) > need_gap) need_gap = ceil_div(reach, rate / u);
@@ -795,6 +805,8 @@ int dsvc_vocoder::ensure_ws(int B, int T) {
 int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int T, unsigned long long seed, int clip0, const int* clip_ids, hipStream_t st) {
     DSVC_TRY(ensure_ws(B, T));
     const int nu = cfg.n_ups, nk = cfg.n_kernels, ch0 = cfg.upsample_initial_channel, M = cfg.num_mels;
+    const bool rb2_type = cfg.resblock == 2;
+    const int ndil = cfg.n_dilations > 0 ? cfg.n_dilations : 3;
     const int prec = cfg.precision;
     {
         const size_t n = (size_t)B * T * M;
@@ -844,10 +856,19 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
             EpiAffine::Args e{U, u * cout, ups[i].bias.as<float>(), cout, u * cout, nullptr, 0, 1.0f, src ? 1 : 0};
             DSVC_TRY(voc_dispatch<EpiAffine>(a, e, prec, st));
         }
-        // MRF: mean over the nk ResBlock1 (models.py:376-382)
+        // MRF: mean over the nk resblocks (models.py:376-382)
         for (int j = 0; j < nk; ++j) {
-            for (int m = 0; m < 3; ++m) {
+            for (int m = 0; m < ndil; ++m) {
                 const size_t idx = ((size_t)i * nk + j) * 3 + m;
+                if (rb2_type) {   // ResBlock2 (models.py:86-91): x = c(leaky_relu(x)) + x, ping-pong U -> A -> Tm -> ...; the last step lands in the MRF mean
+                    const float* xin = (m == 0) ? U : ((m & 1) ? A : Tm);
+                    const bool lastm = (m + 1 == ndil);
+                    float* xout = lastm ? S : ((m & 1) ? Tm : A);
+                    ConvGemmArgs a = conv(rb1[idx], xin, rows, stride, len, 0.1f);
+                    EpiAffine::Args e{xout, cout, rb1[idx].bias.as<float>(), cout, cout, xin, cout, lastm ? 1.0f / (float)nk : 1.0f, (lastm && j > 0) ? 1 : 0};
+                    DSVC_TRY(voc_dispatch<EpiAffine>(a, e, prec, st));
+                    continue;
+                }
 #ifdef DSVC_PROFILING
                 static const bool no_fused = getenv("DSVC_VOC_NO_FUSED") && atoi(getenv("DSVC_VOC_NO_FUSED"));   // A/B knobs
                 static const bool pair_f32 = getenv("DSVC_VOC_PAIR_F32") && atoi(getenv("DSVC_VOC_PAIR_F32"));

@@ -173,11 +173,14 @@ class VocoderHandle:
 
     def __init__(self, state, h, precision="f16_x3", mel_scale=2.30259, use_source=True):
         self._h = ctypes.c_void_p(0)
-        if str(h.get("resblock", "1")) != "1":
-            raise NotImplementedError("only ResBlock1 generators are supported (resblock='1')")
+        rb = str(h.get("resblock", "1"))
+        if rb not in ("1", "2"):
+            raise ValueError("resblock must be '1' or '2' (modules/nsf_hifigan/models.py:337)")
         rates, ksz = list(h["upsample_rates"]), list(h["upsample_kernel_sizes"])
         rks, rds = list(h["resblock_kernel_sizes"]), [list(d) for d in h["resblock_dilation_sizes"]]
-        if len(rates) > 8 or len(rks) > 4 or any(len(d) != 3 for d in rds):
+        ndil = len(rds[0]) if rds else 0
+        # ResBlock1 walks three dilations (models.py:36-55); ResBlock2 is written for two (models.py:77-82) -- any 1..3 of one length is run
+        if len(rates) > 8 or len(rks) > 4 or any(len(d) != ndil for d in rds) or not 1 <= ndil <= 3 or (rb == "1" and ndil != 3):
             raise ValueError("unsupported generator geometry")
         cfg = _lib.VocoderCfg()
         sr = h["sampling_rate"] if "sampling_rate" in h else h["audio_sample_rate"]
@@ -192,6 +195,7 @@ class VocoderHandle:
             cfg.resblock_kernel_sizes[j] = k
             for m, d in enumerate(ds):
                 cfg.resblock_dilations[j][m] = d
+        cfg.resblock, cfg.n_dilations = int(rb), ndil
         cfg.harmonics = 8                                # harmonic_num=8, models.py:334
         cfg.precision = _prec(precision)
         self.cfg = cfg

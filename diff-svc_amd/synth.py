@@ -255,8 +255,11 @@ def vocoder_state(h, seed=0):
         for j, (k, dils) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
             r = "resblocks.%d." % (i * nk + j)
             for m in range(len(dils)):
-                wn(r + "convs1.%d" % m, (c, c, k), 1.2)
-                wn(r + "convs2.%d" % m, (c, c, k), 0.45)
+                if str(h.get("resblock", "1")) == "1":
+                    wn(r + "convs1.%d" % m, (c, c, k), 1.2)
+                    wn(r + "convs2.%d" % m, (c, c, k), 0.45)
+                else:                                      # ResBlock2 (models.py:73-84): one conv per residual step
+                    wn(r + "convs.%d" % m, (c, c, k), 0.55)
     wn("conv_post", (1, ch, 7), 0.6)
     sd["m_source.l_linear.weight"] = _normal("src.w", seed, (1, 9), 1.5)
     sd["m_source.l_linear.bias"] = _normal("src.b", seed, (1,), 0.05)

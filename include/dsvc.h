@@ -157,6 +157,9 @@ typedef struct {
                                     * (nsf_hifigan.py:63-65), 1 for the 24 kHz HifiGAN wrapper (network/vocoders/hifigan.py:64) */
     int32_t use_source;            /* 1: harmonic source + noise convs (NSF: models.py:363-375; HifiGanGenerator with
                                     * use_pitch_embed and an f0, modules/hifigan/hifigan.py:110-116,150-162); 0: plain HiFi-GAN */
+    int32_t resblock;              /* h.resblock: 1 = ResBlock1 (conv pairs, three dilations: models.py:33-64), 2 = ResBlock2 (one conv per
+                                    * residual step, models.py:73-91; n_dilations of them, two in the published configs); 0 means 1 */
+    int32_t n_dilations;           /* entries used of resblock_dilations[j] (ResBlock1: 3); 0 means 3 */
 } dsvc_vocoder_cfg;
 
 int dsvc_vocoder_create(const dsvc_vocoder_cfg* cfg, dsvc_vocoder** out);

@@ -465,7 +465,8 @@ def generator_forward(gw, h, mel, f0, rand_ini, noise, taps=None):
             taps["up%d" % i] = x.clone()
         acc = None
         for j in range(nk):
-            r = _resblock1(gw, "resblocks.%d." % (i * nk + j), x, rks[j], rds[j])
+            rb = _resblock1 if str(h.get("resblock", "1")) == "1" else _resblock2      # models.py:337
+            r = rb(gw, "resblocks.%d." % (i * nk + j), x, rks[j], rds[j])
             acc = r if acc is None else acc + r
         x = acc / nk
         if taps is not None:
@@ -473,6 +474,15 @@ def generator_forward(gw, h, mel, f0, rand_ini, noise, taps=None):
     x = F.leaky_relu(x)                      # default slope 0.01 (models.py:383)
     x = F.conv1d(x, gw["conv_post.weight"], gw["conv_post.bias"], padding=3)
     return torch.tanh(x)
+
+
+def _resblock2(gw, prefix, x, k, dils):
+    """ResBlock2.forward (models.py:86-91): one dilated conv per residual step."""
+    for j, d in enumerate(dils):
+        xt = F.leaky_relu(x, LRELU)
+        xt = F.conv1d(xt, gw[prefix + "convs.%d.weight" % j], gw[prefix + "convs.%d.bias" % j], padding=(k * d - d) // 2, dilation=d)
+        x = xt + x
+    return x
 
 
 def _resblock1(gw, prefix, x, k, dils):

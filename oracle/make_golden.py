@@ -169,6 +169,16 @@ def golden_vocoder(name, h, wseed, clips, T, seed):
     print(name, "wav rms %.4f max %.3f" % (float(np.sqrt((wav ** 2).mean())), float(np.abs(wav).max())))
 
 
+def golden_vocoder_rb2():
+    """Generators built from ResBlock2 (h.resblock = '2': modules/nsf_hifigan/models.py:73-91, selected at :337), the REAL Generator as above:
+    the tiny architecture, and the public V2/V3-style shape of the 44.1 kHz config at reduced width (three kernel sizes x two dilations,
+    channels 256 -> 16, so that every conv engine of the device path sees a ResBlock2 stage)."""
+    tiny2 = dict(synth.tiny_vocoder(rds=((1, 3), (1, 3))), resblock="2")
+    golden_vocoder("vocoder_tiny_rb2", tiny2, 6, clips=[0, 3], T=24, seed=93)
+    wide2 = dict(synth.VOCODER_44K, resblock="2", resblock_dilation_sizes=[[1, 3], [1, 3], [1, 3]])
+    golden_vocoder("vocoder_44k_rb2", wide2, 2, clips=[1], T=12, seed=94)
+
+
 def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500, seed=2026, wseed=0, vseed=1, K=1000, speedup=1, with_wav=True,
                     conditioned=None):
     """The BENCHMARKED configuration (BASELINE configs[1]: 10 s clip, T=861, 44.1 kHz architecture, full 1000-step DDPM) through
@@ -409,6 +419,8 @@ def main():
         return golden_slicer()
     if "--schedule-only" in sys.argv:
         return golden_schedule()
+    if "--rb2-only" in sys.argv:
+        return golden_vocoder_rb2()
     if "--headline-only" in sys.argv:
         return golden_headline()
     if "--headline-extra" in sys.argv:
@@ -433,6 +445,7 @@ def main():
     golden_state_keys()
     golden_vocoder("vocoder_tiny", synth.tiny_vocoder(), 5, clips=[0, 3], T=24, seed=90)
     golden_vocoder("vocoder_44k", dict(synth.VOCODER_44K), 1, clips=[1], T=12, seed=91)
+    golden_vocoder_rb2()
     golden_melspec("melspec_44k", 44100, 2048, 2048, 512, 128, 40, 16000, 20000)
     golden_melspec("melspec_24k", 24000, 512, 512, 128, 80, 30, 12000, 6000)
     tiny = synth.tiny_hparams()

@@ -428,7 +428,7 @@ def test_cond_builder_device_pitch_path_equals_host_path():
     cbd.check_alignment()
     bad = m2p.clone(); bad[0, 5] = hub.shape[1] + 3
     out_bad = cbd(hub.cuda(), mel2ph=bad.cuda(), f0=f0.clone().cuda())
-    assert (out_bad["decoder_inp"][0, 5] == 0).all()
+    assert torch.equal(out_bad["decoder_inp"][0, 5], cbd.pitch_embed.weight[out_bad["pitch_pred"][0, 5, 0]])     # zero content + the frame's pitch embedding
     cbd(hub.cuda(), mel2ph=m2p.cuda(), f0=f0.clone().cuda())                   # a later valid call does not clear it
     with pytest.raises(IndexError, match="mel2ph holds an index outside"):
         cbd.check_alignment()

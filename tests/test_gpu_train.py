@@ -417,8 +417,9 @@ def test_workspace_reuse_across_batch_shapes_equals_fresh_trainers():
     """The reference's max_tokens loader changes (B, T) every step (training/task/tts.py:60-88).  Round 3 re-zeroed the whole workspace then
     (1.9 GB at the benchmarked batch); now only the rows a step never writes are cleared when an allocation is re-used under a new layout
     (k_zero_gap_rows: the gap rows between clips -- the convs' zero padding -- and the tail).  One trainer stepping through four shapes, growing
-    and shrinking in B and T so that stale activations sit in every kind of row the new layout does not write, must give bit for bit the loss and
-    gradients of a FRESH trainer (whole-workspace memset) at each shape."""
+    and shrinking in B and T so that stale activations sit in every kind of row the new layout does not write, must give the loss and gradients
+    of a FRESH trainer (whole-workspace memset) at each shape -- to the 1e-7 that two fresh trainers differ by themselves (bias gradients and the
+    loss are float-atomic sums); a stale row read as data would show at 1e-2."""
     from diffsvc_amd.train import DiffusionTrainerHip
     hp = dict(synth.tiny_hparams(K=50), diff_loss_type="l2")
     sd = synth.acoustic_state(hp, 3)
@@ -432,6 +433,6 @@ def test_workspace_reuse_across_batch_shapes_equals_fresh_trainers():
         grads = tr.grads.clone()
         fresh = DiffusionTrainerHip(hp, sd)
         loss_f = fresh.forward_backward(hub, m2p, f0.clone(), mels, t, seed=5 + i, clip_ids=ids).item()
-        assert loss == loss_f, (i, B, T, loss, loss_f)
-        assert torch.equal(grads, fresh.grads), (i, B, T, (grads - fresh.grads).abs().max().item())
+        assert abs(loss - loss_f) <= 1e-6 * abs(loss_f), (i, B, T, loss, loss_f)
+        assert (grads - fresh.grads).abs().max().item() <= 2e-6 * grads.abs().max().item(), (i, B, T, (grads - fresh.grads).abs().max().item())
         del fresh

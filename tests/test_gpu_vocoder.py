@@ -19,10 +19,12 @@ def vocoder_for(h, wseed, precision="f16_x3"):
     return VocoderHandle(synth.vocoder_state(h, wseed), h, precision=precision)
 
 
-@pytest.mark.parametrize("name", ["vocoder_tiny", "vocoder_44k"])
+@pytest.mark.parametrize("name", ["vocoder_tiny", "vocoder_44k", "vocoder_tiny_rb2", "vocoder_44k_rb2"])
 def test_vocoder_vs_reference_golden(name):
     g = load_golden(name)
     h = synth.tiny_vocoder() if "tiny" in name else dict(synth.VOCODER_44K)
+    if name.endswith("_rb2"):            # generators built from ResBlock2 (models.py:73-91, :337): one conv per residual step, two dilations
+        h = dict(h, resblock="2", resblock_dilation_sizes=[[1, 3]] * len(h["resblock_kernel_sizes"]))
     voc = vocoder_for(h, int(g["wseed"]))
     clips = [int(c) for c in g["clips"]]
     wavs = []
