@@ -336,6 +336,8 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     gload(ringA, lo6A, tile_of(0), 0);
     gepi.init(ge, tile_of(0), row0, lane, acc);
     TL_STAMP(1);
+    // (a counted vmcnt(22) + bare barrier here -- only the DMA'd tile waited for, ring and accumulator-init loads in flight across the barrier --
+    //  measured neutral for the W6 kernels: hipcc issues the weight ring LAST, so the first MFMA waits for everything anyway; profiles/r4p_*)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TL_STAMP(2);
     __syncthreads();
@@ -542,6 +544,8 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             prio_group(g >> 1);
             oload(ringB, lo6B, mt, g + 1);
             if (!G6 && g == g_issue2 && !last) { oepi.init(oe, mt_n, row0, lane, nxt); nxt_issued = true; }
+            // (G6 with HALF a prefetched set -- N-tiles 0 and 1, 32 registers -- still put 9-15 scratch accesses into every loop iteration:
+            //  141.6 instead of 132.7 us per layer, profiles/r4o_w6_time_half_prefetch.txt)
             // (G6 -- no registers for `nxt` -- with plain loads of the next tiles at this point to warm the L2: 139 instead of 133 us per layer, not kept)
             __builtin_amdgcn_sched_barrier(0);
             group2(ringA, lo6A, wg6, g);
@@ -563,9 +567,9 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
         TL_STAMP(9 + 2 * po);
         if (!last) {
             if constexpr (G6) {
-                // G6 has no registers for a second accumulator set beside its code operands (a prefetched `nxt` made the allocator spill whole
-                // accumulator tiles inside the loops: 166 us per layer): the next pass's residual / skip tiles are loaded straight into the
-                // accumulators once this pass's stores are out; the other wave of the SIMD covers the wait
+                // G6 has no registers for a WHOLE second accumulator set beside its code operands (a prefetched `nxt` made the allocator spill
+                // whole accumulator tiles inside the loops: 166 us per layer); without any prefetch the next pass's tiles load into the
+                // accumulators after this pass's stores and the wait is exposed (133 us)
                 oepi.init(oe, mt_n, row0, lane, acc);
             } else {
 #pragma unroll
