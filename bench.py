@@ -75,8 +75,10 @@ def latency_floor(precision, measured_us):
       tail       split-K reduction through LDS + gate epilogue + store drain, ~0.5 us (stamps)
     at the 2.4 GHz the chip holds in this regime (the matrix pipe is mostly idle)."""
     clk = 2.4e3                                   # cycles per us
-    planes = 2 if precision in ("f16_w2", "f16_x3t") else 1
-    mpp = 3 if precision == "f16_x3t" else planes
+    # f16_x3t (round 4): the lo plane of a k16 step is 384 B of fp6 codes instead of a 1 KiB fp16 fragment, and of the three products one is a
+    # K = 64 six-bit MFMA (a quarter of four fp16 ones): 2.25 units per product
+    planes = 1.375 if precision == "f16_x3t" else (2 if precision == "f16_w2" else 1)
+    mpp = 2.25 if precision == "f16_x3t" else planes
     row_bytes = 384 * 2 * (2 if precision == "f16_x3t" else 1)
     dma = (32 + 2 * 3.75) * row_bytes / 64.0 / clk + 0.3            # mean dilation of the 1, 2, 4, 8 cycle
     stream = 3 * 72 * planes * 1024 / 64.0 / clk
@@ -112,8 +114,8 @@ def dominant_kernel_roofline(handle, B, precision):
         roof = {"bound": "mfma", "kernel": "tgemm_kernel<TEpiGate> (dilated k=3 conv + hoisted cond projection + gate, one residual layer)",
                 "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_F16,
                 "avg_launch_us": us, "frames_per_launch": frames, "traffic": None,
-                "algorithmic_bytes": ((814 * 2 + 3072 + 768 * 2) if precision == "f16_x3t" else BYTES_PER_FRAME_GATE) * frames
-                                     + (2 if precision in ("f16_w2", "f16_x3t") else 1) * WEIGHT_BYTES_GATE}
+                "algorithmic_bytes": int(((814 * 2 + 3072 + 768 * 2) if precision == "f16_x3t" else BYTES_PER_FRAME_GATE) * frames
+                                         + (1.375 if precision == "f16_x3t" else (2 if precision == "f16_w2" else 1)) * WEIGHT_BYTES_GATE)}
         tfile = {1: "gate_traffic.json", 32: "gate_traffic_b32.json"}.get(B)
         if B == 1:
             roof.update(latency_floor(precision, us))
@@ -136,7 +138,7 @@ def dominant_kernel_roofline(handle, B, precision):
     # (+ split activations) MFMAs per product, so the matrix pipe itself is that many times busier
     # (f16_w6: a 6-bit K = 64 MFMA takes a quarter of the four fp16 MFMAs it replaces -- 1.25 units per product, 1.5 in the output 1x1 with the
     #  g_lo correction: 1.3125 over a layer's flops)
-    mpp = 3 if precision in ("f16_x3t", "f16_x3") else (2 if precision == "f16_w2" else (1.3125 if precision == "f16_w6" else (1.25 if precision == "f16_w6n" else 1)))
+    mpp = 3 if precision == "f16_x3" else (2.25 if precision == "f16_x3t" else (2 if precision == "f16_w2" else (1.3125 if precision == "f16_w6" else (1.25 if precision == "f16_w6n" else 1))))
     alg_tf = roof["achieved"] if roof["bound"] == "mfma" else roof["mfma_tflops"]
     roof["mfma_per_product"] = mpp
     roof["pipe_tflops"] = alg_tf * mpp
@@ -436,7 +438,8 @@ def main():
             "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "dtype_detail": "fp16 MFMA operands (%s%s), fp32 accumulate, fp32 residual/skip/state" % (
-                prec, ": hi + lo weight planes and split hi | lo activations, 3 MFMAs per product -- fp32-class" if prec.startswith("f16_x3") else ""),
+                prec, ": hi + lo weights (the lo plane as 6-bit codes on the block-scaled MFMA in the small tilings) and split hi | lo activations -- "
+                      "fp32-class" if prec.startswith("f16_x3") else ""),
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: single 10 s clip per GPU, 44.1 kHz, full %d-step DDPM + NSF-HiFiGAN" % args.ddpm_steps) if B == 1 else
                                    ("BASELINE configs[3] share: %d x 10 s clips per GPU in one batch (%d clips over %d GPU(s)), 44.1 kHz, full %d-step DDPM "

@@ -24,6 +24,8 @@ def parse_precision(p):
         return int(p[0]), int(p[1])
     if isinstance(p, int):
         return p, 1
+    if p == "f16_x3t":                                   # (64 dithered roundings of the fp6 w_lo codes its small tilings use since round 4)
+        return PREC_F16_X3T, 64
     if p in PRECISIONS:
         return PRECISIONS[p], 1
     if p.startswith("f16_d") and p[5:].isdigit() and int(p[5:]) >= 1:

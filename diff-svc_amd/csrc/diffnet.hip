@@ -177,16 +177,18 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
     if constexpr (NA == 2) {
         // split activations (F16_X3T): rows are [hi | lo] planes, twice the LDS per frame -> 64-frame tiles for big batches, the same
         // split-K / small-batch tilings otherwise
-        if (rows_alloc / 128 >= 48) {
+        if (rows_alloc / 128 >= 48) {       // (two N-tiles per wave: the fp16 lo plane, whatever a.w6 says)
             const int tiles = rows_alloc / 64, passes = ceil_div(a.m_tiles, 8);
             int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
             return tgemm_launch<2, 8, 2, KG, NW, Epi, 1, 1, 2>(a, e, rows_alloc, ms, st);
         }
         const int tiles = rows_alloc / 32, passes = ceil_div(a.m_tiles, 4);
         int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
+        // (a.w6: the w_lo * x_hi term of these small tilings on the 6-bit MFMA -- the caller packed the code plane and knows the dither variant)
         if (tiles * ceil_div(a.m_tiles, 3) <= 256)
-            return tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 3, 2>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st);
-        return tgemm_launch<1, 4, 2, KG, NW, Epi, 1, 1, 2>(a, e, rows_alloc, ms, st);
+            return a.w6 ? tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 3, 2, 1>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st)
+                        : tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 3, 2>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st);
+        return a.w6 ? tgemm_launch<1, 4, 2, KG, NW, Epi, 1, 1, 2, 1>(a, e, rows_alloc, ms, st) : tgemm_launch<1, 4, 2, KG, NW, Epi, 1, 1, 2>(a, e, rows_alloc, ms, st);
     }
     if (rows_alloc / 128 >= 48) {
         // (64-frame tiles x 4 waves, two workgroups per CU, measured 2.41 vs 2.22 ms per step: every weight is streamed twice as
@@ -265,6 +267,16 @@ struct dsvc_denoiser {
                                  // halves' MFMAs, which hide under the layer's memory-bound output phase, then cost 342 us per step as their
                                  // own kernel: the step time is unchanged (+-1 %).  Built, parity-tested, not the default.
     bool is_w6() const { return cfg.precision == DSVC_PREC_F16_W6 || cfg.precision == DSVC_PREC_F16_W6N; }
+    int dbg_x3t_w6_off = 0;      // 1: a DSVC_PREC_F16_X3T handle keeps the fp16 lo plane in its small tilings too (A/B of the 6-bit w_lo * x_hi term)
+    // the 6-bit w_lo plane of layer l for a small split-activation tiling: only when the dither variant is known at launch (the sampler's steps;
+    // dsvc_denoiser_forward with per-clip steps keeps the fp16 lo plane)
+    void set_w6(TGemmArgs& a, const std::vector<TPacked6>& t6, int l, int host_step, const StepRef& step, float xscale, int xbyte) const {
+        if (dbg_x3t_w6_off || t6.empty() || !t6[l].codes.p || step.per_clip || (t6[l].n_variants > 1 && host_step < 0)) return;
+        const TPacked6& t = t6[l];
+        a.w6 = t.codes.as<unsigned>() + (t.n_variants > 1 ? (size_t)(host_step % t.n_variants) * t.variant_dwords : 0);
+        a.sc6 = (127 + t.e6) | (xbyte << 8);
+        a.x6_scale = xscale;
+    }
     int dbg_w6_off = 0;          // 1: a DSVC_PREC_F16_W6 handle runs its fused layers with the fp16 lo plane (= f16_w2): the A/B partner of the 6-bit product
     int dbg_two_launch = 0;      // 1: run a residual layer as its two tgemm launches even where the fused kernel is the choice (bit-equality
                                  // test); -1: the fused kernel wherever it is SUPPORTED (>= 48 tiles), not only where it is faster (>= 120)
@@ -436,7 +448,7 @@ int dsvc_denoiser::finalize_t() {
     int max_dil = 1;
     for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     guard = round_up(max_dil, 8);
-    const bool w6 = is_w6();
+    const bool w6 = is_w6() || cfg.precision == DSVC_PREC_F16_X3T;      // (X3T: the small tilings' w_lo * x_hi term runs on the same code planes)
     const int planes = (cfg.precision == DSVC_PREC_F16_W2 || cfg.precision == DSVC_PREC_F16_X3T || w6) ? 2 : 1;
     const int nvar = (planes == 1 && cfg.weight_variants > 1) ? cfg.weight_variants : 1;       // (F16 and F16_MIX)
 #define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
@@ -471,7 +483,7 @@ int dsvc_denoiser::finalize_t() {
         if (w6) DSVC_TRY(tpack6(outl6_t[l], *wo, 2 * C, C, 1, 2 * C / 32, cfg.weight_variants > 1 ? cfg.weight_variants : 1, 1.0f, 4000u + l,
                                 [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, nullptr));
         // ... and the output projection's weights THEMSELVES as fp6 codes (nearest, one variant): the weight operand of the 6-bit g_lo correction
-        if (w6) DSVC_TRY(tpack6(out6_t[l], *wo, 2 * C, C, 1, 2 * C / 32, 1, 1.0f, 3000u + l,
+        if (is_w6()) DSVC_TRY(tpack6(out6_t[l], *wo, 2 * C, C, 1, 2 * C / 32, 1, 1.0f, 3000u + l,
                                 [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, nullptr, true));
         // output 1x1: tiles 0..C/32-1 residual half (conv channels 0..C-1), then the skip half (C..2C-1)
         DSVC_TRY(tpack(out_t[l], *wo, 2 * C, C, 1, 2 * C / 32, out_w2 ? 2 : planes, out_w2 ? 1 : nvar, 1.0f, 1001u + 2 * l, false,
@@ -688,12 +700,14 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         }
         {   // K5+K6 (+ hoisted K4, K3 already folded into xh): dilated conv, gate (net.py:67-77)
             TGemmArgs a = targs(xh_row0(), Cp, dil_t[l], 3, 1 << (l % cfg.dilation_cycle));
+            if (NA == 2) set_w6(a, dil6_t, l, host_step, step, 4.0f, 129);
             TEpiGate::Args e{cproj.as<float>() + (size_t)l * rows_alloc * 2 * C, gh.as<_Float16>(), C, Cp * NA, NA == 2 ? Cp : 0};
             DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, dil_t[l].planes, rows_alloc, st, NA));
         }
         {   // K7+K8: output projection, residual / skip (net.py:79-84,131) + next layer's FiLM (K3)
             const bool last = l + 1 == L;
             TGemmArgs a = targs(gh.as<_Float16>(), Cp, out_t[l], 1, 1);
+            if (NA == 2) set_w6(a, outl6_t, l, host_step, step, 0.0625f, 123);
             TEpiResSkip::Args e{xres.as<float>(), last ? nullptr : xh_row0(), skip.as<float>(), last ? skiph.as<_Float16>() : nullptr,
                                 out_t[l].bias.as<float>(), last ? nullptr : film.as<float>() + (size_t)(l + 1) * C, L * C, step, C, Cp * NA,
                                 l == 0 ? 1 : 0, rm, stream_big, NA == 2 ? Cp : 0};
@@ -892,7 +906,7 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
     // The captured segment is one period of the dither schedule (64 steps for f16_d64) replayed from a period-aligned step, so
     // every kernel node knows its weight variant at capture time and passes it by value: the alternative -- a scalar load of the
     // step in front of every kernel's weight stream -- costs ~0.4 us x 43 kernels per step in the single-clip regime.
-    const int nvar = (den->tpath && (den->cfg.precision == DSVC_PREC_F16 || den->cfg.precision == DSVC_PREC_F16_MIX || den->is_w6())
+    const int nvar = (den->tpath && (den->cfg.precision == DSVC_PREC_F16 || den->cfg.precision == DSVC_PREC_F16_MIX || den->is_w6() || den->cfg.precision == DSVC_PREC_F16_X3T)
                       && den->cfg.weight_variants > 1) ? den->cfg.weight_variants : 1;
     const int UNROLL = (nvar > 1 && nvar <= 64) ? nvar : 10;
     const bool aligned = UNROLL == nvar && nvar > 1;
@@ -1142,6 +1156,7 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     else if (k == "two_launch_layer") d->dbg_two_launch = value > 0 ? 1 : (value < 0 ? -1 : 0);
     else if (k == "w6_off") d->dbg_w6_off = value ? 1 : 0;
     else if (k == "g6_off") d->dbg_g6_off = value ? 1 : 0;
+    else if (k == "x3t_w6_off") d->dbg_x3t_w6_off = value ? 1 : 0;
     else if (k == "layer_prio") d->layer_prio = value;
     else if (k == "defer_skip") {
         d->defer_skip = value != 0;
@@ -1235,7 +1250,8 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
         // ~6 us host launch latency to every sample); the quotient includes the ~1.5 us inter-kernel gaps
         // a different diffusion step per round: with dithered weights every step streams its own variant from HBM, and
         // a fixed step would time the kernels on L2/MALL-warm weights instead
-        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, s->step_dev.as<int>(), ((it + 2) * 37) % s->K);
+        const int hstep = ((it + 2) * 37) % s->K;
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, s->step_dev.as<int>(), hstep);
         DSVC_HIP(hipEventRecord(e0, st));
         for (int l = 0; l < L; ++l) {
 #ifdef DSVC_PROFILING
@@ -1263,6 +1279,7 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
                 a.w = d->dil_t[l].w.as<_Float16>(); a.m_tiles = d->dil_t[l].m_tiles; a.w_planes = d->dil_t[l].planes;
                 a.variant_halfs = (long long)d->dil_t[l].variant_halfs; a.n_variants = d->dil_t[l].n_variants;
                 a.step_ptr = s->step_dev.as<int>(); a.step_off = 0; a.clip_rows = d->Tp;
+                if (d->NA == 2) d->set_w6(a, d->dil6_t, l, hstep, StepRef{s->step_dev.as<int>(), 0, 0}, 4.0f, 129);      // the kernel the sampler's steps run
                 TEpiGate::Args e{d->cproj.as<float>() + (size_t)l * d->rows_alloc * 2 * C, d->gh.as<_Float16>(), C, d->Cp * d->NA, d->NA == 2 ? d->Cp : 0};
                 DSVC_TRY(tlaunch_prec<TEpiGate>(a, e, d->dil_t[l].planes, d->rows_alloc, st, d->NA));
             } else {

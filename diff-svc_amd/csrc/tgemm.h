@@ -60,6 +60,12 @@ struct TGemmArgs {
                             //  dependent scalar load, ~0.4 us per kernel in the single-clip regime, out of the front of the weight stream)
     int clip_rows;          // rows per clip (clip stride) or 0: the K-loop stagger is keyed on a tile's position inside its clip, so a
                             // clip computes bit-identically alone and inside a batch
+    // W6 kernels (round 4; the small-batch split-activation tilings): the w_lo * x_hi term on the block-scaled 6-bit MFMA.  `w6` = fp6 codes of
+    // the w_lo plane (k_tpack6: one 1536-B fragment per (m_tile, tap, 64 input channels); the variant to use), sc6 = the E8M0 bytes of the
+    // weight scale | the activation scale << 8, x6_scale = what the activations are divided by before the bf6 conversion
+    const unsigned* w6;
+    int sc6;
+    float x6_scale;
 #ifdef DSVC_PROFILING       // profiling builds only (python -m diffsvc_amd.build --profiling): the product library has neither field nor branch
     unsigned long long* stamps;   // per-wave phase time stamps (s_memrealtime, 100 MHz), 16 per wave (env DSVC_TG_STAMPS)
     int dbg;                // ablation knobs (env DSVC_TG_DEBUG; results are WRONG when set): 1 = no acc-init loads, 2 = no epilogue,
@@ -91,10 +97,22 @@ __host__ __device__ inline int trow_to_ch8(int i) { return 8 * ((i >> 2) & 1) + 
 // 2 * cin halfs, x_lo = fp16(x - x_hi)); a k-step issues W_hi x_hi + W_lo x_hi + W_hi x_lo (the 2^-22 W_lo x_lo term is dropped, as conv_gemm's
 // split scheme does): 3 MFMAs per product from the SAME weight fragments -- the weight stream, which is what bounds the small-batch
 // kernels, is that of f16_w2.
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1>
+typedef int tg_v6i __attribute__((ext_vector_type(6)));
+typedef int tg_v8i __attribute__((ext_vector_type(8)));
+typedef _Float16 tg_half16 __attribute__((ext_vector_type(16)));
+typedef _Float16 tg_half32 __attribute__((ext_vector_type(32)));
+constexpr int TFRAG6_DWORDS = 384;        // one k_tpack6 fragment: [lane 64][16 B] + [lane 64][8 B]
+
+// W6 = 1 (round 4, NA = 2 and NT_N = 1 only: the single-clip / small-batch tilings of DSVC_PREC_F16_X3T): of the three products
+// W_hi x_hi + W_hi x_lo + W_lo x_hi the last one runs as ONE K = 64 block-scaled 6-bit MFMA per group -- w_lo as time-dithered fp6 codes,
+// x_hi converted to bf6 in registers from the four fragments the fp16 MFMAs read (tlayer.h's W6 scheme).  These kernels are bound by the
+// weight stream and by in-order issue, not by the matrix pipe: the lo plane shrinks from 1 KiB to 384 B per k16 step and 12 MFMAs per
+// group become 8 + 1.
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0>
 __global__ void __launch_bounds__(64 * WAVES * KS, MINW) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     static_assert(NA == 1 || NW == 2, "split activations are combined with hi + lo weight planes");
+    static_assert(!W6 || (NA == 2 && NT_N == 1 && KG == 4), "W6: the small split-activation tilings, 64 input channels per group");
     constexpr int TN = 32 * NT_N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -157,18 +175,53 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     // epilogue / memory waits sit under the other's MFMAs instead of both stalling together
     if (WAVES > 4 && wave >= 4 && !TG_DBG(a, 16)) __builtin_amdgcn_s_setprio(1);     // waves w and w+4 share SIMD (w & 3)
 
+    // (W6: ring[u][1] holds nothing -- the lo plane of the group is the 24-byte code string `c6` -- and p6 is its fragment)
     auto load_group = [&](half8 (&ring)[KG][NW], const _Float16* p) {
 #pragma unroll
         for (int u = 0; u < KG; ++u)
 #pragma unroll
-            for (int q = 0; q < NW; ++q)
+            for (int q = 0; q < (W6 ? 1 : NW); ++q)
                 ring[u][q] = *reinterpret_cast<const half8*>(p + (u * NW + q) * TFRAG_HALFS);
+    };
+    auto load_codes = [&](tg_v6i& c6, const unsigned* p6) {
+        if constexpr (W6) {
+            const int4 lo = *reinterpret_cast<const int4*>(p6 + lane * 4);
+            const int2 hi = *reinterpret_cast<const int2*>(p6 + 256 + lane * 2);
+            c6 = tg_v6i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+        }
     };
     typedef const half8 __attribute__((address_space(3))) * lds_frag_ptr;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned nt_stride = 32u * (unsigned)row_bytes;
-    auto compute_group = [&](const half8 (&ring)[KG][NW], f32x16 (&acc)[NT_N], int g) {
+    auto compute_group = [&](const half8 (&ring)[KG][NW], const tg_v6i& c6, f32x16 (&acc)[NT_N], int g) {
         const int tap = g / gpt, kb = (g - tap * gpt) * KG;
+        if constexpr (W6) {
+            // one N-tile, four k-steps: all eight fragments (x_hi and x_lo of the four steps) are read up front -- the conversion needs the
+            // four x_hi fragments together -- then 4 x (W_hi x_hi, W_hi x_lo), the conversion, and W_lo6 x_hi6
+            const int rr6 = halo + (tap - (a.taps >> 1)) * a.dil + (lane & 31);
+            const unsigned xs6 = (unsigned)(((rr6 & a.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5);
+            const unsigned b0 = lds0 + (unsigned)rr6 * (unsigned)row_bytes, lo_off6 = (unsigned)a.cin * 2u;
+            half8 xh[4], xl[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                xh[kk] = *(lds_frag_ptr)(size_t)(b0 + (((unsigned)kk << 5) ^ xs6));
+                xl[kk] = *(lds_frag_ptr)(size_t)(b0 + (((unsigned)kk << 5) ^ xs6) + lo_off6);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][0], xh[kk], acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[kk][0], xl[kk], acc[0], 0, 0, 0);
+            }
+            const tg_half16 v01 = __builtin_shufflevector(xh[0], xh[1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            const tg_half16 v23 = __builtin_shufflevector(xh[2], xh[3], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            const tg_half32 v = __builtin_shufflevector(v01, v23, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24,
+                                                        25, 26, 27, 28, 29, 30, 31);
+            const tg_v6i q = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(v, a.x6_scale);
+            const tg_v8i a6 = __builtin_shufflevector(c6, c6, 0, 1, 2, 3, 4, 5, -1, -1), b6 = __builtin_shufflevector(q, q, 0, 1, 2, 3, 4, 5, -1, -1);
+            acc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a6, b6, acc[0], 2 /* A: fp6 E2M3 */, 3 /* B: bf6 E3M2 */, 0, a.sc6 & 255, 0,
+                                                                     (a.sc6 >> 8) & 255);
+            return;
+        }
         const int rr = halo + (tap - (a.taps >> 1)) * a.dil + (lane & 31);      // LDS row of this lane's frame, N-tile 0
         // chunk of k16-step k, half h, row r lives at slot (2k + h) ^ (r & swz), i.e. at byte offset
         // (k << 5) ^ xs with xs = ((r & swz) ^ h) << 4.  The group's first step kb is a multiple of KG and kk < KG, so
@@ -240,6 +293,11 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     Epi epi;
     f32x16 acc[NT_N];
     half8 ringA[KG][NW], ringB[KG][NW];
+    tg_v6i codeA = {}, codeB = {};
+    auto load_wg = [&](half8 (&ring)[KG][NW], tg_v6i& c6, int tile, int grp) {      // weight group `grp` of output tile `tile`: fragments (+ W6: codes)
+        load_group(ring, wbase + (long long)tile * tile_halfs + (long long)grp * GROUP_HALFS);
+        if constexpr (W6) load_codes(c6, a.w6 + ((size_t)tile * (size_t)G + (size_t)grp) * TFRAG6_DWORDS);
+    };
     // output-channel passes are visited in a per-workgroup rotated order: all workgroups stream the SAME weights, and
     // without the rotation they all miss L2 on the same fragment at the same moment (the whole chip then advances at
     // first-touch latency); rotated, a tile's first toucher warms it for the other two thirds
@@ -267,10 +325,10 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         const bool active = mt < a.m_tiles;
         const int g0 = ks * G / KS, n = (ks + 1) * G / KS - g0;
         const _Float16* wp = wbase + (long long)(active ? mt : 0) * tile_halfs;
-        if (active && n > 0) load_group(ringA, wp + (long long)gmap(g0) * GROUP_HALFS);
+        if (active && n > 0) load_wg(ringA, codeA, mt, gmap(g0));
         // the second group is put in flight before the barrier too: a ring refill issued inside the loop is waited for at full
         // L2/HBM latency, there is no other work in a 3-group slice to hide it behind
-        if (active && n > 1) load_group(ringB, wp + (long long)gmap(g0 + 1) * GROUP_HALFS);
+        if (active && n > 1) load_wg(ringB, codeB, mt, gmap(g0 + 1));
         stamp(14);
         if (active && ks == 0 && !TG_DBG(a, 1)) {
             epi.init(ea, mt, row0, lane, acc);
@@ -300,14 +358,14 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         if (active && !TG_DBG(a, 8)) {
             int i = 0;
             for (; i + 1 < n; i += 2) {
-                if (i > 0) load_group(ringB, wp + (long long)gmap(g0 + i + 1) * GROUP_HALFS);
+                if (i > 0) load_wg(ringB, codeB, mt, gmap(g0 + i + 1));
                 __builtin_amdgcn_sched_barrier(0);
-                compute_group(ringA, acc, gmap(g0 + i));
-                if (i + 2 < n) load_group(ringA, wp + (long long)gmap(g0 + i + 2) * GROUP_HALFS);
+                compute_group(ringA, codeA, acc, gmap(g0 + i));
+                if (i + 2 < n) load_wg(ringA, codeA, mt, gmap(g0 + i + 2));
                 __builtin_amdgcn_sched_barrier(0);
-                compute_group(ringB, acc, gmap(g0 + i + 1));
+                compute_group(ringB, codeB, acc, gmap(g0 + i + 1));
             }
-            if (i < n) compute_group(ringA, acc, gmap(g0 + i));
+            if (i < n) compute_group(ringA, codeA, acc, gmap(g0 + i));
         }
         stamp(9);
         // partial sums of slices 1 .. KS-1 -> LDS [slice][tile wave][N-tile][quad][lane] (16 B per lane: conflict-free)
@@ -340,7 +398,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     int pi = next_active(blockIdx.y);
     int mt = pi >= 0 ? tile_of(pi) : 0;
     if (pi >= 0) {
-        load_group(ringA, wbase + (long long)(TG_DBG(a, 32) ? 0 : mt) * tile_halfs + (long long)gmap(0) * GROUP_HALFS);
+        load_wg(ringA, codeA, TG_DBG(a, 32) ? 0 : mt, gmap(0));
         stamp(14);
         if TG_DBG(a, 1) {
 #pragma unroll
@@ -382,26 +440,26 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         int g = (TG_DBG(a, 8) || (TG_DBG(a, 256) && wave >= WAVES / 2)) ? G : 0;      // dbg 256: half the waves skip their MFMAs
         for (; g + 1 < G; g += 2) {     // straight-line body (no branch around the prefetches): IR-level sinking cannot move one below its group
             if constexpr (STAMPS) if TG_DBG(a, 2048) {                         // profiling: no weight stream inside the loop
-                compute_group(ringA, acc, gmap(g));
-                compute_group(ringA, acc, gmap(g + 1));
+                compute_group(ringA, codeA, acc, gmap(g));
+                compute_group(ringA, codeA, acc, gmap(g + 1));
                 if constexpr (STAMPS) if (TG_STAMPS(a) && g < 8) stamp(4 + (g >> 1));
                 continue;
             }
-            load_group(ringB, wp + (long long)wgrp(g + 1) * GROUP_HALFS);      // ringB <- group g+1, under group g's MFMAs
+            load_wg(ringB, codeB, TG_DBG(a, 32) ? 0 : mt, wgrp(g + 1));        // ringB <- group g+1, under group g's MFMAs
             if (g == g_issue && pn >= 0 && !TG_DBG(a, 128)) { issue_next_init(); nxt_issued = true; }
             __builtin_amdgcn_sched_barrier(0);
-            compute_group(ringA, acc, gmap(g));
+            compute_group(ringA, codeA, acc, gmap(g));
             const int gn = g + 2 < G ? g + 2 : G - 1;
-            load_group(ringA, wp + (long long)wgrp(gn) * GROUP_HALFS);         // ringA <- group g+2, under group g+1's MFMAs
+            load_wg(ringA, codeA, TG_DBG(a, 32) ? 0 : mt, wgrp(gn));           // ringA <- group g+2, under group g+1's MFMAs
             __builtin_amdgcn_sched_barrier(0);
-            compute_group(ringB, acc, gmap(g + 1));
+            compute_group(ringB, codeB, acc, gmap(g + 1));
             if constexpr (STAMPS) if (TG_STAMPS(a) && g < 8) stamp(4 + (g >> 1));
         }
-        if (g < G) compute_group(ringA, acc, gmap(g));                         // odd group count: the tail group
+        if (g < G) compute_group(ringA, codeA, acc, gmap(g));                  // odd group count: the tail group
         stamp(9);
         // the next tile's weight stream starts before this tile's epilogue, so its latency sits under the epilogue
         if (pn >= 0) {
-            load_group(ringA, wbase + (long long)(TG_DBG(a, 32) ? 0 : mt_n) * tile_halfs + (long long)gmap(0) * GROUP_HALFS);
+            load_wg(ringA, codeA, TG_DBG(a, 32) ? 0 : mt_n, gmap(0));
             if (!nxt_issued) issue_next_init();                                // short K loops (or dbg 128): issue here instead
         }
         if (!TG_DBG(a, 2)) epi.finish(ea, mt, row0, lane, acc);
@@ -455,8 +513,9 @@ inline void tstamp_dump(const char* prefix) {
 }
 
 // n_rows must be a multiple of 32*NT_N; m_split = number of blockIdx.y slices the output-channel passes are dealt over
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1>
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0>
 inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, int m_split, hipStream_t stream) {
+    if (W6 && (!a.w6 || a.n_variants != 1 || a.cin % 64 != 0)) return fail(DSVC_EINVAL, "tgemm: the W6 kernels need the code plane of the variant to use");
     if (a.cin % (16 * KG) != 0) return fail(DSVC_EINVAL, "tgemm: cin %d not a multiple of %d", a.cin, 16 * KG);
     if (n_rows % (32 * NT_N) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N);
     if (a.w_planes != NW) return fail(DSVC_EINVAL, "tgemm: weights packed with %d plane(s), kernel streams %d", a.w_planes, NW);
@@ -466,7 +525,7 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
     const char* dbg_s = getenv("DSVC_TG_DEBUG");           // profiling ablations only; results are WRONG when set
     a.dbg = dbg_s ? atoi(dbg_s) : 0;
 #endif
-    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS, NA>;
+    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS, NA, W6>;
     const size_t smem = tgemm_smem<NT_N>(a.taps, a.dil, a.cin * NA) + (size_t)(KS - 1) * WAVES * NT_N * 4096;
     if (smem > 160 * 1024) return fail(DSVC_EINVAL, "tgemm: %zu B of LDS requested", smem);
     static thread_local size_t smem_set = 0;

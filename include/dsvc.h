@@ -41,6 +41,10 @@ enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM
  *   F16_X3T: the same operand scheme on the tgemm engine (activation rows hold [x_hi | x_lo] planes; the weight stream is F16_W2's):
  *            the fp32-class scheme at the speed class of the small-batch tgemm kernels (3.3e-5 ... 4.9e-5 mel after 1000 steps on 21
  *            goldens, +14 ... 20 % over F16_W2 up to six 10 s clips, 1.5 ... 1.9x beyond).  "auto": DDPM calls under 6000 frames, PLMS, forward().
+ *            Round 4: in the 32-frame tilings (up to ~6 clips) and when the caller knows the step (the sampler's DDPM loop), the w_lo * x_hi
+ *            product runs as one K = 64 six-bit MFMA per 64 input channels on time-dithered fp6 codes of w_lo (weight_variants roundings):
+ *            the lo plane streams 384 B instead of 1 KiB per k16 step -- 0.391 instead of 0.417 ms per step for one clip, 7.6e-5 ... 8.4e-5
+ *            instead of 3.2e-5 ... 3.3e-5 mel after 1000 steps.
  *   F16_W6 : (round 4) F16_W2 with every correction term on the block-scaled 6-bit matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, 4x the
  *            fp16 MFMA rate) inside the fused layer kernel.  Per 64 input channels: 16 fp16 MFMAs (w_hi x) + 4 six-bit ones (w_lo as
  *            time-dithered fp6 E2M3 codes -- weight_variants roundings, one power-of-two scale per conv -- against x converted to bf6 E3M2 in
@@ -71,7 +75,7 @@ typedef struct {
     int32_t dilation_cycle;  /* dilation_cycle_length                             (net.py:94)  */
     int32_t max_steps;       /* number of integer diffusion steps to tabulate (timesteps)      */
     int32_t precision;       /* DSVC_PREC_* for the two big per-layer contractions              */
-    int32_t weight_variants; /* DSVC_PREC_F16 / F16_MIX / F16_W6: number of dithered weight roundings (<= 1: nearest) */
+    int32_t weight_variants; /* DSVC_PREC_F16 / F16_MIX / F16_W6 / F16_X3T: number of dithered weight roundings (<= 1: nearest) */
 } dsvc_denoiser_cfg;
 
 int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out);
