@@ -14,7 +14,10 @@ output 1x1; ``"f16_x3"`` splits the activations as well (3 MFMAs, fp32-class).  
 * DDPM, up to 6 ten-second clips per call (< ``BATCHED_FRAMES`` mel frames): ``f16_x3t`` -- fp32-class (hi + lo weights AND split
   activations, 3 MFMAs) on the tgemm engine.  The small-batch kernels are bound by the weight stream and by latency, not by MFMAs, so the
   third MFMA costs 14 ... 20 % there (0.418 ms per step for one clip against 0.366 at f16_w2) and buys 3.3e-5 ... 4.9e-5 mel error after 1000
-  steps on every real-reference golden instead of 6e-4 ... 9e-4 (round 3; profiles/r3l_auto_sweep.txt, r3l_pytest_gpu.txt).
+  steps on every real-reference golden instead of 6e-4 ... 9e-4 (round 3; profiles/r3l_auto_sweep.txt, r3l_pytest_gpu.txt).  Round 4: inside
+  the sampler's DDPM loop the w_lo * x_hi product of these tilings is one 6-bit MFMA per 64 input channels on time-dithered fp6 codes of w_lo
+  (0.391 instead of 0.417 ms per step; 7e-5 ... 9e-5 on the 21 goldens, conditioned checkpoints included); PLMS and ``forward()`` keep the
+  fp16 lo plane -- PLMS amplifies the 1e-5-relative weight error of a single dither variant to 4.7e-4 (measured).
 * DDPM, larger calls: ``f16_w6`` (round 4) -- f16_w2's operand scheme (exact weights as fp16 hi + w_lo, fp16 activations) with every
   correction term on the block-scaled 6-bit matrix instruction inside the fused layer kernel (w_lo as time-dithered fp6 codes against
   bf6(x) converted in registers: 16 fp16 + 4 six-bit MFMAs per 64 input channels instead of 32 fp16 ones), plus a 6-bit correction of the
