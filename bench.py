@@ -38,7 +38,7 @@ FAST_SIDE = "f16_w6n"                              # the faster operand scheme r
 # Per-clip maximum mel error of the shipped batched precision (f16_w6) over the 64 real-reference goldens of two 32-clip batches
 # (tests/test_gpu_headline.py::test_batch_of_32_full_chain_every_clip_with_a_golden[random|random2-shipped], profiles/r4*_b32_goldens.txt):
 # Gumbel fit (mu, beta) of the 64 maxima -> P(a clip exceeds the 1e-3 bar) and P(a 256-clip job holds such a clip)
-B32_ERROR_FIT = {"precision": "f16_w6", "clips": 64, "worst": 5.97e-4, "gumbel_mu": 4.67e-4, "gumbel_beta": 3.3e-5,
+B32_ERROR_FIT = {"precision": "f16_w6", "clips": 64, "worst": 6.12e-4, "gumbel_mu": 4.62e-4, "gumbel_beta": 3.5e-5,
                  "source": "profiles/r4_b32_goldens.txt"}
 PEAK_HBM_GBS = 8000.0                              # HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
 # algorithmic HBM bytes per frame of one residual layer, C = 384, fp16 operands / fp32 residual + skip + cproj:
