@@ -455,3 +455,20 @@ def test_deferred_skip_contraction_taps_and_equivalence(precision):
     d = (a - b).abs().max().item()
     print("deferred vs in-layer skip accumulation (%s), 20 DDPM steps at 8 x 861: max |diff| of the state %.2e" % (precision, d))
     assert torch.isfinite(a).all() and 0.0 < d < 2e-4
+
+
+@pytest.mark.parametrize("precision", ["f16_w6", "f16_w6n", "f16_w2"])
+def test_fused_layer_kernels_on_the_24k_architecture(precision):
+    """The fused layer kernel's two-block instantiations (C = 256: the 24 kHz demo architecture, BASELINE configs[0]'s shapes) -- every other test of
+    the batched path runs the three-block 44.1 kHz ones.  8 clips x T = 861 on the fused kernel (forced: the automatic choice needs >= 120 tiles), a
+    30-step DDPM chain, every clip against the oracle's chain from the same Philox noise: f16_w6 / f16_w6n (the 6-bit correction products and the
+    gate-output correction with NB = 2) and f16_w2 stay in the fp16-activation class (a wrong code layout shows at >= 1e-2)."""
+    hp = dict(synth.HPARAMS_24K, K_step=30)
+    sd, den, smp = make_handles(hp, 2, precision)
+    den.debug_set("two_launch_layer", -1)
+    clips, T, n_units, seed = list(range(8)), 861, 500, 41
+    ref = oracle_sample(hp, sd, clips, T, n_units, 1, seed, 30)
+    mel = smp.sample(ref["cond_t"].cuda(), 30, mel2ph=ref["mel2ph"].cuda(), seed=seed, first_clip=0, use_graph=False).cpu()
+    errs = [(mel[b] - ref["mel_out"][b]).abs().max().item() for b in range(len(clips))]
+    print("24 kHz architecture, fused layer kernel, %s: 30-step mel max-abs err per clip %s" % (precision, ["%.1e" % e for e in errs]))
+    assert torch.isfinite(mel).all() and max(errs) < 2e-3, errs
