@@ -603,7 +603,7 @@ __device__ inline _Float16 tg_round_dither(float w, float thresh) {
     return frac > thresh ? hi : lo;
 }
 
-__global__ void k_tpack(const float* __restrict__ src, const int* __restrict__ rowmap, const float* __restrict__ rowscale,
+static __global__ void k_tpack(const float* __restrict__ src, const int* __restrict__ rowmap, const float* __restrict__ rowscale,
                         _Float16* __restrict__ dst, int I, int taps, int cin_pad, int fold, int m_tiles, int planes, int n_variants,
                         float scale, unsigned salt) {
     const int nk16 = cin_pad >> 4;
@@ -671,7 +671,7 @@ __host__ __device__ inline int tg_e2m3_floor(float a) {
     return 24 + (int)((a - 4.0f) * 2.0f);
 }
 
-__global__ void k_tpack6(const float* __restrict__ src, const int* __restrict__ rowmap, const float* __restrict__ rowscale,
+static __global__ void k_tpack6(const float* __restrict__ src, const int* __restrict__ rowmap, const float* __restrict__ rowscale,
                          unsigned* __restrict__ dst, int I, int taps, int cin_pad, int m_tiles, int n_variants, float scale, float inv6,
                          unsigned salt, int whole) {         // whole: the codes are those of w itself (the g_lo correction's weight operand), not of w_lo
     const int nq = cin_pad >> 6;

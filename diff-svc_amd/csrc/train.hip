@@ -27,6 +27,7 @@
 #include "cg_util.h"
 #include "wgrad.h"
 #include "pgemm.h"
+#include "tepi_util.h"
 
 using namespace dsvc;
 
@@ -126,6 +127,200 @@ struct EpBwd {
         *p = e.accumulate ? *p + v : v;
     }
 };
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the FORWARD pass of the residual layers on the sampler's tgemm engine (tgemm.h, NA = 2: the activations as fp16 [hi | lo] row planes
+// written by the producing epilogue and DMA'd straight into LDS, weights streamed in fragment order -- the same three-MFMA split products as
+// conv_gemm, 2.2x its rate at this shape).  The backward pass keeps reading the fp32 frame-major stores (x^l, sigma, tau, g, skip), which these
+// epilogues write as 16-byte pieces of a lane's 8 / 16 consecutive channels.
+//   accumulator of N-tile nt = frame row0 + 32 nt + (lane & 31); h = lane >> 5
+//   gate kernel:  registers 0..7 = gate, 8..15 = filter pre-activations of g-channels 16 m_tile + 8 h + (r & 7), PRE-SCALED by -log2(e) /
+//                 -2 log2(e) through the packed weight rows and the hoisted conditioner projection (diffnet_t.h: gate_act_scaled)
+//   out kernel:   registers = channels 32 m_tile + 16 h + r; tiles [0, C/32) are the residual half, [C/32, 2C/32) the skip half
+// ------------------------------------------------------------------------------------------------
+// W_c,l cond + b_c,l + b_d,l for ALL layers, accumulator-tiled per layer (what the gate kernels load as their accumulator init)
+struct TEpiCprojT {
+    struct Args { float* out; long long slab; int mpl; const float* bd; const float* bc; long long layer_stride; int C; };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int l = mt / e.mpl, ml = mt - l * e.mpl;
+        const int cg = 16 * ml + 8 * (lane >> 5);
+        const float* bd = e.bd + (long long)l * e.layer_stride + cg;
+        const float* bc = e.bc + (long long)l * e.layer_stride + cg;
+        float b[16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { b[r] = GATE_SCALE * (bd[r] + bc[r]); b[8 + r] = FILT_SCALE * (bd[e.C + r] + bc[e.C + r]); }
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            float* p = e.out + (long long)l * e.slab + tiled_lane_base(row0 + 32 * nt, e.mpl, ml, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                st4(p + 256 * q, f32x4{acc[nt][4 * q] + b[4 * q], acc[nt][4 * q + 1] + b[4 * q + 1], acc[nt][4 * q + 2] + b[4 * q + 2], acc[nt][4 * q + 3] + b[4 * q + 3]});
+        }
+    }
+};
+
+// gate forward (net.py:71-77): sigma, tau (kept for the backward pass), g = sigma tau as fp32 rows and as the output projection's fp16 planes
+struct TEpiGateT {
+    struct Args { const float* cproj; float* sig; float* tau; float* g; _Float16* gh; int C, Cp; RowInfo ri; };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int n_mt = e.C >> 4;
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const float* p = e.cproj + tiled_lane_base(row0 + 32 * nt, n_mt, mt, lane);
+            const f32x4 v0 = ld4_nt(p), v1 = ld4_nt(p + 256), v2 = ld4_nt(p + 512), v3 = ld4_nt(p + 768);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[nt][i] = v0[i]; acc[nt][4 + i] = v1[i]; acc[nt][8 + i] = v2[i]; acc[nt][12 + i] = v3[i]; }
+        }
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int cg = 16 * mt + 8 * (lane >> 5);
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            const bool ok = e.ri.valid(frame);
+            float s[8], t[8], gv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float bf = __builtin_amdgcn_fmed3f(acc[nt][8 + r], -43.28f, 43.28f);      // |b| <= 15 (gate_act_scaled)
+                const float e1 = __builtin_amdgcn_exp2f(acc[nt][r]), e2 = __builtin_amdgcn_exp2f(bf);
+                s[r] = __builtin_amdgcn_rcpf(1.0f + e1);
+                t[r] = (1.0f - e2) * __builtin_amdgcn_rcpf(1.0f + e2);
+                gv[r] = ok ? s[r] * t[r] : 0.f;
+            }
+            const size_t o = (size_t)frame * e.C + cg;
+            st4(e.sig + o, f32x4{s[0], s[1], s[2], s[3]}); st4(e.sig + o + 4, f32x4{s[4], s[5], s[6], s[7]});
+            st4(e.tau + o, f32x4{t[0], t[1], t[2], t[3]}); st4(e.tau + o + 4, f32x4{t[4], t[5], t[6], t[7]});
+            st4(e.g + o, f32x4{gv[0], gv[1], gv[2], gv[3]}); st4(e.g + o + 4, f32x4{gv[4], gv[5], gv[6], gv[7]});
+            half8 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { hi[r] = (_Float16)gv[r]; lo[r] = (_Float16)(gv[r] - (float)hi[r]); }
+            _Float16* q = e.gh + (size_t)frame * (2 * e.Cp) + cg;
+            *reinterpret_cast<half8*>(q) = hi;
+            *reinterpret_cast<half8*>(q + e.Cp) = lo;
+        }
+    }
+};
+
+// output projection forward (net.py:79-84): x^{l+1} = (x^l + r) / sqrt 2 into the next slab (+ the next gate's operand planes fp16(x^{l+1} + film_{l+1})),
+// skip += s; invalid rows -> 0 everywhere (the convs' zero padding)
+struct TEpiResSkipT {
+    struct Args { const float* x; float* xnext; float* skip; _Float16* xh; const float* bias; const float* film; int film_stride; int C, Cp; int first; RowInfo ri; };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int rt = e.C >> 5;
+        const bool res = mt < rt;
+        const int cb = (res ? mt : mt - rt) * 32 + 16 * (lane >> 5);
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            if (!res && e.first) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+            } else {
+                const float* p = (res ? e.x : e.skip) + (size_t)(row0 + 32 * nt + (lane & 31)) * e.C + cb;
+                const f32x4 v0 = ld4(p), v1 = ld4(p + 4), v2 = ld4(p + 8), v3 = ld4(p + 12);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[nt][i] = v0[i]; acc[nt][4 + i] = v1[i]; acc[nt][8 + i] = v2[i]; acc[nt][12 + i] = v3[i]; }
+            }
+        }
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int rt = e.C >> 5;
+        const bool res = mt < rt;
+        const int cb = (res ? mt : mt - rt) * 32 + 16 * (lane >> 5);
+        float b[16];
+        {
+            const float* bp = e.bias + (res ? 0 : e.C) + cb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const f32x4 v = ld4(bp + 4 * q); b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3]; }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            const bool ok = e.ri.valid(frame);
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = ok ? (res ? (acc[nt][i] + b[i]) * RSQRT2 : acc[nt][i] + b[i]) : 0.f;
+            float* p = (res ? e.xnext : e.skip) + (size_t)frame * e.C + cb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st4(p + 4 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+            if (res && e.xh) {
+                float hv[16];
+                if (ok) {
+                    const float* fp = e.film + (size_t)(frame / e.ri.clip_stride) * e.film_stride + cb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 f = ld4(fp + 4 * q);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hv[4 * q + i] = v[4 * q + i] + f[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) hv[i] = 0.f;
+                }
+                store_hi_lo16(e.xh + (size_t)frame * (2 * e.Cp) + cb, e.Cp, hv);
+            }
+        }
+    }
+};
+
+// fp32 rows [rows][ld_src] (+ add[clip]) -> fp16 [hi | lo] row planes [rows][2 Cp]: the tgemm operand of layer 0 and of the conditioner
+// projection; invalid rows and the channel padding are written as zeros
+__global__ void k_rows_to_planes(const float* __restrict__ src, int ld_src, int C, const float* __restrict__ add, int add_stride,
+                                 _Float16* __restrict__ dst, int Cp, RowInfo ri, int rows) {
+    const int per_row = Cp >> 2;
+    const long long n = (long long)rows * per_row;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / per_row), c4 = (int)(i - (long long)row * per_row) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c4 < C && ri.valid(row)) {
+            const f32x4 x = ld4(src + (size_t)row * ld_src + c4);
+            const float* ap = add ? add + (size_t)(row / ri.clip_stride) * add_stride + c4 : nullptr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = x[j] + (ap ? ap[j] : 0.f);
+        }
+        _Float16* q = dst + (size_t)row * (2 * Cp) + c4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const _Float16 h = (_Float16)v[j];
+            q[j] = h;
+            q[Cp + j] = (_Float16)(v[j] - (float)h);
+        }
+    }
+}
+
+// the step's weight re-packs into tgemm fragment order, one launch (tgemm.h: k_tpack with two planes, one variant): blockIdx.y = descriptor
+struct TPackDesc { const float* src; const int* rowmap; const float* rowscale; _Float16* dst; int I, taps, cin_pad, m_tiles; };
+__global__ void k_tpack_batch(const TPackDesc* __restrict__ descs) {
+    const TPackDesc d = descs[blockIdx.y];
+    const int nk16 = d.cin_pad >> 4;
+    const long long total = (long long)d.m_tiles * d.taps * nk16 * 512;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        long long r = idx;
+        const int e = (int)(r & 7), l = (int)((r >> 3) & 63);
+        r >>= 9;
+        const int k = (int)(r % nk16); r /= nk16;
+        const int tap = (int)(r % d.taps);
+        const int mt = (int)(r / d.taps);
+        const int row = mt * 32 + (l & 31), ci = k * 16 + 8 * (l >> 5) + e;
+        const int o = d.rowmap[row];
+        const float w = (o >= 0 && ci < d.I) ? d.src[((size_t)o * d.I + ci) * d.taps + tap] * (d.rowscale ? d.rowscale[row] : 1.0f) : 0.f;
+        const _Float16 hi = (_Float16)w;
+        _Float16* f = d.dst + ((((size_t)mt * d.taps + tap) * nk16 + k) * 2) * 512 + l * 8 + e;
+        f[0] = hi;
+        f[512] = (_Float16)(w - (float)hi);
+    }
+}
 
 constexpr int WGRAD_MAX_TILES = 288;     // frame slices x output tiles of one weight-gradient GEMM (workgroups per launch; 128 KB of scratch each)
 
@@ -605,10 +800,24 @@ struct dsvc_trainer {
 
     DevBuf gatemap;                                // packed column -> conv channel of the paired gate layout
 
+    // round 4: the residual layers' FORWARD on the tgemm engine (C % 32 == 0; other widths keep the conv_gemm forward)
+    bool tfwd = false;
+    int Cp = 0, Hp = 0;                            // channels of a plane: C / H rounded up to 128
+    static constexpr int TGUARD = 64;              // zero rows in front of and behind xhP (the dilated conv's halo at the first / last tile)
+    DevBuf xhP, ghP, condHP;                       // fp16 [hi | lo] row planes: x^l + film_l [TGUARD + rows + TGUARD][2 Cp], g_l [rows][2 Cp], cond [rows][2 Hp]
+    DevBuf gate_t, out_t, cproj_t;                 // fragment-ordered hi|lo weights of every layer (k_tpack_batch, per step)
+    size_t gate_halfs = 0, out_halfs = 0, cproj_halfs = 0;     // per layer
+    DevBuf t_gate_rm, t_gate_rs, t_out_rm;         // packed row -> source channel (+ the gate rows' pre-scale)
+    std::vector<TPackDesc> tpack_q;
+    DevBuf tpack_dev;
+    std::vector<char> tpack_cached;
+    template <class Epi> int tg(const _Float16* x, int cin, int taps, int dil, const _Float16* w, int m_tiles, const typename Epi::Args& e, hipStream_t st);
+
     ~dsvc_trainer() {
         for (DevBuf* b : {&sa, &sb, &spec_min, &spec_max, &xt, &xs, &sig, &tau, &g, &skip, &ypre, &s2pre, &eps, &deps, &condT, &tstep,
                           &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre,
-                          &dh0, &loss, &AT, &BT, &wpart, &gatemap, &pack_dev, &wplane_dev, &bin_count, &bin_cursor, &bin_segs, &bin_nsegs, &bin_order, &bin_S})
+                          &dh0, &loss, &AT, &BT, &wpart, &gatemap, &pack_dev, &wplane_dev, &bin_count, &bin_cursor, &bin_segs, &bin_nsegs, &bin_order, &bin_S,
+                          &xhP, &ghP, &condHP, &gate_t, &out_t, &cproj_t, &t_gate_rm, &t_gate_rs, &t_out_rm, &tpack_dev})
             b->release();
         for (APlanes* a : {&condP, &dyP, &dOP}) a->buf.release();
         wp_call.w.release();
@@ -707,6 +916,10 @@ int dsvc_trainer::flush_packs(hipStream_t st) {
         DSVC_TRY(upload(wplane_dev, wplane_cached, wplane_q.data(), wplane_q.size() * sizeof(WPlaneDesc)));
         hipLaunchKernelGGL(k_wplanes_batch, dim3(96, (unsigned)wplane_q.size()), dim3(256), 0, st, wplane_dev.as<WPlaneDesc>());
     }
+    if (!tpack_q.empty()) {
+        DSVC_TRY(upload(tpack_dev, tpack_cached, tpack_q.data(), tpack_q.size() * sizeof(TPackDesc)));
+        hipLaunchKernelGGL(k_tpack_batch, dim3(96, (unsigned)tpack_q.size()), dim3(256), 0, st, tpack_dev.as<TPackDesc>());
+    }
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
@@ -753,9 +966,21 @@ int dsvc_trainer::pg(const APlanes& ap, const WPlanes& wp, int b_row0, int n_col
     return pgemm_launch<Epi>(a, rows_p, n_cols, e, st);
 }
 
+// one tgemm launch of the training forward: 64-frame tiles x 8 waves, split activations (the batched tiling of DSVC_PREC_F16_X3T)
+template <class Epi>
+int dsvc_trainer::tg(const _Float16* x, int cin, int taps, int dil, const _Float16* w, int m_tiles, const typename Epi::Args& e, hipStream_t st) {
+    TGemmArgs a{};
+    a.x = x; a.cin = cin; a.taps = taps; a.dil = dil; a.w = w; a.m_tiles = m_tiles; a.w_planes = 2; a.variant_halfs = 0; a.n_variants = 1;
+    a.step_ptr = nullptr; a.step_off = 0;
+    a.clip_rows = 64;       // = the tile: every tile starts its K loop at group 0, so a row's sums are formed in the same order whatever batch it sits in
+    const int tiles = rows / 64, passes = ceil_div(m_tiles, 8);
+    int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
+    return tgemm_launch<2, 8, 2, 4, 2, Epi, 1, 1, 2>(a, e, rows, ms, st);
+}
+
 int dsvc_trainer::repack(hipStream_t st) {
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
-    pack_q.clear(); wplane_q.clear();
+    pack_q.clear(); wplane_q.clear(); tpack_q.clear();
     const float isl = 1.0f / sqrtf((float)L);
     const int* gm = gatemap.as<int>();
     // forward (natural [O][I][taps] sources)
@@ -773,12 +998,19 @@ int dsvc_trainer::repack(hipStream_t st) {
     w_d.resize(L); w_o.resize(L); wp_oT.resize(L); wp_dT.resize(L);
     for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
-        DSVC_TRY(pack(w_d[l], P(q + "dilated_conv.weight"), gm, 2 * C, 3, C, 2 * C, (long long)C * 3, 3, 1, 0, 1.0f, st));
-        DSVC_TRY(pack(w_o[l], P(q + "output_projection.weight"), nullptr, 2 * C, 1, C, 2 * C, C, 1, 0, 0, 1.0f, st));
+        if (tfwd) {     // forward on the tgemm engine: fragment-ordered hi|lo planes (gate rows paired and pre-scaled, diffnet_t.h)
+            const int mpl = C / 16;
+            tpack_q.push_back(TPackDesc{P(q + "dilated_conv.weight"), t_gate_rm.as<int>(), t_gate_rs.as<float>(), gate_t.as<_Float16>() + (size_t)l * gate_halfs, C, 3, Cp, mpl});
+            tpack_q.push_back(TPackDesc{P(q + "output_projection.weight"), t_out_rm.as<int>(), nullptr, out_t.as<_Float16>() + (size_t)l * out_halfs, C, 1, Cp, mpl});
+            tpack_q.push_back(TPackDesc{P(q + "conditioner_projection.weight"), t_gate_rm.as<int>(), t_gate_rs.as<float>(), cproj_t.as<_Float16>() + (size_t)l * cproj_halfs, H, 1, Hp, mpl});
+        } else {
+            DSVC_TRY(pack(w_d[l], P(q + "dilated_conv.weight"), gm, 2 * C, 3, C, 2 * C, (long long)C * 3, 3, 1, 0, 1.0f, st));
+            DSVC_TRY(pack(w_o[l], P(q + "output_projection.weight"), nullptr, 2 * C, 1, C, 2 * C, C, 1, 0, 0, 1.0f, st));
+        }
         // transposed (data gradients): W^T(row = input channel, k = output channel) = W[k][row]
         DSVC_TRY(wplanes(wp_oT[l], 0, C, P(q + "output_projection.weight"), nullptr, C, 1, 2 * C, 1, C, 0, 0, 1.0f, st));
         // the conditioner projections of all layers in the gates' paired gate | filter row order, stacked
-        DSVC_TRY(wplanes(wp_call, l * c2p, L * c2p, P(q + "conditioner_projection.weight"), gm, 2 * C, 1, H, H, 1, 0, 0, 1.0f, st));
+        if (!tfwd) DSVC_TRY(wplanes(wp_call, l * c2p, L * c2p, P(q + "conditioner_projection.weight"), gm, 2 * C, 1, H, H, 1, 0, 0, 1.0f, st));
         // transposed conv: dxin[c] = sum_tap sum_o W_d[o][c][2 - tap] * dy[row + (tap-1)*d][o]
         DSVC_TRY(wplanes(wp_dT[l], 0, C, P(q + "dilated_conv.weight"), nullptr, C, 3, 2 * C, 3, (long long)C * 3, 1, 1, 1.0f, st));
     }
@@ -828,6 +1060,29 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     }
     rows_p = round_up(nr, 256);
     DSVC_TRY(aplanes(condP, round_up(H, 32), st)); DSVC_TRY(aplanes(dyP, 2 * C, st)); DSVC_TRY(aplanes(dOP, 2 * C, st));
+    tfwd = C % 32 == 0 && H % 4 == 0 && max_dil <= TGUARD;
+    if (tfwd) {
+        Cp = round_up(C, 128); Hp = round_up(H, 128);
+        const int mpl = C / 16;
+        DSVC_TRY(z(xhP, (r + 2 * TGUARD) * 2 * Cp * 2)); DSVC_TRY(z(ghP, r * 2 * Cp * 2)); DSVC_TRY(z(condHP, r * 2 * Hp * 2));
+        gate_halfs = tpacked_halfs(mpl, 3, Cp, 2, 1); out_halfs = tpacked_halfs(mpl, 1, Cp, 2, 1); cproj_halfs = tpacked_halfs(mpl, 1, Hp, 2, 1);
+        DSVC_TRY(gate_t.alloc(gate_halfs * L * 2)); DSVC_TRY(out_t.alloc(out_halfs * L * 2)); DSVC_TRY(cproj_t.alloc(cproj_halfs * L * 2));
+        if (!t_gate_rm.p) {
+            std::vector<int> grm(mpl * 32), orm(mpl * 32);
+            std::vector<float> grs(mpl * 32);
+            for (int q = 0; q < mpl * 32; ++q) {
+                const int mt = q >> 5, i = q & 31;
+                grm[q] = (i >> 4) * C + mt * 16 + trow_to_ch8(i & 15);
+                grs[q] = i < 16 ? GATE_SCALE : FILT_SCALE;
+                orm[q] = mt * 32 + trow_to_ch16(i);
+            }
+            DSVC_TRY(t_gate_rm.alloc(grm.size() * 4)); DSVC_TRY(t_gate_rs.alloc(grs.size() * 4)); DSVC_TRY(t_out_rm.alloc(orm.size() * 4));
+            DSVC_HIP(hipMemcpyAsync(t_gate_rm.p, grm.data(), grm.size() * 4, hipMemcpyHostToDevice, st));
+            DSVC_HIP(hipMemcpyAsync(t_gate_rs.p, grs.data(), grs.size() * 4, hipMemcpyHostToDevice, st));
+            DSVC_HIP(hipMemcpyAsync(t_out_rm.p, orm.data(), orm.size() * 4, hipMemcpyHostToDevice, st));
+            DSVC_HIP(hipStreamSynchronize(st));
+        }
+    }
     // weight-gradient operands (wgrad.h): frames contiguous, zero beyond the data rows and in the channel padding
     ldT = round_up(B * T, 128);                                  // real frames only (no gap rows); whole 32-frame stages, 64-frame split tiles
     cp128 = round_up(C, 128); hp128 = round_up(H, 128);
@@ -987,6 +1242,36 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
         DSVC_TRY(launch<EpStore>(a, e, st));
     }
     const int c2p = round_up(2 * C, 128);
+    if (tfwd) {
+        // the residual layers on the tgemm engine (epilogues above): operands as fp16 [hi | lo] row planes, every layer's stores as fp32 rows
+        const int mpl = C / 16;
+        _Float16* xh = xhP.as<_Float16>() + (size_t)TGUARD * 2 * Cp;
+        const size_t tslab = r * 2 * C;                                    // one layer of the accumulator-tiled conditioner projection (in ypre)
+        const RowInfo ri_all{Tp, Tp, nr};
+        hipLaunchKernelGGL(k_rows_to_planes, dim3(2048), dim3(256), 0, st, xs.as<float>(), C, C, filmB.as<float>(), L * C, xh, Cp, ri, rows);
+        hipLaunchKernelGGL(k_rows_to_planes, dim3(2048), dim3(256), 0, st, condT.as<float>(), H, H, (const float*)nullptr, 0, condHP.as<_Float16>(), Hp, ri_all, rows);
+        {
+            const std::string q0 = "denoise_fn.residual_layers.0.", q1 = "denoise_fn.residual_layers.1.";
+            const long long lstride = L > 1 ? index.at(q1 + "dilated_conv.bias").first - index.at(q0 + "dilated_conv.bias").first : 0;
+            TEpiCprojT::Args e{ypre.as<float>(), (long long)tslab, mpl, P(q0 + "dilated_conv.bias"), P(q0 + "conditioner_projection.bias"), lstride, C};
+            DSVC_TRY(tg<TEpiCprojT>(condHP.as<_Float16>(), Hp, 1, 1, cproj_t.as<_Float16>(), L * mpl, e, st));
+        }
+        for (int l = 0; l < L; ++l) {
+            const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
+            const int d = 1 << (l % cfg.dilation_cycle);
+            float* xl = xs.as<float>() + (size_t)l * slab;
+            {
+                TEpiGateT::Args e{ypre.as<float>() + (size_t)l * tslab, sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab,
+                                  g.as<float>() + (size_t)l * slab, ghP.as<_Float16>(), C, Cp, ri};
+                DSVC_TRY(tg<TEpiGateT>(xh, Cp, 3, d, gate_t.as<_Float16>() + (size_t)l * gate_halfs, mpl, e, st));
+            }
+            {
+                TEpiResSkipT::Args e{xl, xs.as<float>() + (size_t)(l + 1) * slab, skip.as<float>(), l + 1 < L ? xh : nullptr, P(q + "output_projection.bias"),
+                                     filmB.as<float>() + (size_t)(l + 1 < L ? l + 1 : l) * C, L * C, C, Cp, l == 0 ? 1 : 0, ri};
+                DSVC_TRY(tg<TEpiResSkipT>(ghP.as<_Float16>(), Cp, 1, 1, out_t.as<_Float16>() + (size_t)l * out_halfs, mpl, e, st));
+            }
+        }
+    } else {
     {   // ypre_l = W_c,l cond for ALL layers in one launch (pgemm.h: cond as fp16 hi|lo planes, the stacked projection weights), in the gates'
         // packed column order (both biases are added, in natural order, by the gate epilogue)
         DSVC_TRY(split_rows(condP, condT.as<float>(), H, H, nullptr, 0, st));
@@ -1009,6 +1294,7 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             EpResSkipFwd::Args e{xl, xs.as<float>() + (size_t)(l + 1) * slab, skip.as<float>(), P(q + "output_projection.bias"), C, l == 0 ? 1 : 0, ri};
             DSVC_TRY(launch<EpResSkipFwd>(a, e, st));
         }
+    }
     }
     {   // s2pre = W_s skip/sqrt(L) + b ;  eps = W_out relu(s2pre) + b   (net.py:131-134)
         ConvGemmArgs a = base(skip.as<float>(), C, C, w_skip, 1);
