@@ -66,6 +66,9 @@ struct TGemmArgs {
     const unsigned* w6;
     int sc6;
     float x6_scale;
+    // KP kernels (round 4; the trainer's data-gradient GEMMs, whose 2C-channel split rows do not fit LDS whole): input channels per plane that
+    // one K phase brings into LDS (% 128 == 0, divides cin); the phases are double-buffered, see the KP path of the kernel
+    int kp_cin;
 #ifdef DSVC_PROFILING       // profiling builds only (python -m diffsvc_amd.build --profiling): the product library has neither field nor branch
     unsigned long long* stamps;   // per-wave phase time stamps (s_memrealtime, 100 MHz), 16 per wave (env DSVC_TG_STAMPS)
     int dbg;                // ablation knobs (env DSVC_TG_DEBUG; results are WRONG when set): 1 = no acc-init loads, 2 = no epilogue,
@@ -108,11 +111,15 @@ constexpr int TFRAG6_DWORDS = 384;        // one k_tpack6 fragment: [lane 64][16
 // x_hi converted to bf6 in registers from the four fragments the fp16 MFMAs read (tlayer.h's W6 scheme).  These kernels are bound by the
 // weight stream and by in-order issue, not by the matrix pipe: the lo plane shrinks from 1 KiB to 384 B per k16 step and 12 MFMAs per
 // group become 8 + 1.
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0>
+// KP = 1 (round 4, NA = 2 and KS = 1: the trainer's data-gradient GEMMs): the K axis is STREAMED through LDS in phases of a.kp_cin input channels
+// per plane instead of being resident -- a 64-frame tile of [hi | lo] rows of 2C = 768 channels is 192 KB.  Two buffers: the DMA of phase p + 1
+// is issued right behind the barrier that publishes phase p, so it runs under phase p's MFMAs; one barrier per phase.
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0, int KP = 0>
 __global__ void __launch_bounds__(64 * WAVES * KS, MINW) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     static_assert(NA == 1 || NW == 2, "split activations are combined with hi + lo weight planes");
     static_assert(!W6 || (NA == 2 && NT_N == 1 && KG == 4), "W6: the small split-activation tilings, 64 input channels per group");
+    static_assert(!KP || (KS == 1 && !W6), "KP: streamed K phases on the plain tilings");
     constexpr int TN = 32 * NT_N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -140,7 +147,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     const int row_bytes = row_halfs * 2;
 
     // ---- stage the time tile: HBM/L2 -> LDS by DMA, swizzled on the source side ----
-    {
+    if constexpr (!KP) {
         const int total = rows_lds * chunks;             // 16-B slots
         const int dq = (WAVES * KS * 64) / chunks, dr = (WAVES * KS * 64) - dq * chunks;
         int slot = wave_all * 64 + lane;
@@ -192,9 +199,13 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     };
     typedef const half8 __attribute__((address_space(3))) * lds_frag_ptr;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned nt_stride = 32u * (unsigned)row_bytes;
+    // what compute_group reads (KP: the current phase buffer, its narrower rows and its groups per tap; otherwise the resident tile)
+    unsigned cg_lds = lds0, cg_row_bytes = (unsigned)row_bytes, cg_lo_off = (unsigned)a.cin * 2u;
+    int cg_gpt = gpt;
+    if constexpr (KP) { cg_row_bytes = (unsigned)(a.kp_cin * NA * 2); cg_lo_off = (unsigned)a.kp_cin * 2u; cg_gpt = (a.kp_cin >> 4) / KG; }
+    const unsigned nt_stride = 32u * cg_row_bytes;
     auto compute_group = [&](const half8 (&ring)[KG][NW], const tg_v6i& c6, f32x16 (&acc)[NT_N], int g) {
-        const int tap = g / gpt, kb = (g - tap * gpt) * KG;
+        const int tap = g / cg_gpt, kb = (g - tap * cg_gpt) * KG;
         if constexpr (W6) {
             // one N-tile, four k-steps: all eight fragments (x_hi and x_lo of the four steps) are read up front -- the conversion needs the
             // four x_hi fragments together -- then 4 x (W_hi x_hi, W_hi x_lo), the conversion, and W_lo6 x_hi6
@@ -228,7 +239,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         // ((kb + kk) << 5) ^ xs = ((kb << 5) ^ xs) ^ (kk << 5): one per-group VALU, then an immediate XOR per step.
         const unsigned xs = (unsigned)(((rr & a.swz) ^ (lane >> 5)) << 4) ^ ((unsigned)kb << 5);
         unsigned base[NT_N];
-        base[0] = lds0 + (unsigned)rr * (unsigned)row_bytes;
+        base[0] = cg_lds + (unsigned)rr * cg_row_bytes;
 #pragma unroll
         for (int nt = 1; nt < NT_N; ++nt) base[nt] = base[nt - 1] + nt_stride;
         // keep the per-group bases materialised: without this LLVM re-derives every address from scratch (4-5 VALU per ds_read)
@@ -237,7 +248,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         // B fragments: BQ-deep software pipeline -- step kk computes from bq[kk % BQ] while steps kk+1 .. kk+BQ-1 are in flight
         constexpr int BQ = 2;                                          // (3- and 4-deep pipelines measured 3-4 % slower)
         half8 bq[BQ][NT_N], bl[BQ][NA == 2 ? NT_N : 1];
-        const unsigned lo_off = (unsigned)a.cin * 2u;                  // the lo plane of a row starts cin halfs in: the swizzle only touches the low
+        const unsigned lo_off = cg_lo_off;                             // the lo plane of a row starts cin halfs in: the swizzle only touches the low
                                                                        // four chunk bits and cin / 8 is a multiple of 16, so lo = hi address + cin * 2
 #pragma unroll
         for (int d = 0; d < BQ - 1; ++d) {
@@ -319,6 +330,73 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     const int rk = (!STAGGER || TG_DBG(a, 1024)) ? 0 : (int)((tiles_pc ? blockIdx.x % tiles_pc : blockIdx.x) % (unsigned)G);
     auto gmap = [&](int g) { if constexpr (!STAGGER) return g; const int x = g + rk; return x >= G ? x - G : x; };
     auto wgrp = [&](int g) { return TG_DBG(a, 4096) ? 0 : gmap(g); };    // dbg 4096: the ring re-reads group 0 (L1-hot weight stream)
+    if constexpr (KP) {
+        // ---- streamed-K flow ----
+        const int kpc = a.kp_cin, n_ph = a.cin / kpc;
+        const int chunks_l = (kpc * NA) >> 3, cpp = kpc >> 3;                 // 16-B chunks per LDS row / per plane of it
+        const unsigned buf_bytes = (((unsigned)rows_lds * cg_row_bytes) + 1023u) & ~1023u;
+        const int Gp = a.taps * cg_gpt;                                      // groups of one phase
+        const int total = rows_lds * chunks_l;
+        const _Float16* xrow0 = a.x + (long long)(row0 - halo) * row_halfs;
+        auto dma = [&](int p, int b) {      // phase p -> buffer b: LDS slot (row r, chunk c') holds chunk c = c' ^ (r & swz) of [hi kpc | lo kpc]
+            const int dq = (WAVES * 64) / chunks_l, dr = (WAVES * 64) - dq * chunks_l;
+            int slot = wave_all * 64 + lane;
+            int r = slot / chunks_l, c = slot - r * chunks_l;
+            for (int it = wave_all; it * 64 < total; it += WAVES) {
+                const int rc = r < rows_lds ? r : rows_lds - 1;
+                const int cs = c ^ (rc & a.swz);
+                const int plane = cs >= cpp ? 1 : 0;
+                const _Float16* src = xrow0 + (long long)rc * row_halfs + plane * a.cin + p * kpc + ((cs - plane * cpp) << 3);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + (size_t)b * buf_bytes + it * 1024), 16, 0, 0);
+                c += dr; r += dq;
+                if (c >= chunks_l) { c -= chunks_l; r += 1; }
+            }
+        };
+        auto gidx = [&](int p, int gl) { const int tap = gl / cg_gpt; return tap * gpt + p * cg_gpt + (gl - tap * cg_gpt); };   // group of the weight stream
+        Epi epi;
+        f32x16 acc[NT_N];
+        half8 ringA[KG][NW], ringB[KG][NW];
+        tg_v6i c6 = {};
+        const int passes_ = (a.m_tiles + WAVES - 1) / WAVES;
+        int ph = 0;                                                          // running phase count: buffer = ph & 1
+        dma(0, 0);
+        for (int pi = blockIdx.y; pi < passes_; pi += gridDim.y) {
+            const int mt = pi * WAVES + wave;
+            const bool active = mt < a.m_tiles;
+            const long long tbase = (long long)(active ? mt : 0) * G * GROUP_HALFS;
+            if (active) {
+                load_group(ringA, wbase + tbase + (long long)gidx(0, 0) * GROUP_HALFS);
+                epi.init(ea, mt, row0, lane, acc);
+            }
+            for (int p = 0; p < n_ph; ++p, ++ph) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of phase p have landed ...
+                __builtin_amdgcn_s_barrier();                               // ... everyone's have, and nobody still reads the other buffer
+                asm volatile("" ::: "memory");
+                const bool more = p + 1 < n_ph || pi + (int)gridDim.y < passes_;
+                if (more) dma(p + 1 < n_ph ? p + 1 : 0, (ph + 1) & 1);
+                cg_lds = lds0 + (unsigned)(ph & 1) * buf_bytes;
+                if (active) {
+                    int gl = 0;
+                    for (; gl + 1 < Gp; gl += 2) {
+                        load_group(ringB, wbase + tbase + (long long)gidx(p, gl + 1) * GROUP_HALFS);
+                        __builtin_amdgcn_sched_barrier(0);
+                        compute_group(ringA, c6, acc, gl);
+                        if (gl + 2 < Gp) load_group(ringA, wbase + tbase + (long long)gidx(p, gl + 2) * GROUP_HALFS);
+                        else if (p + 1 < n_ph) load_group(ringA, wbase + tbase + (long long)gidx(p + 1, 0) * GROUP_HALFS);
+                        __builtin_amdgcn_sched_barrier(0);
+                        compute_group(ringB, c6, acc, gl + 1);
+                    }
+                    if (gl < Gp) {
+                        compute_group(ringA, c6, acc, gl);
+                        if (p + 1 < n_ph) load_group(ringA, wbase + tbase + (long long)gidx(p + 1, 0) * GROUP_HALFS);
+                    }
+                }
+            }
+            if (active) epi.finish(ea, mt, row0, lane, acc);
+        }
+        return;
+    }
     if constexpr (KS > 1) {
         // ---- split-K flow: one tile per wave triple, gridDim.y == passes (host-checked), reduction through LDS ----
         const int mt = blockIdx.y * WAVES + wave;
@@ -513,20 +591,23 @@ inline void tstamp_dump(const char* prefix) {
 }
 
 // n_rows must be a multiple of 32*NT_N; m_split = number of blockIdx.y slices the output-channel passes are dealt over
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0>
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0, int KP = 0>
 inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, int m_split, hipStream_t stream) {
     if (W6 && (!a.w6 || a.n_variants != 1 || a.cin % 64 != 0)) return fail(DSVC_EINVAL, "tgemm: the W6 kernels need the code plane of the variant to use");
     if (a.cin % (16 * KG) != 0) return fail(DSVC_EINVAL, "tgemm: cin %d not a multiple of %d", a.cin, 16 * KG);
     if (n_rows % (32 * NT_N) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N);
     if (a.w_planes != NW) return fail(DSVC_EINVAL, "tgemm: weights packed with %d plane(s), kernel streams %d", a.w_planes, NW);
-    a.swz = tgemm_swizzle_mask(a.cin * NA);
+    a.swz = tgemm_swizzle_mask((KP ? a.kp_cin : a.cin) * NA);
     if (NA == 2 && (a.cin / 8) % 16 != 0) return fail(DSVC_EINVAL, "tgemm: split activations need cin %% 128 == 0 (got %d)", a.cin);
+    if (KP && (NA != 2 || a.kp_cin <= 0 || a.kp_cin % 128 != 0 || a.cin % a.kp_cin != 0))
+        return fail(DSVC_EINVAL, "tgemm: %d-channel K phases of %d split channels", a.kp_cin, a.cin);
 #ifdef DSVC_PROFILING
     const char* dbg_s = getenv("DSVC_TG_DEBUG");           // profiling ablations only; results are WRONG when set
     a.dbg = dbg_s ? atoi(dbg_s) : 0;
 #endif
-    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS, NA, W6>;
-    const size_t smem = tgemm_smem<NT_N>(a.taps, a.dil, a.cin * NA) + (size_t)(KS - 1) * WAVES * NT_N * 4096;
+    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS, NA, W6, KP>;
+    const size_t smem = KP ? 2 * tgemm_smem<NT_N>(a.taps, a.dil, a.kp_cin * NA)
+                           : tgemm_smem<NT_N>(a.taps, a.dil, a.cin * NA) + (size_t)(KS - 1) * WAVES * NT_N * 4096;
     if (smem > 160 * 1024) return fail(DSVC_EINVAL, "tgemm: %zu B of LDS requested", smem);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {

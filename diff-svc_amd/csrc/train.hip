@@ -274,6 +274,92 @@ struct TEpiResSkipT {
     }
 };
 
+// ---- backward, data gradients (streamed-K kernels: tgemm.h KP) ----
+// dg = W_o^T dO through the gate:  dy_a = dg tau sigma (1 - sigma),  dy_b = dg sigma (1 - tau^2); dy as fp32 rows (weight gradients, pitch-bin
+// sums) and as the transposed conv's operand planes [hi 2C | lo 2C]
+struct TEpiGateBwdT {
+    struct Args { const float* sig; const float* tau; float* dy; _Float16* dyh; int C, C2p; RowInfo ri; };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int cb = mt * 32 + 16 * (lane >> 5);
+        if (cb >= e.C) return;
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            const bool ok = e.ri.valid(frame);
+            const size_t o = (size_t)frame * e.C + cb;
+            float da[16], db[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 s = ld4(e.sig + o + 4 * q), t = ld4(e.tau + o + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = acc[nt][4 * q + i];
+                    da[4 * q + i] = ok ? v * t[i] * s[i] * (1.0f - s[i]) : 0.f;
+                    db[4 * q + i] = ok ? v * s[i] * (1.0f - t[i] * t[i]) : 0.f;
+                }
+            }
+            float* pa = e.dy + (size_t)frame * (2 * e.C) + cb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                st4(pa + 4 * q, f32x4{da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]});
+                st4(pa + e.C + 4 * q, f32x4{db[4 * q], db[4 * q + 1], db[4 * q + 2], db[4 * q + 3]});
+            }
+            _Float16* ph = e.dyh + (size_t)frame * (2 * e.C2p) + cb;
+            store_hi_lo16(ph, e.C2p, da);
+            store_hi_lo16(ph + e.C, e.C2p, db);
+        }
+    }
+};
+
+// dxin = convT(dy) (kept: its per-clip column sums are the FiLM gradient), dx <- dx / sqrt 2 + dxin, and the residual half of the next layer's
+// dO = dx / sqrt 2 as fp32 rows (weight gradients) and operand planes
+struct TEpiDxT {
+    struct Args { float* dx; float* dxin; float* dO; _Float16* dOh; int C, C2p; RowInfo ri; };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int cb = mt * 32 + 16 * (lane >> 5);
+        if (cb >= e.C) return;
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            const bool ok = e.ri.valid(frame);
+            const size_t o = (size_t)frame * e.C + cb;
+            float ov[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 x = ld4(e.dx + o + 4 * q);
+                f32x4 vi, vx, vo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vi[i] = ok ? acc[nt][4 * q + i] : 0.f;
+                    vx[i] = x[i] * RSQRT2 + vi[i];
+                    vo[i] = vx[i] * RSQRT2;
+                    ov[4 * q + i] = vo[i];
+                }
+                st4(e.dxin + o + 4 * q, vi);
+                st4(e.dx + o + 4 * q, vx);
+                st4(e.dO + (size_t)frame * (2 * e.C) + cb + 4 * q, vo);
+            }
+            store_hi_lo16(e.dOh + (size_t)frame * (2 * e.C2p) + cb, e.C2p, ov);
+        }
+    }
+};
+
 // fp32 rows [rows][ld_src] (+ add[clip]) -> fp16 [hi | lo] row planes [rows][2 Cp]: the tgemm operand of layer 0 and of the conditioner
 // projection; invalid rows and the channel padding are written as zeros
 __global__ void k_rows_to_planes(const float* __restrict__ src, int ld_src, int C, const float* __restrict__ add, int add_stride,
@@ -300,7 +386,9 @@ __global__ void k_rows_to_planes(const float* __restrict__ src, int ld_src, int 
 }
 
 // the step's weight re-packs into tgemm fragment order, one launch (tgemm.h: k_tpack with two planes, one variant): blockIdx.y = descriptor
-struct TPackDesc { const float* src; const int* rowmap; const float* rowscale; _Float16* dst; int I, taps, cin_pad, m_tiles; };
+// element (packed row -> o, input channel ci, tap) = src[o * s_o + ci * s_i + (flip ? taps - 1 - tap : tap) * s_tap]: a Conv1d weight [O][I][taps] as it
+// stands (s_o = I * taps, s_i = taps, s_tap = 1) or transposed for the data gradients
+struct TPackDesc { const float* src; const int* rowmap; const float* rowscale; _Float16* dst; int I, taps, cin_pad, m_tiles; long long s_o, s_i, s_tap; int flip; };
 __global__ void k_tpack_batch(const TPackDesc* __restrict__ descs) {
     const TPackDesc d = descs[blockIdx.y];
     const int nk16 = d.cin_pad >> 4;
@@ -314,7 +402,7 @@ __global__ void k_tpack_batch(const TPackDesc* __restrict__ descs) {
         const int mt = (int)(r / d.taps);
         const int row = mt * 32 + (l & 31), ci = k * 16 + 8 * (l >> 5) + e;
         const int o = d.rowmap[row];
-        const float w = (o >= 0 && ci < d.I) ? d.src[((size_t)o * d.I + ci) * d.taps + tap] * (d.rowscale ? d.rowscale[row] : 1.0f) : 0.f;
+        const float w = (o >= 0 && ci < d.I) ? d.src[o * d.s_o + ci * d.s_i + (d.flip ? d.taps - 1 - tap : tap) * d.s_tap] * (d.rowscale ? d.rowscale[row] : 1.0f) : 0.f;
         const _Float16 hi = (_Float16)w;
         _Float16* f = d.dst + ((((size_t)mt * d.taps + tap) * nk16 + k) * 2) * 512 + l * 8 + e;
         f[0] = hi;
@@ -807,17 +895,24 @@ struct dsvc_trainer {
     DevBuf xhP, ghP, condHP;                       // fp16 [hi | lo] row planes: x^l + film_l [TGUARD + rows + TGUARD][2 Cp], g_l [rows][2 Cp], cond [rows][2 Hp]
     DevBuf gate_t, out_t, cproj_t;                 // fragment-ordered hi|lo weights of every layer (k_tpack_batch, per step)
     size_t gate_halfs = 0, out_halfs = 0, cproj_halfs = 0;     // per layer
+    // ... and the two data-gradient GEMMs of the backward pass (streamed-K kernels: their 2C-channel split rows do not fit LDS whole)
+    bool tbwd = false;
+    int C2p = 0;                                   // 2C rounded up to 128
+    DevBuf dOh, dyh;                               // planes of dO [rows][2 C2p] and of dy [TGUARD + rows + TGUARD][2 C2p]
+    DevBuf oT_t, dT_t;                             // W_o^T and the flipped W_d^T, rows = input channels of the layer
+    size_t oT_halfs = 0, dT_halfs = 0;
     DevBuf t_gate_rm, t_gate_rs, t_out_rm;         // packed row -> source channel (+ the gate rows' pre-scale)
     std::vector<TPackDesc> tpack_q;
     DevBuf tpack_dev;
     std::vector<char> tpack_cached;
-    template <class Epi> int tg(const _Float16* x, int cin, int taps, int dil, const _Float16* w, int m_tiles, const typename Epi::Args& e, hipStream_t st);
+    template <class Epi, int KP = 0>
+    int tg(const _Float16* x, int cin, int taps, int dil, const _Float16* w, int m_tiles, const typename Epi::Args& e, hipStream_t st, int kp_cin = 0);
 
     ~dsvc_trainer() {
         for (DevBuf* b : {&sa, &sb, &spec_min, &spec_max, &xt, &xs, &sig, &tau, &g, &skip, &ypre, &s2pre, &eps, &deps, &condT, &tstep,
                           &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre,
                           &dh0, &loss, &AT, &BT, &wpart, &gatemap, &pack_dev, &wplane_dev, &bin_count, &bin_cursor, &bin_segs, &bin_nsegs, &bin_order, &bin_S,
-                          &xhP, &ghP, &condHP, &gate_t, &out_t, &cproj_t, &t_gate_rm, &t_gate_rs, &t_out_rm, &tpack_dev})
+                          &xhP, &ghP, &condHP, &gate_t, &out_t, &cproj_t, &t_gate_rm, &t_gate_rs, &t_out_rm, &tpack_dev, &dOh, &dyh, &oT_t, &dT_t})
             b->release();
         for (APlanes* a : {&condP, &dyP, &dOP}) a->buf.release();
         wp_call.w.release();
@@ -967,15 +1062,22 @@ int dsvc_trainer::pg(const APlanes& ap, const WPlanes& wp, int b_row0, int n_col
 }
 
 // one tgemm launch of the training forward: 64-frame tiles x 8 waves, split activations (the batched tiling of DSVC_PREC_F16_X3T)
-template <class Epi>
-int dsvc_trainer::tg(const _Float16* x, int cin, int taps, int dil, const _Float16* w, int m_tiles, const typename Epi::Args& e, hipStream_t st) {
+template <class Epi, int KP>
+int dsvc_trainer::tg(const _Float16* x, int cin, int taps, int dil, const _Float16* w, int m_tiles, const typename Epi::Args& e, hipStream_t st, int kp_cin) {
     TGemmArgs a{};
+    a.kp_cin = kp_cin;
     a.x = x; a.cin = cin; a.taps = taps; a.dil = dil; a.w = w; a.m_tiles = m_tiles; a.w_planes = 2; a.variant_halfs = 0; a.n_variants = 1;
     a.step_ptr = nullptr; a.step_off = 0;
-    a.clip_rows = 64;       // = the tile: every tile starts its K loop at group 0, so a row's sums are formed in the same order whatever batch it sits in
+    // the K loops start at staggered groups (clip_rows = 0: keyed on the tile index).  Measured on the 64 x 128 golden: with every tile summing in
+    // the SAME order (clip_rows = 64) the most cancellation-prone gradients sit 7.8e-4 from the fp64 evaluation instead of 2.1e-4 -- the
+    // accumulation's rounding is then the same function of the data in all 8704 rows and does not average out in the weight-gradient
+    // contraction over the frames; the price is that a row's last bits depend on where its tile sits in the batch (profiles/r4_tfwd_tests.txt)
+    a.clip_rows = 0;
     const int tiles = rows / 64, passes = ceil_div(m_tiles, 8);
     int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
-    return tgemm_launch<2, 8, 2, 4, 2, Epi, 1, 1, 2>(a, e, rows, ms, st);
+    // (9..12 output tiles -- C = 384 has 12 in the data-gradient GEMMs -- are a full pass of 8 waves plus a half-empty one, 2 x tiles workgroups;
+    //  twelve waves doing all tiles in one pass, 136 workgroups instead of 272, measured slower: 10.70 against 10.45 ms per step)
+    return tgemm_launch<2, 8, 2, 4, 2, Epi, 1, 1, 2, 0, KP>(a, e, rows, ms, st);
 }
 
 int dsvc_trainer::repack(hipStream_t st) {
@@ -1000,19 +1102,27 @@ int dsvc_trainer::repack(hipStream_t st) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
         if (tfwd) {     // forward on the tgemm engine: fragment-ordered hi|lo planes (gate rows paired and pre-scaled, diffnet_t.h)
             const int mpl = C / 16;
-            tpack_q.push_back(TPackDesc{P(q + "dilated_conv.weight"), t_gate_rm.as<int>(), t_gate_rs.as<float>(), gate_t.as<_Float16>() + (size_t)l * gate_halfs, C, 3, Cp, mpl});
-            tpack_q.push_back(TPackDesc{P(q + "output_projection.weight"), t_out_rm.as<int>(), nullptr, out_t.as<_Float16>() + (size_t)l * out_halfs, C, 1, Cp, mpl});
-            tpack_q.push_back(TPackDesc{P(q + "conditioner_projection.weight"), t_gate_rm.as<int>(), t_gate_rs.as<float>(), cproj_t.as<_Float16>() + (size_t)l * cproj_halfs, H, 1, Hp, mpl});
+            tpack_q.push_back(TPackDesc{P(q + "dilated_conv.weight"), t_gate_rm.as<int>(), t_gate_rs.as<float>(), gate_t.as<_Float16>() + (size_t)l * gate_halfs, C, 3, Cp, mpl,
+                                        (long long)C * 3, 3, 1, 0});
+            tpack_q.push_back(TPackDesc{P(q + "output_projection.weight"), t_out_rm.as<int>(), nullptr, out_t.as<_Float16>() + (size_t)l * out_halfs, C, 1, Cp, mpl, C, 1, 1, 0});
+            tpack_q.push_back(TPackDesc{P(q + "conditioner_projection.weight"), t_gate_rm.as<int>(), t_gate_rs.as<float>(), cproj_t.as<_Float16>() + (size_t)l * cproj_halfs, H, 1, Hp, mpl,
+                                        H, 1, 1, 0});
+            if (tbwd) {   // transposed: packed row = input channel c of the layer, K = its 2C output channels
+                // W_o^T(c, k) = W_o[k][c]
+                tpack_q.push_back(TPackDesc{P(q + "output_projection.weight"), t_out_rm.as<int>(), nullptr, oT_t.as<_Float16>() + (size_t)l * oT_halfs, 2 * C, 1, C2p, C / 32, 1, C, 1, 0});
+                // transposed conv: dxin[c] = sum_tap sum_o W_d[o][c][2 - tap] * dy[row + (tap-1)*d][o]
+                tpack_q.push_back(TPackDesc{P(q + "dilated_conv.weight"), t_out_rm.as<int>(), nullptr, dT_t.as<_Float16>() + (size_t)l * dT_halfs, 2 * C, 3, C2p, C / 32, 3, (long long)C * 3, 1, 1});
+            }
         } else {
             DSVC_TRY(pack(w_d[l], P(q + "dilated_conv.weight"), gm, 2 * C, 3, C, 2 * C, (long long)C * 3, 3, 1, 0, 1.0f, st));
             DSVC_TRY(pack(w_o[l], P(q + "output_projection.weight"), nullptr, 2 * C, 1, C, 2 * C, C, 1, 0, 0, 1.0f, st));
         }
         // transposed (data gradients): W^T(row = input channel, k = output channel) = W[k][row]
-        DSVC_TRY(wplanes(wp_oT[l], 0, C, P(q + "output_projection.weight"), nullptr, C, 1, 2 * C, 1, C, 0, 0, 1.0f, st));
+        if (!tbwd) DSVC_TRY(wplanes(wp_oT[l], 0, C, P(q + "output_projection.weight"), nullptr, C, 1, 2 * C, 1, C, 0, 0, 1.0f, st));
         // the conditioner projections of all layers in the gates' paired gate | filter row order, stacked
         if (!tfwd) DSVC_TRY(wplanes(wp_call, l * c2p, L * c2p, P(q + "conditioner_projection.weight"), gm, 2 * C, 1, H, H, 1, 0, 0, 1.0f, st));
         // transposed conv: dxin[c] = sum_tap sum_o W_d[o][c][2 - tap] * dy[row + (tap-1)*d][o]
-        DSVC_TRY(wplanes(wp_dT[l], 0, C, P(q + "dilated_conv.weight"), nullptr, C, 3, 2 * C, 3, (long long)C * 3, 1, 1, 1.0f, st));
+        if (!tbwd) DSVC_TRY(wplanes(wp_dT[l], 0, C, P(q + "dilated_conv.weight"), nullptr, C, 3, 2 * C, 3, (long long)C * 3, 1, 1, 1.0f, st));
     }
     return flush_packs(st);
 }
@@ -1061,12 +1171,18 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     rows_p = round_up(nr, 256);
     DSVC_TRY(aplanes(condP, round_up(H, 32), st)); DSVC_TRY(aplanes(dyP, 2 * C, st)); DSVC_TRY(aplanes(dOP, 2 * C, st));
     tfwd = C % 32 == 0 && H % 4 == 0 && max_dil <= TGUARD;
+    tbwd = false;
     if (tfwd) {
         Cp = round_up(C, 128); Hp = round_up(H, 128);
         const int mpl = C / 16;
         DSVC_TRY(z(xhP, (r + 2 * TGUARD) * 2 * Cp * 2)); DSVC_TRY(z(ghP, r * 2 * Cp * 2)); DSVC_TRY(z(condHP, r * 2 * Hp * 2));
         gate_halfs = tpacked_halfs(mpl, 3, Cp, 2, 1); out_halfs = tpacked_halfs(mpl, 1, Cp, 2, 1); cproj_halfs = tpacked_halfs(mpl, 1, Hp, 2, 1);
         DSVC_TRY(gate_t.alloc(gate_halfs * L * 2)); DSVC_TRY(out_t.alloc(out_halfs * L * 2)); DSVC_TRY(cproj_t.alloc(cproj_halfs * L * 2));
+        tbwd = true;
+        C2p = round_up(2 * C, 128);
+        DSVC_TRY(z(dOh, r * 2 * C2p * 2)); DSVC_TRY(z(dyh, (r + 2 * TGUARD) * 2 * C2p * 2));
+        oT_halfs = tpacked_halfs(C / 32, 1, C2p, 2, 1); dT_halfs = tpacked_halfs(C / 32, 3, C2p, 2, 1);
+        DSVC_TRY(oT_t.alloc(oT_halfs * L * 2)); DSVC_TRY(dT_t.alloc(dT_halfs * L * 2));
         if (!t_gate_rm.p) {
             std::vector<int> grm(mpl * 32), orm(mpl * 32);
             std::vector<float> grs(mpl * 32);
@@ -1330,6 +1446,8 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
     }
     DSVC_HIP(hipMemsetAsync(dx.p, 0, r * C * 4, st));                                                                 // d x^L = 0: the loss sees x only through skip
     hipLaunchKernelGGL(k_copy_cols, dim3(ew), dim3(256), 0, st, dx.as<float>(), dO.as<float>(), nr, C, 2 * C, 0, 0.0f);   // ... so the residual half of dO starts at 0
+    if (tbwd)   // dO as the operand planes of the top layer's dg = W_o^T dO (the layers' epilogues refresh the residual half; the skip half is the same for all)
+        hipLaunchKernelGGL(k_rows_to_planes, dim3(2048), dim3(256), 0, st, dO.as<float>(), 2 * C, 2 * C, (const float*)nullptr, 0, dOh.as<_Float16>(), C2p, ri, rows);
     // cond^T planes once (weight gradients of every conditioner projection): the last segment of the layers' k axis, which nothing else writes
     DSVC_TRY(split_t(false, 3 * cp128, condT.as<float>(), H, H, nullptr, 0, 0, st));
     if (ta->pitch) {   // frames by pitch bin, once per step (the pitch-embedding gradient: k_bin_sums per layer, one product at the end)
@@ -1350,16 +1468,20 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
         const int d = 1 << (l % cfg.dilation_cycle);
         const float* xl = xs.as<float>() + (size_t)l * slab;
         const float* gl = g.as<float>() + (size_t)l * slab;
-        DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias"), &dOP));   // + dO as pgemm planes
+        DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias"), tbwd ? nullptr : &dOP));   // + dO as pgemm planes
         DSVC_TRY(split_t(false, 0, gl, C, C, nullptr, 0, 0, st));
         DSVC_TRY(wgrad_nt(2 * C, cp128, 0, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
-        {   // dg = W_o^T dO -> dy (fp32 for the weight-gradient planes, fp16 hi|lo planes for the two data gradients below)
+        if (tbwd) {   // dg = W_o^T dO -> dy, K = 2C streamed in phases of 256 (128 where 2C is not a multiple of 256) channels
+            TEpiGateBwdT::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(),
+                                 dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p, C, C2p, ri};
+            DSVC_TRY((tg<TEpiGateBwdT, 1>(dOh.as<_Float16>(), C2p, 1, 1, oT_t.as<_Float16>() + (size_t)l * oT_halfs, C / 32, e, st, C2p % 256 == 0 ? 256 : 128)));
+        } else {   // dg = W_o^T dO -> dy (fp32 for the weight-gradient planes, fp16 hi|lo planes for the two data gradients below)
             EpGateBwd::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(), C, ri};
             DSVC_TRY(pg<EpGateBwd>(dOP, wp_oT[l], 0, C, 1, 1, e, st));
         }
         // dW_d[o][c][tap] = sum_n dy[n][o] (x^l + film)[n + (tap-1) d][c]  and  dW_c[o][h] = sum_n dy[n][o] cond[n][h]  share dy^T: ONE
         // contraction over the k axis [tap 0 | tap 1 | tap 2 | cond]
-        DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "dilated_conv.bias"), &dyP));   // + dy as pgemm planes
+        DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "dilated_conv.bias"), tbwd ? nullptr : &dyP));   // + dy as pgemm planes
         DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
         DSVC_TRY(split_t(false, 0, xl, C, C, filmB.as<float>() + (size_t)l * C, L * C, d, st));
         {
@@ -1374,12 +1496,15 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             hipLaunchKernelGGL(k_bin_sums, dim3(ceil_div(B * T, 32) + cfg.pitch_vocab, ceil_div(2 * C, 256)), dim3(64), 0, st, dy.as<float>(), 2 * C,
                                bin_order.as<int>(), bin_segs.as<int>(), bin_nsegs.as<int>(), T, Tp,
                                bin_S.as<float>() + (size_t)l * cfg.pitch_vocab * 2 * C, 2 * C);
-        {   // dxin = convT(dy)
+        if (tbwd) {   // dxin = convT(dy); dx <- dx / sqrt 2 + dxin; the residual half of dO (rows and planes) <- dx / sqrt 2
+            TEpiDxT::Args e{dx.as<float>(), dxin.as<float>(), dO.as<float>(), dOh.as<_Float16>(), C, C2p, ri};
+            DSVC_TRY((tg<TEpiDxT, 1>(dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p, C2p, 3, d, dT_t.as<_Float16>() + (size_t)l * dT_halfs, C / 32, e, st, (C2p % 256 == 0 && (64 + 2 * d) * 2048 <= 160 * 1024) ? 256 : 128)));      // (two phase buffers of 64 + 2d rows in LDS)
+        } else {   // dxin = convT(dy)
             EpBwd::Args e{dxin.as<float>(), C, C, nullptr, 0, 1.0f, 0, ri};
             DSVC_TRY(pg<EpBwd>(dyP, wp_dT[l], 0, C, 3, d, e, st));
         }
         hipLaunchKernelGGL(k_clip_colsum, dim3(ceil_div(C, 64), B), dim3(256), 0, st, dxin.as<float>(), dfilm.as<float>() + (size_t)l * C, T, C, Tp, L * C);
-        hipLaunchKernelGGL(k_dx_update, dim3(ew), dim3(256), 0, st, dx.as<float>(), dxin.as<float>(), dO.as<float>(), nr, C);
+        if (!tbwd) hipLaunchKernelGGL(k_dx_update, dim3(ew), dim3(256), 0, st, dx.as<float>(), dxin.as<float>(), dO.as<float>(), nr, C);
     }
     // the step-embedding side of these layers: d diffusion_projection from dfilm_l (the FiLM gradient) -- with them the layers' gradients are final
     if (batched_small) {

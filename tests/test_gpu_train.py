@@ -410,7 +410,11 @@ def test_train_step_at_the_benchmarked_batch_equals_the_mean_of_its_sub_batches(
         if err > worst:
             worst, worst_name = err, name
     print("train step 64 x 128 vs the mean of its four quarters: loss %.6f / %.6f, worst gradient rel-L2 difference %.2e (%s)" % (loss_full, loss_avg, worst, worst_name))
-    assert torch.isfinite(g_full).all() and worst < 2e-5, (worst, worst_name)
+    # (round 4: the forward runs on the tgemm engine, whose K loops start at a group that depends on the tile's index in the BATCH -- a quarter's
+    #  rows are summed in another order than the same rows of the whole batch, so the two differ by fp32 rounding: 2.8e-5 on the most
+    #  cancellation-prone tensor, a conditioner projection whose fp32 autograd gradient is itself 2.7e-4 from the fp64 one; with one fixed
+    #  order everywhere the difference is 1.8e-6, but the golden test's distance to fp64 grows from 2.1e-4 to 7.8e-4: csrc/train.hip, tg())
+    assert torch.isfinite(g_full).all() and worst < 1e-4, (worst, worst_name)
 
 
 def test_workspace_reuse_across_batch_shapes_equals_fresh_trainers():
