@@ -609,7 +609,8 @@ def main():
                                         "ms_per_step": ms_t, "value": 64 * 128 / (ms_t * 1e-3), "unit": "frames/s", "final_loss": loss_t,
                                         "precision": "split fp16 operands (fp32-class), fp32 master weights",
                                         "roofline": {"bound": "mfma", "scope": "whole step (forward + backward + clip + AdamW), not one kernel: the largest "
-                                                     "kernel, pgemm_kernel<EpBwd>, is 22 % of it (profiles/)",
+                                                     "kernels are wgrad_nt_kernel (16 %) and the transposed conv on the tgemm engine (14 %) "
+                                                     "(profiles/r4u_kernel_stats_train.csv)",
                                                      "algorithmic_tflop_per_step": train_step_flops(hp, 64 * 128) / 1e12, "achieved": tfl,
                                                      "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": tfl / PEAK_TFLOPS_F16, "mfma_per_product": 3,
                                                      "pipe_frac": 3 * tfl / PEAK_TFLOPS_F16}}

@@ -402,7 +402,6 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         const int mt = blockIdx.y * WAVES + wave;
         const bool active = mt < a.m_tiles;
         const int g0 = ks * G / KS, n = (ks + 1) * G / KS - g0;
-        const _Float16* wp = wbase + (long long)(active ? mt : 0) * tile_halfs;
         if (active && n > 0) load_wg(ringA, codeA, mt, gmap(g0));
         // the second group is put in flight before the barrier too: a ring refill issued inside the loop is waited for at full
         // L2/HBM latency, there is no other work in a 3-group slice to hide it behind
@@ -500,7 +499,6 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     // sits behind its burst, and the chip-wide HBM demand is spread instead of arriving from every workgroup at once.
     const int g_issue = (WAVES > 4 && wave >= WAVES / 2) ? ((G / 2) & ~1) : 0;
     while (pi >= 0) {
-        const _Float16* wp = wbase + (long long)(TG_DBG(a, 32) ? 0 : mt) * tile_halfs;      // dbg 32: every tile streams tile 0 (L2-hot)
         const int pn = next_active(pi + gridDim.y);
         const int mt_n = pn >= 0 ? tile_of(pn) : 0;
         f32x16 nxt[NT_N];

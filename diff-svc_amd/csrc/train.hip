@@ -3,10 +3,13 @@
 // Reference: network/diff/diffusion.py:200-225 (q_sample, p_losses), network/diff/net.py:58-135 (the network that is
 // differentiated), training/task/SVC_task.py:60-66,116-125 (AdamW, optimizer_step), utils/pl_utils.py:1081-1084 (grad-norm clip).
 //
-// Every contraction -- forward, data gradients and weight gradients -- runs on the conv_gemm MFMA engine with split fp16 operands
-// (w = w_hi + w_lo, x = x_hi + x_lo: fp32-class products, fp32 accumulate), so the gradients match the reference's fp32 autograd
-// to ~1e-5 and nothing about the optimisation trajectory changes.  Layout as in inference: fp32 frame-major rows
-// (row = clip*Tp + t, gap rows zero = the convs' zero padding).
+// Every contraction runs on MFMA with split fp16 operands (w = w_hi + w_lo, x = x_hi + x_lo: three products, fp32 accumulate -- fp32-class), so
+// the gradients match the reference's fp32 autograd to ~1e-5 and nothing about the optimisation trajectory changes.  The residual layers --
+// 93 % of the FLOPs -- run on the sampler's tgemm engine (tgemm.h; round 4): activations as fp16 [hi | lo] row planes written by the producing
+// epilogue and DMA'd straight into LDS, weights re-packed per step into fragment order (k_tpack_batch); the data gradients' 2C-channel
+// operands are streamed through LDS in K phases (tgemm.h KP).  The small projections at both ends stay on conv_gemm.h, the weight gradients
+// on wgrad.h.  Layout: fp32 frame-major rows (row = clip*Tp + t, gap rows zero = the convs' zero padding) for everything the backward
+// pass re-reads.
 //   forward   y = conv_dil(x + film) + W_c cond + b ;  g = sigmoid(y_a) tanh(y_b) ;  [r; s] = W_o g + b ;  x' = (x + r)/sqrt2 ; skip += s
 //             (sigma, tau, g and every layer's x are kept: ~1.3 GB for the 64 x 128-frame batch)
 //   backward  dO = [dx/sqrt2 ; dskip] ;  dg = W_o^T dO ;  dy = dg (tau sigma(1-sigma) ; sigma(1-tau^2)) ;  dx = dx/sqrt2 + convT(dy) ;
@@ -26,7 +29,6 @@
 #include "../../include/dsvc.h"
 #include "cg_util.h"
 #include "wgrad.h"
-#include "pgemm.h"
 #include "tepi_util.h"
 
 using namespace dsvc;
@@ -53,64 +55,6 @@ struct EpStore {
         v += e.bias ? e.bias[col] : 0.f;
         if (e.relu) v = fmaxf(v, 0.f);
         e.out[(size_t)row * e.ld + col] = e.ri.valid(row) ? v : 0.f;
-    }
-};
-
-// the stacked conditioner projection: column block l (of `cw` columns) goes to its own [rows][cw] slab, so that a layer's gate epilogue
-// reads rows 3 KB apart, not L * 3 KB
-struct EpStoreSlabs {
-    static constexpr bool PAIRED = false;
-    struct Args { float* out; int cw; long long slab; RowInfo ri; };
-    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
-        const int l = col / e.cw;
-        e.out[(size_t)l * e.slab + (size_t)row * e.cw + (col - l * e.cw)] = e.ri.valid(row) ? v : 0.f;
-    }
-};
-
-// gate forward (net.py:71-77): packed column pairs (tile 2q = gate half, 2q+1 = filter half of channels 32q..32q+31)
-struct EpGateFwd {
-    static constexpr bool PAIRED = true;
-    // ldy: row stride of ypre (all layers' conditioner projections side by side)
-    struct Args { const float* ypre; const float* bd; const float* bc; float* sig; float* tau; float* g; int C; RowInfo ri; int ldy; };
-    __device__ __forceinline__ void pair(const Args& e, int row, int ct0, int j, float vg, float vf) const {
-        const float* yp = e.ypre + (size_t)row * e.ldy + ct0 * 32 + j;
-        const int c = (ct0 >> 1) * 32 + j;                  // g-channel: conv channels c (gate -> sigmoid) and C + c (filter -> tanh)
-        const float a = vg + yp[0] + e.bd[c] + e.bc[c], b = vf + yp[32] + e.bd[e.C + c] + e.bc[e.C + c];
-        const float s = 1.0f / (1.0f + expf(-a)), t = tanhf(b);
-        const size_t o = (size_t)row * e.C + (ct0 >> 1) * 32 + j;
-        const bool ok = e.ri.valid(row);
-        e.sig[o] = s; e.tau[o] = t; e.g[o] = ok ? s * t : 0.f;
-    }
-};
-
-// output projection forward (net.py:79-84): cols < C residual, cols >= C skip
-struct EpResSkipFwd {
-    static constexpr bool PAIRED = false;
-    struct Args { const float* x; float* xnext; float* skip; const float* bias; int C; int first; RowInfo ri; };
-    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
-        v += e.bias[col];
-        const bool ok = e.ri.valid(row);
-        if (col < e.C) {
-            const size_t o = (size_t)row * e.C + col;
-            e.xnext[o] = ok ? (e.x[o] + v) * RSQRT2 : 0.f;
-        } else {
-            const size_t o = (size_t)row * e.C + (col - e.C);
-            e.skip[o] = ok ? (e.first ? v : e.skip[o] + v) : 0.f;
-        }
-    }
-};
-
-// dg = W_o^T dO, then through the gate:  dy_a = dg tau sigma (1 - sigma),  dy_b = dg sigma (1 - tau^2)   (natural channel order)
-struct EpGateBwd {
-    static constexpr bool PAIRED = false;
-    struct Args { const float* sig; const float* tau; float* dy; int C; RowInfo ri; };
-    __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
-        if (col >= e.C) return;
-        const size_t o = (size_t)row * e.C + col;
-        const float s = e.sig[o], t = e.tau[o];
-        const bool ok = e.ri.valid(row);
-        e.dy[(size_t)row * (2 * e.C) + col] = ok ? v * t * s * (1.0f - s) : 0.f;
-        e.dy[(size_t)row * (2 * e.C) + e.C + col] = ok ? v * s * (1.0f - t * t) : 0.f;
     }
 };
 
@@ -565,17 +509,6 @@ __global__ void k_clip_colsum(const float* __restrict__ src, float* __restrict__
     if (sub == 0 && c < C) dst[(size_t)b * dst_ld + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// dx <- dx/sqrt2 + dxin ;  dOa[row][0..C) <- dx/sqrt2  (the residual half of the next layer's dO)
-__global__ void k_dx_update(float* __restrict__ dx, const float* __restrict__ dxin, float* __restrict__ dO, int rows, int C) {
-    const size_t n = (size_t)rows * C;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / C), c = (int)(i - (size_t)row * C);
-        const float v = dx[i] * RSQRT2 + dxin[i];
-        dx[i] = v;
-        dO[(size_t)row * (2 * C) + c] = v * RSQRT2;
-    }
-}
-
 // dst[row][off + c] = src[row][c] * scale
 __global__ void k_copy_cols(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld_dst, int off, float scale) {
     const size_t n = (size_t)rows * C;
@@ -840,19 +773,6 @@ struct Packed {
     int n_ctiles = 0, taps = 1, cin_pad = 0;
 };
 
-// pgemm.h operands: weight planes [2][rows_pad][taps * K_pad], activation planes [2][64 guard + rows_p + 64 guard][ld] (zero outside the data)
-struct WPlanes {
-    DevBuf w;
-    int rows_pad = 0, taps = 1, K_pad = 0;
-    long long plane() const { return (long long)rows_pad * taps * K_pad; }
-};
-struct APlanes {
-    DevBuf buf;
-    int ld = 0;
-    long long plane = 0;
-    _Float16* base() const { return buf.as<_Float16>(); }       // fragment-tiled (wgrad.h pl_off); data row r is tiled row r + 64
-};
-
 }  // namespace
 
 // =================================================================================================
@@ -877,26 +797,17 @@ struct dsvc_trainer {
     DevBuf dx, dxin, dO, dy, ds2pre, dh0, loss;
     DevBuf bin_count, bin_cursor, bin_segs, bin_nsegs, bin_order, bin_S;     // frames sorted by pitch bin; S_l[vocab][2C] per layer
     DevBuf AT, BT;                                 // dY^T and X^T as channel-major fp16 hi|lo planes: [2][a_rows | b_rows][ldT]
-    APlanes condP, dyP, dOP;                       // fragment-tiled fp16 hi|lo planes of cond and of a layer's dy / dO (pgemm.h operands)
-    int rows_p = 0;                                // nr rounded up to the 256-row tile
-    WPlanes wp_call;                               // every layer's conditioner projection, stacked: [L * 2C][H]
-    std::vector<WPlanes> wp_dT, wp_oT;
-    std::vector<Packed> w_d, w_o;
     DevBuf wpart;                                  // frame-slice partial tiles of one weight-gradient GEMM
     // per-step repacked weights
     Packed w_in, w_skip, w_fin, w_finT, w_skipT;
 
-    DevBuf gatemap;                                // packed column -> conv channel of the paired gate layout
-
-    // round 4: the residual layers' FORWARD on the tgemm engine (C % 32 == 0; other widths keep the conv_gemm forward)
-    bool tfwd = false;
+    // round 4: the residual layers on the tgemm engine
     int Cp = 0, Hp = 0;                            // channels of a plane: C / H rounded up to 128
     static constexpr int TGUARD = 64;              // zero rows in front of and behind xhP (the dilated conv's halo at the first / last tile)
     DevBuf xhP, ghP, condHP;                       // fp16 [hi | lo] row planes: x^l + film_l [TGUARD + rows + TGUARD][2 Cp], g_l [rows][2 Cp], cond [rows][2 Hp]
     DevBuf gate_t, out_t, cproj_t;                 // fragment-ordered hi|lo weights of every layer (k_tpack_batch, per step)
     size_t gate_halfs = 0, out_halfs = 0, cproj_halfs = 0;     // per layer
     // ... and the two data-gradient GEMMs of the backward pass (streamed-K kernels: their 2C-channel split rows do not fit LDS whole)
-    bool tbwd = false;
     int C2p = 0;                                   // 2C rounded up to 128
     DevBuf dOh, dyh;                               // planes of dO [rows][2 C2p] and of dy [TGUARD + rows + TGUARD][2 C2p]
     DevBuf oT_t, dT_t;                             // W_o^T and the flipped W_d^T, rows = input channels of the layer
@@ -911,17 +822,11 @@ struct dsvc_trainer {
     ~dsvc_trainer() {
         for (DevBuf* b : {&sa, &sb, &spec_min, &spec_max, &xt, &xs, &sig, &tau, &g, &skip, &ypre, &s2pre, &eps, &deps, &condT, &tstep,
                           &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre,
-                          &dh0, &loss, &AT, &BT, &wpart, &gatemap, &pack_dev, &wplane_dev, &bin_count, &bin_cursor, &bin_segs, &bin_nsegs, &bin_order, &bin_S,
+                          &dh0, &loss, &AT, &BT, &wpart, &pack_dev, &bin_count, &bin_cursor, &bin_segs, &bin_nsegs, &bin_order, &bin_S,
                           &xhP, &ghP, &condHP, &gate_t, &out_t, &cproj_t, &t_gate_rm, &t_gate_rs, &t_out_rm, &tpack_dev, &dOh, &dyh, &oT_t, &dT_t})
             b->release();
-        for (APlanes* a : {&condP, &dyP, &dOP}) a->buf.release();
-        wp_call.w.release();
         if (step_err) (void)hipHostFree(step_err);
-        for (auto* v : {&wp_dT, &wp_oT})
-            for (auto& p : *v) p.w.release();
         auto rel = [](Packed& p) { p.w.release(); };
-        for (auto* v : {&w_d, &w_o})
-            for (auto& p : *v) rel(p);
         rel(w_in); rel(w_skip); rel(w_fin); rel(w_finT); rel(w_skipT);
     }
 
@@ -934,21 +839,15 @@ struct dsvc_trainer {
     int pack(Packed& pk, const float* src, const int* colmap, int cout_pad, int taps, int cin, int cout, long long s_col, long long s_ci,
              long long s_tap, int flip, float scale, hipStream_t st);
     int repack(hipStream_t st);
-    std::vector<PackDesc> pack_q;                  // the weight re-packs of a step, queued by pack() / wplanes() and launched together
-    std::vector<WPlaneDesc> wplane_q;
-    DevBuf pack_dev, wplane_dev;
-    std::vector<char> pack_cached, wplane_cached;
+    std::vector<PackDesc> pack_q;                  // the weight re-packs of a step, queued by pack() and launched together
+    DevBuf pack_dev;
+    std::vector<char> pack_cached;
     int flush_packs(hipStream_t st);
-    int wplanes(WPlanes& wp, int row0, int rows_total, const float* src, const int* rowmap, int n_rows, int taps, int cin, long long s_row, long long s_ci,
-                long long s_tap, int flip, float scale, hipStream_t st);
-    int aplanes(APlanes& ap, int ld, hipStream_t st);
-    int split_rows(const APlanes& ap, const float* src, int ld_src, int C, const float* add, int add_stride, hipStream_t st);
-    template <class Epi> int pg(const APlanes& ap, const WPlanes& wp, int b_row0, int n_cols, int taps, int dil, const typename Epi::Args& e, hipStream_t st);
     // operand planes: rows [row0, row0 + C) of AT (a_side) or BT <- src[frame][0..C) (+ add[clip]) over the real frames; dil > 0: the three
     // taps of a dilated conv's input (frames t - dil, t, t + dil) into rows row0 + {0, 1, 2} * cp128
     // colsum != nullptr (dil == 0 only): colsum[c] += sum over the frames of src[.][c] -- the bias gradient rides on the pass that reads dY anyway
     int split_t(bool a_side, int row0, const float* src, int ld_src, int C, const float* add, int add_stride, int dil, hipStream_t st,
-                float* colsum = nullptr, const APlanes* rowp = nullptr);
+                float* colsum = nullptr);
     // dW[o][k] = sum_n AT[o][n] * BT[b_row0 + k][n] for o < O, k < K_pad; the k axis is cut into the segments of `segs`
     int wgrad_nt(int O, int K_pad, int b_row0, const WgradSegs& segs, float scale, hipStream_t st);
     // one training step in phases (so that a data-parallel host can all-reduce the gradients of finished layers while the backward pass of
@@ -1007,58 +906,12 @@ int dsvc_trainer::flush_packs(hipStream_t st) {
         DSVC_TRY(upload(pack_dev, pack_cached, pack_q.data(), pack_q.size() * sizeof(PackDesc)));
         hipLaunchKernelGGL(k_pack_w_batch, dim3(96, (unsigned)pack_q.size()), dim3(256), 0, st, pack_dev.as<PackDesc>());
     }
-    if (!wplane_q.empty()) {
-        DSVC_TRY(upload(wplane_dev, wplane_cached, wplane_q.data(), wplane_q.size() * sizeof(WPlaneDesc)));
-        hipLaunchKernelGGL(k_wplanes_batch, dim3(96, (unsigned)wplane_q.size()), dim3(256), 0, st, wplane_dev.as<WPlaneDesc>());
-    }
     if (!tpack_q.empty()) {
         DSVC_TRY(upload(tpack_dev, tpack_cached, tpack_q.data(), tpack_q.size() * sizeof(TPackDesc)));
         hipLaunchKernelGGL(k_tpack_batch, dim3(96, (unsigned)tpack_q.size()), dim3(256), 0, st, tpack_dev.as<TPackDesc>());
     }
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
-}
-
-// rows [row0, row0 + round_up(n_rows, 128)) of a weight-plane set with rows_total rows (a stacked set is filled by several calls)
-int dsvc_trainer::wplanes(WPlanes& wp, int row0, int rows_total, const float* src, const int* rowmap, int n_rows, int taps, int cin, long long s_row,
-                          long long s_ci, long long s_tap, int flip, float scale, hipStream_t st) {
-    wp.rows_pad = round_up(rows_total, 128); wp.taps = taps; wp.K_pad = round_up(cin, 32);
-    const int ldb = taps * wp.K_pad;
-    DSVC_TRY(wp.w.alloc((size_t)2 * wp.rows_pad * ldb * 2));
-    const int rows_here = round_up(n_rows, 128) < wp.rows_pad - row0 ? round_up(n_rows, 128) : wp.rows_pad - row0;
-    (void)st;
-    wplane_q.push_back(WPlaneDesc{src, rowmap, wp.w.as<_Float16>() + (size_t)row0 * ldb, wp.plane(), rows_here, n_rows, taps, wp.K_pad, cin, s_row, s_ci,
-                                  s_tap, flip, scale});
-    return DSVC_OK;
-}
-
-int dsvc_trainer::aplanes(APlanes& ap, int ld, hipStream_t st) {
-    ap.ld = ld;
-    ap.plane = (long long)(rows_p + 128) * ld;
-    const size_t bytes = (size_t)2 * ap.plane * 2;
-    DSVC_TRY(ap.buf.alloc(bytes));
-    DSVC_HIP(hipMemsetAsync(ap.buf.p, 0, bytes, st));
-    return DSVC_OK;
-}
-
-int dsvc_trainer::split_rows(const APlanes& ap, const float* src, int ld_src, int C, const float* add, int add_stride, hipStream_t st) {
-    if (C % 8 || C > ap.ld) return fail(DSVC_EINVAL, "split_rows: %d channels into planes of %d", C, ap.ld);
-    hipLaunchKernelGGL(k_split_rows, dim3(2048), dim3(256), 0, st, src, ld_src, ap.base(), ap.plane, ap.ld, nr, C, add, add_stride, Tp, wsT, nr);
-    DSVC_HIP(hipGetLastError());
-    return DSVC_OK;
-}
-
-// C[row][col] = EPI(sum A[row + tap shift][k] * B[b_row0 + col][tap, k]) over the data rows, n_cols output columns (pgemm.h)
-template <class Epi>
-int dsvc_trainer::pg(const APlanes& ap, const WPlanes& wp, int b_row0, int n_cols, int taps, int dil, const typename Epi::Args& e, hipStream_t st) {
-    if (taps != wp.taps || wp.K_pad > ap.ld || b_row0 + round_up(n_cols, 128) > wp.rows_pad || dil > 64)
-        return fail(DSVC_EINVAL, "pgemm: operand planes do not match (taps %d/%d, K %d/%d, rows %d+%d/%d)", taps, wp.taps, wp.K_pad, ap.ld, b_row0, n_cols, wp.rows_pad);
-    PGemmArgs a{};
-    a.a = ap.base(); a.a_plane = ap.plane; a.lda = ap.ld;
-    a.b = wp.w.as<_Float16>() + (size_t)b_row0 * wp.taps * wp.K_pad; a.b_plane = wp.plane(); a.ldb = wp.taps * wp.K_pad;
-    a.n_rows = nr;
-    a.K = wp.K_pad; a.taps = taps; a.dil = dil;
-    return pgemm_launch<Epi>(a, rows_p, n_cols, e, st);
 }
 
 // one tgemm launch of the training forward: 64-frame tiles x 8 waves, split activations (the batched tiling of DSVC_PREC_F16_X3T)
@@ -1082,9 +935,8 @@ int dsvc_trainer::tg(const _Float16* x, int cin, int taps, int dil, const _Float
 
 int dsvc_trainer::repack(hipStream_t st) {
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
-    pack_q.clear(); wplane_q.clear(); tpack_q.clear();
+    pack_q.clear(); tpack_q.clear();
     const float isl = 1.0f / sqrtf((float)L);
-    const int* gm = gatemap.as<int>();
     // forward (natural [O][I][taps] sources)
     DSVC_TRY(pack(w_in, P("denoise_fn.input_projection.weight"), nullptr, C, 1, M, C, M, 1, 0, 0, 1.0f, st));
     DSVC_TRY(pack(w_skip, P("denoise_fn.skip_projection.weight"), nullptr, C, 1, C, C, C, 1, 0, 0, isl, st));        // sum(skip)/sqrt(L) folded (net.py:131)
@@ -1092,37 +944,22 @@ int dsvc_trainer::repack(hipStream_t st) {
     // transposed (data gradients): W^T(col = input channel, ci = output channel) = W[ci][col]
     DSVC_TRY(pack(w_finT, P("denoise_fn.output_projection.weight"), nullptr, C, 1, M, C, 1, C, 0, 0, 1.0f, st));
     DSVC_TRY(pack(w_skipT, P("denoise_fn.skip_projection.weight"), nullptr, C, 1, C, C, 1, C, 0, 0, isl, st));
-    // Which engine runs which layer GEMM was measured (profiles/r3u, r3G, r3H_kernel_stats_train.csv against r3p): the gate conv and the output
-    // projection stay on conv_gemm (79 / 60 us against 88 / 80 on pgemm.h -- both engines pull ~8 TB/s through the L2s at these tile shapes);
-    // the transposed conv, dg = W_o^T dO (128-row tiles: 86 / 64 us against 110 / 89) and ALL layers' conditioner projections as one stacked
-    // operand (490 us against 20 x 32) run on pgemm.h.  pgemm operands: weights as fragment-tiled fp16 hi|lo planes, rows = output channels.
-    const int c2p = round_up(2 * C, 128);
-    w_d.resize(L); w_o.resize(L); wp_oT.resize(L); wp_dT.resize(L);
+    // The residual layers (round 4): every layer GEMM -- gate conv, output projection, the stacked conditioner projections, dg = W_o^T dO and the
+    // transposed conv -- runs on the tgemm engine (tgemm.h) with fragment-ordered fp16 hi|lo weights: gate rows paired and pre-scaled (tepi_util.h),
+    // the data gradients' operands transposed (packed row = input channel c of the layer, K = its 2C output channels).  Rounds 2-3 ran them on
+    // conv_gemm.h / a plane-based engine: 96 / 62 / 27 / 63 / 77 us per layer against 64 / 39 / 12 / 48 / 77 now (profiles/r4z, r4u_kernel_stats_train.csv).
+    const int mpl = C / 16;
     for (int l = 0; l < L; ++l) {
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
-        if (tfwd) {     // forward on the tgemm engine: fragment-ordered hi|lo planes (gate rows paired and pre-scaled, diffnet_t.h)
-            const int mpl = C / 16;
-            tpack_q.push_back(TPackDesc{P(q + "dilated_conv.weight"), t_gate_rm.as<int>(), t_gate_rs.as<float>(), gate_t.as<_Float16>() + (size_t)l * gate_halfs, C, 3, Cp, mpl,
-                                        (long long)C * 3, 3, 1, 0});
-            tpack_q.push_back(TPackDesc{P(q + "output_projection.weight"), t_out_rm.as<int>(), nullptr, out_t.as<_Float16>() + (size_t)l * out_halfs, C, 1, Cp, mpl, C, 1, 1, 0});
-            tpack_q.push_back(TPackDesc{P(q + "conditioner_projection.weight"), t_gate_rm.as<int>(), t_gate_rs.as<float>(), cproj_t.as<_Float16>() + (size_t)l * cproj_halfs, H, 1, Hp, mpl,
-                                        H, 1, 1, 0});
-            if (tbwd) {   // transposed: packed row = input channel c of the layer, K = its 2C output channels
-                // W_o^T(c, k) = W_o[k][c]
-                tpack_q.push_back(TPackDesc{P(q + "output_projection.weight"), t_out_rm.as<int>(), nullptr, oT_t.as<_Float16>() + (size_t)l * oT_halfs, 2 * C, 1, C2p, C / 32, 1, C, 1, 0});
-                // transposed conv: dxin[c] = sum_tap sum_o W_d[o][c][2 - tap] * dy[row + (tap-1)*d][o]
-                tpack_q.push_back(TPackDesc{P(q + "dilated_conv.weight"), t_out_rm.as<int>(), nullptr, dT_t.as<_Float16>() + (size_t)l * dT_halfs, 2 * C, 3, C2p, C / 32, 3, (long long)C * 3, 1, 1});
-            }
-        } else {
-            DSVC_TRY(pack(w_d[l], P(q + "dilated_conv.weight"), gm, 2 * C, 3, C, 2 * C, (long long)C * 3, 3, 1, 0, 1.0f, st));
-            DSVC_TRY(pack(w_o[l], P(q + "output_projection.weight"), nullptr, 2 * C, 1, C, 2 * C, C, 1, 0, 0, 1.0f, st));
-        }
-        // transposed (data gradients): W^T(row = input channel, k = output channel) = W[k][row]
-        if (!tbwd) DSVC_TRY(wplanes(wp_oT[l], 0, C, P(q + "output_projection.weight"), nullptr, C, 1, 2 * C, 1, C, 0, 0, 1.0f, st));
-        // the conditioner projections of all layers in the gates' paired gate | filter row order, stacked
-        if (!tfwd) DSVC_TRY(wplanes(wp_call, l * c2p, L * c2p, P(q + "conditioner_projection.weight"), gm, 2 * C, 1, H, H, 1, 0, 0, 1.0f, st));
+        tpack_q.push_back(TPackDesc{P(q + "dilated_conv.weight"), t_gate_rm.as<int>(), t_gate_rs.as<float>(), gate_t.as<_Float16>() + (size_t)l * gate_halfs, C, 3, Cp, mpl,
+                                    (long long)C * 3, 3, 1, 0});
+        tpack_q.push_back(TPackDesc{P(q + "output_projection.weight"), t_out_rm.as<int>(), nullptr, out_t.as<_Float16>() + (size_t)l * out_halfs, C, 1, Cp, mpl, C, 1, 1, 0});
+        tpack_q.push_back(TPackDesc{P(q + "conditioner_projection.weight"), t_gate_rm.as<int>(), t_gate_rs.as<float>(), cproj_t.as<_Float16>() + (size_t)l * cproj_halfs, H, 1, Hp, mpl,
+                                    H, 1, 1, 0});
+        // W_o^T(c, k) = W_o[k][c]
+        tpack_q.push_back(TPackDesc{P(q + "output_projection.weight"), t_out_rm.as<int>(), nullptr, oT_t.as<_Float16>() + (size_t)l * oT_halfs, 2 * C, 1, C2p, C / 32, 1, C, 1, 0});
         // transposed conv: dxin[c] = sum_tap sum_o W_d[o][c][2 - tap] * dy[row + (tap-1)*d][o]
-        if (!tbwd) DSVC_TRY(wplanes(wp_dT[l], 0, C, P(q + "dilated_conv.weight"), nullptr, C, 3, 2 * C, 3, (long long)C * 3, 1, 1, 1.0f, st));
+        tpack_q.push_back(TPackDesc{P(q + "dilated_conv.weight"), t_out_rm.as<int>(), nullptr, dT_t.as<_Float16>() + (size_t)l * dT_halfs, 2 * C, 3, C2p, C / 32, 3, (long long)C * 3, 1, 1});
     }
     return flush_packs(st);
 }
@@ -1168,17 +1005,12 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
         DSVC_TRY(z(bin_count, (size_t)V * 4)); DSVC_TRY(z(bin_cursor, (size_t)V * 4)); DSVC_TRY(z(bin_segs, (size_t)max_segs * 12));
         DSVC_TRY(z(bin_nsegs, 16)); DSVC_TRY(z(bin_order, (size_t)B * T * 4)); DSVC_TRY(z(bin_S, (size_t)L * V * 2 * C * 4));
     }
-    rows_p = round_up(nr, 256);
-    DSVC_TRY(aplanes(condP, round_up(H, 32), st)); DSVC_TRY(aplanes(dyP, 2 * C, st)); DSVC_TRY(aplanes(dOP, 2 * C, st));
-    tfwd = C % 32 == 0 && H % 4 == 0 && max_dil <= TGUARD;
-    tbwd = false;
-    if (tfwd) {
+    {   // operands of the residual layers' GEMMs on the tgemm engine (channels % 64 == 0, hidden % 16 == 0, dilations <= TGUARD: checked at create)
         Cp = round_up(C, 128); Hp = round_up(H, 128);
         const int mpl = C / 16;
         DSVC_TRY(z(xhP, (r + 2 * TGUARD) * 2 * Cp * 2)); DSVC_TRY(z(ghP, r * 2 * Cp * 2)); DSVC_TRY(z(condHP, r * 2 * Hp * 2));
         gate_halfs = tpacked_halfs(mpl, 3, Cp, 2, 1); out_halfs = tpacked_halfs(mpl, 1, Cp, 2, 1); cproj_halfs = tpacked_halfs(mpl, 1, Hp, 2, 1);
         DSVC_TRY(gate_t.alloc(gate_halfs * L * 2)); DSVC_TRY(out_t.alloc(out_halfs * L * 2)); DSVC_TRY(cproj_t.alloc(cproj_halfs * L * 2));
-        tbwd = true;
         C2p = round_up(2 * C, 128);
         DSVC_TRY(z(dOh, r * 2 * C2p * 2)); DSVC_TRY(z(dyh, (r + 2 * TGUARD) * 2 * C2p * 2));
         oT_halfs = tpacked_halfs(C / 32, 1, C2p, 2, 1); dT_halfs = tpacked_halfs(C / 32, 3, C2p, 2, 1);
@@ -1215,27 +1047,18 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
         loss_scale = (float)ldexp(1.0, k);
     }
     hipLaunchKernelGGL(k_iota, dim3(ceil_div(B, 256)), dim3(256), 0, st, iotaB.as<int>(), 0, B);
-    if (!gatemap.p) {
-        // packed column p of a gate GEMM <-> conv channel: group = p/64, half = (p/32)&1, j = p%32  ->  half*C + group*32 + j
-        std::vector<int> gm(2 * C);
-        for (int p = 0; p < 2 * C; ++p) gm[p] = ((p >> 5) & 1) * C + (p >> 6) * 32 + (p & 31);
-        DSVC_TRY(gatemap.alloc(gm.size() * 4));
-        DSVC_HIP(hipMemcpyAsync(gatemap.p, gm.data(), gm.size() * 4, hipMemcpyHostToDevice, st));
-        DSVC_HIP(hipStreamSynchronize(st));
-    }
     wsB = B; wsT = T;
     return DSVC_OK;
 }
 
 int dsvc_trainer::split_t(bool a_side, int row0, const float* src, int ld_src, int C, const float* add, int add_stride, int dil, hipStream_t st,
-                          float* colsum, const APlanes* rowp) {
+                          float* colsum) {
     DevBuf& buf = a_side ? AT : BT;
     const int nrows = a_side ? a_rows : b_rows;
     if (row0 < 0 || row0 + (dil > 0 ? 2 * cp128 : 0) + C > nrows || dil > 64) return fail(DSVC_EINVAL, "split_t: rows [%d, %d) outside the %d-row operand planes", row0, row0 + C, nrows);
     const long long plane = (long long)nrows * ldT;
     hipLaunchKernelGGL(k_split_t, dim3(ldT / 64, ceil_div(C, 64)), dim3(256), 0, st, src, ld_src, buf.as<_Float16>() + (size_t)row0 * ldT, plane, ldT, C,
-                       add, add_stride, SplitRows{Tp, wsT, wsB}, dil > 0 ? 3 : 1, dil, (long long)cp128 * ldT, 1.0f, dil > 0 ? nullptr : colsum,
-                       rowp && dil == 0 ? rowp->base() : nullptr, rowp ? rowp->plane : 0, rowp ? rowp->ld : 0);
+                       add, add_stride, SplitRows{Tp, wsT, wsB}, dil > 0 ? 3 : 1, dil, (long long)cp128 * ldT, 1.0f, dil > 0 ? nullptr : colsum);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
@@ -1357,8 +1180,7 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
         EpStore::Args e{xs.as<float>(), C, P("denoise_fn.input_projection.bias"), C, 1, ri};
         DSVC_TRY(launch<EpStore>(a, e, st));
     }
-    const int c2p = round_up(2 * C, 128);
-    if (tfwd) {
+    {
         // the residual layers on the tgemm engine (epilogues above): operands as fp16 [hi | lo] row planes, every layer's stores as fp32 rows
         const int mpl = C / 16;
         _Float16* xh = xhP.as<_Float16>() + (size_t)TGUARD * 2 * Cp;
@@ -1387,30 +1209,6 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
                 DSVC_TRY(tg<TEpiResSkipT>(ghP.as<_Float16>(), Cp, 1, 1, out_t.as<_Float16>() + (size_t)l * out_halfs, mpl, e, st));
             }
         }
-    } else {
-    {   // ypre_l = W_c,l cond for ALL layers in one launch (pgemm.h: cond as fp16 hi|lo planes, the stacked projection weights), in the gates'
-        // packed column order (both biases are added, in natural order, by the gate epilogue)
-        DSVC_TRY(split_rows(condP, condT.as<float>(), H, H, nullptr, 0, st));
-        EpStoreSlabs::Args e{ypre.as<float>(), c2p, (long long)r * c2p, RowInfo{Tp, Tp, nr}};
-        DSVC_TRY(pg<EpStoreSlabs>(condP, wp_call, 0, L * c2p, 1, 1, e, st));
-    }
-    for (int l = 0; l < L; ++l) {
-        const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
-        const int d = 1 << (l % cfg.dilation_cycle);
-        float* xl = xs.as<float>() + (size_t)l * slab;
-        {   // gate: y = conv_dil(x + film) + ypre + biases
-            ConvGemmArgs a = base(xl, C, C, w_d[l], d);
-            a.film = filmB.as<float>() + (size_t)l * C; a.film_step_stride = L * C; a.step_ptr = iotaB.as<int>(); a.step_off = 0; a.step_per_clip = 1;
-            EpGateFwd::Args e{ypre.as<float>() + (size_t)l * r * c2p, P(q + "dilated_conv.bias"), P(q + "conditioner_projection.bias"),
-                              sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, g.as<float>() + (size_t)l * slab, C, ri, c2p};
-            DSVC_TRY(launch<EpGateFwd>(a, e, st));
-        }
-        {   // [r; s] = W_o g + b   (net.py:79-84)
-            ConvGemmArgs a = base(g.as<float>() + (size_t)l * slab, C, C, w_o[l], 1);
-            EpResSkipFwd::Args e{xl, xs.as<float>() + (size_t)(l + 1) * slab, skip.as<float>(), P(q + "output_projection.bias"), C, l == 0 ? 1 : 0, ri};
-            DSVC_TRY(launch<EpResSkipFwd>(a, e, st));
-        }
-    }
     }
     {   // s2pre = W_s skip/sqrt(L) + b ;  eps = W_out relu(s2pre) + b   (net.py:131-134)
         ConvGemmArgs a = base(skip.as<float>(), C, C, w_skip, 1);
@@ -1446,7 +1244,7 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
     }
     DSVC_HIP(hipMemsetAsync(dx.p, 0, r * C * 4, st));                                                                 // d x^L = 0: the loss sees x only through skip
     hipLaunchKernelGGL(k_copy_cols, dim3(ew), dim3(256), 0, st, dx.as<float>(), dO.as<float>(), nr, C, 2 * C, 0, 0.0f);   // ... so the residual half of dO starts at 0
-    if (tbwd)   // dO as the operand planes of the top layer's dg = W_o^T dO (the layers' epilogues refresh the residual half; the skip half is the same for all)
+    // dO as the operand planes of the top layer's dg = W_o^T dO (the layers' epilogues refresh the residual half; the skip half is the same for all)
         hipLaunchKernelGGL(k_rows_to_planes, dim3(2048), dim3(256), 0, st, dO.as<float>(), 2 * C, 2 * C, (const float*)nullptr, 0, dOh.as<_Float16>(), C2p, ri, rows);
     // cond^T planes once (weight gradients of every conditioner projection): the last segment of the layers' k axis, which nothing else writes
     DSVC_TRY(split_t(false, 3 * cp128, condT.as<float>(), H, H, nullptr, 0, 0, st));
@@ -1468,20 +1266,17 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
         const int d = 1 << (l % cfg.dilation_cycle);
         const float* xl = xs.as<float>() + (size_t)l * slab;
         const float* gl = g.as<float>() + (size_t)l * slab;
-        DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias"), tbwd ? nullptr : &dOP));   // + dO as pgemm planes
+        DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias")));
         DSVC_TRY(split_t(false, 0, gl, C, C, nullptr, 0, 0, st));
         DSVC_TRY(wgrad_nt(2 * C, cp128, 0, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
-        if (tbwd) {   // dg = W_o^T dO -> dy, K = 2C streamed in phases of 256 (128 where 2C is not a multiple of 256) channels
+        {   // dg = W_o^T dO -> dy, K = 2C streamed in phases of 256 (128 where 2C is not a multiple of 256) channels
             TEpiGateBwdT::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(),
                                  dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p, C, C2p, ri};
             DSVC_TRY((tg<TEpiGateBwdT, 1>(dOh.as<_Float16>(), C2p, 1, 1, oT_t.as<_Float16>() + (size_t)l * oT_halfs, C / 32, e, st, C2p % 256 == 0 ? 256 : 128)));
-        } else {   // dg = W_o^T dO -> dy (fp32 for the weight-gradient planes, fp16 hi|lo planes for the two data gradients below)
-            EpGateBwd::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(), C, ri};
-            DSVC_TRY(pg<EpGateBwd>(dOP, wp_oT[l], 0, C, 1, 1, e, st));
         }
         // dW_d[o][c][tap] = sum_n dy[n][o] (x^l + film)[n + (tap-1) d][c]  and  dW_c[o][h] = sum_n dy[n][o] cond[n][h]  share dy^T: ONE
         // contraction over the k axis [tap 0 | tap 1 | tap 2 | cond]
-        DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "dilated_conv.bias"), tbwd ? nullptr : &dyP));   // + dy as pgemm planes
+        DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "dilated_conv.bias")));
         DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
         DSVC_TRY(split_t(false, 0, xl, C, C, filmB.as<float>() + (size_t)l * C, L * C, d, st));
         {
@@ -1496,15 +1291,11 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             hipLaunchKernelGGL(k_bin_sums, dim3(ceil_div(B * T, 32) + cfg.pitch_vocab, ceil_div(2 * C, 256)), dim3(64), 0, st, dy.as<float>(), 2 * C,
                                bin_order.as<int>(), bin_segs.as<int>(), bin_nsegs.as<int>(), T, Tp,
                                bin_S.as<float>() + (size_t)l * cfg.pitch_vocab * 2 * C, 2 * C);
-        if (tbwd) {   // dxin = convT(dy); dx <- dx / sqrt 2 + dxin; the residual half of dO (rows and planes) <- dx / sqrt 2
+        {   // dxin = convT(dy); dx <- dx / sqrt 2 + dxin; the residual half of dO (rows and planes) <- dx / sqrt 2
             TEpiDxT::Args e{dx.as<float>(), dxin.as<float>(), dO.as<float>(), dOh.as<_Float16>(), C, C2p, ri};
             DSVC_TRY((tg<TEpiDxT, 1>(dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p, C2p, 3, d, dT_t.as<_Float16>() + (size_t)l * dT_halfs, C / 32, e, st, (C2p % 256 == 0 && (64 + 2 * d) * 2048 <= 160 * 1024) ? 256 : 128)));      // (two phase buffers of 64 + 2d rows in LDS)
-        } else {   // dxin = convT(dy)
-            EpBwd::Args e{dxin.as<float>(), C, C, nullptr, 0, 1.0f, 0, ri};
-            DSVC_TRY(pg<EpBwd>(dyP, wp_dT[l], 0, C, 3, d, e, st));
         }
         hipLaunchKernelGGL(k_clip_colsum, dim3(ceil_div(C, 64), B), dim3(256), 0, st, dxin.as<float>(), dfilm.as<float>() + (size_t)l * C, T, C, Tp, L * C);
-        if (!tbwd) hipLaunchKernelGGL(k_dx_update, dim3(ew), dim3(256), 0, st, dx.as<float>(), dxin.as<float>(), dO.as<float>(), nr, C);
     }
     // the step-embedding side of these layers: d diffusion_projection from dfilm_l (the FiLM gradient) -- with them the layers' gradients are final
     if (batched_small) {

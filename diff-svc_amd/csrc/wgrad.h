@@ -21,7 +21,7 @@
 namespace dsvc {
 
 // ---- fragment-tiled planes ------------------------------------------------------------------------------------------------------------
-// Every fp16 operand plane of wgrad.h / pgemm.h is stored in the order an MFMA fragment wants it: a [R rows][K] plane is cut into pieces of
+// Every fp16 operand plane of wgrad.h is stored in the order an MFMA fragment wants it: a [R rows][K] plane is cut into pieces of
 // 32 rows x 16 k, piece (row / 32, k / 16) is 1 KiB and holds, for lane l = (row % 32) + 32 * ((k / 8) % 2), the 8 halves k % 8 = 0..7.
 // A piece is then ONE contiguous 1 KiB global_load_lds per wave (a row-major plane made that instruction touch 32 cache lines for 32 bytes
 // each: 17 GB/s per CU, profiles/r3t_kernel_stats_train.csv), and a row-shifted piece (a conv tap) is two contiguous runs.
@@ -35,7 +35,6 @@ __host__ __device__ __forceinline__ size_t pl_off(int row, int k, int K) {
 // n_taps = 3:  the three taps of a dilated conv's input in one pass over src: tap j goes to plane rows + j * tap_rows and holds the frame
 //              t + (j - 1) * dil of the SAME clip, or the conv's zero padding when that leaves the clip.
 // colsum (n_taps = 1): colsum[c] += sum_m of the values written (a bias gradient: dY is read here anyway).
-// rowp (n_taps = 1): the values once more as frame-major tiled planes with the clips' gap rows (dY as the A operand of pgemm.h's data gradients).
 // Columns past the last real frame are written as zeros.  256 threads; n_out % 64 == 0, dil <= 64; channels >= C of a padded plane are left as
 // they are (callers ignore them).
 struct SplitRows { int clip_stride, clip_len, n_clips; };
@@ -44,8 +43,7 @@ struct SplitRows { int clip_stride, clip_len, n_clips; };
 // 16-byte loads along the channels (256 B per row), 16-byte stores along the frames.  grid (n_out / 64, ceil(C / 64)); C % 4 == 0.
 __global__ __launch_bounds__(256) void k_split_t(const float* __restrict__ src, int ld_src, _Float16* __restrict__ dst, long long plane_halfs,
                                                  int ldT, int C, const float* __restrict__ add, int add_stride, SplitRows ri, int n_taps, int dil,
-                                                 long long tap_halfs, float scale, float* __restrict__ colsum, _Float16* __restrict__ rowp,
-                                                 long long rowp_plane, int rowp_ld) {
+                                                 long long tap_halfs, float scale, float* __restrict__ colsum) {
     __shared__ float tile[64 + 128][68];
     const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int halo = n_taps == 3 ? dil : 0;
@@ -73,25 +71,6 @@ __global__ __launch_bounds__(256) void k_split_t(const float* __restrict__ src, 
 #pragma unroll 8
         for (int i = 0; i < 64; ++i) sum += tile[i][threadIdx.x];
         atomicAdd(colsum + c0 + threadIdx.x, sum);
-    }
-    if (rowp) {          // the same values as FRAME-major tiled planes (a pgemm.h A operand: row = clip * clip_stride + t + 64 guard rows, k = channel)
-        const int tn = threadIdx.x & 63, m = n0 + tn;
-        if (m < n_real) {
-            const int clip = m / ri.clip_len, t = m - clip * ri.clip_len;
-            for (int cg = threadIdx.x >> 6; cg < 8; cg += 4) {              // channels c0 + 8 cg .. + 7
-                if (c0 + cg * 8 >= C) break;
-                half8 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = tile[tn][cg * 8 + e];
-                    hi[e] = (_Float16)v;
-                    lo[e] = (_Float16)(v - (float)hi[e]);
-                }
-                _Float16* p = rowp + pl_off(clip * ri.clip_stride + t + 64, c0 + cg * 8, rowp_ld);
-                *reinterpret_cast<half8*>(p) = hi;
-                *reinterpret_cast<half8*>(p + rowp_plane) = lo;
-            }
-        }
     }
     // write: thread = (channel c0 + cw, frames n0 + 8 g .. + 7) -> one 16-byte store per plane into the fragment-tiled layout
     const int cw = threadIdx.x & 63;
