@@ -929,7 +929,8 @@ int dsvc_trainer::tg(const _Float16* x, int cin, int taps, int dil, const _Float
     const int tiles = rows / 64, passes = ceil_div(m_tiles, 8);
     int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
     // (9..12 output tiles -- C = 384 has 12 in the data-gradient GEMMs -- are a full pass of 8 waves plus a half-empty one, 2 x tiles workgroups;
-    //  twelve waves doing all tiles in one pass, 136 workgroups instead of 272, measured slower: 10.70 against 10.45 ms per step)
+    //  twelve waves doing all tiles in one pass, 136 workgroups instead of 272, measured slower: 10.70 against 10.45 ms per step; so did one
+    //  workgroup per tile running both passes: 11.17)
     return tgemm_launch<2, 8, 2, 4, 2, Epi, 1, 1, 2, 0, KP>(a, e, rows, ms, st);
 }
 
