@@ -6,7 +6,12 @@ reference CPU path uses; for device tensors by ``dsvc_pitch_coarse`` (csrc/cond.
 at which that very expression steps to the next bin (``coarse_thresholds``: bisection with the reference expression, once per
 hparams) -- no device log/pow decides a bin and nothing leaves the device.  The gather / embedding / mask are exact data movement.
 Registered under the attribute name ``fs2`` so a reference checkpoint's ``fs2.*`` keys load strictly; the
-parameters the disabled FastSpeech2 branches own (mel_out, pitch_predictor) are accepted and kept as buffers."""
+parameters the disabled FastSpeech2 branches own (mel_out, pitch_predictor) are accepted and kept as buffers.
+
+``use_energy_embed`` (fs2.py:81-82,143-144,240-247; round 4): decoder_inp additionally gets energy_embed[clamp(energy * 256 // 4, max=255)]
+before the mask -- an exact embedding lookup, done with torch ops behind the device builder (both shipped configs leave it off).  The
+speaker branches (``use_spk_id`` / ``use_spk_embed``) stay rejected: the reference's own constructor has ``spk_embed_proj`` commented out
+(fs2.py:32-39, "not used"), so its forward raises AttributeError on them and no checkpoint of this architecture carries such a table."""
 import numpy as np
 import torch
 from torch import nn
@@ -78,6 +83,10 @@ class CondBuilder(nn.Module):
         self.pitch_embed = nn.Embedding(300, self.hidden_size, self.padding_idx)
         nn.init.normal_(self.pitch_embed.weight, mean=0, std=self.hidden_size ** -0.5)
         nn.init.constant_(self.pitch_embed.weight[self.padding_idx], 0)
+        if hparams.get("use_energy_embed"):                       # fs2.py:81-82
+            self.energy_embed = nn.Embedding(256, self.hidden_size, self.padding_idx)
+            nn.init.normal_(self.energy_embed.weight, mean=0, std=self.hidden_size ** -0.5)
+            nn.init.constant_(self.energy_embed.weight[self.padding_idx], 0)
         self._extras = {}          # checkpointed-but-unused fs2.* tensors (mel_out, pitch_predictor, ...)
         self._thr_dev = None       # (device, thresholds) of the device pitch path
         self._oob = None           # sticky device flag: a device-path call saw mel2ph outside [0, N] (check_alignment)
@@ -85,7 +94,8 @@ class CondBuilder(nn.Module):
     # accept (and round-trip) the fs2.* tensors of the branches that are disabled by no_fs2 / use_pe=False
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         for k in list(state_dict.keys()):
-            if k.startswith(prefix) and not k.startswith(prefix + "pitch_embed."):
+            if k.startswith(prefix) and not k.startswith(prefix + "pitch_embed.") and not (
+                    k.startswith(prefix + "energy_embed.") and hasattr(self, "energy_embed")):
                 self._extras[k[len(prefix):]] = state_dict[k].detach().clone()
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
         for k in list(unexpected_keys):
@@ -183,9 +193,19 @@ class CondBuilder(nn.Module):
     def forward(self, hubert, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
                 skip_decoder=True, spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, **kwargs):
         hp = self.hp
-        if hp.get("use_spk_embed") or hp.get("use_spk_id") or hp.get("use_energy_embed") or not hp.get("no_fs2", False):
-            raise NotImplementedError("only the no_fs2 / pitch-embed configuration of the reference is supported")
+        if hp.get("use_spk_embed") or hp.get("use_spk_id"):
+            raise NotImplementedError("use_spk_id / use_spk_embed: the reference's FastSpeech2 never creates spk_embed_proj (fs2.py:32-39 is "
+                                      "commented out), so its own forward fails on these configurations")
+        if not hp.get("no_fs2", False):
+            raise NotImplementedError("only the no_fs2 configuration of the reference is supported (the FFT encoder / decoder are out of scope)")
         ret = {"mel2ph": mel2ph}
+        e_emb = None
+        if hp.get("use_energy_embed"):                                        # add_energy (fs2.py:240-247)
+            if energy is None:
+                raise ValueError("use_energy_embed: forward() needs the frame energies (the reference indexes None here)")
+            ret["energy_pred"] = energy
+            e_idx = torch.clamp(energy.to(hubert.device) * 256 // 4, max=255).long()
+            e_emb = self.energy_embed(e_idx)
         dev = hubert.device
         if hp.get("pitch_norm", "log") != "log":
             raise NotImplementedError("pitch_norm must be 'log'")
@@ -193,6 +213,9 @@ class CondBuilder(nn.Module):
             # NOT differentiable: the tensors below carry no autograd graph even with grad enabled (the drop-ins are inference modules; the
             # training branch, GaussianDiffusionHip.forward(infer=False), gets d pitch_embed from dsvc_trainer_step, not from a graph over this)
             dec, cond, f0_denorm, coarse = self._build_device(hubert, mel2ph, f0, uv)
+            if e_emb is not None:                                             # (x + e) * mask = x * mask + e * mask: the mask is 0 / 1
+                dec = dec + e_emb.detach() * (mel2ph > 0).to(dec.dtype)[:, :, None]
+                cond = dec.transpose(1, 2).contiguous()
             ret.update(f0_denorm=f0_denorm, pitch_pred=coarse.unsqueeze(-1), decoder_inp=dec, cond_bht=cond)
             return ret
         padded = F.pad(hubert, [0, 0, 1, 0])
@@ -209,5 +232,5 @@ class CondBuilder(nn.Module):
         ret["f0_denorm"] = f0_denorm.to(dev)
         ret["pitch_pred"] = coarse.unsqueeze(-1).to(dev)
         emb = self.pitch_embed(coarse.to(dev))
-        ret["decoder_inp"] = (gathered + emb) * nonpad
+        ret["decoder_inp"] = ((gathered + emb) + e_emb) * nonpad if e_emb is not None else (gathered + emb) * nonpad
         return ret

@@ -156,6 +156,8 @@ class GaussianDiffusionHip(nn.Module):
     def forward(self, hubert, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None, infer=False,
                 **kwargs):
         if not infer:      # training branch: the pitch embedding's gradient comes from dsvc_trainer_step, not from an autograd graph over fs2
+            if self.hp.get("use_energy_embed"):
+                raise NotImplementedError("training with use_energy_embed: dsvc_trainer_step produces no gradient for fs2.energy_embed.weight")
             with torch.no_grad():
                 ret = self.fs2(hubert, mel2ph, spk_embed, None, f0, uv, energy, skip_decoder=True, infer=False)
             ret.pop("cond_bht", None)

@@ -361,9 +361,10 @@ def f0_to_coarse(f0, hp):
     return (m + 0.5).long()
 
 
-def build_cond(sd, hubert, mel2ph, f0, hp):
+def build_cond(sd, hubert, mel2ph, f0, hp, energy=None):
     """FastSpeech2.forward, ``no_fs2: true`` branch (fs2.py:94-154) + add_pitch (fs2.py:185-238):
-    cond = (gather(pad(hubert), mel2ph) + pitch_embed[coarse(2**f0)]) * (mel2ph > 0).
+    cond = (gather(pad(hubert), mel2ph) + pitch_embed[coarse(2**f0)]) * (mel2ph > 0);
+    with ``use_energy_embed`` (fs2.py:143-144, add_energy :240-247) + energy_embed[clamp(energy * 256 // 4, max=255)] inside the mask.
     Returns (decoder_inp [B,T,H], f0_denorm [B,T], coarse [B,T])."""
     padded = F.pad(hubert, [0, 0, 1, 0])
     idx = mel2ph[..., None].repeat([1, 1, hubert.shape[-1]])
@@ -373,7 +374,10 @@ def build_cond(sd, hubert, mel2ph, f0, hp):
     f0_denorm = torch.where(mel2ph == 0, torch.zeros_like(f0_denorm), f0_denorm)
     coarse = f0_to_coarse(f0_denorm, hp)
     emb = F.embedding(coarse, sd["fs2.pitch_embed.weight"])
-    return (gathered + emb) * nonpad, f0_denorm, coarse
+    dec = gathered + emb
+    if hp.get("use_energy_embed"):
+        dec = dec + F.embedding(torch.clamp(energy * 256 // 4, max=255).long(), sd["fs2.energy_embed.weight"])
+    return dec * nonpad, f0_denorm, coarse
 
 
 def get_align(n_mel, n_units):

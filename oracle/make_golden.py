@@ -112,6 +112,33 @@ def golden_sampler(name, hp, wseed, clips, T, n_units, speedup, seed, conditione
     print(name, "mel range %.3f..%.3f" % (lo, hi))
 
 
+def golden_cond_energy(name="cond_energy_tiny", clips=(0, 1, 2), T=40, n_units=23, wseed=3):
+    """The ``use_energy_embed`` branch of the condition builder through the REAL FastSpeech2.forward (modules/fastspeech/fs2.py:81-82,143-144,
+    240-247) with ``no_fs2: true``: decoder_inp = (gather + pitch_embed + energy_embed[clamp(energy * 256 // 4, max=255)]) * mask.  The
+    GaussianDiffusion of the reference owns it as ``self.fs2``; only that module is run here (skip_decoder=True)."""
+    hp = dict(synth.tiny_hparams(K=50), use_energy_embed=True)
+    refshim.set_hparams(hp)
+    from modules.fastspeech.fs2 import FastSpeech2
+    fs2 = FastSpeech2(None, hp["audio_num_mel_bins"]).eval()
+    H = hp["hidden_size"]
+    g = np.random.Generator(np.random.PCG64(SEED + 31))
+    pw = (g.standard_normal((300, H)) * H ** -0.5).astype(np.float32); pw[0] = 0
+    ew = (g.standard_normal((256, H)) * H ** -0.5).astype(np.float32); ew[0] = 0
+    with torch.no_grad():
+        fs2.pitch_embed.weight.copy_(torch.from_numpy(pw))
+        fs2.energy_embed.weight.copy_(torch.from_numpy(ew))
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    m2p[0, T - 6:] = 0                                     # padded frames
+    energy = torch.from_numpy(g.uniform(0.0, 4.5, size=(len(clips), T)).astype(np.float32))     # beyond 4.0: the clamp at bin 255
+    with torch.no_grad():
+        ret = fs2(hub.clone(), mel2ph=m2p.clone(), f0=f0.clone(), uv=None, energy=energy.clone(), skip_decoder=True, infer=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), hubert=hub.numpy(), mel2ph=m2p.numpy(), f0=f0.numpy(), energy=energy.numpy(),
+                        pitch_embed=pw, energy_embed=ew, decoder_inp=ret["decoder_inp"].numpy(), f0_denorm=ret["f0_denorm"].numpy(),
+                        pitch=ret["pitch_pred"].numpy())
+    print(name, "decoder_inp", tuple(ret["decoder_inp"].shape), "energy bins", int((energy * 256 // 4).clamp(max=255).min()), "..",
+          int((energy * 256 // 4).clamp(max=255).max()))
+
+
 def vocoder_inputs(h, clips, T):
     M = h["num_mels"]
     mels, f0s = [], []
@@ -421,6 +448,8 @@ def main():
         return golden_schedule()
     if "--rb2-only" in sys.argv:
         return golden_vocoder_rb2()
+    if "--cond-energy" in sys.argv:
+        return golden_cond_energy()
     if "--headline-only" in sys.argv:
         return golden_headline()
     if "--headline-extra" in sys.argv:
@@ -470,6 +499,7 @@ def main():
     golden_slicer()
     golden_slicer_demo_input()
     golden_schedule()
+    golden_cond_energy()
 
 
 def golden_plms_conditioned():

@@ -435,3 +435,24 @@ def test_cond_builder_device_pitch_path_equals_host_path():
     cbd.check_alignment()
     with pytest.raises((IndexError, RuntimeError)):
         cb(hub, mel2ph=bad, f0=f0.clone())                                     # the host path IS torch.gather
+
+
+@pytest.mark.gpu
+def test_cond_builder_energy_branch_on_the_device_vs_real_fastspeech2():
+    """use_energy_embed through the device builder (dsvc_cond_build + the energy lookup behind it) against the golden minted from the REAL
+    FastSpeech2.forward (tests/golden/cond_energy_tiny.npz): decoder_inp bit for bit, and cond_bht is its transpose."""
+    import os
+    import numpy as np
+    from diffsvc_amd import synth
+    from diffsvc_amd.cond import CondBuilder
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cond_energy_tiny.npz"))
+    hp = dict(synth.tiny_hparams(K=50), use_energy_embed=True)
+    cb = CondBuilder(hp)
+    cb.load_state_dict({"pitch_embed.weight": torch.from_numpy(g["pitch_embed"]), "energy_embed.weight": torch.from_numpy(g["energy_embed"])}, strict=True)
+    cb = cb.cuda()
+    hub, m2p, f0, en = (torch.from_numpy(g[k]).cuda() for k in ("hubert", "mel2ph", "f0", "energy"))
+    with torch.no_grad():
+        ret = cb(hub, mel2ph=m2p, f0=f0.clone(), energy=en, infer=True)
+    assert np.array_equal(ret["decoder_inp"].cpu().numpy(), g["decoder_inp"])
+    assert torch.equal(ret["cond_bht"], ret["decoder_inp"].transpose(1, 2))
+    assert np.array_equal(ret["pitch_pred"].cpu().numpy(), g["pitch"])
