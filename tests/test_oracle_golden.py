@@ -125,6 +125,14 @@ def test_mel_filterbank_hash_and_product_copy():
     assert np.array_equal(O.mel_filterbank(24000, 512, 80, 30, 12000), melfb.mel_filterbank(24000, 512, 80, 30, 12000))
     # every filter is a non-negative triangle with at least one non-zero bin
     assert (fb >= 0).all() and (fb.sum(1) > 0).all()
+    # the only values of librosa ITSELF available offline: the two examples its documentation of librosa.filters.mel prints
+    #   >>> librosa.filters.mel(sr=22050, n_fft=2048)            -> array([[ 0.   ,  0.016, ...,  0.   ,  0.   ], ...
+    #   >>> librosa.filters.mel(sr=22050, n_fft=2048, fmax=8000) -> array([[ 0.  ,  0.02, ...,  0.  ,  0.  ], ...
+    # (n_mels = 128, fmin = 0, Slaney scale and normalisation: the defaults nvSTFT.py:88 relies on) -- three and two decimals, but they fix the
+    # scale (Slaney, not HTK: 0.045 / 0.056 there), the area normalisation (un-normalised peaks are ~1) and the bin alignment of the first filter
+    for fmax, digits, want in ((11025.0, 3, 0.016), (8000.0, 2, 0.02)):
+        doc = O.mel_filterbank(22050, 2048, 128, 0.0, fmax)
+        assert doc.shape == (128, 1025) and round(float(doc[0, 1]), digits) == want and abs(float(doc[0, 0])) == 0.0 and doc[0, -1] == 0.0, (fmax, doc[0, :3])
 
 
 @pytest.mark.parametrize("with_source", [True, False])
