@@ -150,7 +150,7 @@ def test_train_step_vs_real_reference_golden(case):
     on a stride-8 lattice).  Nothing of the oracle restatement is in this comparison.
     bench64x128_l2 (round 4, tests/golden/train_grads_bench.npz) is BASELINE configs[4] AT THE BENCHMARKED SIZE: exactly the batch
     `bench.py --train` times on rank 0 (64 clips x 128 frames = 8 704 rows: the many-row conv tilings, the XCD-sliced weight gradients, the
-    128-row pgemm tiles, the 2^14 loss scale) through the real reference's forward(infer=False) + backward()."""
+    64-frame tgemm layer tilings, the 2^14 loss scale) through the real reference's forward(infer=False) + backward()."""
     from diffsvc_amd.train import DiffusionTrainerHip
     from make_golden import TRAIN_CASES, TRAIN_CASES_BENCH
     from util import load_golden
@@ -383,9 +383,39 @@ def test_reference_style_training_loop_through_the_drop_in_module():
     assert loss2.item() < loss.item()
 
 
+def test_train_step_with_several_output_passes_per_workgroup_equals_the_mean_of_its_halves():
+    """Beyond 256 frame tiles (here 24 clips x 840 frames = 20 352 rows = 318 tiles of 64 frames) a workgroup of the layer kernels walks ALL
+    output-channel passes of its tile itself -- in the streamed-K data-gradient kernels that means re-streaming the K phases per pass, with the
+    next pass's first phase in flight under the last phase of the current one (tgemm.h, KP path).  No other test reaches that schedule; the
+    halves (159 tiles) run one pass per workgroup.  Same size-independent property as the test below, same bar."""
+    from diffsvc_amd.train import DiffusionTrainerHip
+    hp = dict(synth.HPARAMS_44K, diff_loss_type="l1")
+    sd = synth.acoustic_state(hp, 3)
+    clips, T, n_units, seed = list(range(24)), 840, 480, 11
+    hub, m2p, f0, mels, t = (v.cuda() for v in _batch(hp, clips, T, n_units, seed))
+    ids = torch.tensor(clips, dtype=torch.int32, device="cuda")
+    tr = DiffusionTrainerHip(hp, sd)
+    loss_full = tr.forward_backward(hub, m2p, f0.clone(), mels, t, seed=seed, clip_ids=ids).item()
+    g_full = tr.grads.clone()
+    g_avg, loss_avg = torch.zeros_like(g_full), 0.0
+    for q in range(2):
+        sl = slice(12 * q, 12 * q + 12)
+        loss_avg += tr.forward_backward(hub[sl], m2p[sl], f0[sl].clone(), mels[sl], t[sl], seed=seed, clip_ids=ids[sl]).item() / 2
+        g_avg += tr.grads / 2
+    assert abs(loss_full - loss_avg) <= 5e-6 * abs(loss_full), (loss_full, loss_avg)
+    worst, worst_name = 0.0, None
+    for name, off, n in tr.h.layout:
+        a, b = g_full[off:off + n], g_avg[off:off + n]
+        err = (a - b).norm().item() / max(b.norm().item(), 1e-30)
+        if err > worst:
+            worst, worst_name = err, name
+    print("train step 24 x 840 (318 tiles) vs the mean of its halves: loss %.6f / %.6f, worst gradient rel-L2 difference %.2e (%s)" % (loss_full, loss_avg, worst, worst_name))
+    assert torch.isfinite(g_full).all() and worst < 1e-4, (worst, worst_name)
+
+
 def test_train_step_at_the_benchmarked_batch_equals_the_mean_of_its_sub_batches():
     """BASELINE configs[4] as bench.py times it: 64 clips x 128 frames on the 44.1 kHz architecture (8 704 rows: the many-row conv tilings, the
-    sliced weight-gradient GEMMs with XCD-local slices, the 128-row pgemm tiles, 2^14 loss scale).  The loss is a mean over equal-sized clips, so
+    sliced weight-gradient GEMMs with XCD-local slices, the 64-frame tgemm layer tilings, 2^14 loss scale).  The loss is a mean over equal-sized clips, so
     the step on the whole batch must equal the average of the steps on its four 16-clip quarters -- which run on the small-batch tilings (fewer
     slices, other tile shapes): a size-independent consistency check of every gradient tensor at the benchmarked size."""
     from diffsvc_amd.train import DiffusionTrainerHip
