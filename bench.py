@@ -386,7 +386,13 @@ def main():
                               "config": {"workload": "BASELINE configs[4]: training step on a 64 x 128-frame mel batch per GPU, gradient all-reduce (mean) "
                                                      "of 32 M fp32 over the ranks", "clips_per_gpu": Bt, "mel_frames": Tt, "loss": hp["diff_loss_type"],
                                          "parallelism": "data-parallel x%d" % world},
-                              "rccl": comm_info(dist, world, SHARE_DEVICE), "final_loss": loss}))
+                              "rccl": comm_info(dist, world, SHARE_DEVICE), "final_loss": loss,
+                              "roofline": {"bound": "mfma", "scope": "whole step per GPU (forward + backward + clip + AdamW), not one kernel: the largest kernels are "
+                                           "wgrad_nt_kernel (16 %) and the transposed conv on the tgemm engine (14 %), profiles/r4u_kernel_stats_train.csv",
+                                           "algorithmic_tflop_per_step": train_step_flops(hp, Bt * Tt) / 1e12,
+                                           "achieved": train_step_flops(hp, Bt * Tt) / (ms * 1e-3) / 1e12, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
+                                           "frac": train_step_flops(hp, Bt * Tt) / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_F16, "mfma_per_product": 3, "traffic": None},
+                              "cpu_baseline": None}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
