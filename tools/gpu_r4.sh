@@ -78,5 +78,14 @@ pmc32)
   done
   python $ROOT/tools/rocprof_traffic.py $OUT/${TAG}_pmc32_FETCH_SIZE $OUT/${TAG}_pmc32_WRITE_SIZE "tlayer_kernel" $OUT/${TAG}_layer_traffic_b32.json "tools/prof_sampler.py 32 12 $P (eager launches)"
   rm -rf $OUT/${TAG}_pmc32_FETCH_SIZE $OUT/${TAG}_pmc32_WRITE_SIZE; cd $ROOT ;;
+pmctrain)
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmct_$c -o pmc -- python $ROOT/bench.py --train --steps 3 --warmup 1 > $OUT/${TAG}_pmct_$c.log 2>&1
+  done
+  for k in TEpiDxT TEpiGateT TEpiGateBwdT TEpiResSkipT wgrad_nt_kernel; do
+    python $ROOT/tools/rocprof_traffic.py $OUT/${TAG}_pmct_FETCH_SIZE $OUT/${TAG}_pmct_WRITE_SIZE "$k" $OUT/${TAG}_train_traffic_$k.json "bench.py --train --steps 3 --warmup 1"
+  done
+  rm -rf $OUT/${TAG}_pmct_FETCH_SIZE $OUT/${TAG}_pmct_WRITE_SIZE; cd $ROOT ;;
 esac
 done
