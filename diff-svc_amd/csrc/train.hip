@@ -974,7 +974,8 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     const int M = cfg.mel_bins, H = cfg.hidden, C = cfg.channels, L = cfg.layers;
     int max_dil = 1;
     for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
-    if (max_dil > 64) return fail(DSVC_EINVAL, "trainer: dilation %d too large", max_dil);
+    // (the dilated conv and its transpose keep a 64-frame tile + both halos in LDS: whole up to dilation 16, as two 128-channel K phases up to 32)
+    if (max_dil > 32) return fail(DSVC_EINVAL, "trainer: dilation %d too large (dilation_cycle_length <= 6 is supported)", max_dil);
     Tp = round_up((T + max_dil < 32 ? 32 : T + max_dil), 8);                       // gap >= the largest dilation (the convs' zero padding); every gap row is work for the conv kernels
     nr = B * Tp;
     rows = round_up(nr, 128);                   // the contraction length of the weight-gradient GEMMs: a multiple of the staged chunk
@@ -1202,7 +1203,8 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             {
                 TEpiGateT::Args e{ypre.as<float>() + (size_t)l * tslab, sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab,
                                   g.as<float>() + (size_t)l * slab, ghP.as<_Float16>(), C, Cp, ri};
-                DSVC_TRY(tg<TEpiGateT>(xh, Cp, 3, d, gate_t.as<_Float16>() + (size_t)l * gate_halfs, mpl, e, st));
+                if (tgemm_smem<2>(3, d, 2 * Cp) <= 160 * 1024) DSVC_TRY(tg<TEpiGateT>(xh, Cp, 3, d, gate_t.as<_Float16>() + (size_t)l * gate_halfs, mpl, e, st));
+                else DSVC_TRY((tg<TEpiGateT, 1>(xh, Cp, 3, d, gate_t.as<_Float16>() + (size_t)l * gate_halfs, mpl, e, st, 128)));      // wide halos: streamed K
             }
             {
                 TEpiResSkipT::Args e{xl, xs.as<float>() + (size_t)(l + 1) * slab, skip.as<float>(), l + 1 < L ? xh : nullptr, P(q + "output_projection.bias"),

@@ -21,16 +21,19 @@ def _batch(hp, clips, T, n_units, seed):
     return hub, m2p, f0, mels, t
 
 
-@pytest.mark.parametrize("arch,loss_type", [("tiny", "l2"), ("tiny", "l1"), ("44k", "l2"), ("24k", "l1")])
+@pytest.mark.parametrize("arch,loss_type", [("tiny", "l2"), ("tiny", "l1"), ("44k", "l2"), ("24k", "l1"), ("cycle6", "l2")])
 def test_train_step_loss_and_gradients_vs_autograd(arch, loss_type):
     """Forward + backward: the loss and EVERY gradient tensor (43 for the tiny architecture, 171 for the 44.1 kHz one, plus the
     pitch embedding reached through cond).  All contractions run at split-fp16 (fp32-class) precision and the backward pass is
     loss-scaled into fp16's normal range: per-tensor relative L2 error <= 5e-5 of autograd's (measured 4e-6 ... 1e-5), worst printed."""
     from diffsvc_amd.train import DiffusionTrainerHip
-    hp = dict(synth.tiny_hparams(K=50) if arch == "tiny" else (synth.HPARAMS_44K if arch == "44k" else synth.HPARAMS_24K), diff_loss_type=loss_type)
+    hp = dict({"tiny": synth.tiny_hparams(K=50), "44k": synth.HPARAMS_44K, "24k": synth.HPARAMS_24K,
+               "cycle6": dict(synth.HPARAMS_44K, residual_layers=6, dilation_cycle_length=6)}[arch], diff_loss_type=loss_type)
     sd = synth.acoustic_state(hp, 3)
-    # (24k: the demo config's shapes -- 80 mel bins, 256 channels -- and a frame count that is not a multiple of anything)
-    clips, T, n_units, seed = {"tiny": ([0, 1, 2], 40, 23, 5), "44k": ([4, 9], 64, 37, 6), "24k": ([1, 2, 3], 51, 29, 7)}[arch]
+    # (24k: the demo config's shapes -- 80 mel bins, 256 channels -- and a frame count that is not a multiple of anything;
+    #  cycle6: dilations 1 .. 32 at 384 channels -- the 64-frame tile with a dilation-32 halo does not fit LDS whole, the gate conv then streams its
+    #  K axis in phases like the transposed conv always does)
+    clips, T, n_units, seed = {"tiny": ([0, 1, 2], 40, 23, 5), "44k": ([4, 9], 64, 37, 6), "24k": ([1, 2, 3], 51, 29, 7), "cycle6": ([4, 9], 80, 47, 8)}[arch]
     hub, m2p, f0, mels, t = _batch(hp, clips, T, n_units, seed)
     m2p[0, T - 5:] = 0                                        # a clip with padded frames: no pitch-embedding gradient there
     noise = O.ddpm_noise_ref_layout(seed, clips, 0, T, hp["audio_num_mel_bins"], O.PURPOSE_TRAIN_NOISE)
