@@ -422,11 +422,19 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         // everything (its fence waits vmcnt(0)), so the bare barrier is used: the tile was written by DMA, not by ds_write, and
         // each wave's own vmcnt wait + the barrier is exactly what makes it visible (cdna_hip_programming.md 5.7 item 1).
         {
-            const int later = (active && n > 0 ? 1 : 0) + (active && n > 1 ? 1 : 0);      // rings of KG*NW = 8 loads each
+            const int later = (active && n > 0 ? 1 : 0) + (active && n > 1 ? 1 : 0);      // rings of KG*NW = 8 loads each ...
             static_assert(KG * NW == 8, "the counted vmcnt immediates below assume 8 loads per ring");
-            if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (W6) {       // ... W6: KG hi fragments + the code string's two loads = 6 (an allowance of 8 per ring would let the barrier
+                                      // pass with up to four of this wave's DMA pieces still in flight -- round 4 shipped that for a while; found by
+                                      // reading, never by a test: the pieces are the oldest loads and had always landed)
+                if (later == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         stamp(2);
         __builtin_amdgcn_s_barrier();
