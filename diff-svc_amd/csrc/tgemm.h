@@ -114,9 +114,13 @@ constexpr int TFRAG6_DWORDS = 384;        // one k_tpack6 fragment: [lane 64][16
 // KP = 1 (round 4, NA = 2 and KS = 1: the trainer's data-gradient GEMMs): the K axis is STREAMED through LDS in phases of a.kp_cin input channels
 // per plane instead of being resident -- a 64-frame tile of [hi | lo] rows of 2C = 768 channels is 192 KB.  Two buffers: the DMA of phase p + 1
 // is issued right behind the barrier that publishes phase p, so it runs under phase p's MFMAs; one barrier per phase.
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0, int KP = 0>
+// FS = 2 (round 4; the vocoder's 128-channel stage: four 32-channel output tiles do not fill eight waves): the workgroup's time tile holds FS
+// frame sub-tiles of 32 NT_N frames, waves [0, WAVES/FS) work on the first, the rest on the second -- same LDS tile, same weight stream.
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0, int KP = 0, int FS = 1>
 __global__ void __launch_bounds__(64 * WAVES * KS, MINW) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
+    static_assert(FS == 1 || (KS == 1 && !KP && WAVES % FS == 0), "frame sub-tiles: the resident-tile flow only");
+    constexpr int WM = WAVES / FS;                       // waves (= output tiles of a pass) per frame sub-tile
     static_assert(NA == 1 || NW == 2, "split activations are combined with hi + lo weight planes");
     static_assert(!W6 || (NA == 2 && NT_N == 1 && KG == 4), "W6: the small split-activation tilings, 64 input channels per group");
     static_assert(!KP || (KS == 1 && !W6), "KP: streamed K phases on the plain tilings");
@@ -128,7 +132,8 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = KS > 1 ? wave_all % WAVES : wave_all;      // which output tile of the pass
     const int ks = KS > 1 ? wave_all / WAVES : 0;               // which slice of the K loop
-    const int row0 = blockIdx.x * TN;
+    const int fb = FS > 1 ? (wave_all / WM) * TN : 0;         // this wave's frame sub-tile inside the workgroup's time tile
+    const int row0 = blockIdx.x * TN * FS + fb;
     constexpr bool STAMPS = NT_N == 1;                    // the phase stamps exist only in the small-batch kernels: in the 128-frame
                                                           // tiling their few SGPRs/VGPRs tip the register allocation into spills
     auto stamp = [&](int i) {
@@ -141,7 +146,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     };
     stamp(0);
     const int halo = (a.taps >> 1) * a.dil;
-    const int rows_lds = TN + 2 * halo;
+    const int rows_lds = TN * FS + 2 * halo;
     const int row_halfs = a.cin * NA;                    // NA = 2: [hi plane | lo plane]
     const int chunks = row_halfs >> 3;                   // 16-B chunks per row
     const int row_bytes = row_halfs * 2;
@@ -152,7 +157,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
         const int dq = (WAVES * KS * 64) / chunks, dr = (WAVES * KS * 64) - dq * chunks;
         int slot = wave_all * 64 + lane;
         int r = slot / chunks, c = slot - r * chunks;
-        const _Float16* xrow0 = a.x + (long long)(row0 - halo) * row_halfs;
+        const _Float16* xrow0 = a.x + (long long)(row0 - fb - halo) * row_halfs;
         for (int it = wave_all; it * 64 < total && !TG_DBG(a, 4); it += WAVES * KS) {
             const int rc = r < rows_lds ? r : rows_lds - 1;            // lanes past the tile re-read its last row
             const _Float16* src = xrow0 + (long long)rc * row_halfs + ((c ^ (rc & a.swz)) << 3);
@@ -175,7 +180,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     const _Float16* wbase = a.w + (long long)variant * a.variant_halfs + lane * 8;
     const int gpt = (a.cin >> 4) / KG;                   // groups per tap
     const int G = a.taps * gpt;                          // groups per output tile
-    const int passes = (a.m_tiles + WAVES - 1) / WAVES;
+    const int passes = (a.m_tiles + WM - 1) / WM;
     const long long tile_halfs = (long long)G * GROUP_HALFS;
 
     // two waves share a SIMD (waves w and w + 4): give one of them priority so the pair drifts apart and one wave's
@@ -233,7 +238,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
                                                                      (a.sc6 >> 8) & 255);
             return;
         }
-        const int rr = halo + (tap - (a.taps >> 1)) * a.dil + (lane & 31);      // LDS row of this lane's frame, N-tile 0
+        const int rr = halo + (tap - (a.taps >> 1)) * a.dil + fb + (lane & 31);      // LDS row of this lane's frame, N-tile 0
         // chunk of k16-step k, half h, row r lives at slot (2k + h) ^ (r & swz), i.e. at byte offset
         // (k << 5) ^ xs with xs = ((r & swz) ^ h) << 4.  The group's first step kb is a multiple of KG and kk < KG, so
         // ((kb + kk) << 5) ^ xs = ((kb << 5) ^ xs) ^ (kk << 5): one per-group VALU, then an immediate XOR per step.
@@ -313,7 +318,7 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     // without the rotation they all miss L2 on the same fragment at the same moment (the whole chip then advances at
     // first-touch latency); rotated, a tile's first toucher warms it for the other two thirds
     const int rot = gridDim.y == 1 && !TG_DBG(a, 64) ? (int)(blockIdx.x % (unsigned)passes) : 0;
-    auto tile_of = [&](int pi) { const int p = pi + rot; return (p < passes ? p : p - passes) * WAVES + wave; };
+    auto tile_of = [&](int pi) { const int p = pi + rot; return (p < passes ? p : p - passes) * WM + (FS > 1 ? wave % WM : wave); };
     auto next_active = [&](int pi) {                      // next position of this workgroup's sequence where this wave has a tile
         for (; pi < passes; pi += gridDim.y)
             if (tile_of(pi) < a.m_tiles) return pi;
@@ -597,11 +602,11 @@ inline void tstamp_dump(const char* prefix) {
 }
 
 // n_rows must be a multiple of 32*NT_N; m_split = number of blockIdx.y slices the output-channel passes are dealt over
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0, int KP = 0>
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0, int KP = 0, int FS = 1>
 inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, int m_split, hipStream_t stream) {
     if (W6 && (!a.w6 || a.n_variants != 1 || a.cin % 64 != 0)) return fail(DSVC_EINVAL, "tgemm: the W6 kernels need the code plane of the variant to use");
     if (a.cin % (16 * KG) != 0) return fail(DSVC_EINVAL, "tgemm: cin %d not a multiple of %d", a.cin, 16 * KG);
-    if (n_rows % (32 * NT_N) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N);
+    if (n_rows % (32 * NT_N * FS) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N * FS);
     if (a.w_planes != NW) return fail(DSVC_EINVAL, "tgemm: weights packed with %d plane(s), kernel streams %d", a.w_planes, NW);
     a.swz = tgemm_swizzle_mask((KP ? a.kp_cin : a.cin) * NA);
     if (NA == 2 && (a.cin / 8) % 16 != 0) return fail(DSVC_EINVAL, "tgemm: split activations need cin %% 128 == 0 (got %d)", a.cin);
@@ -611,16 +616,16 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
     const char* dbg_s = getenv("DSVC_TG_DEBUG");           // profiling ablations only; results are WRONG when set
     a.dbg = dbg_s ? atoi(dbg_s) : 0;
 #endif
-    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS, NA, W6, KP>;
+    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS, NA, W6, KP, FS>;
     const size_t smem = KP ? 2 * tgemm_smem<NT_N>(a.taps, a.dil, a.kp_cin * NA)
-                           : tgemm_smem<NT_N>(a.taps, a.dil, a.cin * NA) + (size_t)(KS - 1) * WAVES * NT_N * 4096;
+                           : tgemm_smem<NT_N * FS>(a.taps, a.dil, a.cin * NA) + (size_t)(KS - 1) * WAVES * NT_N * 4096;
     if (smem > 160 * 1024) return fail(DSVC_EINVAL, "tgemm: %zu B of LDS requested", smem);
     static thread_local size_t smem_set = 0;
     if (smem > 64 * 1024 && smem > smem_set) {
         DSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         smem_set = smem;
     }
-    const int passes = ceil_div(a.m_tiles, WAVES);
+    const int passes = ceil_div(a.m_tiles, WAVES / FS);
     if (m_split < 1) m_split = 1;
     if (m_split > passes) m_split = passes;
     if (KS > 1 && m_split != passes) return fail(DSVC_EINVAL, "tgemm: the split-K tiling needs one output tile per wave (m_split %d, passes %d)", m_split, passes);
@@ -642,7 +647,7 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
         }
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(n_rows / (32 * NT_N), m_split), dim3(64 * WAVES * KS), smem, stream, a, ea);
+    hipLaunchKernelGGL(kern, dim3(n_rows / (32 * NT_N * FS), m_split), dim3(64 * WAVES * KS), smem, stream, a, ea);
     DSVC_HIP(hipGetLastError());
 #ifdef DSVC_PROFILING
     if (stamp_path && tstamp_log().used == tstamp_log().slots) tstamp_dump(stamp_path);

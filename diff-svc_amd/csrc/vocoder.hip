@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "conv_gemm.h"
+#include "tepi_util.h"
 
 using namespace dsvc;
 
@@ -597,6 +598,132 @@ __global__ void k_noise_conv(const float* __restrict__ har, const float* __restr
 }  // namespace
 
 // =================================================================================================
+// ------------------------------------------------------------------------------------------------
+// Round 4: the MRF convs of the WIDE stages (128 / 256 channels: 60 % of the generator's time) on the sampler's tgemm engine (tgemm.h, split
+// activations: the same three-MFMA products as conv_gemm's staging path, 1.5-1.8x its rate -- the operand arrives as fp16 [hi | lo] row
+// planes of lrelu(x), written by the producing epilogue and DMA'd into LDS, instead of being split from fp32 rows on the way in).
+//   step of a ResBlock1 (models.py:57-64):  xt = c1(lrelu(x))  -> only lrelu(xt) is ever used: planes, no fp32 store  (TEpiVocMid)
+//                                           x  = c2(lrelu(xt)) + x  -> fp32 rows (the residual stream / the MRF mean) + planes of lrelu(x)
+//                                                                      for the next step; the residual is the accumulator init  (TEpiVocOut)
+//   step of a ResBlock2 (models.py:86-91):  x  = c(lrelu(x)) + x    (TEpiVocOut)
+// Planes are zero on gap rows (the convs' zero padding); the fp32 rows are not masked (every reader masks, as on the conv_gemm path).
+// ------------------------------------------------------------------------------------------------
+struct VRows {
+    int stride, len, n_rows;
+    __device__ __forceinline__ bool valid(int row) const { return row < n_rows && (row - (row / stride) * stride) < len; }
+};
+
+struct TEpiVocMid {
+    struct Args { _Float16* ph; const float* bias; int C; VRows vr; };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int cb = mt * 32 + 16 * (lane >> 5);
+        if (cb >= e.C) return;
+        float b[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const f32x4 v = ld4(e.bias + cb + 4 * q); b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3]; }
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            const bool ok = e.vr.valid(frame);
+            float hv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const float v = acc[nt][i] + b[i]; hv[i] = ok ? (v > 0.f ? v : 0.1f * v) : 0.f; }
+            store_hi_lo16(e.ph + (size_t)frame * (2 * e.C) + cb, e.C, hv);
+        }
+    }
+};
+
+struct TEpiVocOut {
+    struct Args { const float* res; float* out; _Float16* ph; const float* bias; int C; float alpha; int accumulate; VRows vr; };
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int cb = mt * 32 + 16 * (lane >> 5);
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const float* p = e.res + (size_t)(row0 + 32 * nt + (lane & 31)) * e.C + cb;
+            const f32x4 v0 = ld4(p), v1 = ld4(p + 4), v2 = ld4(p + 8), v3 = ld4(p + 12);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[nt][i] = v0[i]; acc[nt][4 + i] = v1[i]; acc[nt][8 + i] = v2[i]; acc[nt][12 + i] = v3[i]; }
+        }
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+        const int cb = mt * 32 + 16 * (lane >> 5);
+        if (cb >= e.C) return;
+        float b[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const f32x4 v = ld4(e.bias + cb + 4 * q); b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3]; }
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) {
+            const int frame = row0 + 32 * nt + (lane & 31);
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = acc[nt][i] + b[i];
+            float* po = e.out + (size_t)frame * e.C + cb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o{v[4 * q] * e.alpha, v[4 * q + 1] * e.alpha, v[4 * q + 2] * e.alpha, v[4 * q + 3] * e.alpha};
+                if (e.accumulate) { const f32x4 old = ld4(po + 4 * q); o[0] += old[0]; o[1] += old[1]; o[2] += old[2]; o[3] += old[3]; }
+                st4(po + 4 * q, o);
+            }
+            if (e.ph) {
+                const bool ok = e.vr.valid(frame);
+                float hv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hv[i] = ok ? (v[i] > 0.f ? v[i] : 0.1f * v[i]) : 0.f;
+                store_hi_lo16(e.ph + (size_t)frame * (2 * e.C) + cb, e.C, hv);
+            }
+        }
+    }
+};
+
+// planes of lrelu(x) for the first step of every resblock of a stage (x = the upsampled signal + source, fp32 rows)
+__global__ void k_lrelu_planes(const float* __restrict__ x, _Float16* __restrict__ ph, int C, VRows vr, int rows) {
+    const int per_row = C >> 2;
+    const long long n = (long long)rows * per_row;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / per_row), c4 = (int)(i - (long long)row * per_row) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vr.valid(row)) {
+            const f32x4 a = ld4(x + (size_t)row * C + c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = a[j] > 0.f ? a[j] : 0.1f * a[j];
+        }
+        _Float16* q = ph + (size_t)row * (2 * C) + c4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const _Float16 h = (_Float16)v[j];
+            q[j] = h;
+            q[C + j] = (_Float16)(v[j] - (float)h);
+        }
+    }
+}
+
+constexpr int VT_GUARD = 32;          // zero rows in front of / behind a plane buffer (the largest resblock halo is (11 / 2) * 5 = 25)
+
+// tiling: 256 channels = 8 output tiles = one per wave; 128 channels = 4 tiles, the workgroup's eight waves then cover TWO 64-frame sub-tiles
+template <class Epi>
+int vt_launch(const _Float16* x, int C, int taps, int dil, const _Float16* w, const typename Epi::Args& e, int rows, hipStream_t st) {
+    TGemmArgs a{};
+    a.x = x; a.cin = C; a.taps = taps; a.dil = dil; a.w = w; a.m_tiles = C / 32; a.w_planes = 2; a.variant_halfs = 0; a.n_variants = 1;
+    a.step_ptr = nullptr; a.step_off = 0;
+    // clip_rows = the frame tile: every tile walks its K loop from group 0, so a clip's samples are bit-identical alone and at any batch position
+    // (the staggered starts of tgemm's small tilings are a latency measure for grids that do not fill the chip)
+    a.clip_rows = 64;
+    if (C == 128) return tgemm_launch<2, 8, 2, 4, 2, Epi, 1, 1, 2, 0, 0, 2>(a, e, rows, 1, st);
+    if (rows / 64 >= 200) return tgemm_launch<2, 8, 2, 4, 2, Epi, 1, 1, 2>(a, e, rows, 1, st);
+    a.clip_rows = 32;
+    return tgemm_launch<1, 8, 2, 4, 2, Epi, 1, 1, 2>(a, e, rows, 1, st);          // few rows (one clip at the 256-channel stage): 32-frame tiles fill the chip
+}
+
 struct dsvc_vocoder {
     dsvc_vocoder_cfg cfg;
     std::map<std::string, std::vector<float>> host;
@@ -609,6 +736,11 @@ struct dsvc_vocoder {
     std::vector<int> nc_k, nc_s, nc_pad;
     std::vector<PackedConv> rb1, rb2;            // [stage*nk*3 + j*3 + m]
     std::vector<DevBuf> rb1_f32, rb2_f32;        // same index: [tap][ci][co] fp32 for the narrow stages' fused pair kernel (else empty)
+    std::vector<DevBuf> rb1_t, rb2_t;            // same index: tgemm fragment order (hi | lo planes) for the wide stages' convs (else empty)
+    DevBuf pl[8][4];                             // per wide stage: [VT_GUARD + rows + VT_GUARD][2 C] fp16 operand planes -- lrelu(x_stage), xt, two ping-pong.
+                                                 // (Not shared between stages: the guard rows are zero because nothing ever writes them, and another
+                                                 //  stage's rows would land on them -- row pitch and row count differ)
+    bool wide(int cout) const { return cfg.precision == DSVC_PREC_F16_X3 && (cout == 128 || cout == 256); }
     DevBuf lin_w, lin_b;
     int gap_frames = 8;
 
@@ -624,6 +756,9 @@ struct dsvc_vocoder {
         for (auto& p : rb2) rel(p);
         for (auto& b : rb1_f32) b.release();
         for (auto& b : rb2_f32) b.release();
+        for (auto& b : rb1_t) b.release();
+        for (auto& b : rb2_t) b.release();
+        for (auto& st : pl) for (auto& b : st) b.release();
         for (auto& b : nc_w) b.release();
         for (auto& b : nc_b) b.release();
         for (DevBuf* b : {&lin_w, &lin_b, &mel_in, &har, &frames, &fl00, &buf[0], &buf[1], &buf[2], &buf[3], &buf[4]}) b->release();
@@ -686,6 +821,24 @@ int dsvc_vocoder::finalize() {
     ups.resize(nu); nc_w.resize(nu); nc_b.resize(nu); nc_k.resize(nu); nc_s.resize(nu); nc_pad.resize(nu);
     rb1.resize((size_t)nu * nk * 3); rb2.resize((size_t)nu * nk * 3);
     rb1_f32.resize(rb1.size()); rb2_f32.resize(rb2.size());
+    rb1_t.resize(rb1.size()); rb2_t.resize(rb2.size());
+    auto pack_t = [&](DevBuf& dst, const std::vector<float>& wsrc, int c, int rk) -> int {     // [O][I][K] fp32 -> tgemm fragments (tgemm.h: k_tpack)
+        const int mt = c / 32;
+        std::vector<int> rm(mt * 32);
+        for (int r = 0; r < mt * 32; ++r) rm[r] = (r >> 5) * 32 + trow_to_ch16(r & 31);
+        DevBuf dsrc, drm;
+        DSVC_TRY(upload(dsrc, wsrc.data(), wsrc.size() * 4));
+        DSVC_TRY(upload(drm, rm.data(), rm.size() * 4));
+        const size_t halfs = tpacked_halfs(mt, rk, c, 2, 1);
+        DSVC_TRY(dst.alloc(halfs * 2));
+        const long long total = (long long)halfs / 2;
+        hipLaunchKernelGGL(k_tpack, dim3((unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535)), dim3(256), 0, 0, dsrc.as<float>(), drm.as<int>(),
+                           (const float*)nullptr, dst.as<_Float16>(), c, rk, c, 0, mt, 2, 1, 1.0f, 0u);
+        DSVC_HIP(hipGetLastError());
+        DSVC_HIP(hipDeviceSynchronize());
+        dsrc.release(); drm.release();
+        return DSVC_OK;
+    };
     int need_gap = 3;
     int rate = 1;
     for (int i = 0; i < nu; ++i) {
@@ -736,12 +889,14 @@ int dsvc_vocoder::finalize() {
                     const std::vector<float>* b1 = plain(base + "convs." + std::to_string(m) + ".bias", cout);
                     if (!b1) return DSVC_ESTATE;
                     DSVC_TRY(pack_conv(rb1[idx], cout, rk, cout, d, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b1->data(), cout));
+                    if (wide(cout)) DSVC_TRY(pack_t(rb1_t[idx], w, cout, rk));
                     continue;
                 }
                 DSVC_TRY(folded(base + "convs1." + std::to_string(m), (size_t)cout * cout * rk, cout, w));
                 const std::vector<float>* b1 = plain(base + "convs1." + std::to_string(m) + ".bias", cout);
                 if (!b1) return DSVC_ESTATE;
                 DSVC_TRY(pack_conv(rb1[idx], cout, rk, cout, d, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b1->data(), cout));
+                if (wide(cout)) DSVC_TRY(pack_t(rb1_t[idx], w, cout, rk));
                 auto pack_f32 = [&](DevBuf& dst) {      // [tap][ci][co]
                     std::vector<float> t((size_t)rk * cout * cout);
                     for (int tap = 0; tap < rk; ++tap)
@@ -755,6 +910,7 @@ int dsvc_vocoder::finalize() {
                 const std::vector<float>* b2 = plain(base + "convs2." + std::to_string(m) + ".bias", cout);
                 if (!b2) return DSVC_ESTATE;
                 DSVC_TRY(pack_conv(rb2[idx], cout, rk, cout, 1, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b2->data(), cout));
+                if (wide(cout)) DSVC_TRY(pack_t(rb2_t[idx], w, cout, rk));
                 if (narrow) DSVC_TRY(pack_f32(rb2_f32[idx]));
             }
         }
@@ -798,6 +954,19 @@ int dsvc_vocoder::ensure_ws(int B, int T) {
         if (e > mx) mx = e;
     }
     for (int i = 0; i < 5; ++i) DSVC_TRY(buf[i].alloc(mx * 4));
+    {   // operand planes of the wide stages (tgemm path): rows * 2 C halfs + guards, zeroed once (the epilogues write zeros on gap rows)
+        int r2 = 1;
+        for (int i = 0; i < cfg.n_ups; ++i) {
+            r2 *= cfg.upsample_rates[i];
+            const int c = cfg.upsample_initial_channel >> (i + 1);
+            if (!wide(c)) continue;
+            const size_t e = (frames_total * r2 + 2 * VT_GUARD) * 2 * c * 2;
+            for (int q = 0; q < 4; ++q) {
+                DSVC_TRY(pl[i][q].alloc(e));
+                DSVC_HIP(hipMemset(pl[i][q].p, 0, pl[i][q].bytes));
+            }
+        }
+    }
     wsB = B; wsT = T;
     return DSVC_OK;
 }
@@ -857,9 +1026,32 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
             DSVC_TRY(voc_dispatch<EpiAffine>(a, e, prec, st));
         }
         // MRF: mean over the nk resblocks (models.py:376-382)
+        const bool tw = wide(cout) && rows % 128 == 0;
+        const VRows vr{stride, len, rows};
+        auto plane = [&](int q) { return pl[i][q].as<_Float16>() + (size_t)VT_GUARD * 2 * cout; };
+        if (tw) hipLaunchKernelGGL(k_lrelu_planes, dim3(2048), dim3(256), 0, st, U, plane(0), cout, vr, rows);
         for (int j = 0; j < nk; ++j) {
             for (int m = 0; m < ndil; ++m) {
                 const size_t idx = ((size_t)i * nk + j) * 3 + m;
+                if (tw) {      // the wide stages on the tgemm engine (epilogues above); planes: 0 = lrelu(U), 1 = xt, 2 / 3 = ping-pong
+                    const bool lastm = (m + 1 == ndil);
+                    const float* xin = (m == 0) ? U : A;
+                    float* xout = lastm ? S : A;
+                    const float al = lastm ? 1.0f / (float)nk : 1.0f;
+                    const int accu = (lastm && j > 0) ? 1 : 0;
+                    const _Float16* pin = (m == 0) ? plane(0) : plane(2 + ((m - 1) & 1));
+                    _Float16* pout = lastm ? nullptr : plane(2 + (m & 1));
+                    if (rb2_type) {
+                        TEpiVocOut::Args e{xin, xout, pout, rb1[idx].bias.as<float>(), cout, al, accu, vr};
+                        DSVC_TRY(vt_launch<TEpiVocOut>(pin, cout, rb1[idx].taps, rb1[idx].dil, rb1_t[idx].as<_Float16>(), e, rows, st));
+                    } else {
+                        TEpiVocMid::Args e1{plane(1), rb1[idx].bias.as<float>(), cout, vr};
+                        DSVC_TRY(vt_launch<TEpiVocMid>(pin, cout, rb1[idx].taps, rb1[idx].dil, rb1_t[idx].as<_Float16>(), e1, rows, st));
+                        TEpiVocOut::Args e2{xin, xout, pout, rb2[idx].bias.as<float>(), cout, al, accu, vr};
+                        DSVC_TRY(vt_launch<TEpiVocOut>(plane(1), cout, rb2[idx].taps, rb2[idx].dil, rb2_t[idx].as<_Float16>(), e2, rows, st));
+                    }
+                    continue;
+                }
                 if (rb2_type) {   // ResBlock2 (models.py:86-91): x = c(leaky_relu(x)) + x, ping-pong U -> A -> Tm -> ...; the last step lands in the MRF mean
                     const float* xin = (m == 0) ? U : ((m & 1) ? A : Tm);
                     const bool lastm = (m + 1 == ndil);
