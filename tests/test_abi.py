@@ -48,7 +48,7 @@ def test_hot_kernels_do_not_spill():
     from diffsvc_amd import build
     build.build(verbose=False)
     res = build.kernel_resources("diffnet.hip")
-    hot = {k: v for k, v in res.items() if "tgemm_kernelILi4ELi8ELi2ELi8ELi1E" in k and k.endswith("ELi1ELi1ELi0ELi0EEEvNS_9TGemmArgsENT4_4ArgsE")}
+    hot = {k: v for k, v in res.items() if "tgemm_kernelILi4ELi8ELi2ELi8ELi1E" in k and k.endswith("ELi1ELi1ELi0ELi0ELi1EEEvNS_9TGemmArgsENT4_4ArgsE")}
     gate = [v for k, v in hot.items() if "TEpiGate" in k]
     out = [v for k, v in hot.items() if "TEpiResSkip" in k]
     assert len(gate) == 1 and len(out) == 1, sorted(hot)
@@ -63,6 +63,9 @@ def test_hot_kernels_do_not_spill():
     tr = build.kernel_resources("train.hip")
     tk = {k: v for k, v in tr.items() if "tgemm_kernelILi2ELi8ELi2ELi4ELi2E" in k}
     assert len(tk) == 6 and all(v["spill"] == 0 and v["scratch"] == 0 for v in tk.values()), tk
+    # the vocoder's wide-stage kernels (round 4: tgemm with split activations; 128 channels as two frame sub-tiles per workgroup)
+    vk = {k: v for k, v in build.kernel_resources("vocoder.hip").items() if "tgemm_kernel" in k}
+    assert len(vk) == 6 and all(v["spill"] == 0 and v["scratch"] == 0 for v in vk.values()), vk
     for tag, limit in (("ELi0ELi2EEEv", 128), ("ELi0ELi1EEEv", 96), ("ELi0ELi0EEEv", 64)):
         k = [v for name, v in res.items() if "tlayer_kernelILi3ELi4ELi2ELi0ELi2ELi0" in name and tag in name]
         assert len(k) == 1 and k[0]["scratch"] <= limit, (tag, k)
