@@ -740,7 +740,7 @@ struct dsvc_vocoder {
     DevBuf pl[8][4];                             // per wide stage: [VT_GUARD + rows + VT_GUARD][2 C] fp16 operand planes -- lrelu(x_stage), xt, two ping-pong.
                                                  // (Not shared between stages: the guard rows are zero because nothing ever writes them, and another
                                                  //  stage's rows would land on them -- row pitch and row count differ)
-    bool wide(int cout) const { return cfg.precision == DSVC_PREC_F16_X3 && (cout == 128 || cout == 256); }
+    bool t_stage[8] = {};                        // stage i runs its resblock convs on the tgemm engine: split precision, 128 / 256 channels, halos within VT_GUARD
     DevBuf lin_w, lin_b;
     int gap_frames = 8;
 
@@ -875,6 +875,12 @@ int dsvc_vocoder::finalize() {
             DSVC_TRY(upload(nc_w[i], nw->data(), nw->size() * 4)); DSVC_TRY(upload(nc_b[i], nb->data(), nb->size() * 4));
         }
         // resblocks (ResBlock1, models.py:33-64: conv pairs; ResBlock2, models.py:73-91: one conv per residual step)
+        {
+            int mh = 0;
+            for (int j = 0; j < nk; ++j)
+                for (int m = 0; m < ndil; ++m) { const int hh = (cfg.resblock_kernel_sizes[j] / 2) * cfg.resblock_dilations[j][m]; if (hh > mh) mh = hh; }
+            t_stage[i] = cfg.precision == DSVC_PREC_F16_X3 && (cout == 128 || cout == 256) && mh <= VT_GUARD;
+        }
         for (int j = 0; j < nk; ++j) {
             const int rk = cfg.resblock_kernel_sizes[j];
             if (!(rk & 1)) return fail(DSVC_EINVAL, "vocoder: even resblock kernel size");
@@ -889,14 +895,14 @@ int dsvc_vocoder::finalize() {
                     const std::vector<float>* b1 = plain(base + "convs." + std::to_string(m) + ".bias", cout);
                     if (!b1) return DSVC_ESTATE;
                     DSVC_TRY(pack_conv(rb1[idx], cout, rk, cout, d, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b1->data(), cout));
-                    if (wide(cout)) DSVC_TRY(pack_t(rb1_t[idx], w, cout, rk));
+                    if (t_stage[i]) DSVC_TRY(pack_t(rb1_t[idx], w, cout, rk));
                     continue;
                 }
                 DSVC_TRY(folded(base + "convs1." + std::to_string(m), (size_t)cout * cout * rk, cout, w));
                 const std::vector<float>* b1 = plain(base + "convs1." + std::to_string(m) + ".bias", cout);
                 if (!b1) return DSVC_ESTATE;
                 DSVC_TRY(pack_conv(rb1[idx], cout, rk, cout, d, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b1->data(), cout));
-                if (wide(cout)) DSVC_TRY(pack_t(rb1_t[idx], w, cout, rk));
+                if (t_stage[i]) DSVC_TRY(pack_t(rb1_t[idx], w, cout, rk));
                 auto pack_f32 = [&](DevBuf& dst) {      // [tap][ci][co]
                     std::vector<float> t((size_t)rk * cout * cout);
                     for (int tap = 0; tap < rk; ++tap)
@@ -910,7 +916,7 @@ int dsvc_vocoder::finalize() {
                 const std::vector<float>* b2 = plain(base + "convs2." + std::to_string(m) + ".bias", cout);
                 if (!b2) return DSVC_ESTATE;
                 DSVC_TRY(pack_conv(rb2[idx], cout, rk, cout, 1, [&](int co, int tap, int ci) { return w[((size_t)co * cout + ci) * rk + tap]; }, b2->data(), cout));
-                if (wide(cout)) DSVC_TRY(pack_t(rb2_t[idx], w, cout, rk));
+                if (t_stage[i]) DSVC_TRY(pack_t(rb2_t[idx], w, cout, rk));
                 if (narrow) DSVC_TRY(pack_f32(rb2_f32[idx]));
             }
         }
@@ -959,7 +965,7 @@ int dsvc_vocoder::ensure_ws(int B, int T) {
         for (int i = 0; i < cfg.n_ups; ++i) {
             r2 *= cfg.upsample_rates[i];
             const int c = cfg.upsample_initial_channel >> (i + 1);
-            if (!wide(c)) continue;
+            if (!t_stage[i]) continue;
             const size_t e = (frames_total * r2 + 2 * VT_GUARD) * 2 * c * 2;
             for (int q = 0; q < 4; ++q) {
                 DSVC_TRY(pl[i][q].alloc(e));
@@ -1026,7 +1032,7 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
             DSVC_TRY(voc_dispatch<EpiAffine>(a, e, prec, st));
         }
         // MRF: mean over the nk resblocks (models.py:376-382)
-        const bool tw = wide(cout) && rows % 128 == 0;
+        const bool tw = t_stage[i] && rows % 128 == 0;
         const VRows vr{stride, len, rows};
         auto plane = [&](int q) { return pl[i][q].as<_Float16>() + (size_t)VT_GUARD * 2 * cout; };
         if (tw) hipLaunchKernelGGL(k_lrelu_planes, dim3(2048), dim3(256), 0, st, U, plane(0), cout, vr, rows);
