@@ -573,6 +573,37 @@ __global__ void k_source_samples(const float* __restrict__ f0, const SrcFrame* _
 // written (not accumulated) into the stage's frame-major buffer before the transposed conv adds onto it.
 // w is stored TRANSPOSED, [K][cout]: the lanes of a wave hold consecutive output channels, so a tap's weights are one coalesced load (with the
 // checkpoint's [cout][K] every lane read its own cache line: 68 us per stage for 28 MB of output, round 4 profile)
+// conv_post + tanh (models.py:357,383-385): Conv1d(c_last, 1, 7, padding 3) on leaky_relu(x, 0.01) -- ONE output channel, so this is a 7 x c_last
+// dot product per sample, not a GEMM (as a 32-column MFMA tile it took 174 us per clip for 49 M multiply-adds).  fp32 FMAs, a block of 256
+// samples stages its 262 rows (already through the leaky ReLU, zero outside the clip) in LDS with an odd row pitch.
+__global__ void __launch_bounds__(256) k_conv_post(const float* __restrict__ x, const float* __restrict__ w /* [c][7] */, const float* __restrict__ bias,
+                                                   float* __restrict__ wav, int C, int clip_stride, int clip_len) {
+    extern __shared__ float sm[];                  // [262][C + 1] rows, then [7][C] weights (tap-major)
+    const int clip = blockIdx.y, n0 = blockIdx.x * 256;
+    const int pitch = C + 1;
+    float* wl = sm + 262 * pitch;
+    for (int i = threadIdx.x; i < 7 * C; i += 256) { const int tap = i / C, ci = i - tap * C; wl[i] = w[ci * 7 + tap]; }
+    const int c4n = C >> 2;
+    for (int i = threadIdx.x; i < 262 * c4n; i += 256) {
+        const int r = i / c4n, c4 = (i - r * c4n) * 4;
+        const int n = n0 - 3 + r;
+        f32x4 v{0.f, 0.f, 0.f, 0.f};
+        if (n >= 0 && n < clip_len) v = ld4(x + ((size_t)clip * clip_stride + n) * C + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[r * pitch + c4 + j] = v[j] > 0.f ? v[j] : 0.01f * v[j];
+    }
+    __syncthreads();
+    const int n = n0 + threadIdx.x;
+    if (n >= clip_len) return;
+    float acc = 0.f;
+    for (int tap = 0; tap < 7; ++tap) {
+        const float* xr = sm + (threadIdx.x + tap) * pitch;
+        const float* wr = wl + tap * C;
+        for (int ci = 0; ci < C; ++ci) acc = fmaf(wr[ci], xr[ci], acc);
+    }
+    wav[(size_t)clip * clip_len + n] = tanhf(acc + bias[0]);
+}
+
 // any channel count (one output per thread and pass)
 __global__ void k_noise_conv_any(const float* __restrict__ har, const float* __restrict__ w, const float* __restrict__ bias,
                                  float* __restrict__ out, int cout, int K, int s, int pad, int len_out, int len_in, int stride_out, int stride_in) {
@@ -765,6 +796,7 @@ struct dsvc_vocoder {
     int hop = 1, dim = 9;
 
     PackedConv conv_pre, conv_post;
+    DevBuf conv_post_w;                          // conv_post's weights as they come, fp32 [c_last][7] (k_conv_post)
     std::vector<PackedConv> ups;                 // polyphase transposed convs
     std::vector<DevBuf> nc_w, nc_b;              // noise convs (plain fp32)
     std::vector<int> nc_k, nc_s, nc_pad;
@@ -784,7 +816,7 @@ struct dsvc_vocoder {
 
     ~dsvc_vocoder() {
         auto rel = [](PackedConv& p) { p.w.release(); p.bias.release(); };
-        rel(conv_pre); rel(conv_post);
+        rel(conv_pre); rel(conv_post); conv_post_w.release();
         for (auto& p : ups) rel(p);
         for (auto& p : rb1) rel(p);
         for (auto& p : rb2) rel(p);
@@ -965,6 +997,7 @@ int dsvc_vocoder::finalize() {
         const std::vector<float>* b = plain("conv_post.bias", 1);
         if (!b) return DSVC_ESTATE;
         DSVC_TRY(pack_conv(conv_post, 1, 7, cl, 1, [&](int, int tap, int ci) { return w[(size_t)ci * 7 + tap]; }, b->data(), 1));
+        DSVC_TRY(upload(conv_post_w, w.data(), (size_t)cl * 7 * 4));
     }
     if (cfg.use_source) {
         const std::vector<float>* lw = plain("m_source.l_linear.weight", dim);
@@ -1174,9 +1207,16 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
         prev = S;
     }
     {   // x = tanh(conv_post(leaky_relu(x)))  -- F.leaky_relu default slope 0.01 (models.py:383-385)
-        ConvGemmArgs a = conv(conv_post, prev, B * Tp * rate, Tp * rate, T * rate, 0.01f);
-        EpiTanhWav::Args e{wav, conv_post.bias.as<float>(), Tp * rate, T * rate};
-        DSVC_TRY(voc_dispatch<EpiTanhWav>(a, e, prec, st));
+        const int cl = ch0 >> nu;
+        const size_t psm = ((size_t)262 * (cl + 1) + 7 * cl) * 4;
+        if (prec == DSVC_PREC_F16_X3 && cl % 4 == 0 && psm <= 64 * 1024) {      // one output channel: fp32 dot products (k_conv_post)
+            hipLaunchKernelGGL(k_conv_post, dim3(ceil_div(T * rate, 256), B), dim3(256), psm, st, prev, conv_post_w.as<float>(), conv_post.bias.as<float>(),
+                               wav, cl, Tp * rate, T * rate);
+        } else {
+            ConvGemmArgs a = conv(conv_post, prev, B * Tp * rate, Tp * rate, T * rate, 0.01f);
+            EpiTanhWav::Args e{wav, conv_post.bias.as<float>(), Tp * rate, T * rate};
+            DSVC_TRY(voc_dispatch<EpiTanhWav>(a, e, prec, st));
+        }
     }
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
