@@ -401,7 +401,7 @@ def main():
 
     B = args.clips_per_gpu if args.clips_per_gpu > 0 else (1 if world == 1 else 32)
     # what the timed chain runs at: precision="auto" picks by sampler and by the size of the call (DiffNetHip.precision_for)
-    prec = pipe.model.denoise_fn.precision_for("plms" if args.speedup > 1 else "ddpm", args.speedup, frames=B * T_FRAMES)
+    prec = pipe.model.denoise_fn.precision_for("plms" if args.speedup > 1 else "ddpm", args.speedup, frames=B * T_FRAMES, clips=B)
     n_clips = B * world
     my_clips = shard_clips(n_clips, rank, world) if world > 1 else list(range(B))
     hub, m2p, f0 = make_inputs(my_clips, dev)
@@ -437,7 +437,7 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel (dilated conv + gate), HIP events on the launch stream ----
-        roof = dominant_kernel_roofline(pipe.model._handle("plms" if args.speedup > 1 else "ddpm", args.speedup, frames=B * T_FRAMES), B, prec)
+        roof = dominant_kernel_roofline(pipe.model._handle("plms" if args.speedup > 1 else "ddpm", args.speedup, frames=B * T_FRAMES, clips=B), B, prec)
         result = {
             "metric": "audio-sec/wall-sec (RTF) end-to-end 44.1kHz %d-step %s + NSF-HiFiGAN" % (
                 args.ddpm_steps, "DDPM" if args.speedup <= 1 else "PLMS/%d" % args.speedup),
@@ -496,8 +496,8 @@ def main():
             torch.cuda.synchronize(); tb = time.perf_counter()
             pipe.infer(hb, mb, fb, seed=2)
             torch.cuda.synchronize(); tb = time.perf_counter() - tb
-            precb = pipe.model.denoise_fn.precision_for("ddpm", 1, frames=Bb * T_FRAMES)
-            broof = dominant_kernel_roofline(pipe.model._handle("ddpm", 1, frames=Bb * T_FRAMES), Bb, precb)
+            precb = pipe.model.denoise_fn.precision_for("ddpm", 1, frames=Bb * T_FRAMES, clips=Bb)
+            broof = dominant_kernel_roofline(pipe.model._handle("ddpm", 1, frames=Bb * T_FRAMES, clips=Bb), Bb, precb)
             result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
                                  "clips_per_gpu": Bb, "precision": precb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
                                  "s_per_batch": tb, "roofline": broof}

@@ -169,6 +169,9 @@ int tpack6(TPacked6& tp, const std::vector<float>& src, int O, int I, int taps, 
     return DSVC_OK;
 }
 
+// f16_w6 / f16_w6n below the throughput tiling's minimum: 64-frame tiles from this many of them, 32-frame tiles below (measured: profiles/r5a_mid_sweep.txt)
+constexpr int MID_NT2_TILES = 160;
+
 // tiling choice of the tgemm path: 128-frame tiles x 8 waves when the batch fills the chip, otherwise 32-frame tiles
 // x 4 waves with the output-channel passes spread over blockIdx.y
 template <class Epi, int NW, int NA = 1>
@@ -331,8 +334,11 @@ struct dsvc_denoiser {
     int eval_conv(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, hipStream_t st);
     int eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step);
     int finalize_t();
-    // the whole residual layer as one kernel (tlayer.h) -- the throughput tiling only
-    bool fused_layer_ok() const;
+    // the whole residual layer as one kernel (tlayer.h): N-tiles of 32 frames per workgroup (4 = the throughput tiling, 2 / 1 = the mid-size
+    // batches of the 6-bit schemes), or 0 = the layer runs as its two tgemm launches
+    int fused_nt() const;
+    bool fused_layer_ok() const { return fused_nt() > 0; }
+    int dbg_fused_nt = 0;        // "fused_nt": force the tile width of the fused kernel (A/B of the mid-size tilings); 0 = automatic
     bool defer_ok() const { return fused_layer_ok() && defer_skip && skipall_t.m_tiles > 0 && gall.p && tskip_supported(cfg.channels, rows_alloc); }
     int launch_fused_layer(int l, const StepRef& step, hipStream_t st, int host_step);
 };
@@ -740,18 +746,29 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
     return DSVC_OK;
 }
 
-bool dsvc_denoiser::fused_layer_ok() const {
-    // one workgroup per 128-frame tile and no channel split: below ~120 tiles (18 x 10 s clips) the chip is better filled by the two
-    // launches with their output channels spread over blockIdx.y (profiles/r3l_auto_sweep.txt: 8 clips 1.11 vs 2.10 ms per step,
-    // 16 clips 2.05 vs 2.21, 20 clips 2.48 vs 2.32)
-    if (dbg_two_launch > 0 || !tpath || NA != 1 || rows_alloc / 128 < (dbg_two_launch < 0 ? 48 : 120)) return false;
+int dsvc_denoiser::fused_nt() const {
+    // 128-frame tiles: one workgroup per tile and no channel split -- below ~120 tiles (18 x 10 s clips) most CUs have no workgroup
+    // (profiles/r3l_auto_sweep.txt: 8 clips 2.10 ms per step against 1.11 for the two launches with their output channels over blockIdx.y).
+    // Round 5: the 6-bit schemes (f16_w6 / f16_w6n) then run the SAME kernel on 64- or 32-frame tiles instead of falling back to the two-launch
+    // tilings, which have no 6-bit products (they computed f16_w2 -- the scheme whose error tail failed the ship bar).
+    if (dbg_two_launch > 0 || !tpath || NA != 1 || rows_alloc / 128 < 48) return 0;
     int max_dil = 1;
     for (int l = 0; l < cfg.layers; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
-    return tlayer_supported(cfg.channels, Cp, max_dil, rows_alloc);
+    const bool w6 = is_w6() && dbg_w6_off == 0 && !defer_skip;
+    int nt = 4;
+    if (dbg_fused_nt == 1 || dbg_fused_nt == 2 || dbg_fused_nt == 4) nt = dbg_fused_nt;
+    else if (rows_alloc / 128 < 120 && dbg_two_launch >= 0) {
+        if (!w6) return 0;                                // (f16_w2 / f16_mN / f16_dN: the two launches, as before)
+        nt = rows_alloc / 64 >= MID_NT2_TILES ? 2 : 1;
+    }
+    if (nt != 4 && !w6) return 0;
+    return tlayer_supported(cfg.channels, Cp, max_dil, rows_alloc, nt) ? nt : 0;
 }
 
 int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st, int host_step) {
     const int C = cfg.channels, L = cfg.layers;
+    const int nt = fused_nt();
+    if (nt == 0) return fail(DSVC_ESTATE, "denoiser: the fused layer kernel does not cover this call");
     const bool last = l + 1 == L;
     auto wargs = [&](const TPacked& tp, int taps, int dil) {
         TGemmArgs a{};
@@ -783,7 +800,7 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
         const TPacked6& o6 = outl6_t[l];
         TLayerW6 w6{t6.codes.as<unsigned>(), (long long)t6.variant_dwords, t6.e6, t6.n_variants};
         w6.out_lo_codes = o6.codes.as<unsigned>(); w6.out_lo_variant_dwords = (long long)o6.variant_dwords; w6.eol6 = o6.e6;
-        if (cfg.precision == DSVC_PREC_F16_W6 && dbg_g6_off == 0 && tlayer_smem(ga.dil, Cp, true) <= 160 * 1024) {      // (a dilation beyond 8 leaves no room for the code block beside the time tile)
+        if (cfg.precision == DSVC_PREC_F16_W6 && dbg_g6_off == 0 && tlayer_smem(ga.dil, Cp, true, nt) <= 160 * 1024) {      // (a dilation beyond 8 leaves no room for the code block beside the time tile)
             w6.out_codes = out6_t[l].codes.as<unsigned>(); w6.eo6 = out6_t[l].e6;
         }
         TGemmArgs ga6 = ga;
@@ -793,7 +810,7 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
             w6.out_lo_codes += (size_t)(host_step % o6.n_variants) * o6.variant_dwords;
             w6.n_variants = 1;
         }
-        return tlayer_launch<2>(ga6, cp, oa, oe, C, rows_alloc, 0, st, nullptr, 0, &w6);
+        return tlayer_launch<2>(ga6, cp, oa, oe, C, rows_alloc, 0, st, nullptr, 0, &w6, nt);
     }
     if (dil_t[l].planes == 1 && out_t[l].planes == 2) return tlayer_launch<1, 2>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl, layer_prio);      // F16_MIX
     return dil_t[l].planes == 2 ? tlayer_launch<2>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl, layer_prio) : tlayer_launch<1>(ga, cp, oa, oe, C, rows_alloc, pf, st, gl, layer_prio);
@@ -1162,6 +1179,7 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     else if (k == "g6_off") d->dbg_g6_off = value ? 1 : 0;
     else if (k == "x3t_w6_off") d->dbg_x3t_w6_off = value ? 1 : 0;
     else if (k == "layer_prio") d->layer_prio = value;
+    else if (k == "fused_nt") d->dbg_fused_nt = value;
     else if (k == "defer_skip") {
         d->defer_skip = value != 0;
         if (d->defer_skip && d->wsB > 0 && !d->gall.p) { d->wsB = 0; d->wsT = 0; }      // rebuild the workspace with the gate-output buffer
@@ -1315,9 +1333,9 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
     *avg_us = (float)(total * 1000.0 / count);
     *rows = d->rows;
 #ifdef DSVC_PROFILING
-    if (kind) *kind = (d->fused_layer_ok() && !getenv("DSVC_PROFILE_KERNEL")) ? 1 : 0;
+    if (kind) *kind = (d->fused_layer_ok() && !getenv("DSVC_PROFILE_KERNEL")) ? d->fused_nt() : 0;
 #else
-    if (kind) *kind = d->fused_layer_ok() ? 1 : 0;
+    if (kind) *kind = d->fused_nt();
 #endif
     return DSVC_OK;
 }

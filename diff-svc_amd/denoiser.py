@@ -24,8 +24,10 @@ output 1x1; ``"f16_x3"`` splits the activations as well (3 MFMAs, fp32-class).  
   gate output's own fp16 rounding in the output 1x1.  The maximum mel error of a 1000-step chain is a heavy-tailed statistic: on the 31 + n
   real-reference goldens of two 32-clip batches it is 4.0e-4 ... 5.7e-4 (Gumbel fit: P(a clip > 1e-3) ~ 5e-9), conditioned checkpoints
   1.3e-4 ... 1.7e-4; f16_w2 itself measures 6.2e-4 ... 9.1e-4 there (P ~ 1e-3 per clip -- one 256-clip job in four holds a clip over the
-  bar on a random-init checkpoint) at 9 % more time per step.  Calls between 6000 frames and the fused kernel's minimum (about 18 clips)
-  run f16_w2 on the two-launch tilings.  ``f16_w6n`` = the same without the gate-output correction: f16_w2's error class, another 6 % faster.
+  bar on a random-init checkpoint) at 9 % more time per step.  Round 5: calls between the batched threshold (48 tiles of 128 rows = 7
+  ten-second clips) and the 128-frame tiling's minimum (120 tiles = 18 clips) run the SAME kernel -- 6-bit corrections included -- on 64- or
+  32-frame tiles (until round 4 they fell back to f16_w2 on the two-launch tilings: the scheme whose error tail failed the ship bar).
+  ``f16_w6n`` = the same without the gate-output correction: f16_w2's error class, another 6 % faster.
 * PLMS/PNDM, whose Adams-Bashforth extrapolation amplifies a single evaluation's rounding: ``f16_x3t`` (7e-6 on the 50-iteration golden
   at T=861; 26 ms per 10 s clip).  With fp16 activations even exact weights leave that chain at (8.2 +- 1.2)e-4 over ten (clip, noise)
   pairs, one of them at 1.08e-3 (profiles/r2w_precision_spread.txt).
@@ -63,8 +65,11 @@ class _ResidualBlockParams(nn.Module):
 
 class DiffNetHip(nn.Module):
     AUTO = {"ddpm": "f16_x3t", "ddpm_batched": "f16_w6", "plms": "f16_x3t", "plms_coarse": "f16_x3t", "forward": "f16_x3t"}
-    BATCHED_FRAMES = 6000          # B * T from which a DDPM call takes the batched precision (7 ten-second clips: f16_x3t costs +14 ... 20 % below
-                                   # that and +50 ... 90 % above, profiles/r3l_auto_sweep.txt)
+    BATCHED_FRAMES = 6000          # B * T from which a DDPM call takes the batched precision when only the frame count is known (7 ten-second
+                                   # clips: f16_x3t costs +14 ... 20 % below that and +50 ... 90 % above, profiles/r3l_auto_sweep.txt)
+    BATCHED_TILES = 48             # ... and, when the batch shape is known, the rule itself: the call's rows fill >= 48 tiles of 128 rows -- from
+                                   # there the C library runs f16_w6 on its fused layer kernel (csrc/diffnet.hip: fused_nt), below it the handle
+                                   # would fall back to f16_w2 on the two-launch tilings, so `auto` stays on f16_x3t
 
     def __init__(self, in_dims=80, hparams=None, precision="auto"):
         super().__init__()
@@ -93,20 +98,34 @@ class DiffNetHip(nn.Module):
     def _params_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.precision,)
 
-    def precision_for(self, use, speedup=1, frames=None):
+    def workspace_tiles(self, clips, T):
+        """128-row tiles of the C workspace for a [clips, T] call (csrc/diffnet.hip: ensure_ws -- a clip occupies round_up(T + largest
+        dilation, 32) rows, the batch is rounded up to whole tiles)."""
+        max_dil = 2 ** min(self.dilation_cycle - 1, self.n_layers - 1)
+        tp = (T + max_dil + 31) // 32 * 32
+        return (clips * tp + 127) // 128
+
+    def precision_for(self, use, speedup=1, frames=None, clips=None):
         """The operand precision used for ``use`` in {'ddpm', 'plms', 'forward'} (PLMS: also by its step interval; DDPM: also by the
-        call's size, ``frames`` = B * T)."""
+        call's size, ``frames`` = B * T, with ``clips`` = B the exact rule of BATCHED_TILES)."""
         if self.precision != "auto":
             return self.precision
         if use == "plms" and speedup > 20:
             use = "plms_coarse"
-        if use == "ddpm" and frames is not None and frames >= self.BATCHED_FRAMES:
-            use = "ddpm_batched"
+        if use == "ddpm" and frames is not None:
+            if self.channels not in (256, 384):
+                batched = False                          # (the fused layer kernel is built for 2 or 3 channel blocks of 128: csrc/tlayer.h)
+            elif clips is not None and clips > 0:
+                batched = self.workspace_tiles(clips, frames // clips) >= self.BATCHED_TILES
+            else:
+                batched = frames >= self.BATCHED_FRAMES
+            if batched:
+                use = "ddpm_batched"
         return self.AUTO[use]
 
-    def handle(self, use="forward", speedup=1, frames=None):
+    def handle(self, use="forward", speedup=1, frames=None, clips=None):
         """The C handle for a use; rebuilt whenever a parameter tensor changes (load_state_dict, .to(), in-place edits)."""
-        prec = self.precision_for(use, speedup, frames)
+        prec = self.precision_for(use, speedup, frames, clips)
         key = self._params_key()
         cur = self._handles.get(prec)
         if cur is None or cur[1] != key:

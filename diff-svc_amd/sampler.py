@@ -139,10 +139,10 @@ class GaussianDiffusionHip(nn.Module):
         pitch = ret["pitch_pred"].detach().squeeze(-1) if "pitch_pred" in ret else None
         return _DiffLoss.apply(self, (ref_mels.detach(), cond, t, pitch, mel2ph, seed), *params)
 
-    def _handle(self, use="ddpm", speedup=1, frames=None):
-        den = self.denoise_fn.handle(use, speedup, frames)
+    def _handle(self, use="ddpm", speedup=1, frames=None, clips=None):
+        den = self.denoise_fn.handle(use, speedup, frames, clips)
         key = (id(den),) + tuple((b.data_ptr(), b._version) for b in self.buffers(recurse=False))
-        slot = self.denoise_fn.precision_for(use, speedup, frames)
+        slot = self.denoise_fn.precision_for(use, speedup, frames, clips)
         cur = self._samplers.get(slot)
         if cur is None or cur[1] != key:
             # a sampler handle keeps its denoiser handle (up to 3 GB of packed weights) alive: drop every slot whose denoiser handle
@@ -172,7 +172,7 @@ class GaussianDiffusionHip(nn.Module):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         speedup = hp.get("pndm_speedup") or 1
-        smp = self._handle("plms" if speedup > 1 else "ddpm", speedup, frames=cond.shape[0] * cond.shape[2])
+        smp = self._handle("plms" if speedup > 1 else "ddpm", speedup, frames=cond.shape[0] * cond.shape[2], clips=cond.shape[0])
         x_init = ref = None
         if kwargs.get("use_gt_mel"):
             # diffusion.py:255-261: x = q_sample(norm_spec(ref_mels), t-1); norm_spec, q_sample and the noise draw (x_T Philox

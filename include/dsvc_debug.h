@@ -38,7 +38,8 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
  * measured with HIP events on the launch stream over back-to-back launches of all layers (a different dither variant per round:
  * weights as cold as in the real chain), and the number of frames (rows) one launch processed.
  * kind (may be NULL) receives which kernel that is: 0 = the gate kernel (dilated conv + conditioner projection + gate: small
- * batches run a layer as two launches), 1 = the fused residual-layer kernel (gate GEMM + output projection: the throughput tiling). */
+ * batches run a layer as two launches), > 0 = the fused residual-layer kernel (gate GEMM + output projection) and the number of
+ * 32-frame N-tiles a workgroup covers: 4 = the throughput tiling, 2 / 1 = the mid-size tilings of f16_w6 / f16_w6n (round 5). */
 int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters,
                                      float* avg_us, int64_t* rows, int32_t* kind, void* stream);
 

@@ -403,6 +403,68 @@ def test_batch_of_32_full_chain_every_clip_with_a_golden(ckpt, which):
         assert worst < 1e-4, errs
 
 
+@pytest.mark.parametrize("B", [8, 12, 16])
+def test_mid_batch_auto_every_clip_with_a_golden(B):
+    """what precision='auto' REALLY runs between the batched threshold (7 ten-second clips) and the 128-frame tiling's
+    minimum (18 clips).  Until round 4 that was f16_w2 on the two-launch tilings (the handle fell back silently) -- the scheme that failed
+    the 9.0e-4 ship bar on the 64-golden study.  Round 5: the f16_w6 handle runs the fused layer kernel on 64- / 32-frame tiles there
+    (csrc/diffnet.hip: fused_nt), 6-bit correction products and gate-output correction included.  8, 12 and 16 clips x T=861 in ONE batch,
+    1000 steps, the precision DiffNetHip.precision_for picks, NO debug knob; every clip has a real-reference golden (clips 0..15 of rank 0's
+    share) and must stay <= 9.0e-4; the kernel that ran is asserted to be the fused one."""
+    from diffsvc_amd.denoiser import DiffNetHip
+    from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
+    from make_golden import SPREAD_SEED, share_golden
+    hp = dict(synth.HPARAMS_44K)
+    net = DiffNetHip(128, hparams=hp)
+    precision = net.precision_for("ddpm", 1, frames=B * 861, clips=B)
+    assert precision == _shipped(batched=True), precision
+    sd = synth.acoustic_state(hp, 0)
+    den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=precision, prefix="denoise_fn.")
+    smp = SamplerHandle(den, sd)
+    clips = list(range(B))
+    hub, m2p, f0 = clip_batch(hp, clips, 861, 500)
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    mel = smp.sample(cond.transpose(1, 2).contiguous().cuda(), 1000, mel2ph=m2p.cuda(), seed=SPREAD_SEED, first_clip=0, use_graph=True).cpu()
+    assert torch.isfinite(mel).all()
+    errs = []
+    for c in clips:
+        name, row = share_golden(c)
+        g = load_golden(name)
+        assert int(g["seed"]) == SPREAD_SEED and int(g["clips"][row]) == c
+        errs.append((c, (mel[c] - torch.from_numpy(g["mel_out"][row])).abs().max().item()))
+    worst = max(e[1] for e in errs)
+    nt = smp.profile_gate_kernel(B, 861, 1)[2]
+    mu, beta, p1, p256 = gumbel_fit([e[1] for e in errs])
+    print("mid batch of %d (auto -> %s, fused layer kernel on %d-frame tiles): worst %.2e; per clip %s" % (B, precision, 32 * nt, worst, ["%d: %.2e" % e for e in errs]))
+    print("mid batch of %d: Gumbel fit of the %d per-clip maxima mu %.3e beta %.3e -> P(clip > 1e-3) %.2e" % (B, B, mu, beta, p1))
+    assert nt in (1, 2), nt                              # the fused kernel's mid-size tilings, not the two-launch fallback (0)
+    assert worst <= SHIP_BAR, errs
+
+
+@pytest.mark.parametrize("precision", ["f16_w6", "f16_w6n"])
+def test_mid_size_tilings_of_the_fused_layer_kernel_equal_the_128_frame_tiling_bit_for_bit(precision):
+    """The fused layer kernel on 64- and 32-frame tiles (round 5: tlayer_kernel<..., NT = 2 / 1>) issues the same products in the same order
+    for every accumulator as on 128-frame tiles -- a frame's K loops do not depend on which workgroup holds it -- so a 20-step DDPM chain at
+    8 x T=861 comes out bit-identical on all three (tile DMA and halo, g blocks and 6-bit code rows in LDS scaled by NT / 4, the output
+    phase's prefetched accumulator sets that only the small tiles have registers for)."""
+    hp = dict(synth.HPARAMS_44K, K_step=20)
+    sd, den, smp = make_handles(hp, 0, precision)
+    clips, T, n_units, seed = list(range(8)), 861, 500, 77
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    cond = cond.transpose(1, 2).contiguous().cuda()
+    out = {}
+    for nt in (4, 2, 1):
+        den.debug_set("fused_nt", nt)
+        out[nt] = smp.sample(cond, 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False, return_x=True)[1]
+        assert smp.profile_gate_kernel(8, T, 1)[2] == nt
+    den.debug_set("fused_nt", 0)
+    assert torch.isfinite(out[4]).all()
+    d2, d1 = (out[2] - out[4]).abs().max().item(), (out[1] - out[4]).abs().max().item()
+    print("fused layer kernel %s, 64- / 32-frame tiles vs 128-frame tiles: max |diff| %.3e / %.3e" % (precision, d2, d1))
+    assert torch.equal(out[2], out[4]) and torch.equal(out[1], out[4]), (d2, d1)
+
+
 @pytest.mark.parametrize("precision", ["f16_w2", "f16_m64"])
 def test_deferred_skip_contraction_taps_and_equivalence(precision):
     """The deferred skip path (debug_set 'defer_skip' 1; not the default: time-neutral): the layer kernels write the gate
@@ -457,15 +519,18 @@ def test_deferred_skip_contraction_taps_and_equivalence(precision):
     assert torch.isfinite(a).all() and 0.0 < d < 2e-4
 
 
-@pytest.mark.parametrize("precision", ["f16_w6", "f16_w6n", "f16_w2"])
+@pytest.mark.parametrize("precision", ["f16_w6", "f16_w6n", "f16_w2", "f16_w6/2", "f16_w6/1", "f16_w6n/1"])
 def test_fused_layer_kernels_on_the_24k_architecture(precision):
     """The fused layer kernel's two-block instantiations (C = 256: the 24 kHz demo architecture, BASELINE configs[0]'s shapes) -- every other test of
     the batched path runs the three-block 44.1 kHz ones.  8 clips x T = 861 on the fused kernel (forced: the automatic choice needs >= 120 tiles), a
     30-step DDPM chain, every clip against the oracle's chain from the same Philox noise: f16_w6 / f16_w6n (the 6-bit correction products and the
     gate-output correction with NB = 2) and f16_w2 stay in the fp16-activation class (a wrong code layout shows at >= 1e-2)."""
+    precision, _, nt = precision.partition("/")           # "/2", "/1": the 64- / 32-frame tiles of the mid-size batches (round 5)
     hp = dict(synth.HPARAMS_24K, K_step=30)
     sd, den, smp = make_handles(hp, 2, precision)
     den.debug_set("two_launch_layer", -1)
+    if nt:
+        den.debug_set("fused_nt", int(nt))
     clips, T, n_units, seed = list(range(8)), 861, 500, 41
     ref = oracle_sample(hp, sd, clips, T, n_units, 1, seed, 30)
     mel = smp.sample(ref["cond_t"].cuda(), 30, mel2ph=ref["mel2ph"].cuda(), seed=seed, first_clip=0, use_graph=False).cpu()
