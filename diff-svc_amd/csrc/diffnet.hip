@@ -169,8 +169,17 @@ int tpack6(TPacked6& tp, const std::vector<float>& src, int O, int I, int taps, 
     return DSVC_OK;
 }
 
-// f16_w6 / f16_w6n below the throughput tiling's minimum: 64-frame tiles from this many of them, 32-frame tiles below (measured: profiles/r5a_mid_sweep.txt)
-constexpr int MID_NT2_TILES = 160;
+// compute units of the current device (the fused layer kernel runs one workgroup per CU: its tile width is chosen by rounds of workgroups)
+inline int device_cus() {
+    static thread_local int dev_cached = -1, cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev != dev_cached) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+        dev_cached = dev;
+    }
+    return cus;
+}
 
 // tiling choice of the tgemm path: 128-frame tiles x 8 waves when the batch fills the chip, otherwise 32-frame tiles
 // x 4 waves with the output-channel passes spread over blockIdx.y
@@ -757,9 +766,23 @@ int dsvc_denoiser::fused_nt() const {
     const bool w6 = is_w6() && dbg_w6_off == 0 && !defer_skip;
     int nt = 4;
     if (dbg_fused_nt == 1 || dbg_fused_nt == 2 || dbg_fused_nt == 4) nt = dbg_fused_nt;
-    else if (rows_alloc / 128 < 120 && dbg_two_launch >= 0) {
-        if (!w6) return 0;                                // (f16_w2 / f16_mN / f16_dN: the two launches, as before)
-        nt = rows_alloc / 64 >= MID_NT2_TILES ? 2 : 1;
+    else if (dbg_two_launch < 0) nt = 4;                  // (tests: the throughput tiling wherever it is supported)
+    else if (!w6) {
+        if (rows_alloc / 128 < 120) return 0;             // f16_w2 / f16_mN / f16_dN: the two launches below ~18 clips, as before
+    } else {
+        // f16_w6 / f16_w6n: the tile width that needs the least time over its rounds of workgroups (one per CU).  A workgroup streams the
+        // layer's whole weight set whatever its width: measured 45 / 65 / 125 us per layer for 32- / 64- / 128-frame tiles with every CU
+        // holding one (profiles/r5a_mid_sweep.txt: 8 clips on 32-frame tiles 1.01 ms per step, 16 clips on 64-frame tiles 1.44, 32 clips on
+        // 128-frame tiles 2.65; the two-launch f16_w2 layer these sizes ran until round 4: 1.06 / 1.94 / --).  The three widths give
+        // bit-identical results (tests/test_gpu_headline.py), so the choice is a pure scheduling decision.
+        const int cus = device_cus();
+        const int cost[3] = {45, 65, 125}, width[3] = {1, 2, 4};
+        long best = -1;
+        for (int i = 0; i < 3; ++i) {
+            if (rows_alloc % (32 * width[i])) continue;
+            const long c = (long)ceil_div(rows_alloc / (32 * width[i]), cus) * cost[i];
+            if (best < 0 || c < best) { best = c; nt = width[i]; }
+        }
     }
     if (nt != 4 && !w6) return 0;
     return tlayer_supported(cfg.channels, Cp, max_dil, rows_alloc, nt) ? nt : 0;

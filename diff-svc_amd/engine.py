@@ -178,10 +178,16 @@ class VocoderHandle:
             raise ValueError("resblock must be '1' or '2' (modules/nsf_hifigan/models.py:337)")
         rates, ksz = list(h["upsample_rates"]), list(h["upsample_kernel_sizes"])
         rks, rds = list(h["resblock_kernel_sizes"]), [list(d) for d in h["resblock_dilation_sizes"]]
-        ndil = len(rds[0]) if rds else 0
-        # ResBlock1 walks three dilations (models.py:36-55); ResBlock2 is written for two (models.py:77-82) -- any 1..3 of one length is run
-        if len(rates) > 8 or len(rks) > 4 or any(len(d) != ndil for d in rds) or not 1 <= ndil <= 3 or (rb == "1" and ndil != 3):
+        # ResBlock1 builds convs1 / convs2 from dilation[0..2] (models.py:36-55), ResBlock2 exactly two convs from dilation[0] and dilation[1]
+        # (models.py:77-82) -- whatever the length of the list: longer lists are accepted and their tail ignored, shorter ones raise an
+        # IndexError in the reference's constructor (here: ValueError)
+        ndil = 3 if rb == "1" else 2
+        if len(rates) > 8 or len(rks) > 4 or not rds:
             raise ValueError("unsupported generator geometry")
+        if any(len(d) < ndil for d in rds):
+            raise ValueError("resblock '%s' needs %d dilations per kernel size, got %s (modules/nsf_hifigan/models.py:%s)"
+                             % (rb, ndil, rds, "36-55" if rb == "1" else "77-82"))
+        rds = [d[:ndil] for d in rds]
         cfg = _lib.VocoderCfg()
         sr = h["sampling_rate"] if "sampling_rate" in h else h["audio_sample_rate"]
         cfg.num_mels, cfg.upsample_initial_channel, cfg.sampling_rate = h["num_mels"], h["upsample_initial_channel"], sr

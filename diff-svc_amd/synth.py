@@ -254,8 +254,9 @@ def vocoder_state(h, seed=0):
         c = ch0 // (2 ** (i + 1))
         for j, (k, dils) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
             r = "resblocks.%d." % (i * nk + j)
-            for m in range(len(dils)):
-                if str(h.get("resblock", "1")) == "1":
+            rb1 = str(h.get("resblock", "1")) == "1"
+            for m in range(3 if rb1 else 2):               # the reference builds 3 conv pairs / 2 convs whatever the list's length (models.py:36-55, 77-82)
+                if rb1:
                     wn(r + "convs1.%d" % m, (c, c, k), 1.2)
                     wn(r + "convs2.%d" % m, (c, c, k), 0.45)
                 else:                                      # ResBlock2 (models.py:73-84): one conv per residual step

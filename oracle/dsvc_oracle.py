@@ -481,8 +481,9 @@ def generator_forward(gw, h, mel, f0, rand_ini, noise, taps=None):
 
 
 def _resblock2(gw, prefix, x, k, dils):
-    """ResBlock2.forward (models.py:86-91): one dilated conv per residual step."""
-    for j, d in enumerate(dils):
+    """ResBlock2.forward (models.py:86-91): one dilated conv per residual step -- exactly two of them, built from dilation[0] and dilation[1]
+    whatever the length of the config's list (models.py:77-82)."""
+    for j, d in enumerate(dils[:2]):
         xt = F.leaky_relu(x, LRELU)
         xt = F.conv1d(xt, gw[prefix + "convs.%d.weight" % j], gw[prefix + "convs.%d.bias" % j], padding=(k * d - d) // 2, dilation=d)
         x = xt + x
@@ -491,7 +492,7 @@ def _resblock2(gw, prefix, x, k, dils):
 
 def _resblock1(gw, prefix, x, k, dils):
     """ResBlock1.forward (models.py:57-64)."""
-    for j, d in enumerate(dils):
+    for j, d in enumerate(dils[:3]):                       # (three pairs from dilation[0..2], models.py:36-55)
         xt = F.leaky_relu(x, LRELU)
         xt = F.conv1d(xt, gw[prefix + "convs1.%d.weight" % j], gw[prefix + "convs1.%d.bias" % j],
                       padding=(k * d - d) // 2, dilation=d)

@@ -204,6 +204,10 @@ def golden_vocoder_rb2():
     golden_vocoder("vocoder_tiny_rb2", tiny2, 6, clips=[0, 3], T=24, seed=93)
     wide2 = dict(synth.VOCODER_44K, resblock="2", resblock_dilation_sizes=[[1, 3], [1, 3], [1, 3]])
     golden_vocoder("vocoder_44k_rb2", wide2, 2, clips=[1], T=12, seed=94)
+    # a valid reference config with THREE-entry dilation lists under resblock '2' (e.g. a V1 config switched to ResBlock2): the reference still
+    # builds two convs per block, from dilation[0] and dilation[1] (models.py:77-82) -- ADVICE r4: the drop-in asked for a non-existent convs.2
+    tiny2d3 = dict(synth.tiny_vocoder(rds=((1, 3, 5), (2, 4, 7))), resblock="2")
+    golden_vocoder("vocoder_tiny_rb2_d3", tiny2d3, 7, clips=[2], T=24, seed=95)
 
 
 def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500, seed=2026, wseed=0, vseed=1, K=1000, speedup=1, with_wav=True,

@@ -19,12 +19,14 @@ def vocoder_for(h, wseed, precision="f16_x3"):
     return VocoderHandle(synth.vocoder_state(h, wseed), h, precision=precision)
 
 
-@pytest.mark.parametrize("name", ["vocoder_tiny", "vocoder_44k", "vocoder_tiny_rb2", "vocoder_44k_rb2"])
+@pytest.mark.parametrize("name", ["vocoder_tiny", "vocoder_44k", "vocoder_tiny_rb2", "vocoder_44k_rb2", "vocoder_tiny_rb2_d3"])
 def test_vocoder_vs_reference_golden(name):
     g = load_golden(name)
     h = synth.tiny_vocoder() if "tiny" in name else dict(synth.VOCODER_44K)
     if name.endswith("_rb2"):            # generators built from ResBlock2 (models.py:73-91, :337): one conv per residual step, two dilations
         h = dict(h, resblock="2", resblock_dilation_sizes=[[1, 3]] * len(h["resblock_kernel_sizes"]))
+    if name.endswith("_rb2_d3"):         # ... under a config whose lists hold THREE dilations: the reference builds two convs from the first two (models.py:77-82)
+        h = dict(h, resblock="2", resblock_dilation_sizes=[[1, 3, 5], [2, 4, 7]])
     voc = vocoder_for(h, int(g["wseed"]))
     clips = [int(c) for c in g["clips"]]
     wavs = []

@@ -427,3 +427,19 @@ def test_bench_spawns_its_own_ranks_and_refuses_a_mismatched_world(train):
     assert d["ms_per_step"] >= 19.0                          # the slower rank's clock (rank 1 sleeps 20 ms per step), not rank 0's
     bad = subprocess.run(cmd, capture_output=True, text=True, timeout=60, cwd=root, env=dict(env, WORLD_SIZE="3", RANK="0"))
     assert bad.returncode == 2 and "WORLD_SIZE=3" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
+def test_resblock_geometry_follows_the_reference_constructors():
+    """ResBlock2 builds exactly two convs from dilation[0] and dilation[1] whatever the list's length (modules/nsf_hifigan/
+    models.py:77-82), ResBlock1 three pairs from dilation[0..2] (:36-55).  A list that is too short raises in the reference's constructor
+    (IndexError) -- here a ValueError before any device work; a longer list is accepted and its tail ignored: the synthetic checkpoint
+    for a three-entry ResBlock2 config holds convs.0 / convs.1 only, like the real Generator's (tests/golden/vocoder_tiny_rb2_d3.npz runs it)."""
+    from diffsvc_amd.engine import VocoderHandle
+    h1 = dict(synth.tiny_vocoder(rds=((1,), (1,))), resblock="2")
+    with pytest.raises(ValueError, match="needs 2 dilations"):
+        VocoderHandle({}, h1)
+    h2 = dict(synth.tiny_vocoder(rds=((1, 3), (1, 3))), resblock="1")
+    with pytest.raises(ValueError, match="needs 3 dilations"):
+        VocoderHandle({}, h2)
+    sd = synth.vocoder_state(dict(synth.tiny_vocoder(rds=((1, 3, 5), (2, 4, 7))), resblock="2"), 7)
+    assert not any(".convs.2." in k for k in sd) and any(".convs.1." in k for k in sd)

@@ -86,12 +86,14 @@ def test_philox_known_answer():
     assert abs(float(z.mean())) < 0.15 and abs(float(z.std()) - 1.0) < 0.1
 
 
-@pytest.mark.parametrize("name", ["vocoder_tiny", "vocoder_44k", "vocoder_tiny_rb2", "vocoder_44k_rb2"])
+@pytest.mark.parametrize("name", ["vocoder_tiny", "vocoder_44k", "vocoder_tiny_rb2", "vocoder_44k_rb2", "vocoder_tiny_rb2_d3"])
 def test_vocoder_matches_reference(name):
     g = load_golden(name)
     h = synth.tiny_vocoder() if "tiny" in name else dict(synth.VOCODER_44K)
     if name.endswith("_rb2"):            # generators built from ResBlock2 (models.py:73-91, :337): one conv per residual step, two dilations
         h = dict(h, resblock="2", resblock_dilation_sizes=[[1, 3]] * len(h["resblock_kernel_sizes"]))
+    if name.endswith("_rb2_d3"):         # ... under a config whose lists hold THREE dilations: the reference builds two convs from the first two (models.py:77-82)
+        h = dict(h, resblock="2", resblock_dilation_sizes=[[1, 3, 5], [2, 4, 7]])
     gw = O.fold_weight_norm(synth.vocoder_state(h, int(g["wseed"])))
     clips = [int(c) for c in g["clips"]]
     T = g["mel"].shape[1]
