@@ -36,10 +36,10 @@ FLOP_PER_FRAME_OUTPROJ = 2 * 384 * 768            # ... and its 1x1 output proje
 PEAK_TFLOPS_F16 = 2500.0                           # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 FAST_SIDE = "f16_w6n"                              # the faster operand scheme reported beside the shipped one (see `faster_scheme`)
 # Per-clip maximum mel error of the shipped batched precision (f16_w6) over the 64 real-reference goldens of two 32-clip batches
-# (tests/test_gpu_headline.py::test_batch_of_32_full_chain_every_clip_with_a_golden[random|random2-shipped], profiles/r4*_b32_goldens.txt):
-# Gumbel fit (mu, beta) of the 64 maxima -> P(a clip exceeds the 1e-3 bar) and P(a 256-clip job holds such a clip)
-B32_ERROR_FIT = {"precision": "f16_w6", "clips": 64, "worst": 6.12e-4, "gumbel_mu": 4.62e-4, "gumbel_beta": 3.5e-5,
-                 "source": "profiles/r4_b32_goldens.txt"}
+# (tests/test_gpu_headline.py::test_batch_of_32_full_chain_every_clip_with_a_golden[random|random2-shipped]): Gumbel fit (mu, beta) of the 64
+# maxima -> P(a clip exceeds the 1e-3 bar) and P(a 256-clip job holds such a clip).  Not a constant of this file any more: read from
+# profiles/b32_error_fit.json (tools/b32_error_fit.py writes it from the test's output), which carries the hash of the kernel sources it was
+# measured on -- reported as null, with the reason, once a kernel source has changed (load_error_fit).
 PEAK_HBM_GBS = 8000.0                              # HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
 # algorithmic HBM bytes per frame of one residual layer, C = 384, fp16 operands / fp32 residual + skip + cproj:
 #   gate kernel alone : xh in 768*(1 + 2d/128 averaged over d = 1,2,4,8 -> 1.06) + cproj 3072 + g out 768
@@ -160,6 +160,20 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
+def load_error_fit(precision):
+    """(fit dict, None) from profiles/b32_error_fit.json, or (None, why) when it is missing, stale or for another precision."""
+    path = os.path.join(ROOT, "profiles", "b32_error_fit.json")
+    if not os.path.exists(path):
+        return None, "no error fit committed (profiles/b32_error_fit.json; tools/b32_error_fit.py)"
+    with open(path) as f:
+        fit = json.load(f)
+    if fit.get("csrc_sha16") != kernel_sources_sha():
+        return None, "stale: the fit was measured on kernel sources %s, this tree is %s" % (fit.get("csrc_sha16"), kernel_sources_sha())
+    if fit.get("precision") != precision:
+        return None, "the fit is for %s, the batch ran at %s" % (fit.get("precision"), precision)
+    return fit, None
+
+
 def load_traffic(name, precision):
     """(bytes_per_launch, source) of a committed PMC measurement, or (None, why) when it is missing, was taken on other kernel
     sources (tools/rocprof_traffic.py stamps the file with kernel_sources_sha()) or at another operand precision."""
@@ -241,6 +255,17 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def same_workload_fields(value, solo_value, world, what):
+    """an N > 1 line carries its own same-workload 1-GPU denominator.  `--gpus 1` times ONE clip per GPU (BASELINE
+    configs[1]) and `--gpus N` 32 clips per GPU (configs[3]): dividing the two `value`s would read the batch size as scaling.  So every
+    N > 1 run first lets rank 0 run its own share alone, un-gathered, while the other ranks wait, and the line says what N GPUs buy over
+    THAT: speedup_vs_1gpu_same_workload = value / same_workload_1gpu, scaling_efficiency = speedup / N (weak scaling: 1.0 is ideal)."""
+    if world <= 1 or solo_value is None:
+        return {}
+    return {"same_workload_1gpu": solo_value, "same_workload_1gpu_what": what,
+            "speedup_vs_1gpu_same_workload": value / solo_value, "scaling_efficiency": value / solo_value / world}
+
+
 def comm_info(dist, world, share_device):
     """What moved the bytes between the ranks: backend, world size and (RCCL) library version -- on the JSON line of every N > 1 run."""
     if world <= 1 or dist is None:
@@ -266,20 +291,38 @@ def train_batch(hp, B, T, rank, device):
     return tuple(torch.from_numpy(v).to(device) for v in (hub, m2p, f0, mels))
 
 
-def time_train_steps(hp, sd, B, T, steps, warmup, rank, device, sync):
-    """ms per optimisation step of DiffusionTrainerHip (forward + backward + gradient all-reduce over the ranks + clip + AdamW)."""
+def time_train_steps(hp, sd, B, T, steps, warmup, rank, device, sync, world=1):
+    """(ms per optimisation step of DiffusionTrainerHip -- forward + backward + gradient all-reduce over the ranks + clip + AdamW --, final
+    loss, solo ms).  solo ms (world > 1 only, else None): rank 0 ALONE stepping on its own batch without the all-reduce while the other
+    ranks wait at a barrier -- the same per-GPU workload on one GPU, measured in this very run, so that the N-GPU line carries its own
+    denominator (the optimiser state is put back afterwards: the replicas stay identical)."""
     from diffsvc_amd.train import DiffusionTrainerHip
     tr = DiffusionTrainerHip(dict(hp, lr=1e-4), sd)
     hub, m2p, f0, mels = train_batch(hp, B, T, rank, device)
     loss = None
     for i in range(warmup):
         loss = tr.train_step(hub, m2p, f0, mels, seed=10 + i, first_clip=rank * B)
+    solo = None
+    if world > 1:
+        sync()
+        if rank == 0:
+            keep = [t.clone() for t in (tr.params, tr.exp_avg, tr.exp_avg_sq)], tr.global_step
+            n = max(2, min(steps, 5))
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(n):
+                t_solo = torch.randint(0, int(hp.get("K_step", hp["timesteps"])), (B,), device=device)
+                tr.forward_backward(hub, m2p, f0, mels, t_solo, seed=50 + i, first_clip=0)
+                tr.optimizer_step(reduced=True)                 # (reduced=True: no all-reduce -- one GPU's step)
+            torch.cuda.synchronize(); solo = (time.perf_counter() - t0) / n * 1e3
+            for dst, src in zip((tr.params, tr.exp_avg, tr.exp_avg_sq), keep[0]):
+                dst.copy_(src)
+            tr.global_step = keep[1]
     sync()
     t0 = time.perf_counter()
     for i in range(steps):
         loss = tr.train_step(hub, m2p, f0, mels, seed=100 + i, first_clip=rank * B)
     sync()
-    return (time.perf_counter() - t0) / steps * 1e3, float(loss.item())
+    return (time.perf_counter() - t0) / steps * 1e3, float(loss.item()), solo
 
 
 def main():
@@ -337,7 +380,11 @@ def main():
         # no hot path, no number: every rank sleeps its "steps" between the same barriers, the MAX over the ranks is taken the same way,
         # and rank 0 prints a line that says what it is
         import time as _t
+        solo = None
         if world > 1:
+            dist.barrier()
+            if rank == 0:                                     # (the same-workload 1-GPU leg of the real run: rank 0 alone, the others at the barrier)
+                ts = _t.perf_counter(); _t.sleep(0.01); solo = 1.0 / (_t.perf_counter() - ts)
             dist.barrier()
         t0 = _t.perf_counter()
         for _ in range(args.steps):
@@ -350,7 +397,8 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "dry run of the launch contract (no GPU work)", "value": None, "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": float(el.item()) / max(args.steps, 1) * 1e3, "dry_run": True,
-                              "scaling": "weak", "rccl": comm_info(dist, world, True), "train": bool(args.train)}))
+                              "scaling": "weak", "rccl": comm_info(dist, world, True), "train": bool(args.train),
+                              **same_workload_fields(world * args.steps / float(el.item()), solo, world, "dry run: rank 0 sleeping alone")}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -372,7 +420,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
         Bt, Tt = 64, 128
-        ms, loss = time_train_steps(hp, sd, Bt, Tt, args.steps, args.warmup, rank, dev, sync_t)
+        ms, loss, solo_ms = time_train_steps(hp, sd, Bt, Tt, args.steps, args.warmup, rank, dev, sync_t, world)
         if world > 1:
             tmax = torch.tensor([ms], device="cpu" if SHARE_DEVICE else dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -387,6 +435,8 @@ def main():
                                                      "of 32 M fp32 over the ranks", "clips_per_gpu": Bt, "mel_frames": Tt, "loss": hp["diff_loss_type"],
                                          "parallelism": "data-parallel x%d" % world},
                               "rccl": comm_info(dist, world, SHARE_DEVICE), "final_loss": loss,
+                              **same_workload_fields(world * Bt * Tt / (ms * 1e-3), None if solo_ms is None else Bt * Tt / (solo_ms * 1e-3), world,
+                                                     "rank 0 alone, %d x %d-frame batch, forward + backward + clip + AdamW without the all-reduce" % (Bt, Tt)),
                               "roofline": {"bound": "mfma", "scope": "whole step per GPU (forward + backward + clip + AdamW), not one kernel: the largest kernels are "
                                            "wgrad_nt_kernel (16 %) and the transposed conv on the tgemm engine (14 %), profiles/r4u_kernel_stats_train.csv",
                                            "algorithmic_tflop_per_step": train_step_flops(hp, Bt * Tt) / 1e12,
@@ -421,6 +471,16 @@ def main():
 
     for i in range(args.warmup):
         one_step(100 + i)
+    solo_value = None
+    if world > 1:
+        # the same per-GPU workload on ONE GPU, measured in this run: rank 0 alone on its own share, no gather, the others at the barrier
+        sync()
+        if rank == 0:
+            if args.warmup == 0:
+                pipe.infer(hub, m2p, f0, speedup=args.speedup, seed=150, clip_ids=clip_ids, use_graph=not args.no_graph, full_length=True)
+            torch.cuda.synchronize(); ts = time.perf_counter()
+            pipe.infer(hub, m2p, f0, speedup=args.speedup, seed=151, clip_ids=clip_ids, use_graph=not args.no_graph, full_length=True)
+            torch.cuda.synchronize(); solo_value = B * CLIP_SECONDS / (time.perf_counter() - ts)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -457,6 +517,8 @@ def main():
                        "gather": "int16 PCM" if pcm16 else "fp32 PCM"},
             "finite_output": ok,
             "rccl": comm_info(dist, world, SHARE_DEVICE),
+            **same_workload_fields(value, solo_value, world, "rank 0 alone on its own %d-clip share (cond -> %d-step %s -> NSF-HiFiGAN), no gather, "
+                                   "the other ranks waiting at a barrier" % (B, args.ddpm_steps, "DDPM" if args.speedup <= 1 else "PLMS/%d" % args.speedup)),
             "roofline": roof,
         }
         if os.environ.get("DSVC_BENCH_PCM_STATS") == "1":       # test hook: per-clip moments of the gathered PCM of the last step
@@ -501,11 +563,14 @@ def main():
             result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
                                  "clips_per_gpu": Bb, "precision": precb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
                                  "s_per_batch": tb, "roofline": broof}
-            if precb == B32_ERROR_FIT["precision"]:
+            fit, why = load_error_fit(precb)
+            if fit:
                 import math
-                p1 = 1.0 - math.exp(-math.exp(-(1e-3 - B32_ERROR_FIT["gumbel_mu"]) / B32_ERROR_FIT["gumbel_beta"]))
-                result["batched"]["mel_error_vs_reference"] = dict(B32_ERROR_FIT, bar=1e-3, p_clip_over_bar=p1,
-                                                                   p_over_bar_per_256_clips=1.0 - (1.0 - p1) ** 256)
+                p1 = 1.0 - math.exp(-math.exp(-(1e-3 - fit["gumbel_mu"]) / fit["gumbel_beta"]))
+                result["batched"]["mel_error_vs_reference"] = dict(fit, bar=1e-3, p_clip_over_bar=p1, p_over_bar_per_256_clips=1.0 - (1.0 - p1) ** 256)
+            else:
+                result["batched"]["mel_error_vs_reference"] = None
+                result["batched"]["mel_error_vs_reference_missing"] = why
             # the sustained MFMA rate again, on the chip as the batched run leaves it (hot, clocks settled)
             sustained["after_batched"] = probe_mfma()
             sustained.update(operands="random fp16, register-resident v_mfma_f32_32x32x16_f16 loop, 2 waves/SIMD, every CU",
@@ -609,7 +674,7 @@ def main():
             # BASELINE configs[4]: the training step (64 clips x 128 frames: diffusion loss forward + backward + clip + AdamW)
             try:
                 torch.cuda.empty_cache()
-                ms_t, loss_t = time_train_steps(hp, sd, 64, 128, 5, 2, 0, dev, torch.cuda.synchronize)
+                ms_t, loss_t, _ = time_train_steps(hp, sd, 64, 128, 5, 2, 0, dev, torch.cuda.synchronize)
                 tfl = train_step_flops(hp, 64 * 128) / (ms_t * 1e-3) / 1e12
                 result["train_step"] = {"workload": "BASELINE configs[4]: diffusion loss fwd+bwd + AdamW on a 64 x 128-frame mel batch, 1 GPU",
                                         "ms_per_step": ms_t, "value": 64 * 128 / (ms_t * 1e-3), "unit": "frames/s", "final_loss": loss_t,

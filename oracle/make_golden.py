@@ -13,6 +13,7 @@ import sys
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -391,6 +392,37 @@ def golden_train_bench_f64():
     np.savez_compressed(os.path.join(OUT, "train_grads_bench_f64.npz"), **out)
 
 
+def golden_train_bench_kinks():
+    """Where the benchmarked training batch sits on a ReLU kink: the FLOAT64 pre-activations of the two ReLUs of DiffNet
+    (input projection, net.py:120-123; skip projection, :132-133) on exactly the batch of train_grads_bench.npz -- per output channel the
+    smallest |pre-activation| over all frames, and the frame it occurs at.  A weight-gradient ROW of these two convs jumps by one frame's
+    whole term when the fp32 evaluation's sign of such a pre-activation differs from the fp64 one's; tests/test_gpu_train.py may set ONE row
+    of these two tensors aside -- and only if this file says that row has a pre-activation within fp32 rounding of zero."""
+    (name, arch, loss_type, clips, T, n_units, seed), = TRAIN_CASES_BENCH
+    hp = dict(synth.HPARAMS_44K, diff_loss_type=loss_type)
+    sd = synth.acoustic_state(hp, 3)
+    hub, m2p, f0, mels, t = (torch.from_numpy(v) for v in synth.train_batch_kat(hp, clips, T, n_units, seed))
+    noise = O.ddpm_noise_ref_layout(seed, list(clips), 0, T, hp["audio_num_mel_bins"], O.PURPOSE_TRAIN_NOISE)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    out = {}
+    with torch.no_grad():
+        cond, _, _ = O.build_cond(sd64, hub.double(), m2p, f0.double().clone(), hp)
+        x0 = O.norm_spec(sd64, mels.double()).transpose(1, 2)[:, None, :, :]
+        x_noisy = O.q_sample(sd64, x0, t, noise.double())
+        taps = {}
+        O.diffnet_forward(sd64, x_noisy, t, cond.transpose(1, 2), hp["dilation_cycle_length"], taps=taps)
+        pre = {"denoise_fn.input_projection.weight": F.conv1d(x_noisy[:, 0], sd64["denoise_fn.input_projection.weight"], sd64["denoise_fn.input_projection.bias"]),
+               "denoise_fn.skip_projection.weight": F.conv1d(taps["skip"], sd64["denoise_fn.skip_projection.weight"], sd64["denoise_fn.skip_projection.bias"])}
+    for k, v in pre.items():
+        a = v.abs().permute(1, 0, 2).reshape(v.shape[1], -1)              # [channel][clip * T + frame]
+        mn, at = a.min(1)
+        out[k + "/min_abs_preact"] = mn.numpy()
+        out[k + "/at"] = at.numpy()
+        order = mn.argsort()[:3]
+        print("%s: rows nearest a ReLU kink %s, |pre-activation| %s (median row %.2e)" % (k, order.tolist(), ["%.1e" % mn[i].item() for i in order], mn.median().item()))
+    np.savez_compressed(os.path.join(OUT, "train_grads_bench_kinks.npz"), **out)
+
+
 def golden_melspec(name, sr, n_fft, win, hop, n_mels, fmin, fmax, n_samples):
     """STFT.get_mel of the REAL reference (nvSTFT.py:72-104).  Two shims are unavoidable on this image:
     librosa's mel filterbank is replaced by the oracle's restatement (librosa is not installed), and
@@ -450,6 +482,8 @@ def main():
         return golden_slicer()
     if "--schedule-only" in sys.argv:
         return golden_schedule()
+    if "--train-kinks" in sys.argv:
+        return golden_train_bench_kinks()
     if "--rb2-only" in sys.argv:
         return golden_vocoder_rb2()
     if "--cond-energy" in sys.argv:

@@ -153,7 +153,13 @@ def test_train_step_vs_real_reference_golden(case):
     on a stride-8 lattice).  Nothing of the oracle restatement is in this comparison.
     bench64x128_l2 (round 4, tests/golden/train_grads_bench.npz) is BASELINE configs[4] AT THE BENCHMARKED SIZE: exactly the batch
     `bench.py --train` times on rank 0 (64 clips x 128 frames = 8 704 rows: the many-row conv tilings, the XCD-sliced weight gradients, the
-    64-frame tgemm layer tilings, the 2^14 loss scale) through the real reference's forward(infer=False) + backward()."""
+    64-frame tgemm layer tilings, the 2^14 loss scale) through the real reference's forward(infer=False) + backward().
+    A dependency of this case worth knowing: its "at most twice the fp32 reference's own distance from the float64 values"
+    criterion is met BECAUSE the tgemm tilings start each frame tile's K loop at a staggered weight group (csrc/tgemm.h: STAGGER / gmap) -- a
+    latency measure of the single-clip regime that here decorrelates the accumulation's rounding from row to row, so that it averages out in
+    the weight-gradient contraction over 8 192 frames: 2.1e-4 from the fp64 values on the most cancellation-prone tensors (1.64x the
+    reference's own distance) with the stagger, 7.8e-4 (5.2x: outside the bar) with one fixed summation order in every tile.
+    Removing the stagger from the trainer's tilings is therefore a parity change, not a refactoring."""
     from diffsvc_amd.train import DiffusionTrainerHip
     from make_golden import TRAIN_CASES, TRAIN_CASES_BENCH
     from util import load_golden
@@ -171,6 +177,12 @@ def test_train_step_vs_real_reference_golden(case):
     # oracle/make_golden.py::golden_train_bench_f64), so each tensor is ALSO measured against the fp64 values: the HIP step has to be within
     # 5e-5 of the fp32 reference, or at least as close to the fp64 values as the fp32 reference is
     g64 = load_golden("train_grads_bench_f64") if case.startswith("bench") else None
+    # ... and the two weight tensors whose OUTPUT passes a ReLU (input projection net.py:120-123, skip projection :132-133) may have ONE row set
+    # aside -- only where oracle/make_golden.py::golden_train_bench_kinks (float64) finds a pre-activation of that very row within fp32 rounding
+    # of zero: the row's gradient then jumps by one frame's whole term with the sign the fp32 arithmetic happens to give it.  Every other tensor
+    # is measured whole (the exclusion used to apply to every tensor with >= 8 rows and could hide a single-row indexing bug)
+    gk = load_golden("train_grads_bench_kinks") if case.startswith("bench") else None
+    KINK_EPS = 2e-6
     kinds, kink_rows = {}, {}
     worst, worst_name, worst_norm, worst64, worst64_name, worst_ratio = 0.0, None, 0.0, 0.0, None, 0.0
     for k, ref_norm in zip((str(n) for n in g[case + "/names"]), g[case + "/norms"]):
@@ -188,16 +200,18 @@ def test_train_step_vs_real_reference_golden(case):
             r64 = torch.from_numpy(g64[case + "/grad/" + k])
             e_ref = (ref.double() - r64).norm().item() / r64.norm().item()
             d2 = (part.double() - r64).pow(2)
-            if d2.dim() >= 2 and d2.shape[0] >= 8:
-                # ... measured WITHOUT the single worst output row: a weight gradient behind a ReLU (skip_projection.weight) changes by ~1e-3 of
-                # ONE row when one of its 3.1 M mask bits differs from the fp64 evaluation's (a pre-activation within 1e-7 of zero) -- measured:
-                # row 232 at 1.1e-3, the median row at 1.4e-6, 6.7e-5 over the tensor.  That is a kink of the function, not operand precision.
+            e_hip = d2.sum().sqrt().item() / r64.norm().item()
+            if gk is not None and (k + "/min_abs_preact") in gk.files:
+                # a weight gradient behind a ReLU changes by ~1e-3 of ONE row when one of its 3.1 M mask bits differs from the fp64 evaluation's --
+                # measured: skip_projection.weight row 232 (|pre-activation| 9e-7 in float64) at 1.1e-3, the median row at 1.4e-6, 6.7e-5 over the
+                # tensor.  That is a kink of the function, not operand precision: the worst row is set aside IF it is such a row.
                 rows2 = d2.reshape(d2.shape[0], -1).sum(1)
-                kinked = (rows2.sum() - rows2.max()).sqrt().item() / r64.norm().item()
-                kink_rows[k] = (rows2.max().sqrt() / r64.reshape(r64.shape[0], -1)[rows2.argmax()].norm()).item()
-                e_hip = kinked
-            else:
-                e_hip = d2.sum().sqrt().item() / r64.norm().item()
+                wr = int(rows2.argmax())
+                true_row = wr * (8 if got.shape[0] != part.shape[0] else 1)           # (larger tensors are stored on a stride-8 lattice)
+                near = float(gk[k + "/min_abs_preact"][true_row])
+                kink_rows[k] = (true_row, (rows2.max().sqrt() / r64.reshape(r64.shape[0], -1)[wr].norm()).item(), near)
+                if near < KINK_EPS:
+                    e_hip = (rows2.sum() - rows2.max()).sqrt().item() / r64.norm().item()
             if e_hip > worst64:
                 worst64, worst64_name = e_hip, k
             worst_ratio = max(worst_ratio, e_hip / max(e_ref, 5e-5))
@@ -218,9 +232,10 @@ def test_train_step_vs_real_reference_golden(case):
         for kind, v in kinds.items():
             for e_hip, e_ref, e32 in v:
                 assert e32 < 5e-5 or e_hip <= max(2.0 * e_ref, 5e-5), (kind, e32, e_hip, e_ref)
-        worst_row = max(kink_rows.items(), key=lambda kv: kv[1])
-        print("train step %s   worst single output row of any weight gradient: %.2e (%s)" % (case, worst_row[1], worst_row[0]))
-        assert worst_row[1] < 5e-3, worst_row
+        for k, (row, e_row, near) in kink_rows.items():
+            print("train step %s   %s: worst output row %d at %.2e; smallest |ReLU pre-activation| of that row in float64 %.1e (%s)"
+                  % (case, k, row, e_row, near, "a kink row: set aside" if near < KINK_EPS else "no kink: measured with the tensor"))
+            assert e_row < 5e-3, (k, row, e_row)
     # measured 4e-6 (l2) / 1e-5 (l1) since the backward pass is loss-scaled (d loss / d eps ~ 1e-6 used to sit in fp16's subnormal range, where
     # its hi + lo split kept 4 bits: 8e-4 / 2.5e-3 then)
     assert (worst < 5e-5 or g64 is not None) and worst_norm < 1e-5, (worst, worst_name, worst_norm)

@@ -425,6 +425,9 @@ def test_bench_spawns_its_own_ranks_and_refuses_a_mismatched_world(train):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dry_run"] and d["train"] == train and d["rccl"]["world_size"] == 2 and d["rccl"]["backend"] == "gloo"
     assert d["ms_per_step"] >= 19.0                          # the slower rank's clock (rank 1 sleeps 20 ms per step), not rank 0's
+    # round 5: an N > 1 line carries its own same-workload 1-GPU denominator (rank 0 alone while the others wait), so that nobody divides it
+    # by the one-clip `--gpus 1` headline
+    assert d["same_workload_1gpu"] > 0 and abs(d["scaling_efficiency"] * 2 - d["speedup_vs_1gpu_same_workload"]) < 1e-9
     bad = subprocess.run(cmd, capture_output=True, text=True, timeout=60, cwd=root, env=dict(env, WORLD_SIZE="3", RANK="0"))
     assert bad.returncode == 2 and "WORLD_SIZE=3" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
