@@ -88,6 +88,38 @@ def latency_floor(precision, measured_us):
             "frac_of_latency_floor": floor / measured_us}
 
 
+def res_skip_roofline(handle, precision):
+    """The single clip's OTHER layer kernel (39 % of the headline's GPU time had no roofline entry): tgemm_kernel<TEpiResSkip>,
+    the output 1x1 (K = 384, M = 768: 589 824 FLOP per frame) with the residual / skip read-modify-write and the next layer's FiLM'd operand in
+    its epilogue -- 24 output tiles, three per workgroup, each tile's K loop split over three waves (8 k16 steps per wave).  Priced like the gate
+    kernel: algorithmic FLOPs against the MFMA peak, and against a stated latency floor (same constants as latency_floor: a 1.75 us graph-node
+    boundary, the (32-frame x [hi | lo]) tile through the CU's 64 B/clk path + one L2 round trip, the larger of the per-CU weight stream and the
+    per-SIMD matrix time, 0.5 us of split-K reduction + epilogue + store drain).  PMC traffic: profiles/resskip_traffic.json."""
+    handle.den.debug_set("profile_kernel", 1)
+    try:
+        us, rows, kind = handle.profile_gate_kernel(1, T_FRAMES, 5)
+    finally:
+        handle.den.debug_set("profile_kernel", 0)
+    x3t = precision == "f16_x3t"
+    ach = FLOP_PER_FRAME_OUTPROJ * T_FRAMES / (us * 1e-6) / 1e12
+    planes = 1.375 if x3t else (2 if precision == "f16_w2" else 1)
+    mpp = 2.25 if x3t else planes
+    clk = 2.4e3
+    dma = 32 * 384 * 2 * (2 if x3t else 1) / 64.0 / clk + 0.3
+    stream = 3 * 24 * planes * 1024 / 64.0 / clk
+    matrix = (9 / 4.0) * 8 * mpp * 32 / clk
+    floor = 1.75 + dma + max(stream, matrix) + 0.5
+    act = 768 * (2 if x3t else 1)                         # g in, next xh out: fp16 rows, [hi | lo] planes at f16_x3t
+    roof = {"bound": "mfma", "kernel": "tgemm_kernel<TEpiResSkip> (output 1x1 + residual / skip update + next layer's FiLM'd operand, one residual layer)",
+            "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_F16, "avg_launch_us": us,
+            "frames_per_launch": T_FRAMES, "mfma_per_product": mpp, "pipe_tflops": ach * mpp, "pipe_frac": ach * mpp / PEAK_TFLOPS_F16,
+            "algorithmic_bytes": int((act + 3072 + 3072 + act) * T_FRAMES + planes * WEIGHT_BYTES_OUT),
+            "latency_floor_us": floor, "latency_floor_parts_us": {"boundary": 1.75, "tile_dma": dma, "weight_stream": stream, "matrix": matrix, "tail": 0.5},
+            "frac_of_latency_floor": floor / us}
+    roof["traffic"], roof["traffic_source"] = load_traffic("resskip_traffic.json", precision)
+    return roof
+
+
 def train_step_flops(hp, frames):
     """Algorithmic FLOPs (one multiply-add = 2) of one training step over `frames` valid mel frames: per residual layer the forward (dilated
     conv, conditioner projection, output 1x1), the data gradients (transposed conv, d gate) and the three weight gradients; the conditioner's
@@ -521,6 +553,11 @@ def main():
                                    "the other ranks waiting at a barrier" % (B, args.ddpm_steps, "DDPM" if args.speedup <= 1 else "PLMS/%d" % args.speedup)),
             "roofline": roof,
         }
+        if world == 1 and B == 1 and args.speedup <= 1 and roof["bound"] == "mfma":
+            try:        # the single clip's second layer kernel (39 % of its GPU time), priced the same way
+                result["roofline_res_skip"] = res_skip_roofline(pipe.model._handle("ddpm", 1, frames=B * T_FRAMES, clips=B), prec)
+            except Exception as ex:
+                result["roofline_res_skip"] = {"error": repr(ex)[:300]}
         if os.environ.get("DSVC_BENCH_PCM_STATS") == "1":       # test hook: per-clip moments of the gathered PCM of the last step
             w64 = wav.double()
             result["pcm_stats"] = [[int(i), float(w64[i].sum()), float((w64[i] ** 2).sum())] for i in range(w64.shape[0])]

@@ -184,8 +184,17 @@ inline int device_cus() {
 // tiling choice of the tgemm path: 128-frame tiles x 8 waves when the batch fills the chip, otherwise 32-frame tiles
 // x 4 waves with the output-channel passes spread over blockIdx.y
 template <class Epi, int NW, int NA = 1>
-int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hipStream_t st) {
+int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hipStream_t st, int tail = 0) {
     constexpr int KG = NW == 2 ? 4 : 8;                  // two planes: half the ring depth, same bytes in flight
+    if constexpr (NA == 1 && NW == 2) {
+        // tail > 0 (the three small projections of a step at large batches, A/B knob "tail_tiling"): 32-frame tiles x 4 waves -- 48 KB of LDS at
+        // K = 768, two workgroups per CU whose phases (tile DMA, MFMAs, epilogue) overlap -- instead of 64- / 128-frame tiles with one
+        // workgroup per CU.  1: every output pass its own workgroup; 2: one workgroup walks all passes
+        if (tail > 0 && rows_alloc / 128 >= 48 && a.taps == 1) {
+            const int passes = ceil_div(a.m_tiles, 4);
+            return tgemm_launch<1, 4, 2, KG, NW, Epi>(a, e, rows_alloc, tail == 1 ? passes : 1, st);
+        }
+    }
     if constexpr (NA == 2) {
         // split activations (F16_X3T): rows are [hi | lo] planes, twice the LDS per frame -> 64-frame tiles for big batches, the same
         // split-K / small-batch tilings otherwise
@@ -229,7 +238,8 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
 }
 
 template <class Epi>
-int tlaunch_prec(const TGemmArgs& a, const typename Epi::Args& e, int planes, int rows_alloc, hipStream_t st, int na = 1) {
+int tlaunch_prec(const TGemmArgs& a, const typename Epi::Args& e, int planes, int rows_alloc, hipStream_t st, int na = 1, int tail = 0) {
+    if (tail > 0 && na == 1 && planes == 2) return tlaunch<Epi, 2>(a, e, rows_alloc, st, tail);
     if (na == 2) {
         if (planes != 2) return fail(DSVC_EINVAL, "tgemm: split activations need hi + lo weight planes");
         return tlaunch<Epi, 2, 2>(a, e, rows_alloc, st);
@@ -347,6 +357,8 @@ struct dsvc_denoiser {
     // batches of the 6-bit schemes), or 0 = the layer runs as its two tgemm launches
     int fused_nt() const;
     bool fused_layer_ok() const { return fused_nt() > 0; }
+    int dbg_profile_out = 0;     // "profile_kernel" 1: dsvc_sampler_profile_gate_kernel times the OUTPUT kernel of the two-launch layer instead of the gate kernel
+    int dbg_tail = 0;            // "tail_tiling": tiling of the three small projections at large batches, two bits each (in | skip << 2 | out << 4): see tlaunch
     int dbg_fused_nt = 0;        // "fused_nt": force the tile width of the fused kernel (A/B of the mid-size tilings); 0 = automatic
     bool defer_ok() const { return fused_layer_ok() && defer_skip && skipall_t.m_tiles > 0 && gall.p && tskip_supported(cfg.channels, rows_alloc); }
     int launch_fused_layer(int l, const StepRef& step, hipStream_t st, int host_step);
@@ -707,7 +719,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
     {   // K1: input projection + ReLU (net.py:120-123); emits layer 0's operand xh = fp16(x + film_0)
         TGemmArgs a = targs(xsh.as<_Float16>(), 2 * Mp, in_t, 1, 1);
         TEpiInProj::Args e{xres.as<float>(), xh_row0(), in_t.bias.as<float>(), film.as<float>(), L * C, step, C, Cp * NA, rm, NA == 2 ? Cp : 0};
-        DSVC_TRY(tlaunch_prec<TEpiInProj>(a, e, 2, rows_alloc, st));
+        DSVC_TRY(tlaunch_prec<TEpiInProj>(a, e, 2, rows_alloc, st, 1, dbg_tail & 3));
     }
     const int stop_after = dbg_stop_after;
     const bool fused = fused_layer_ok();
@@ -740,16 +752,16 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
     } else {   // K9a: skip projection + ReLU (net.py:132-133)
         TGemmArgs a = targs(skiph.as<_Float16>(), 2 * Cp, skip_t, 1, 1);
         TEpiReluHalf::Args e{s2h.as<_Float16>(), Cp, skip_t.bias.as<float>(), C};
-        DSVC_TRY(tlaunch_prec<TEpiReluHalf>(a, e, 2, rows_alloc, st));
+        DSVC_TRY(tlaunch_prec<TEpiReluHalf>(a, e, 2, rows_alloc, st, 1, (dbg_tail >> 2) & 3));
     }
     {   // K9b: output projection (net.py:134), optionally fused with the DDPM update (K10)
         TGemmArgs a = targs(s2h.as<_Float16>(), 2 * Cp, fin_t, 1, 1);
         if (tail == TAIL_DDPM) {
             TEpiDdpm::Args e{ddpm->x, xsh.as<_Float16>(), fin_t.bias.as<float>(), M, Mp, ddpm->tab, step, rm, ddpm->seedp, ddpm->clipid};
-            DSVC_TRY(tlaunch_prec<TEpiDdpm>(a, e, 2, rows_alloc, st));
+            DSVC_TRY(tlaunch_prec<TEpiDdpm>(a, e, 2, rows_alloc, st, 1, (dbg_tail >> 4) & 3));
         } else {
             TEpiEps::Args e{eps.as<float>(), M, fin_t.bias.as<float>()};
-            DSVC_TRY(tlaunch_prec<TEpiEps>(a, e, 2, rows_alloc, st));
+            DSVC_TRY(tlaunch_prec<TEpiEps>(a, e, 2, rows_alloc, st, 1, (dbg_tail >> 4) & 3));
         }
     }
     return DSVC_OK;
@@ -1203,6 +1215,8 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     else if (k == "x3t_w6_off") d->dbg_x3t_w6_off = value ? 1 : 0;
     else if (k == "layer_prio") d->layer_prio = value;
     else if (k == "fused_nt") d->dbg_fused_nt = value;
+    else if (k == "tail_tiling") d->dbg_tail = value;
+    else if (k == "profile_kernel") d->dbg_profile_out = value ? 1 : 0;
     else if (k == "defer_skip") {
         d->defer_skip = value != 0;
         if (d->defer_skip && d->wsB > 0 && !d->gall.p) { d->wsB = 0; d->wsT = 0; }      // rebuild the workspace with the gate-output buffer
@@ -1304,10 +1318,11 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
         hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, s->step_dev.as<int>(), hstep);
         DSVC_HIP(hipEventRecord(e0, st));
         for (int l = 0; l < L; ++l) {
+            // which kernel of a two-launch layer: the gate kernel, or ("profile_kernel" 1: bench.py's second single-clip roofline entry) the
+            // output projection / residual + skip kernel
+            const char* which = d->dbg_profile_out ? "out" : nullptr;
 #ifdef DSVC_PROFILING
-            const char* which = getenv("DSVC_PROFILE_KERNEL");          // "out": time the output projection instead (profiling aid)
-#else
-            const char* which = nullptr;
+            if (getenv("DSVC_PROFILE_KERNEL")) which = getenv("DSVC_PROFILE_KERNEL");
 #endif
             if (d->fused_layer_ok() && !which) {                        // the product path at this size is the fused layer kernel
                 DSVC_TRY(d->launch_fused_layer(l, StepRef{s->step_dev.as<int>(), 0, 0}, st, -1));
@@ -1318,6 +1333,11 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
                 a.w = d->out_t[l].w.as<_Float16>(); a.m_tiles = d->out_t[l].m_tiles; a.w_planes = d->out_t[l].planes;
                 a.variant_halfs = (long long)d->out_t[l].variant_halfs; a.n_variants = d->out_t[l].n_variants;
                 a.step_ptr = s->step_dev.as<int>(); a.step_off = 0; a.clip_rows = d->Tp;
+                if (d->NA == 2) {                                                                                          // the kernel the sampler's DDPM steps run
+                    d->ddpm_chain = true;
+                    d->set_w6(a, d->outl6_t, l, hstep, StepRef{s->step_dev.as<int>(), 0, 0}, 0.0625f, 123);
+                    d->ddpm_chain = false;
+                }
                 TEpiResSkip::Args e{d->xres.as<float>(), last ? nullptr : d->xh_row0(), d->skip.as<float>(), last ? d->skiph.as<_Float16>() : nullptr,
                                     d->out_t[l].bias.as<float>(), last ? nullptr : d->film.as<float>() + (size_t)(l + 1) * C, L * C,
                                     StepRef{s->step_dev.as<int>(), 0, 0}, C, d->Cp * d->NA, l == 0 ? 1 : 0, d->rowmap(), d->rows_alloc >= 6144 ? 1 : 0,
@@ -1356,9 +1376,9 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
     *avg_us = (float)(total * 1000.0 / count);
     *rows = d->rows;
 #ifdef DSVC_PROFILING
-    if (kind) *kind = (d->fused_layer_ok() && !getenv("DSVC_PROFILE_KERNEL")) ? d->fused_nt() : 0;
+    if (kind) *kind = (d->fused_layer_ok() && !getenv("DSVC_PROFILE_KERNEL") && !d->dbg_profile_out) ? d->fused_nt() : 0;
 #else
-    if (kind) *kind = d->fused_nt();
+    if (kind) *kind = d->dbg_profile_out ? 0 : d->fused_nt();
 #endif
     return DSVC_OK;
 }

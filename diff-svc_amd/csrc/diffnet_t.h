@@ -90,94 +90,136 @@ struct TEpiResSkip {
                                 // cache -> non-temporal loads and stores (no dirty-line build-up to flush at the kernel boundary)
         int xh_lo;              // > 0: xh rows are [hi | lo] planes (ldh halfs per row, lo plane xh_lo halfs in): split activations
     };
-    template <int NT_N>
-    __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+    // one N-tile's accumulator init (the residual-stream / skip-sum tile of frames row0 + 32 nt ..)
+    __device__ __forceinline__ void init_one(const Args& e, int mt, int row0, int lane, int nt, f32x16& a) const {
         const int rt = e.C >> 5;                            // residual tiles
         const bool res = mt < rt;
-        const int cb = (res ? mt : mt - rt) * 32 + 16 * (lane >> 5);
         const float* base = res ? e.x32 : e.skip;
         const int tl_mt = res ? mt : mt - rt;
+        if (!res && e.first) {
 #pragma unroll
-        for (int nt = 0; nt < NT_N; ++nt) {
-            if (!res && e.first) {
+            for (int i = 0; i < 16; ++i) a[i] = 0.f;
+        } else {
+            const float* p = base + tiled_lane_base(row0 + 32 * nt, rt, tl_mt, lane);
+            f32x4 v0, v1, v2, v3;
+            if (e.stream) { v0 = ld4_nt(p); v1 = ld4_nt(p + 256); v2 = ld4_nt(p + 512); v3 = ld4_nt(p + 768); }
+            else { v0 = ld4(p); v1 = ld4(p + 256); v2 = ld4(p + 512); v3 = ld4(p + 768); }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+            for (int i = 0; i < 4; ++i) { a[i] = v0[i]; a[4 + i] = v1[i]; a[8 + i] = v2[i]; a[12 + i] = v3[i]; }
+        }
+    }
+    template <int NT_N>
+    __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) init_one(e, mt, row0, lane, nt, acc[nt]);
+    }
+    // what an epilogue needs beside the accumulators: the tile's bias, the clips of the lane's NT_N frames (ONE batch of loads at the top, not a
+    // dependent load inside every N-tile's epilogue) and -- when every clip is at the same diffusion step (the sampler's loops) -- the next
+    // layer's FiLM values of the lane's 16 channels once instead of once per N-tile
+    template <int NT_N>
+    struct Ctx { float b[16]; int clip[NT_N]; float film[16]; bool film_shared; };
+    // HOIST = false: only the bias (the two-launch kernels: their register allocation has no room for more live values across the N-tiles)
+    // step_shared: the diffusion step when every clip is at the same one, read ONCE at kernel entry by the caller (a scalar load there instead
+    // of a dependent load in front of every epilogue's FiLM loads), or -1 (per-clip steps / not read yet: e.step.get())
+    template <bool HOIST, int NT_N>
+    __device__ __forceinline__ void prepare(const Args& e, int mt, int row0, int lane, Ctx<NT_N>& c, int step_shared = -1) const {
+        const int rt = e.C >> 5;
+        const bool res = mt < rt;
+        const int cb = (res ? mt : mt - rt) * 32 + 16 * (lane >> 5);
+        const bool need_clip = HOIST && ((res && e.xh) || (!res && e.skiph));
+#pragma unroll
+        for (int nt = 0; nt < NT_N; ++nt) c.clip[nt] = need_clip ? e.rm.rowclip[row0 + 32 * nt + (lane & 31)] : -1;
+        {
+            const float* bp = e.bias + (res ? 0 : e.C) + cb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const f32x4 v = ld4(bp + 4 * q); c.b[4 * q] = v[0]; c.b[4 * q + 1] = v[1]; c.b[4 * q + 2] = v[2]; c.b[4 * q + 3] = v[3]; }
+        }
+        c.film_shared = HOIST && res && e.xh && !e.step.per_clip;
+        if (c.film_shared) {
+            const float* fp = e.film + (size_t)(step_shared >= 0 ? step_shared : e.step.get(0)) * e.film_step_stride + cb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const f32x4 f = ld4(fp + 4 * q); c.film[4 * q] = f[0]; c.film[4 * q + 1] = f[1]; c.film[4 * q + 2] = f[2]; c.film[4 * q + 3] = f[3]; }
+        }
+    }
+    template <bool HOIST, int NT_N>
+    __device__ __forceinline__ void finish_one(const Args& e, int mt, int row0, int lane, int nt, const f32x16& a, const Ctx<NT_N>& c) const {
+        const int rt = e.C >> 5;
+        const bool res = mt < rt;
+        const int cb = (res ? mt : mt - rt) * 32 + 16 * (lane >> 5);
+        const int frame = row0 + 32 * nt + (lane & 31);
+        float v[16];
+        if (res) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = (a[i] + c.b[i]) * 0.70710678118654752440f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = a[i] + c.b[i];
+        }
+        float* p = (res ? e.x32 : e.skip) + tiled_lane_base(row0 + 32 * nt, rt, res ? mt : mt - rt, lane);
+        if (e.stream) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st4_nt(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st4(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+        }
+        if (res && e.xh) {
+            const int clip = HOIST ? c.clip[nt] : e.rm.rowclip[frame];
+            const bool ok = clip >= 0;
+            float hv[16];
+            if (ok && c.film_shared) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hv[i] = v[i] + c.film[i];
+            } else if (ok) {
+                const float* fp = e.film + (size_t)e.step.get(clip) * e.film_step_stride + cb;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 f = ld4(fp + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hv[4 * q + i] = v[4 * q + i] + f[i];
+                }
             } else {
-                const float* p = base + tiled_lane_base(row0 + 32 * nt, rt, tl_mt, lane);
-                f32x4 v0, v1, v2, v3;
-                if (e.stream) { v0 = ld4_nt(p); v1 = ld4_nt(p + 256); v2 = ld4_nt(p + 512); v3 = ld4_nt(p + 768); }
-                else { v0 = ld4(p); v1 = ld4(p + 256); v2 = ld4(p + 512); v3 = ld4(p + 768); }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { acc[nt][i] = v0[i]; acc[nt][4 + i] = v1[i]; acc[nt][8 + i] = v2[i]; acc[nt][12 + i] = v3[i]; }
+                for (int i = 0; i < 16; ++i) hv[i] = 0.f;
             }
+            _Float16* q = e.xh + (size_t)frame * e.ldh + cb;
+            if (e.xh_lo > 0) {
+                store_hi_lo16(q, e.xh_lo, hv);
+            } else {
+                half8 o0, o1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)hv[i]; o1[i] = (_Float16)hv[8 + i]; }
+                *reinterpret_cast<half8*>(q) = o0;
+                *reinterpret_cast<half8*>(q + 8) = o1;
+            }
+        }
+        if (!res && e.skiph) {
+            const bool ok = (HOIST ? c.clip[nt] : e.rm.rowclip[frame]) >= 0;
+            float hv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hv[i] = ok ? v[i] : 0.f;
+            const int cp = e.xh_lo > 0 ? e.xh_lo : e.ldh;          // padded channel count (ldh is twice that when the xh rows are split)
+            store_hi_lo16(e.skiph + (size_t)frame * (2 * cp) + cb, cp, hv);
         }
     }
     template <int NT_N>
     __device__ __forceinline__ void finish(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
-        const int rt = e.C >> 5;
-        const bool res = mt < rt;
-        const int cb = (res ? mt : mt - rt) * 32 + 16 * (lane >> 5);
-        float b[16];
-        {
-            const float* bp = e.bias + (res ? 0 : e.C) + cb;
+        Ctx<NT_N> c;
+        prepare<false>(e, mt, row0, lane, c);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const f32x4 v = ld4(bp + 4 * q); b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3]; }
-        }
+        for (int nt = 0; nt < NT_N; ++nt) finish_one<false>(e, mt, row0, lane, nt, acc[nt], c);
+    }
+    // finish of tile mt and the accumulator init of the wave's NEXT tile mt_n, N-tile by N-tile: an N-tile's init loads go out right behind ITS
+    // stores, while the later N-tiles' epilogues still run.  For the fused layer kernel's G6 output phase (tlayer.h), which has no registers for
+    // a prefetched second accumulator set and used to expose the whole init burst's latency after the last store.
+    template <int NT_N>
+    __device__ __forceinline__ void finish_then_init(const Args& e, int mt, int mt_n, int row0, int lane, f32x16 (&acc)[NT_N], int step_shared = -1) const {
+        Ctx<NT_N> c;
+        prepare<true>(e, mt, row0, lane, c, step_shared);
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) {
-            const int frame = row0 + 32 * nt + (lane & 31);
-            float v[16];
-            if (res) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = (acc[nt][i] + b[i]) * 0.70710678118654752440f;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = acc[nt][i] + b[i];
-            }
-            float* p = (res ? e.x32 : e.skip) + tiled_lane_base(row0 + 32 * nt, rt, res ? mt : mt - rt, lane);
-            if (e.stream) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) st4_nt(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) st4(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
-            }
-            if (res && e.xh) {
-                int clip, tl;
-                const bool ok = e.rm.valid(frame, clip, tl);
-                float hv[16];
-                if (ok) {
-                    const float* fp = e.film + (size_t)e.step.get(clip) * e.film_step_stride + cb;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 f = ld4(fp + 4 * q);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) hv[4 * q + i] = v[4 * q + i] + f[i];
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) hv[i] = 0.f;
-                }
-                _Float16* q = e.xh + (size_t)frame * e.ldh + cb;
-                if (e.xh_lo > 0) {
-                    store_hi_lo16(q, e.xh_lo, hv);
-                } else {
-                    half8 o0, o1;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { o0[i] = (_Float16)hv[i]; o1[i] = (_Float16)hv[8 + i]; }
-                    *reinterpret_cast<half8*>(q) = o0;
-                    *reinterpret_cast<half8*>(q + 8) = o1;
-                }
-            }
-            if (!res && e.skiph) {
-                int clip, tl;
-                const bool ok = e.rm.valid(frame, clip, tl);
-                float hv[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) hv[i] = ok ? v[i] : 0.f;
-                const int cp = e.xh_lo > 0 ? e.xh_lo : e.ldh;          // padded channel count (ldh is twice that when the xh rows are split)
-                store_hi_lo16(e.skiph + (size_t)frame * (2 * cp) + cb, cp, hv);
-            }
+            finish_one<true>(e, mt, row0, lane, nt, acc[nt], c);
+            init_one(e, mt_n, row0, lane, nt, acc[nt]);
         }
     }
 };

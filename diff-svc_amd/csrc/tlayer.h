@@ -392,7 +392,12 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const float gv = gate_act_scaled(acc[nt][r], acc[nt][8 + r]);
+                    float gv = gate_act_scaled(acc[nt][r], acc[nt][8 + r]);
+                    // ONE fp32 value feeds both roundings below.  Left alone, hipcc folds the last multiply of gate_act_scaled into the fp16
+                    // conversion in SOME instantiations (v_fma_mixlo_f16: one rounding from the exact product) and not in others (v_mul_f32 +
+                    // v_cvt: two): g then differs by an fp16 ulp on ~1 value in 2^18 between the tile widths -- g_lo absorbs it, the layer's
+                    // output moved by 3e-6 on 12 of 7168 frames (profiles/r5c_nt_diag.txt) -- and the tilings were not bit-identical
+                    asm volatile("" : "+v"(gv));
                     gq[nt][r] = (_Float16)gv;
                     glo[8 * nt + r] = (_Float16)((gv - (float)gq[nt][r]) * TL_G6_UP);        // exact: |.| <= 16, and the difference has < 11 significant bits left
                 }
@@ -465,6 +470,8 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     // G6 on 128-frame tiles cannot afford a prefetched second accumulator set in the output phase (below); on 64- / 32-frame tiles it can
     // (193 / 155 VGPRs with it)
     constexpr bool NOPF2 = G6 && NT == 4;
+    // the diffusion step of the FiLM rows the residual epilogues add, when all clips share it (the sampler's loops): read here, long before it is needed
+    const int step_sh = (NOPF2 && oe.film && !oe.step.per_clip) ? __builtin_amdgcn_readfirstlane(oe.step.get(0)) : -1;
     const unsigned xs_g = (unsigned)((((lane & 31) & 15) ^ (lane >> 5)) << 4);
     const int g_issue2 = wave >= 4 ? ((G2 / 2) & ~1) : 0;
     if constexpr (DEFER) {
@@ -576,18 +583,16 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             oload_g(wg6, mt_n, 0);
             if (!NOPF2 && !nxt_issued) oepi.init(oe, mt_n, row0, lane, nxt);
         }
-        oepi.finish(oe, mt, row0, lane, acc);
+        // G6 on 128-frame tiles has no registers for a WHOLE second accumulator set beside its code operands (a prefetched `nxt` made the
+        // allocator spill whole accumulator tiles inside the loops: 166 us per layer; half a set: 141.6).  Round 4 loaded the next pass's tiles
+        // into the accumulators after this pass's stores, the whole burst's latency exposed (133 us); round 5 interleaves the two N-tile by
+        // N-tile (TEpiResSkip::finish_then_init): an N-tile's init loads go out right behind ITS stores, under the later N-tiles' epilogues
+        if (NOPF2 && !last) oepi.finish_then_init(oe, mt, mt_n, row0, lane, acc, step_sh);
+        else oepi.finish(oe, mt, row0, lane, acc);
         TL_STAMP(9 + 2 * po);
-        if (!last) {
-            if constexpr (NOPF2) {
-                // G6 has no registers for a WHOLE second accumulator set beside its code operands (a prefetched `nxt` made the allocator spill
-                // whole accumulator tiles inside the loops: 166 us per layer); without any prefetch the next pass's tiles load into the
-                // accumulators after this pass's stores and the wait is exposed (133 us)
-                oepi.init(oe, mt_n, row0, lane, acc);
-            } else {
+        if (!last && !NOPF2) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = nxt[nt];
-            }
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = nxt[nt];
         }
     }
 #ifdef DSVC_PROFILING

@@ -13,7 +13,7 @@ sd = synth.acoustic_state(hp, 0)
 den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=prec, prefix="denoise_fn.")
 smp = SamplerHandle(den, sd)
 cond = torch.randn(B, 256, 861, device="cuda") * 0.5
-smp.sample(cond, 25, seed=1, use_graph=graph)
+smp.sample(cond, 130 if graph else 25, seed=1, use_graph=graph)      # (graph: two dither periods, so that the capture happens here)
 torch.cuda.synchronize(); t0 = time.time()
 smp.sample(cond, steps, seed=2, use_graph=graph)
 torch.cuda.synchronize(); dt = time.time() - t0
