@@ -183,10 +183,14 @@ def dominant_kernel_roofline(handle, B, precision):
 SAMPLER_SOURCES = ("common.h", "common.hip", "tgemm.h", "tlayer.h", "diffnet_t.h", "diffnet_kernels.h", "diffnet.hip")
 
 
-def kernel_sources_sha():
-    """sha256 of the HIP sources the DiffNet / sampler kernels are built from: a PMC traffic file measured on other sources is stale."""
+TRAIN_SOURCES = ("common.h", "common.hip", "tgemm.h", "tepi_util.h", "conv_gemm.h", "wgrad.h", "train.hip")
+
+
+def kernel_sources_sha(names=SAMPLER_SOURCES):
+    """sha256 of the HIP sources the DiffNet / sampler kernels (or, TRAIN_SOURCES, the trainer's) are built from: a PMC traffic file measured on
+    other sources is stale."""
     h = hashlib.sha256()
-    for name in SAMPLER_SOURCES:
+    for name in names:
         with open(os.path.join(ROOT, "diff-svc_amd", "csrc", name), "rb") as fh:
             h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
@@ -204,6 +208,19 @@ def load_error_fit(precision):
     if fit.get("precision") != precision:
         return None, "the fit is for %s, the batch ran at %s" % (fit.get("precision"), precision)
     return fit, None
+
+
+def load_train_traffic():
+    """(bytes per training step, source) of profiles/train_traffic.json (tools/gpu_pmc_r5.sh: every per-step kernel's FETCH_SIZE x 2 + WRITE_SIZE
+    summed), or (None, why) when it is missing or was measured on other trainer sources."""
+    path = os.path.join(ROOT, "profiles", "train_traffic.json")
+    if not os.path.exists(path):
+        return None, "no PMC pass committed (train_traffic.json)"
+    with open(path) as f:
+        tj = json.load(f)
+    if tj.get("csrc_sha16") != kernel_sources_sha(TRAIN_SOURCES):
+        return None, "stale: train_traffic.json was measured on trainer sources %s, this tree is %s" % (tj.get("csrc_sha16"), kernel_sources_sha(TRAIN_SOURCES))
+    return tj.get("bytes_per_step"), tj.get("source")
 
 
 def load_traffic(name, precision):
@@ -357,6 +374,31 @@ def time_train_steps(hp, sd, B, T, steps, warmup, rank, device, sync, world=1):
     return (time.perf_counter() - t0) / steps * 1e3, float(loss.item()), solo
 
 
+def time_variable_shape_steps(hp, sd, device, rounds=3):
+    """ms per optimisation step of ONE DiffusionTrainerHip walking five (B, T) shapes of ~8 192 frames in turn -- what the reference's
+    max_tokens / max_sentences loader hands a step (training/task/tts.py:60-88: batches of equal token count, different length) -- against the
+    fixed-shape 64 x 128 number: the difference is the cost of a shape change (workspace re-layout: gap-row clearing, no re-allocation once the
+    largest shape has been seen)."""
+    from diffsvc_amd.train import DiffusionTrainerHip
+    shapes = [(64, 128), (32, 256), (43, 190), (86, 95), (16, 512)]
+    tr = DiffusionTrainerHip(dict(hp, lr=1e-4), sd)
+    batches = []
+    for i, (B, T) in enumerate(shapes):
+        n_units = max(2, T * N_UNITS // T_FRAMES)
+        hub, m2p, f0, mels, _ = synth.train_batch_kat(hp, range(100 * i, 100 * i + B), T, n_units, 300 + i)
+        batches.append(tuple(torch.from_numpy(v).to(device) for v in (hub, m2p, f0, mels)))
+    for b in batches:                                     # every shape once: allocations grow to the largest
+        tr.train_step(*b, seed=1)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for r in range(rounds):
+        for i, b in enumerate(batches):
+            tr.train_step(*b, seed=10 + 5 * r + i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / (rounds * len(shapes)) * 1e3
+    return {"ms_per_step": ms, "shapes": shapes, "frames_per_step_mean": sum(B * T for B, T in shapes) / len(shapes),
+            "frames_per_s": sum(B * T for B, T in shapes) / len(shapes) / (ms * 1e-3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -473,7 +515,8 @@ def main():
                                            "wgrad_nt_kernel (16 %) and the transposed conv on the tgemm engine (14 %), profiles/r4u_kernel_stats_train.csv",
                                            "algorithmic_tflop_per_step": train_step_flops(hp, Bt * Tt) / 1e12,
                                            "achieved": train_step_flops(hp, Bt * Tt) / (ms * 1e-3) / 1e12, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-                                           "frac": train_step_flops(hp, Bt * Tt) / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_F16, "mfma_per_product": 3, "traffic": None},
+                                           "frac": train_step_flops(hp, Bt * Tt) / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_F16, "mfma_per_product": 3, "traffic": load_train_traffic()[0], "traffic_source": load_train_traffic()[1],
+                                           "traffic_unit": "HBM bytes per step (PMC)"},
                               "cpu_baseline": None}))
         if world > 1:
             dist.barrier()
@@ -721,7 +764,14 @@ def main():
                                                      "(profiles/r4u_kernel_stats_train.csv)",
                                                      "algorithmic_tflop_per_step": train_step_flops(hp, 64 * 128) / 1e12, "achieved": tfl,
                                                      "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": tfl / PEAK_TFLOPS_F16, "mfma_per_product": 3,
-                                                     "pipe_frac": 3 * tfl / PEAK_TFLOPS_F16}}
+                                                     "pipe_frac": 3 * tfl / PEAK_TFLOPS_F16, "traffic": load_train_traffic()[0],
+                                                     "traffic_source": load_train_traffic()[1], "traffic_unit": "HBM bytes per step (PMC)"}}
+                # the reference's max_tokens loader changes (B, T) every step (training/task/tts.py:60-88): ONE trainer alternating through five
+                # batch shapes of about the benchmarked size (8 192 frames each; only the gap rows are cleared on a shape change)
+                try:
+                    result["train_step"]["variable_shape_ms"] = time_variable_shape_steps(hp, sd, dev)
+                except Exception as ex:
+                    result["train_step"]["variable_shape_ms"] = {"error": repr(ex)[:200]}
             except Exception as ex:                                           # never lose the inference line to the extra measurement
                 result["train_step"] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline and world == 1:

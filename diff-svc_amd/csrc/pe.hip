@@ -8,8 +8,12 @@
 // Layout: fp32 frame-major rows [clip * Ts + frame][channel], Ts = max(T + kernel/2, 32): conv_gemm's clip slots, whose gap rows read
 // as zero -- the convolutions' zero padding, so a tap never reaches into the neighbouring clip.  Padding FRAMES (all-zero mel rows
 // inside T) are ordinary rows, as in the reference: only the prenet masks them, ConvStacks and the predictor run over them and
-// GroupNorm counts them.  All contractions run on the conv_gemm MFMA engine with split fp16 operands (fp32-class); norms, positions
-// and the f0 epilogue are row kernels.
+// GroupNorm counts them.  Norms, positions and the f0 epilogue are row kernels.
+// Round 5: every contraction runs on fp32 operands with FLOAT64 accumulation on the matrix cores (v_mfma_f64_16x16x4_f64, k_conv_f64acc below).
+// Until round 4 they ran on the conv_gemm engine with split fp16 operands (22-bit operands: f0 1.3e-5 relative from the reference's).  That is
+// nine times the distance the reference's own fp32 extractor keeps from a float64 evaluation of itself (1.5e-6, oracle/make_golden_cfg0.py) --
+// and the NSF source of the vocoder INTEGRATES f0 into a phase: 1e-5 relative is 0.07 rad after 6 s at 200 Hz, 4e-3 RMS of PCM against a bar
+// of 1e-4.  The extractor is 15 small convolutions (~6 GFLOP per 10 s clip, launch-bound), so there is one path, the exact one.
 #include <math.h>
 
 #include <map>
@@ -135,9 +139,67 @@ __global__ void k_pe_finish(const float* __restrict__ pred, int ldp, const float
 }
 
 struct Packed {
-    DevBuf w;
+    DevBuf w;       // float64 B fragments of v_mfma_f64_16x16x4_f64: [col tile 16][tap][cin_pad / 16][lane 64][4 doubles]
     int n_ctiles = 0, taps = 1, cin_pad = 0;
 };
+
+typedef double pe_f64x4 __attribute__((ext_vector_type(4)));
+typedef float pe_f32x4 __attribute__((ext_vector_type(4)));
+
+// out[row][col] = EPI( sum_tap sum_ci  x[row + tap - taps/2][ci] * W[col][ci][tap] ): fp32 operands, products and the whole K = taps * cin
+// accumulation in FLOAT64 on the matrix cores (v_mfma_f64_16x16x4_f64; a product of two fp32 values is exact in float64), ONE rounding to
+// fp32 per output.  Why not fp32 accumulation: measured (profiles/r5e_pe_tests.txt) -- with v_mfma_f32_32x32x2_f32, 1280-term fp32 chains in 15
+// consecutive convolutions left f0 5e-6 ... 1.5e-5 from a float64 evaluation of the extractor where the reference's own fp32 CPU arithmetic keeps
+// 1.5e-6, and the NSF source turns that into 1.4e-3 ... 4e-3 RMS of PCM.  With float64 accumulation the only fp32 roundings left are the ones
+// every fp32 implementation has (one per layer output, the norms).
+// One wave = 16 frames x 32 channels (two 16 x 16 accumulators of 4 doubles per lane), four waves per workgroup, no LDS: operands are small
+// and L2-resident, the extractor is launch-bound.
+//   A (activations): lane l supplies x[frame l & 15][k], k <-> q = l >> 4;  B (weights): W[k][channel l & 15].  An instruction contracts 4 k
+//   (one per q); a block of 16 input channels is walked in 4 instructions, instruction j taking channels 4 q + j: lane (., q) needs channels
+//   4 q .. 4 q + 3 of the block -- ONE 16-byte load of activations per block, converted to float64 in registers; weights are packed as doubles.
+//   D: lane l holds channel l & 15 of frames 4 i + (l >> 4), i = 0..3 -- the f64 instruction interleaves the rows over the lane groups, unlike
+//   the fp32 ones (measured: tools/micro/f64_probe.hip, profiles/r5f_f64_probe.txt; there is no ISA document in the image).
+template <class Epi>
+__global__ void __launch_bounds__(256) k_conv_f64acc(const float* __restrict__ x, int ldx, int n_rows, int cin_pad, int taps, const double* __restrict__ w,
+                                                      int n_cpairs, const typename Epi::Args e) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rt = wid / n_cpairs, cp = wid - rt * n_cpairs;
+    const int row0 = rt * 16;
+    if (row0 >= n_rows) return;
+    const int r = lane & 15, q = lane >> 4;
+    const int nkb = cin_pad >> 4, pad = taps >> 1;
+    pe_f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const size_t tile_doubles = (size_t)taps * nkb * 256;              // one 16-channel column tile
+    const double* wp = w + (size_t)(2 * cp) * tile_doubles + lane * 4;
+    for (int tap = 0; tap < taps; ++tap) {
+        const int src = row0 + r + tap - pad;
+        // a tap outside its clip's T frames is the conv's zero padding.  Tested here, not left to what the gap rows hold: LayerNorm writes
+        // beta into them (the row kernels run over whole slots), and a slot ends in >= taps/2 gap rows, so no tap reaches another clip's frames
+        const bool ok = src >= 0 && src < n_rows && (src - (src / e.Ts) * e.Ts) < e.T;
+        const float* xp = x + (size_t)(ok ? src : 0) * ldx + 4 * q;
+        const double* wt = wp + (size_t)tap * nkb * 256;
+#pragma unroll 2
+        for (int kb = 0; kb < nkb; ++kb) {
+            pe_f32x4 a = *reinterpret_cast<const pe_f32x4*>(xp + 16 * kb);
+            if (!ok) a = pe_f32x4{0.f, 0.f, 0.f, 0.f};
+            const pe_f64x4 b0 = *reinterpret_cast<const pe_f64x4*>(wt + (size_t)kb * 256);
+            const pe_f64x4 b1 = *reinterpret_cast<const pe_f64x4*>(wt + tile_doubles + (size_t)kb * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double ad = (double)a[j];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, b0[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, b1[j], acc1, 0, 0, 0);
+            }
+        }
+    }
+    Epi epi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        epi.one(e, row0 + 4 * i + q, (2 * cp) * 16 + r, (float)acc0[i]);
+        epi.one(e, row0 + 4 * i + q, (2 * cp + 1) * 16 + r, (float)acc1[i]);
+    }
+}
 
 }  // namespace
 
@@ -183,21 +245,24 @@ struct dsvc_pe {
         if (!v) return DSVC_ESTATE;
         return up(d, v->data(), numel);
     }
-    // torch Conv1d weight [cout][cin][k] (k = 1 for Linear [cout][cin]) -> fragments
+    // torch Conv1d weight [cout][cin][k] (k = 1 for Linear [cout][cin]) -> float64 B fragments (k_conv_f64acc): lane (col, q) of block kb holds
+    // W[col][16 kb + 4 q + j][tap], j = 0..3; column tiles of 16, an even number of them (a wave takes two)
     int pack(Packed& pk, const std::string& key, int cout, int cin, int k) {
         const std::vector<float>* w = get(key, (size_t)cout * cin * k);
         if (!w) return DSVC_ESTATE;
-        DevBuf tmp;
-        DSVC_TRY(up(tmp, w->data(), w->size()));
-        pk.n_ctiles = round_up(ceil_div(cout, 32), 2); pk.taps = k; pk.cin_pad = round_up(cin, 16);
-        const size_t halfs = packed_halfs(pk.n_ctiles, k, pk.cin_pad, 2);
-        DSVC_TRY(pk.w.alloc(halfs * 2));
-        const long long total_el = (long long)halfs / 2;
-        hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((total_el + 255) / 256 < 8192 ? (total_el + 255) / 256 : 8192)), dim3(256), 0, 0, tmp.as<float>(),
-                           (const int*)nullptr, pk.w.as<_Float16>(), pk.n_ctiles, k, pk.cin_pad, cout, cin, (long long)cin * k, (long long)k, 1LL, 0, 1.0f);
-        DSVC_HIP(hipGetLastError());
-        DSVC_HIP(hipDeviceSynchronize());
-        tmp.release();
+        pk.n_ctiles = round_up(ceil_div(cout, 16), 2); pk.taps = k; pk.cin_pad = round_up(cin, 16);
+        const int nkb = pk.cin_pad / 16;
+        std::vector<double> f((size_t)pk.n_ctiles * k * nkb * 256, 0.0);
+        for (int ct = 0; ct < pk.n_ctiles; ++ct)
+            for (int tap = 0; tap < k; ++tap)
+                for (int kb = 0; kb < nkb; ++kb)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 4; ++j) {
+                            const int col = ct * 16 + (l & 15), ci = 16 * kb + 4 * (l >> 4) + j;
+                            if (col < cout && ci < cin) f[((((size_t)ct * k + tap) * nkb + kb) * 64 + l) * 4 + j] = (double)(*w)[((size_t)col * cin + ci) * k + tap];
+                        }
+        DSVC_TRY(pk.w.alloc(f.size() * 8));
+        DSVC_HIP(hipMemcpy(pk.w.p, f.data(), f.size() * 8, hipMemcpyHostToDevice));
         return DSVC_OK;
     }
     int slot_rows(int T) const {
@@ -272,10 +337,11 @@ int dsvc_pe::run(const float* mel, int B, int T, float* pitch_pred, float* f0, h
     const int rows = B * Ts;
     if (T + 1 > table_rows) return fail(DSVC_ESTATE, "pe: %d frames need %d position rows, dsvc_pe_set_positions gave %d", T, T + 1, table_rows);
     auto gemm = [&](const float* x, int ldx, int cin, const Packed& pk, const EpPe::Args& e) -> int {
-        ConvGemmArgs g{};
-        g.x = x; g.ldx = ldx; g.n_rows = rows; g.clip_stride = Ts; g.clip_len = T;
-        g.cin = cin; g.taps = pk.taps; g.dil = 1; g.w = pk.w.as<_Float16>(); g.n_ctiles = pk.n_ctiles; g.w_planes = 2; g.in_slope = 1.0f;
-        return launch<EpPe>(g, e, st);
+        if (ldx % 4 || round_up(cin, 16) != pk.cin_pad || pk.cin_pad > ldx) return fail(DSVC_EINVAL, "pe: operand rows of %d floats (stride %d) against weights packed for %d", cin, ldx, pk.cin_pad);
+        const int waves = ceil_div(rows, 16) * (pk.n_ctiles / 2);
+        hipLaunchKernelGGL(k_conv_f64acc<EpPe>, dim3(ceil_div(waves, 4)), dim3(256), 0, st, x, ldx, rows, pk.cin_pad, pk.taps, pk.w.as<double>(), pk.n_ctiles / 2, e);
+        DSVC_HIP(hipGetLastError());
+        return DSVC_OK;
     };
     float* A = a.as<float>();
     float* Bf = b2.as<float>();

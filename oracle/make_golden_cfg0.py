@@ -51,6 +51,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 KEY, ACC, SEED = 2, 50, 11                                 # key shift in semitones, pndm_speedup (=> 20 iterations), Philox seed
 COND = (1.35, 0.05)                                        # synth.acoustic_state_conditioned(lam, rho)
 WSEED, PESEED, VSEED = 2, 5, 4
+MEL_PERT = 5e-5                                            # size of the mel perturbation of the chained-waveform yardstick (see main)
 
 # ---- no device in the container: .cuda() / .to('cuda') are the identity (the reference hard-codes them, infer_tool.py:155-160) ----
 torch.Tensor.cuda = lambda self, *a, **k: self
@@ -139,7 +140,7 @@ def main():
         in_sr, raw = w.getframerate(), np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
     audio = raw.astype(np.float32) / 32768.0               # what librosa.load(sr=None) returns for 16-bit PCM
     chunks = Slicer(sr=in_sr, db_threshold=-40, min_length=5000, win_l=300, win_s=20, max_silence_kept=500).slice(audio)
-    out = {"key": KEY, "acc": ACC, "seed": SEED, "cond": np.array(COND), "wseed": WSEED, "peseed": PESEED, "vseed": VSEED, "in_sr": in_sr}
+    out = {"mel_pert": MEL_PERT, "key": KEY, "acc": ACC, "seed": SEED, "cond": np.array(COND), "wseed": WSEED, "peseed": PESEED, "vseed": VSEED, "in_sr": in_sr}
     table, f0_tst, f0_pred_all, audio_out = [], [], [], []
     hop, sr_out = ref_hp["hop_size"], ref_hp["audio_sample_rate"]
     for k, v in chunks.items():                            # infer.py:43-67
@@ -173,6 +174,37 @@ def main():
 
                 svc.vocoder.spec2wav = spec2wav
                 _f0_tst, _f0_pred, _audio = svc.infer(buf, key=KEY, acc=ACC, use_pe=True, use_crepe=True, thre=0.05, use_gt_mel=False, add_noise_step=500)
+                # ---- the yardstick of the fully chained waveform.  The NSF source integrates f0 into a phase, so the last
+                # bits of the extractor's f0 move the PCM by far more than the 1e-4 RMS bar.  How far is the REFERENCE's own fp32 chain from the
+                # truth?  (a) the real PitchExtractor evaluated in FLOAT64 on the reference's own sampler output, (b) the real generator (fp32,
+                # same Philox draws) driven by THAT f0 (cast to fp32 as HifiGAN.spec2wav casts every f0, hifigan.py:63).  tests/test_gpu_infer.py
+                # holds the drop-in's chained PCM to twice the distance the reference's chained PCM (`wav` above) keeps from (b).
+                import copy
+                pe64 = copy.deepcopy(svc.pe).double().eval()
+                with torch.no_grad():
+                    f0_64 = pe64(torch.from_numpy(last["mel_out"])[None].double())["f0_denorm_pred"][0].numpy()
+                mel_pred = np.clip(last["mel_out"], ref_hp["mel_vmin"], ref_hp["mel_vmax"])          # after_infer, infer_tool.py:177-183 (no padded frames here)
+                wav_b = spec2wav(mel_pred, f0=f0_64)
+                out["c%d/f0_pred_f64" % c] = np.asarray(f0_64, np.float64)
+                out["c%d/wav_f64f0" % c] = np.asarray(wav_b, np.float32)
+                d_f0 = float(np.max(np.abs(np.asarray(_f0_pred, np.float64) - f0_64) / np.maximum(f0_64, 1.0)))
+                d_wav = float(np.sqrt(np.mean((np.asarray(_audio, np.float64) - np.asarray(wav_b, np.float64)) ** 2)))
+                print("chunk %d: reference fp32 extractor vs its float64 evaluation: f0 %.2e relative; reference chained PCM vs the PCM from the float64 f0: %.2e RMS"
+                      % (c, d_f0, d_wav), flush=True)
+                # ---- ... and how the reference's own chain answers a SMALL CHANGE OF THE MEL (the drop-in's sampler is 5e-5 max-abs from the
+                # reference's here, twenty times inside the 1e-3 mel bar): the real fp32 extractor + generator once more on mel_out + delta,
+                # delta i.i.d. uniform in +-MEL_PERT.  The extractor maps the mel to log2-f0 and the NSF source integrates it: whatever the
+                # arithmetic, a mel that is not bit-identical moves the chained PCM by this much.
+                gd = np.random.Generator(np.random.PCG64(900 + c))
+                mel_p = (last["mel_out"] + MEL_PERT * gd.uniform(-1.0, 1.0, size=last["mel_out"].shape)).astype(np.float32)
+                with torch.no_grad():
+                    f0_p = svc.pe(torch.from_numpy(mel_p)[None])["f0_denorm_pred"][0].numpy()
+                wav_p = spec2wav(np.clip(mel_p, ref_hp["mel_vmin"], ref_hp["mel_vmax"]), f0=f0_p)
+                out["c%d/f0_pred_melpert" % c] = np.asarray(f0_p, np.float32)
+                out["c%d/wav_melpert" % c] = np.asarray(wav_p, np.float32)
+                print("chunk %d: reference chain on its own mel +- %.0e: f0 moves %.2e relative, chained PCM %.2e RMS" % (
+                    c, MEL_PERT, float(np.max(np.abs(f0_p - np.asarray(_f0_pred)) / np.maximum(np.asarray(_f0_pred), 1.0))),
+                    float(np.sqrt(np.mean((np.asarray(wav_p, np.float64) - np.asarray(_audio, np.float64)) ** 2)))), flush=True)
                 svc.vocoder.spec2wav = orig_spec2wav
             finally:
                 torch.randn, torch.rand, torch.randn_like = orig_randn, orig_rand, orig_randn_like
