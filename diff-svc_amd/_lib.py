@@ -23,7 +23,7 @@ def parse_precision(p):
     if isinstance(p, (tuple, list)):
         return int(p[0]), int(p[1])
     if isinstance(p, int):
-        return p, 1
+        return p, 0                                      # (0 = the scheme's default number of dithered roundings, chosen by the library: 64 for the 6-bit schemes)
     if p == "f16_x3t":                                   # (64 dithered roundings of the fp6 w_lo codes its small tilings use since round 4)
         return PREC_F16_X3T, 64
     if p in PRECISIONS:

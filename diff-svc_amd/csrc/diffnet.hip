@@ -303,6 +303,12 @@ struct dsvc_denoiser {
         a.sc6 = (127 + t.e6) | (xbyte << 8);
         a.x6_scale = xscale;
     }
+    // DSVC_PREC_F16_X3T: the fp6 code planes (dil6_t / outl6_t) serve only the sampler's DDPM chain; a handle that runs PLMS or forward() alone never
+    // reads them (they were packed at load for every handle).  The two weight tensors per layer they are packed from stay on the host
+    // (94 MB) until the first DDPM chain packs them.
+    std::map<std::string, std::vector<float>> x3t_src;
+    bool x3t_codes_ready = false;
+    int ensure_x3t_codes();
     int dbg_w6_off = 0;          // 1: a DSVC_PREC_F16_W6 handle runs its fused layers with the fp16 lo plane (= f16_w2): the A/B partner of the 6-bit product
     int dbg_two_launch = 0;      // 1: run a residual layer as its two tgemm launches even where the fused kernel is the choice (bit-equality
                                  // test); -1: the fused kernel wherever it is SUPPORTED (>= 48 tiles), not only where it is faster (>= 120)
@@ -479,7 +485,8 @@ int dsvc_denoiser::finalize_t() {
     int max_dil = 1;
     for (int l = 0; l < L; ++l) { const int d = 1 << (l % cfg.dilation_cycle); if (d > max_dil) max_dil = d; }
     guard = round_up(max_dil, 8);
-    const bool w6 = is_w6() || cfg.precision == DSVC_PREC_F16_X3T;      // (X3T: the small tilings' w_lo * x_hi term runs on the same code planes)
+    const bool x3t = cfg.precision == DSVC_PREC_F16_X3T;
+    const bool w6 = is_w6() || x3t;      // (X3T: the small tilings' w_lo * x_hi term runs on the same code planes -- packed on first use, ensure_x3t_codes)
     const int planes = (cfg.precision == DSVC_PREC_F16_W2 || cfg.precision == DSVC_PREC_F16_X3T || w6) ? 2 : 1;
     const int nvar = (planes == 1 && cfg.weight_variants > 1) ? cfg.weight_variants : 1;       // (F16 and F16_MIX)
 #define GET(var, key, n) const std::vector<float>* var = get(key, (size_t)(n)); if (!var) return DSVC_ESTATE
@@ -508,11 +515,15 @@ int dsvc_denoiser::finalize_t() {
                        bo->data(), 1, &gsc));
         // F16_W6: the same rows' w_lo plane once more as time-dithered fp6 codes for the fused layer kernel's 6-bit product (the fp16 lo plane
         // above serves the two-launch tilings of smaller batches, which compute f16_w2)
-        if (w6) DSVC_TRY(tpack6(dil6_t[l], *wd, 2 * C, C, 3, C / 16, cfg.weight_variants > 1 ? cfg.weight_variants : 1, 1.0f, 2000u + l,
+        if (w6 && !x3t) DSVC_TRY(tpack6(dil6_t[l], *wd, 2 * C, C, 3, C / 16, cfg.weight_variants > 1 ? cfg.weight_variants : 1, 1.0f, 2000u + l,
                                 [&](int r) { const int mt = r >> 5, i = r & 31; return (i >> 4) * C + mt * 16 + trow_to_ch8(i & 15); }, &gsc));
         // ... the output projection's w_lo plane likewise (same dither schedule) ...
-        if (w6) DSVC_TRY(tpack6(outl6_t[l], *wo, 2 * C, C, 1, 2 * C / 32, cfg.weight_variants > 1 ? cfg.weight_variants : 1, 1.0f, 4000u + l,
+        if (w6 && !x3t) DSVC_TRY(tpack6(outl6_t[l], *wo, 2 * C, C, 1, 2 * C / 32, cfg.weight_variants > 1 ? cfg.weight_variants : 1, 1.0f, 4000u + l,
                                 [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, nullptr));
+        if (x3t) {      // the code planes of an X3T handle (64 variants: 1.1 GB at the 44.1 kHz architecture) are packed when a DDPM chain first asks for them
+            x3t_src["d" + std::to_string(l)] = *wd;
+            x3t_src["o" + std::to_string(l)] = *wo;
+        }
         // ... and the output projection's weights THEMSELVES as fp6 codes (nearest, one variant): the weight operand of the 6-bit g_lo correction
         if (is_w6()) DSVC_TRY(tpack6(out6_t[l], *wo, 2 * C, C, 1, 2 * C / 32, 1, 1.0f, 3000u + l,
                                 [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, nullptr, true));
@@ -567,6 +578,26 @@ int dsvc_denoiser::finalize_t() {
                        [&](int r) { const int c = (r >> 5) * 32 + trow_to_ch16(r & 31); return c < M ? c : -1; }, bias.data(), mt * 32));
     }
 #undef GET
+    return DSVC_OK;
+}
+
+int dsvc_denoiser::ensure_x3t_codes() {
+    if (cfg.precision != DSVC_PREC_F16_X3T || x3t_codes_ready || dbg_x3t_w6_off) return DSVC_OK;
+    const int C = cfg.channels, L = cfg.layers;
+    std::vector<float> gsc((size_t)(C / 16) * 32);
+    for (size_t r = 0; r < gsc.size(); ++r) gsc[r] = ((r & 31) < 16) ? GATE_SCALE : FILT_SCALE;
+    const int nv = cfg.weight_variants > 1 ? cfg.weight_variants : 1;
+    for (int l = 0; l < L; ++l) {
+        auto wd = x3t_src.find("d" + std::to_string(l)), wo = x3t_src.find("o" + std::to_string(l));
+        if (wd == x3t_src.end() || wo == x3t_src.end()) return fail(DSVC_ESTATE, "denoiser: the weights the fp6 code planes are packed from are gone");
+        DSVC_TRY(tpack6(dil6_t[l], wd->second, 2 * C, C, 3, C / 16, nv, 1.0f, 2000u + l,
+                        [&](int r) { const int mt = r >> 5, i = r & 31; return (i >> 4) * C + mt * 16 + trow_to_ch8(i & 15); }, &gsc));
+        DSVC_TRY(tpack6(outl6_t[l], wo->second, 2 * C, C, 1, 2 * C / 32, nv, 1.0f, 4000u + l,
+                        [&](int r) { return (r >> 5) * 32 + trow_to_ch16(r & 31); }, nullptr));
+    }
+    x3t_src.clear();
+    x3t_codes_ready = true;
+    ++ws_gen;                    // captured graphs bake the launch sequence
     return DSVC_OK;
 }
 
@@ -835,7 +866,12 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
         const TPacked6& o6 = outl6_t[l];
         TLayerW6 w6{t6.codes.as<unsigned>(), (long long)t6.variant_dwords, t6.e6, t6.n_variants};
         w6.out_lo_codes = o6.codes.as<unsigned>(); w6.out_lo_variant_dwords = (long long)o6.variant_dwords; w6.eol6 = o6.e6;
-        if (cfg.precision == DSVC_PREC_F16_W6 && dbg_g6_off == 0 && tlayer_smem(ga.dil, Cp, true, nt) <= 160 * 1024) {      // (a dilation beyond 8 leaves no room for the code block beside the time tile)
+        if (cfg.precision == DSVC_PREC_F16_W6 && dbg_g6_off == 0) {
+            // (a dilation beyond 8 leaves no room for the g_lo code block beside a 128-frame time tile: refused, not silently run as f16_w6n --
+            //  the gate-output correction is what the scheme's error margin rests on)
+            if (tlayer_smem(ga.dil, Cp, true, nt) > 160 * 1024)
+                return fail(DSVC_EINVAL, "denoiser: f16_w6 needs %zu B of LDS at dilation %d (%d-frame tiles); use f16_w6n, f16_w2 or f16_x3t for this architecture",
+                            tlayer_smem(ga.dil, Cp, true, nt), ga.dil, 32 * nt);
             w6.out_codes = out6_t[l].codes.as<unsigned>(); w6.eo6 = out6_t[l].e6;
         }
         TGemmArgs ga6 = ga;
@@ -1085,6 +1121,10 @@ int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out) {
     if (cfg->weight_variants > 1024) return fail(DSVC_EINVAL, "weight_variants %d > 1024", cfg->weight_variants);
     dsvc_denoiser* d = new dsvc_denoiser();
     d->cfg = *cfg;
+    // weight_variants 0 = the scheme's default: 64 time-dithered roundings of the fp6 w_lo codes for the 6-bit schemes (a caller that passes the bare
+    // enum gets what the precision's NAME means everywhere else; 1 = ask for a single nearest rounding explicitly), 1 otherwise
+    if (d->cfg.weight_variants <= 0)
+        d->cfg.weight_variants = (cfg->precision == DSVC_PREC_F16_X3T || cfg->precision == DSVC_PREC_F16_W6 || cfg->precision == DSVC_PREC_F16_W6N) ? 64 : 1;
     *out = d;
     return DSVC_OK;
 }
@@ -1281,6 +1321,7 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
                            xs, d->xsh.as<_Float16>(), M, d->Mp, d->rowmap(), d->rows);
     if (a->speedup > 1) DSVC_TRY(s->run_plms(a, st));
     else {
+        DSVC_TRY(s->den->ensure_x3t_codes());
         s->den->ddpm_chain = true;                        // (see dsvc_denoiser::ddpm_chain)
         const int rc_chain = s->run_ddpm(a, st);
         s->den->ddpm_chain = false;
@@ -1304,6 +1345,7 @@ int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int3
     DSVC_TRY(d->set_clip_meta(nullptr, 0, nullptr, st));
     if (!d->cond_ready) DSVC_HIP(hipMemsetAsync(d->cproj.p, 0, d->cproj.bytes, st));
     const int C = d->cfg.channels, L = d->cfg.layers;
+    DSVC_TRY(d->ensure_x3t_codes());                      // (the kernels the sampler's DDPM steps run)
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, s->step_dev.as<int>(), 0);
     hipEvent_t e0, e1;
     DSVC_HIP(hipEventCreate(&e0)); DSVC_HIP(hipEventCreate(&e1));

@@ -861,7 +861,7 @@ struct dsvc_vocoder {
     }
 
     int finalize();
-    int ensure_ws(int B, int T);
+    int ensure_ws(int B, int T, hipStream_t st);
     int run(const float* mel, const float* f0, float* wav, int B, int T, unsigned long long seed, int clip0, const int* clip_ids, hipStream_t st);
 };
 
@@ -1011,7 +1011,7 @@ int dsvc_vocoder::finalize() {
     return DSVC_OK;
 }
 
-int dsvc_vocoder::ensure_ws(int B, int T) {
+int dsvc_vocoder::ensure_ws(int B, int T, hipStream_t st) {
     if (B == wsB && T == wsT) return DSVC_OK;
     if (B < 1 || T < 1) return fail(DSVC_EINVAL, "bad batch/frames %d/%d", B, T);
     Tp = round_up(T + gap_frames, 32);
@@ -1030,16 +1030,21 @@ int dsvc_vocoder::ensure_ws(int B, int T) {
         if (e > mx) mx = e;
     }
     for (int i = 0; i < 5; ++i) DSVC_TRY(buf[i].alloc(mx * 4));
-    {   // operand planes of the wide stages (tgemm path): rows * 2 C halfs + guards, zeroed once (the epilogues write zeros on gap rows)
+    {   // operand planes of the wide stages (tgemm path): [VT_GUARD | rows | VT_GUARD] x 2 C halfs.  Only the guard rows have to be cleared: every row
+        // of [0, rows) is rewritten by k_lrelu_planes or a producing epilogue (zeros on gap rows) before a conv reads it.  Round 4 cleared all
+        // four whole buffers of every wide stage with hipMemset on the NULL stream at every (B, T) change -- 117 MB per 10 s clip at the
+        // 128-channel stage, on every chunk of a different length, and not ordered against work in flight on a non-blocking stream.
+        // Now: the leading and the trailing guard of the NEW layout, asynchronously on the caller's stream.
         int r2 = 1;
         for (int i = 0; i < cfg.n_ups; ++i) {
             r2 *= cfg.upsample_rates[i];
             const int c = cfg.upsample_initial_channel >> (i + 1);
             if (!t_stage[i]) continue;
-            const size_t e = (frames_total * r2 + 2 * VT_GUARD) * 2 * c * 2;
+            const size_t row_bytes = (size_t)2 * c * 2, rows = frames_total * r2;
             for (int q = 0; q < 4; ++q) {
-                DSVC_TRY(pl[i][q].alloc(e));
-                DSVC_HIP(hipMemset(pl[i][q].p, 0, pl[i][q].bytes));
+                DSVC_TRY(pl[i][q].alloc((rows + 2 * VT_GUARD) * row_bytes));
+                DSVC_HIP(hipMemsetAsync(pl[i][q].p, 0, VT_GUARD * row_bytes, st));
+                DSVC_HIP(hipMemsetAsync(pl[i][q].as<char>() + (VT_GUARD + rows) * row_bytes, 0, VT_GUARD * row_bytes, st));
             }
         }
     }
@@ -1048,7 +1053,7 @@ int dsvc_vocoder::ensure_ws(int B, int T) {
 }
 
 int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int T, unsigned long long seed, int clip0, const int* clip_ids, hipStream_t st) {
-    DSVC_TRY(ensure_ws(B, T));
+    DSVC_TRY(ensure_ws(B, T, st));
     const int nu = cfg.n_ups, nk = cfg.n_kernels, ch0 = cfg.upsample_initial_channel, M = cfg.num_mels;
     const bool rb2_type = cfg.resblock == 2;
     const int ndil = cfg.n_dilations > 0 ? cfg.n_dilations : 3;

@@ -137,6 +137,16 @@ class DiffNetHip(nn.Module):
             self.invalidate_cond()
         return cur[0]
 
+    def check(self):
+        """Wait for the stream and raise IndexError if a forward() since the last check passed a diffusion step outside [0, timesteps) -- the
+        reference's step embedding accepts any float, its sampler's extract() raises on such a t (diffusion.py:22-25); forward() itself runs
+        on the clamped step rather than synchronise 1000 times per clip.  Call it wherever the result is read back anyway."""
+        for h, _ in self._handles.values():
+            try:
+                h.check()
+            except RuntimeError as ex:
+                raise IndexError(str(ex))
+
     def invalidate_cond(self):
         """Forget which cond the C handle's hoisted conditioner projections belong to (the sampler path overwrites them)."""
         self._cond_ref, self._cond_ver = None, -1

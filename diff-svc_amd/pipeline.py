@@ -110,6 +110,15 @@ class SvcPipeline:
             out += (lens,)
         return out if len(out) > 1 else wav
 
+    def check(self):
+        """The deferred argument checks of the device path, at a point where the caller synchronises anyway (after the PCM has been read, at the
+        end of a job): mel2ph entries outside [0, content frames] -- the reference's torch.gather raises an IndexError at once (fs2.py:100-102),
+        the one-launch device builder keeps a sticky flag instead of a device-to-host read per call -- and diffusion steps outside the schedule
+        on a DiffNetHip.forward() seam (extract() would raise, diffusion.py:22-25).  Synchronises; raises what the reference raises."""
+        self.model.fs2.check_alignment()
+        for h, _ in self.model.denoise_fn._handles.values():
+            h.check()
+
     def _pe_f0(self, mel, clip_lens):
         """``self.pe(outputs['mel_out'])['f0_denorm_pred']`` per clip as the reference's B=1 loop sees it: a clip padded to the batch's T
         must not let the padding frames into its GroupNorm statistics, so clips run at their own length (grouped by length)."""

@@ -209,6 +209,8 @@ class DiffusionTrainerHip:
             self.grads.mul_(1.0 / world)
         return loss
 
+    CHECK_EVERY = 100              # optimiser steps between two reads of the trainer's sticky argument flag (dsvc_trainer_check synchronises)
+
     @torch.no_grad()
     def train_step(self, hubert, mel2ph, f0, mels, t=None, seed=None, first_clip=0, clip_ids=None, overlap=None):
         """One optimisation step: forward + backward, all-reduce (mean) of the gradients over the ranks, gradient-norm clip, AdamW.
@@ -238,6 +240,8 @@ class DiffusionTrainerHip:
             allreduce_mean_(self.grads, self.group)
         lr = self.lr()                                       # step k (0-based) runs at lr0 * 0.5 ** (max(k - 1, 0) // decay_steps)
         self.global_step += 1
+        if self.global_step % self.CHECK_EVERY == 0:
+            self.h.check()                                   # the trainer's sticky "diffusion step outside the schedule" flag: one sync per 100 steps
         hp, n = self.hp, self.h.n_floats
         clip = float(hp.get("clip_grad_norm", 1.0))
         coef = None

@@ -75,7 +75,8 @@ typedef struct {
     int32_t dilation_cycle;  /* dilation_cycle_length                             (net.py:94)  */
     int32_t max_steps;       /* number of integer diffusion steps to tabulate (timesteps)      */
     int32_t precision;       /* DSVC_PREC_* for the two big per-layer contractions              */
-    int32_t weight_variants; /* DSVC_PREC_F16 / F16_MIX / F16_W6 / F16_X3T: number of dithered weight roundings (<= 1: nearest) */
+    int32_t weight_variants; /* DSVC_PREC_F16 / F16_MIX / F16_W6 / F16_W6N / F16_X3T: number of dithered weight roundings; 1 = one nearest rounding,
+                              * 0 = the scheme's default (64 for the three 6-bit schemes, 1 otherwise) */
 } dsvc_denoiser_cfg;
 
 int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out);
@@ -95,7 +96,9 @@ int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t,
 
 /* dsvc_denoiser_forward clamps diffusion steps outside [0, max_steps) on the device (the step embedding is tabulated for the integer
  * steps of the schedule, net.py:32-44,99-103) and raises a sticky flag instead of synchronising on every call of the 1000-calls-per-clip
- * denoiser seam; the flag is reported by the NEXT dsvc_denoiser_forward call, or by this function, which first waits for `stream`. */
+ * denoiser seam; the flag is reported by this function ONLY (it first waits for `stream`, then clears the flag): later, valid forward calls are
+ * executed, not rejected for a predecessor's argument.  The host wrappers call it where they synchronise anyway (DiffNetHip.check(), the
+ * trainer every 100 steps, SvcPipeline.check()). */
 int dsvc_denoiser_check(dsvc_denoiser* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -201,7 +201,7 @@ def test_train_step_vs_real_reference_golden(case):
             e_ref = (ref.double() - r64).norm().item() / r64.norm().item()
             d2 = (part.double() - r64).pow(2)
             e_hip = d2.sum().sqrt().item() / r64.norm().item()
-            if gk is not None and (k + "/min_abs_preact") in gk.files:
+            if gk is not None and (k + "/min_abs_preact") in gk:
                 # a weight gradient behind a ReLU changes by ~1e-3 of ONE row when one of its 3.1 M mask bits differs from the fp64 evaluation's --
                 # measured: skip_projection.weight row 232 (|pre-activation| 9e-7 in float64) at 1.1e-3, the median row at 1.4e-6, 6.7e-5 over the
                 # tensor.  That is a kink of the function, not operand precision: the worst row is set aside IF it is such a row.
