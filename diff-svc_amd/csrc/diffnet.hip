@@ -1253,10 +1253,12 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     else if (k == "w6_off") d->dbg_w6_off = value ? 1 : 0;
     else if (k == "g6_off") d->dbg_g6_off = value ? 1 : 0;
     else if (k == "x3t_w6_off") d->dbg_x3t_w6_off = value ? 1 : 0;
-    else if (k == "layer_prio") d->layer_prio = value;
     else if (k == "fused_nt") d->dbg_fused_nt = value;
-    else if (k == "tail_tiling") d->dbg_tail = value;
     else if (k == "profile_kernel") d->dbg_profile_out = value ? 1 : 0;
+#ifdef DSVC_PROFILING            // tuning knobs of measured-and-not-kept variants: the profiling build only (python -m diffsvc_amd.build --profiling)
+    else if (k == "layer_prio") d->layer_prio = value;
+    else if (k == "tail_tiling") d->dbg_tail = value;
+#endif
     else if (k == "defer_skip") {
         d->defer_skip = value != 0;
         if (d->defer_skip && d->wsB > 0 && !d->gall.p) { d->wsB = 0; d->wsT = 0; }      // rebuild the workspace with the gate-output buffer

@@ -31,7 +31,13 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
  * "g6_off" = 1 make a DSVC_PREC_F16_W6 handle run its fused layers with the fp16 lo planes (= F16_W2) / without the gate-output correction
  * (= F16_W6N): the A/B partners of the 6-bit products on one set of packed weights; "defer_skip" != 0 makes
  * the fused layer kernels write the gate output to HBM and leave the skip halves of all layers to ONE contraction per evaluation with
- * pre-composed skip-projection weights (csrc/tskip.h: 14 % fewer HBM bytes per layer, measured time-neutral; default off). */
+ * pre-composed skip-projection weights (csrc/tskip.h: 14 % fewer HBM bytes per layer, measured time-neutral; default off);
+ * "fused_nt" = 1 / 2 / 4 forces the fused layer kernel onto 32- / 64- / 128-frame tiles (round 5: the tile widths give bit-identical results and
+ * the library picks the one with the fewest rounds of workgroups; 0 = automatic); "x3t_w6_off" = 1 keeps the fp16 lo plane in an F16_X3T handle's
+ * DDPM chain; "profile_kernel" = 1 makes dsvc_sampler_profile_gate_kernel time the output kernel of the two-launch layer instead of the gate kernel.
+ * NONE of these is part of the supported surface: they exist for the parity tests and the bench's roofline entries, they change which kernel
+ * computes a result (never to an unsupported precision), and a deployment should not call this function.  Pure tuning knobs of variants that
+ * were measured and not kept ("layer_prio", "tail_tiling") exist in the -DDSVC_PROFILING build only. */
 int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
 
 /* per-kernel timing for bench.py's roofline: average duration in microseconds of the dominant kernel at this batch size,

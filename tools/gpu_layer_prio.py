@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import diffsvc_amd
+from diffsvc_amd import _lib
+_lib.use_profiling_build()        # the knob this tool turns exists in libdsvc_hip_prof.so only (python -m diffsvc_amd.build --profiling)
 from diffsvc_amd import synth
 from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16_w2"
