@@ -41,7 +41,7 @@ FAST_SIDE = "f16_w6n"                              # the faster operand scheme r
 # profiles/b32_error_fit.json (tools/b32_error_fit.py writes it from the test's output), which carries the hash of the kernel sources it was
 # measured on -- reported as null, with the reason, once a kernel source has changed (load_error_fit).
 PEAK_HBM_GBS = 8000.0                              # HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
-# algorithmic HBM bytes per frame of one residual layer, C = 384, fp16 operands / fp32 residual + skip + cproj:
+# algorithmic HBM bytes per frame of one residual layer (design/tgemm.md), C = 384, fp16 operands / fp32 residual + skip + cproj:
 #   gate kernel alone : xh in 768*(1 + 2d/128 averaged over d = 1,2,4,8 -> 1.06) + cproj 3072 + g out 768
 #   fused layer kernel: xh in 814 + cproj 3072 + x32 in/out 3072 + skip in/out 3072 + next xh out 768   (g never leaves the CU)
 BYTES_PER_FRAME_GATE = 814 + 3072 + 768
@@ -65,7 +65,7 @@ def probe_mfma():
 
 def latency_floor(precision, measured_us):
     """What bounds the single-clip gate kernel is latency, not the 2.5 PF/s roof: 1.5 GFLOP per launch on 224 workgroups.  A stated floor
-    for ONE launch inside the replayed graph, from the measured constants of this part (tools/micro/launch_floor.hip,
+    for ONE launch inside the replayed graph, from the measured constants of this part (design/tgemm.md; tools/micro/launch_floor.hip,
     profiles/r02h_stamps.txt, MI355X_MICROARCH.md):
       boundary   1.75 us  a graph node of an empty kernel (launch_floor.hip)
       tile DMA   the workgroup's (32 + 2 d) x row time tile through the CU's 64 B/clk vector-memory path + one L2 round trip (~0.3 us)
@@ -123,7 +123,7 @@ def res_skip_roofline(handle, precision):
 def train_step_flops(hp, frames):
     """Algorithmic FLOPs (one multiply-add = 2) of one training step over `frames` valid mel frames: per residual layer the forward (dilated
     conv, conditioner projection, output 1x1), the data gradients (transposed conv, d gate) and the three weight gradients; the conditioner's
-    data gradient is never formed.  Tail: input / skip / output projections, forward + data + weight gradients."""
+    data gradient is never formed (design/training.md).  Tail: input / skip / output projections, forward + data + weight gradients."""
     C, H, M, L = hp["residual_channels"], hp["hidden_size"], hp["audio_num_mel_bins"], hp["residual_layers"]
     conv, outp, cond = 2 * C * 2 * C * 3, 2 * C * 2 * C, 2 * H * 2 * C
     per_layer = (conv + cond + outp) + (conv + outp) + (conv + cond + outp)
@@ -131,7 +131,7 @@ def train_step_flops(hp, frames):
     return (per_layer * L + tail) * frames
 
 
-VOCODER_FLOP_PER_FRAME = 649.5e6                   # NSF-HiFiGAN generator, 44.1 kHz config: 512 output samples per mel frame
+VOCODER_FLOP_PER_FRAME = 649.5e6                   # NSF-HiFiGAN generator, 44.1 kHz config (design/other_kernels.md): 512 output samples per mel frame
 
 
 def dominant_kernel_roofline(handle, B, precision):
@@ -665,7 +665,7 @@ def main():
                 if r_["bound"] == "hbm":
                     r_["frac_of_stream_copy"] = r_["achieved"] / 6290.0               # against the 6.29 TB/s a float4 copy reaches (MI355X_MICROARCH.md)
             if FAST_SIDE and precb != FAST_SIDE:
-                # other operand schemes beside the shipped ones: f16_w2 -- round 3's batched default, and what a single clip runs
+                # other operand schemes beside the shipped ones (design/precision.md): f16_w2 -- round 3's batched default, and what a single clip runs
                 # at when the fp32-class f16_x3t is not asked for -- and f16_w6n (f16_w6 without the gate-output correction: f16_w2's error class)
                 fs = {"unit": "audio-sec/wall-sec"}
                 for scheme, with_single, with_batch in (("f16_w2", True, True), (FAST_SIDE, False, True)):
@@ -768,7 +768,7 @@ def main():
                                                      "pipe_frac": 3 * tfl / PEAK_TFLOPS_F16, "traffic": load_train_traffic()[0],
                                                      "traffic_source": load_train_traffic()[1], "traffic_unit": "HBM bytes per step (PMC)"}}
                 # the reference's max_tokens loader changes (B, T) every step (training/task/tts.py:60-88): ONE trainer alternating through five
-                # batch shapes of about the benchmarked size (8 192 frames each; only the gap rows are cleared on a shape change)
+                # batch shapes of about the benchmarked size (8 192 frames each; only the gap rows are cleared on a shape change, design/training.md)
                 try:
                     result["train_step"]["variable_shape_ms"] = time_variable_shape_steps(hp, sd, dev)
                 except Exception as ex:

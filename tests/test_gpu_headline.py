@@ -467,7 +467,7 @@ def test_mid_size_tilings_of_the_fused_layer_kernel_equal_the_128_frame_tiling_b
 
 @pytest.mark.parametrize("precision", ["f16_w2", "f16_m64"])
 def test_deferred_skip_contraction_taps_and_equivalence(precision):
-    """The deferred skip path (debug_set 'defer_skip' 1; not the default: time-neutral): the layer kernels write the gate
+    """The deferred skip path (debug_set 'defer_skip' 1; not the default: time-neutral, design/tlayer.md): the layer kernels write the gate
     output g to HBM and compute only the residual half of the 1x1; ONE [C x L*C] contraction per evaluation (tskip.h) produces
     relu(skip_projection(sum of skips / sqrt(L))) from all layers' g with weights composed at load time.  Checked at 8 x 861: (1) per-layer residual stream x_l and gate output g_l against the oracle
     (g_l is now tappable in the fused form: it is in HBM), (2) the contraction's output against relu(skip_projection(.)) of the oracle,

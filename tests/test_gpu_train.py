@@ -158,7 +158,7 @@ def test_train_step_vs_real_reference_golden(case):
     criterion is met BECAUSE the tgemm tilings start each frame tile's K loop at a staggered weight group (csrc/tgemm.h: STAGGER / gmap) -- a
     latency measure of the single-clip regime that here decorrelates the accumulation's rounding from row to row, so that it averages out in
     the weight-gradient contraction over 8 192 frames: 2.1e-4 from the fp64 values on the most cancellation-prone tensors (1.64x the
-    reference's own distance) with the stagger, 7.8e-4 (5.2x: outside the bar) with one fixed summation order in every tile.
+    reference's own distance) with the stagger, 7.8e-4 (5.2x: outside the bar) with one fixed summation order in every tile (design/training.md).
     Removing the stagger from the trainer's tilings is therefore a parity change, not a refactoring."""
     from diffsvc_amd.train import DiffusionTrainerHip
     from make_golden import TRAIN_CASES, TRAIN_CASES_BENCH
