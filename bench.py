@@ -606,7 +606,7 @@ def main():
             w64 = wav.double()
             result["pcm_stats"] = [[int(i), float(w64[i].sum()), float((w64[i] ** 2).sum())] for i in range(w64.shape[0])]
         # PMC-derived HBM traffic of the same kernel (a separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` pass over this very
-        # command: tools/gpu_round.sh + tools/rocprof_traffic.py; counters cannot be read from inside the process)
+        # command: tools/gpu_pmc_r5.sh + tools/rocprof_traffic.py; counters cannot be read from inside the process)
         if world == 1 and B == 1 and args.speedup <= 1 and not args.no_batched:
             # BASELINE configs[2]: the same clip with the 50-iteration PLMS sampler (pndm_speedup=20, 51 denoiser evaluations)
             pipe.infer(hub, m2p, f0, speedup=20, seed=7)
