@@ -148,7 +148,7 @@ typedef float pe_f32x4 __attribute__((ext_vector_type(4)));
 
 // out[row][col] = EPI( sum_tap sum_ci  x[row + tap - taps/2][ci] * W[col][ci][tap] ): fp32 operands, products and the whole K = taps * cin
 // accumulation in FLOAT64 on the matrix cores (v_mfma_f64_16x16x4_f64; a product of two fp32 values is exact in float64), ONE rounding to
-// fp32 per output.  Why not fp32 accumulation: measured (profiles/r5e_pe_tests.txt) -- with v_mfma_f32_32x32x2_f32, 1280-term fp32 chains in 15
+// fp32 per output.  Why not fp32 accumulation: measured on an intermediate build of round 5 -- with v_mfma_f32_32x32x2_f32, 1280-term fp32 chains in 15
 // consecutive convolutions left f0 5e-6 ... 1.5e-5 from a float64 evaluation of the extractor where the reference's own fp32 CPU arithmetic keeps
 // 1.5e-6, and the NSF source turns that into 1.4e-3 ... 4e-3 RMS of PCM.  With float64 accumulation the only fp32 roundings left are the ones
 // every fp32 implementation has (one per layer output, the norms).
