@@ -180,7 +180,7 @@ def dominant_kernel_roofline(handle, B, precision):
     return roof
 
 
-SAMPLER_SOURCES = ("common.h", "common.hip", "tgemm.h", "tlayer.h", "diffnet_t.h", "diffnet_kernels.h", "diffnet.hip")
+SAMPLER_SOURCES = ("common.h", "common.hip", "tgemm.h", "tlayer.h", "ttail.h", "diffnet_t.h", "diffnet_kernels.h", "diffnet.hip")
 
 
 TRAIN_SOURCES = ("common.h", "common.hip", "tgemm.h", "tepi_util.h", "conv_gemm.h", "wgrad.h", "train.hip")

@@ -13,6 +13,7 @@
 #include "diffnet_t.h"
 #include "tlayer.h"
 #include "tskip.h"
+#include "ttail.h"
 
 using namespace dsvc;
 
@@ -355,9 +356,9 @@ struct dsvc_denoiser {
     // one denoiser evaluation on the frame-major state `x_fm` [rows][M]; `state_half_fresh`: the fp16 copy of the
     // state (tgemm path) is already up to date (the previous DDPM tail wrote it)
     // host_step >= 0: the caller knows the diffusion step (mod the dither period) at launch time -> variants are passed by value
-    int eval(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step = -1);
+    int eval(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step = -1, bool only_inproj = false);
     int eval_conv(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, hipStream_t st);
-    int eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step);
+    int eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step, bool only_inproj);
     int finalize_t();
     // the whole residual layer as one kernel (tlayer.h): N-tiles of 32 frames per workgroup (4 = the throughput tiling, 2 / 1 = the mid-size
     // batches of the 6-bit schemes), or 0 = the layer runs as its two tgemm launches
@@ -365,6 +366,21 @@ struct dsvc_denoiser {
     bool fused_layer_ok() const { return fused_nt() > 0; }
     int dbg_profile_out = 0;     // "profile_kernel" 1: dsvc_sampler_profile_gate_kernel times the OUTPUT kernel of the two-launch layer instead of the gate kernel
     int dbg_tail = 0;            // "tail_tiling": tiling of the three small projections at large batches, two bits each (in | skip << 2 | out << 4): see tlaunch
+    // the fused step tail (ttail.h): skip projection, output projection + posterior step and the NEXT evaluation's input projection in one
+    // launch.  tail_fused_last = the previous eval_t call ended in it: the residual stream / layer-0 operand of this evaluation are already
+    // there, and the fp16 copy `xsh` of the state is NOT (only the three-launch tail refreshes it).  Cleared by whatever starts a chain;
+    // run_ddpm keeps it right across graph launches (the captured steps assume it).
+    bool tail_fused_last = false;
+    int dbg_fused_tail = 1;      // "fused_tail": 0 = the three tgemm launches (A/B, tests), 1 = automatic, 2 / 3 = force 64- / 32-frame tiles
+    // 0 = not fused, 1 = 64-frame tiles, 2 = 32-frame tiles (when the 64-frame tiles would leave half of the CUs without a workgroup)
+    int fused_tail_mode() const {
+        if (!dbg_fused_tail || !is_w6() || !fused_layer_ok() || defer_skip || in_t.n_variants != 1 || skip_t.n_variants != 1 || fin_t.n_variants != 1 ||
+            in_t.planes != 2 || skip_t.planes != 2 || fin_t.planes != 2 || !ttail_supported(cfg.channels, Cp, cfg.mel_bins, Mp, rows_alloc)) return 0;
+        const int m = dbg_fused_tail % 10;
+        if (m == 2) return 1;
+        if (m == 3) return 2;
+        return (rows_alloc / 64) * 2 <= device_cus() ? 2 : 1;
+    }
     int dbg_fused_nt = 0;        // "fused_nt": force the tile width of the fused kernel (A/B of the mid-size tilings); 0 = automatic
     bool defer_ok() const { return fused_layer_ok() && defer_skip && skipall_t.m_tiles > 0 && gall.p && tskip_supported(cfg.channels, rows_alloc); }
     int launch_fused_layer(int l, const StepRef& step, hipStream_t st, int host_step);
@@ -674,8 +690,9 @@ int dsvc_denoiser::prepare_cond(const float* cond_bht, int B, int T, hipStream_t
     return DSVC_OK;
 }
 
-int dsvc_denoiser::eval(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step) {
-    return tpath ? eval_t(x_fm, step, tail, ddpm, state_half_fresh, st, host_step) : eval_conv(x_fm, step, tail, ddpm, st);
+int dsvc_denoiser::eval(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step, bool only_inproj) {
+    if (only_inproj && !tpath) return fail(DSVC_ESTATE, "only_inproj: the tgemm path only");
+    return tpath ? eval_t(x_fm, step, tail, ddpm, state_half_fresh, st, host_step, only_inproj) : eval_conv(x_fm, step, tail, ddpm, st);
 }
 
 int dsvc_denoiser::eval_conv(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, hipStream_t st) {
@@ -729,7 +746,7 @@ int dsvc_denoiser::eval_conv(const float* x_fm, const StepRef& step, Tail tail, 
 }
 
 // the tgemm path: every contraction reads fp16 activations that the previous kernel's epilogue left in HBM/L2
-int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step) {
+int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, const DdpmCtx* ddpm, bool state_half_fresh, hipStream_t st, int host_step, bool only_inproj) {
     const int M = cfg.mel_bins, C = cfg.channels, L = cfg.layers;
     const RowMap rm = rowmap();
     auto targs = [&](const _Float16* x, int cin_pad, const TPacked& tp, int taps, int dil) {
@@ -744,14 +761,19 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         return a;
     };
     const int stream_big = rows_alloc >= 6144 ? 1 : 0;   // (non-temporal residual/skip traffic measured neutral: 2.41 vs 2.42 ms/step)
-    if (!state_half_fresh)
+    const bool fused_last = tail_fused_last;
+    tail_fused_last = false;
+    const int tail_mode = (tail == TAIL_DDPM && dbg_stop_after < 0) ? fused_tail_mode() : 0;
+    const bool have_inproj = fused_last && tail_mode != 0;      // the previous step's fused tail did K1 of this evaluation
+    if ((!state_half_fresh || fused_last) && !have_inproj)
         hipLaunchKernelGGL(k_rows_to_half, dim3(ceil_div(rows * (M / 4), 256) < 2048 ? ceil_div(rows * (M / 4), 256) : 2048), dim3(256), 0, st,
                            x_fm, xsh.as<_Float16>(), M, Mp, rm, rows);
-    {   // K1: input projection + ReLU (net.py:120-123); emits layer 0's operand xh = fp16(x + film_0)
+    if (!have_inproj) {   // K1: input projection + ReLU (net.py:120-123); emits layer 0's operand xh = fp16(x + film_0)
         TGemmArgs a = targs(xsh.as<_Float16>(), 2 * Mp, in_t, 1, 1);
         TEpiInProj::Args e{xres.as<float>(), xh_row0(), in_t.bias.as<float>(), film.as<float>(), L * C, step, C, Cp * NA, rm, NA == 2 ? Cp : 0};
         DSVC_TRY(tlaunch_prec<TEpiInProj>(a, e, 2, rows_alloc, st, 1, dbg_tail & 3));
     }
+    if (only_inproj) { tail_fused_last = tail_mode != 0; return DSVC_OK; }      // (run_ddpm: a chain that starts with a graph launch)
     const int stop_after = dbg_stop_after;
     const bool fused = fused_layer_ok();
     for (int l = 0; l < L; ++l) {
@@ -775,6 +797,22 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
                                 l == 0 ? 1 : 0, rm, stream_big, NA == 2 ? Cp : 0};
             DSVC_TRY(tlaunch_prec<TEpiResSkip>(a, e, out_t[l].planes, rows_alloc, st, NA));
         }
+    }
+    if (tail_mode) {
+        // K9a + K9b + K10 + K1 of the next evaluation in one launch (ttail.h)
+        TTailArgs a{};
+        a.skiph = skiph.as<_Float16>(); a.wsp = skip_t.w.as<_Float16>(); a.wout = fin_t.w.as<_Float16>(); a.win = in_t.w.as<_Float16>();
+        a.bsp = skip_t.bias.as<float>(); a.bout = fin_t.bias.as<float>(); a.bin = in_t.bias.as<float>();
+        a.C = C; a.Cp = Cp; a.M = M; a.Mp = Mp;
+        a.x = ddpm->x; a.tab = ddpm->tab; a.step = step; a.rm = rm; a.seedp = ddpm->seedp; a.clipid = ddpm->clipid;
+        a.x32 = xres.as<float>(); a.xh = xh_row0(); a.ldh = Cp * NA; a.xh_lo = NA == 2 ? Cp : 0;
+        a.film = film.as<float>(); a.film_step_stride = L * C;
+#ifdef DSVC_PROFILING
+        a.stamps = dbg_fused_tail >= 10 ? eps.as<float>() : nullptr;       // fused_tail = 10 + mode: phase stamps into the (unused) eps buffer
+#endif
+        DSVC_TRY(ttail_launch(a, rows_alloc, st, tail_mode == 2));
+        tail_fused_last = true;
+        return DSVC_OK;
     }
     if (fused && defer_ok()) {   // K8 (skip halves of all layers) + K9a in one contraction over the stored gate outputs (tskip.h)
         TSkipArgs a{gall.as<_Float16>(), (long long)rows_alloc * Cp, Cp, L, skipall_t.w.as<_Float16>()};
@@ -1030,7 +1068,14 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
         if (aligned)
             while (n > 0 && (t % UNROLL) != UNROLL - 1) DSVC_TRY(eager_step());     // walk to the period boundary
         while (n >= g_unroll) {
+            // the captured steps were recorded behind an eager step: with the fused tail (ttail.h) the first of them expects its input
+            // projection done by the step before it -- a chain that begins on the period boundary runs that one projection eagerly
+            if (den->fused_tail_mode() && !den->tail_fused_last) {
+                dsvc_denoiser::DdpmCtx e = ddpm_ctx();
+                DSVC_TRY(den->eval(xstate.as<float>(), StepRef{step_dev.as<int>(), 0, 0}, dsvc_denoiser::TAIL_DDPM, &e, true, st, t, true));
+            }
             DSVC_HIP(hipGraphLaunch(gexec, st));
+            den->tail_fused_last = den->fused_tail_mode() != 0;
             n -= g_unroll; t -= g_unroll;
         }
     }
@@ -1254,6 +1299,7 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value) {
     else if (k == "g6_off") d->dbg_g6_off = value ? 1 : 0;
     else if (k == "x3t_w6_off") d->dbg_x3t_w6_off = value ? 1 : 0;
     else if (k == "fused_nt") d->dbg_fused_nt = value;
+    else if (k == "fused_tail") d->dbg_fused_tail = value;
     else if (k == "profile_kernel") d->dbg_profile_out = value ? 1 : 0;
 #ifdef DSVC_PROFILING            // tuning knobs of measured-and-not-kept variants: the profiling build only (python -m diffsvc_amd.build --profiling)
     else if (k == "layer_prio") d->layer_prio = value;
@@ -1302,6 +1348,7 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
     const int B = a->B, T = a->T, M = d->cfg.mel_bins;
     if ((T * M) % 4) return fail(DSVC_EINVAL, "T*mel_bins must be a multiple of 4");
     DSVC_TRY(s->ensure_ws(B, T, st));
+    d->tail_fused_last = false;                           // a new chain: nothing of a previous call's tail applies
     DSVC_TRY(d->set_clip_meta(a->clip_ids, a->first_clip, a->clip_lens, st));
     DSVC_TRY(d->prepare_cond(a->cond, B, T, st));
     float* xs = s->xstate.as<float>();

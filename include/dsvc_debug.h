@@ -34,7 +34,9 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
  * pre-composed skip-projection weights (csrc/tskip.h: 14 % fewer HBM bytes per layer, measured time-neutral; default off);
  * "fused_nt" = 1 / 2 / 4 forces the fused layer kernel onto 32- / 64- / 128-frame tiles (round 5: the tile widths give bit-identical results and
  * the library picks the one with the fewest rounds of workgroups; 0 = automatic); "x3t_w6_off" = 1 keeps the fp16 lo plane in an F16_X3T handle's
- * DDPM chain; "profile_kernel" = 1 makes dsvc_sampler_profile_gate_kernel time the output kernel of the two-launch layer instead of the gate kernel.
+ * DDPM chain; "fused_tail" = 0 runs the tail of a batched f16_w6 DDPM step (skip projection, output projection + posterior step, the next
+ * evaluation's input projection) as the three tgemm launches instead of the one fused kernel (csrc/ttail.h; 1 = automatic, 2 / 3 = its 64- /
+ * 32-frame tiling); "profile_kernel" = 1 makes dsvc_sampler_profile_gate_kernel time the output kernel of the two-launch layer instead of the gate kernel.
  * NONE of these is part of the supported surface: they exist for the parity tests and the bench's roofline entries, they change which kernel
  * computes a result (never to an unsupported precision), and a deployment should not call this function.  Pure tuning knobs of variants that
  * were measured and not kept ("layer_prio", "tail_tiling") exist in the -DDSVC_PROFILING build only. */

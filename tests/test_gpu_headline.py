@@ -465,6 +465,49 @@ def test_mid_size_tilings_of_the_fused_layer_kernel_equal_the_128_frame_tiling_b
     assert torch.equal(out[2], out[4]) and torch.equal(out[1], out[4]), (d2, d1)
 
 
+@pytest.mark.parametrize("arch", ["44k", "24k"])
+def test_fused_step_tail_vs_the_three_launches_and_across_graph_replays(arch):
+    """The tail of a batched DDPM step as ONE kernel (round 5, csrc/ttail.h: skip projection -> output projection + posterior step -> the NEXT
+    evaluation's input projection; the default of the f16_w6 fused-layer path) against the three tgemm launches it replaces (debug_set
+    'fused_tail' 0).  Same operands and split scheme, but the fused kernel walks K in plain order and leaves out W_lo x_lo (2^-22 of a
+    product): one step agrees to fp32 rounding, 20 steps to the chain's own sensitivity (the dither variants move a 20-step state by 3e-5
+    too); its 64- and 32-frame tilings are bit-identical.  Then the host bookkeeping: the captured steps of a hipGraph replay expect their
+    input projection done by the step before them, so a chain that STARTS on the period boundary with an already captured graph (the second
+    call below) has to run that one projection eagerly -- eager, first (capturing) and second (replay-only) call must agree bit for bit.
+    Both instantiations: C = 384 (44.1 kHz) and C = 256 (the 24 kHz architecture of BASELINE configs[0])."""
+    hp = dict(synth.HPARAMS_44K if arch == "44k" else synth.HPARAMS_24K, K_step=192)
+    sd, den, smp = make_handles(hp, 0 if arch == "44k" else 2, "f16_w6")
+    den.debug_set("two_launch_layer", -1)                 # the fused layer kernel at 8 clips (the 24 kHz handle would choose it from 18 clips on)
+    den.debug_set("fused_nt", 2)
+    clips, T, n_units, seed = list(range(8)), 861, 500, 91
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    cond = cond.transpose(1, 2).contiguous().cuda()
+    run = lambda n, graph: smp.sample(cond, n, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=graph, return_x=True)[1]
+    for n, bar in ((1, 1e-6), (20, 2e-4)):
+        out = {}
+        for mode in (0, 2, 3):
+            den.debug_set("fused_tail", mode)
+            out[mode] = run(n, False)
+        d = (out[2] - out[0]).abs().max().item()
+        print("fused step tail (%s), %d steps at 8 x 861: max |diff| of the state vs the three launches %.2e; 32- vs 64-frame tiles identical: %s" % (
+            arch, n, d, torch.equal(out[2], out[3])))
+        assert torch.isfinite(out[2]).all() and 0.0 < d < bar, d
+        assert torch.equal(out[2], out[3])
+    den.debug_set("fused_tail", 1)
+    eager = run(192, False)                               # t = 191: the chain starts on the 64-step period boundary
+    first = run(192, True)                                # captures (one eager step first), then replays
+    second = run(192, True)                               # replays only: the first graph launch opens the chain
+    longer = run(150, True)                               # eager walk to the boundary, two replays, eager steps behind them
+    assert torch.isfinite(eager).all()
+    assert torch.equal(first, eager) and torch.equal(second, eager)
+    assert torch.equal(longer, run(150, False))
+    den.debug_set("fused_tail", 0)
+    d = (run(192, True) - eager).abs().max().item()
+    print("fused step tail (%s), 192 steps through graph replays: bit-identical to eager; vs the three launches %.2e" % (arch, d))
+    assert 0.0 < d < 1e-3
+
+
 @pytest.mark.parametrize("precision", ["f16_w2", "f16_m64"])
 def test_deferred_skip_contraction_taps_and_equivalence(precision):
     """The deferred skip path (debug_set 'defer_skip' 1; not the default: time-neutral, design/tlayer.md): the layer kernels write the gate

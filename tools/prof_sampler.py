@@ -12,6 +12,9 @@ hp = dict(synth.HPARAMS_44K)
 sd = synth.acoustic_state(hp, 0)
 den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=prec, prefix="denoise_fn.")
 smp = SamplerHandle(den, sd)
+for kv in os.environ.get("DSVC_PROF_KNOBS", "").split(","):          # e.g. DSVC_PROF_KNOBS=fused_tail=1 (dsvc_denoiser_debug_set keys)
+    if "=" in kv:
+        den.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
 cond = torch.randn(B, 256, 861, device="cuda") * 0.5
 smp.sample(cond, 130 if graph else 25, seed=1, use_graph=graph)      # (graph: two dither periods, so that the capture happens here)
 torch.cuda.synchronize(); t0 = time.time()

@@ -3,7 +3,7 @@
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) streaming reads
 (MI355X_MICROARCH.md, HBM section), so the read side is doubled."""
 import csv, glob, hashlib, json, os, sys
-SAMPLER_SOURCES = ("common.h", "common.hip", "tgemm.h", "tlayer.h", "diffnet_t.h", "diffnet_kernels.h", "diffnet.hip")   # as bench.py
+SAMPLER_SOURCES = ("common.h", "common.hip", "tgemm.h", "tlayer.h", "ttail.h", "diffnet_t.h", "diffnet_kernels.h", "diffnet.hip")   # as bench.py
 TRAIN_SOURCES = ("common.h", "common.hip", "tgemm.h", "tepi_util.h", "conv_gemm.h", "wgrad.h", "train.hip")                # as bench.py
 def kernel_sources_sha(names=SAMPLER_SOURCES):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
