@@ -513,25 +513,42 @@ __global__ void k_source_frames(const float* __restrict__ f0, SrcFrame* __restri
     }
     const float mult = (float)(h + 1);
     double base = 0.0, delta_acc = 0.0, flprev = 0.0;
-    for (int f = 0; f < T; ++f) {
-        const float fh = f0[(size_t)b * T + f] * mult;
-        const float q = __fdiv_rn(fh, sr);
-        const float r = q - floorf(q);                          // (f / sr) % 1, f >= 0
-        if (f == 0) {
-            const float rad0 = r + ini;                         // rad_values[:, 0, :] += rand_ini  (fp32)
-            base = (double)rad0 - (double)r;
-            flprev = (double)floorf(rad0);                      // floor(fp32(cumsum[0])): no shift at sample 0
-            fl00[b * dim + h] = (float)flprev;
+    // The chain over the frames is sequential (about ten dependent double operations per frame); the f0 loads are not part of it: sixteen frames
+    // are fetched while the previous sixteen run the chain (with the load inside the loop every frame paid a memory round trip: 89 us per clip)
+    constexpr int CH = 16;
+    const float* f0b = f0 + (size_t)b * T;
+    float nxt[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) nxt[k] = k < T ? f0b[k] : 0.f;
+    for (int c0 = 0; c0 < T; c0 += CH) {
+        float cur[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) nxt[k] = c0 + CH + k < T ? f0b[c0 + CH + k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int f = c0 + k;
+            if (f >= T) break;
+            const float fh = cur[k] * mult;
+            const float q = __fdiv_rn(fh, sr);
+            const float r = q - floorf(q);                          // (f / sr) % 1, f >= 0
+            if (f == 0) {
+                const float rad0 = r + ini;                         // rad_values[:, 0, :] += rand_ini  (fp32)
+                base = (double)rad0 - (double)r;
+                flprev = (double)floorf(rad0);                      // floor(fp32(cumsum[0])): no shift at sample 0
+                fl00[b * dim + h] = (float)flprev;
+            }
+            SrcFrame o; o.base = base; o.flprev = flprev; o.delta_acc = delta_acc;
+            fr[((size_t)b * T + f) * dim + h] = o;
+            const double d_end = base + (double)hop * (double)r;
+            const double flend = (double)floorf((float)d_end);
+            const float sr32 = r + (-1.0f);                         // fp32(rad + shift)
+            const double delta = (double)sr32 - ((double)r - 1.0);
+            delta_acc += delta * (flend - flprev);
+            flprev = flend;
+            base = d_end;
         }
-        SrcFrame o; o.base = base; o.flprev = flprev; o.delta_acc = delta_acc;
-        fr[((size_t)b * T + f) * dim + h] = o;
-        const double d_end = base + (double)hop * (double)r;
-        const double flend = (double)floorf((float)d_end);
-        const float sr32 = r + (-1.0f);                         // fp32(rad + shift)
-        const double delta = (double)sr32 - ((double)r - 1.0);
-        delta_acc += delta * (flend - flprev);
-        flprev = flend;
-        base = d_end;
     }
 }
 
@@ -627,30 +644,47 @@ __global__ void k_noise_conv_any(const float* __restrict__ har, const float* __r
     }
 }
 
-template <int NPT>      // the power-of-two widths: outputs per thread = 64 * cout / 256: a thread owns ONE output channel and NPT of the block's 64 output samples
+// The power-of-two widths: a thread owns ONE output channel and NPT of the block's FR = NPT * 256 / cout output samples.  FR = 64 everywhere but
+// at the first stage (256 channels x 6 888 samples per 10 s clip: 108 blocks of 64 samples left 58 % of the CUs idle and ran 180 us; 16 samples per
+// block = 431 blocks).  Four taps per LDS read (ds_read_b128; s and K are multiples of 4 there): the fmaf chain of an output still runs over its
+// taps in ascending order -- bit-identical to the scalar form.
+template <int NPT, int FR = 64>
 __global__ void __launch_bounds__(256) k_noise_conv(const float* __restrict__ har, const float* __restrict__ w, const float* __restrict__ bias,
                                                     float* __restrict__ out, int cout, int K, int s, int pad, int len_out, int len_in,
                                                     int stride_out, int stride_in) {
-    extern __shared__ float sm[];          // [64*s + K] excitation samples
+    extern __shared__ __attribute__((aligned(16))) float sm[];          // [(FR - 1) * s + K] excitation samples
     const int b = blockIdx.y;
-    const int n0 = blockIdx.x * 64;
-    const int span = 63 * s + K;
+    const int n0 = blockIdx.x * FR;
+    const int span = (FR - 1) * s + K;
     const int base = n0 * s - pad;
     for (int i = threadIdx.x; i < span; i += blockDim.x) {
         const int p = base + i;
         sm[i] = (p >= 0 && p < len_in) ? har[(size_t)b * stride_in + p] : 0.f;
     }
     __syncthreads();
-    // tap-major: one (coalesced) weight load per tap feeds NPT outputs; the excitation sample is an LDS broadcast.  Every output still sums its
-    // taps in ascending order with fmaf, as before: bit-identical results
+    // tap-major: one (coalesced) weight load per tap feeds NPT outputs; the excitation sample is an LDS broadcast
     const int co = threadIdx.x % cout, grp = threadIdx.x / cout, G = 256 / cout;
     float acc[NPT];
 #pragma unroll
     for (int q = 0; q < NPT; ++q) acc[q] = 0.f;
-    for (int j = 0; j < K; ++j) {
-        const float wv = w[(size_t)j * cout + co];
+    if (((s | K) & 3) == 0) {
+        for (int j = 0; j < K; j += 4) {
+            float wv[4];
 #pragma unroll
-        for (int q = 0; q < NPT; ++q) acc[q] = fmaf(wv, sm[(grp + q * G) * s + j], acc[q]);
+            for (int t = 0; t < 4; ++t) wv[t] = w[(size_t)(j + t) * cout + co];
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(sm + (grp + q * G) * s + j);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[q] = fmaf(wv[t], x[t], acc[q]);
+            }
+        }
+    } else {
+        for (int j = 0; j < K; ++j) {
+            const float wv = w[(size_t)j * cout + co];
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) acc[q] = fmaf(wv, sm[(grp + q * G) * s + j], acc[q]);
+        }
     }
     const float bv = bias[co];
 #pragma unroll
@@ -1095,18 +1129,18 @@ int dsvc_vocoder::run(const float* mel, const float* f0, float* wav, int B, int 
         float* S = buf[(i & 1) ? 4 : 3].as<float>();
         // x_source = noise_convs[i](har)  (models.py:373) written into U ...
         if (src) {
-            const size_t sm = (size_t)(64 * nc_s[i] + nc_k[i]) * 4;
-            auto nc = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(ceil_div(len, 64), B), dim3(256), sm, st, har.as<float>(), nc_w[i].as<float>(),
+            auto nc = [&](auto kern, int fr) {      // fr output samples per block
+                const size_t sm = (size_t)(fr * nc_s[i] + nc_k[i]) * 4;
+                hipLaunchKernelGGL(kern, dim3(ceil_div(len, fr), B), dim3(256), sm, st, har.as<float>(), nc_w[i].as<float>(),
                                    nc_b[i].as<float>(), U, cout, nc_k[i], nc_s[i], nc_pad[i], len, T * hop, stride, Tp * hop);
             };
             switch (cout) {
-                case 256: nc(k_noise_conv<64>); break;
-                case 128: nc(k_noise_conv<32>); break;
-                case 64: nc(k_noise_conv<16>); break;
-                case 32: nc(k_noise_conv<8>); break;
-                case 16: nc(k_noise_conv<4>); break;
-                default: nc(k_noise_conv_any); break;
+                case 256: nc(k_noise_conv<16, 16>, 16); break;
+                case 128: nc(k_noise_conv<32>, 64); break;
+                case 64: nc(k_noise_conv<16>, 64); break;
+                case 32: nc(k_noise_conv<8>, 64); break;
+                case 16: nc(k_noise_conv<4>, 64); break;
+                default: nc(k_noise_conv_any, 64); break;
             }
         }
         // ... then x = ups[i](leaky_relu(x, 0.1)) + x_source  (models.py:369-375)

@@ -4,6 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import diffsvc_amd
+if os.environ.get("DSVC_USE_PROF"):      # A/B against another build parked as libdsvc_hip_prof.so
+    from diffsvc_amd import _lib
+    _lib.use_profiling_build()
 from diffsvc_amd import synth
 from diffsvc_amd.engine import VocoderHandle
 B, reps = int(sys.argv[1]), int(sys.argv[2])
