@@ -144,7 +144,7 @@ struct TEpiGateT {
             const size_t o = (size_t)frame * e.C + cg;
             st4(e.sig + o, f32x4{s[0], s[1], s[2], s[3]}); st4(e.sig + o + 4, f32x4{s[4], s[5], s[6], s[7]});
             st4(e.tau + o, f32x4{t[0], t[1], t[2], t[3]}); st4(e.tau + o + 4, f32x4{t[4], t[5], t[6], t[7]});
-            st4(e.g + o, f32x4{gv[0], gv[1], gv[2], gv[3]}); st4(e.g + o + 4, f32x4{gv[4], gv[5], gv[6], gv[7]});
+            if (e.g) { st4(e.g + o, f32x4{gv[0], gv[1], gv[2], gv[3]}); st4(e.g + o + 4, f32x4{gv[4], gv[5], gv[6], gv[7]}); }      // (null: nothing reads g as fp32 rows, wgrad_fm takes the planes)
             half8 hi, lo;
 #pragma unroll
             for (int r = 0; r < 8; ++r) { hi[r] = (_Float16)gv[r]; lo[r] = (_Float16)(gv[r] - (float)hi[r]); }
@@ -297,7 +297,7 @@ struct TEpiDxT {
                 }
                 st4(e.dxin + o + 4 * q, vi);
                 st4(e.dx + o + 4 * q, vx);
-                st4(e.dO + (size_t)frame * (2 * e.C) + cb + 4 * q, vo);
+                if (e.dO) st4(e.dO + (size_t)frame * (2 * e.C) + cb + 4 * q, vo);
             }
             store_hi_lo16(e.dOh + (size_t)frame * (2 * e.C2p) + cb, e.C2p, ov);
         }
@@ -541,14 +541,16 @@ __global__ void k_relu_bwd(const float* __restrict__ in, const float* __restrict
 // in LDS with the global loads running along whichever index is contiguous in memory (one thread per output with a stride-ldb operand
 // measured 357 us for the 20 diffusion projections); blockIdx.z walks a batch of independent problems (one per residual layer).
 struct SmallBatch { const float* A[32]; const float* B[32]; float* C[32]; const float* bias[32]; int n; };
+// (round 5: a thread's 4 x 4 outputs are ADJACENT rows / columns -- one ds_read_b128 per operand and k instead of four ds_read_b32, 16-byte
+//  stores; the k order of every output's fp32 chain is unchanged)
 __global__ __launch_bounds__(256) void k_gemm_small_b(const SmallBatch t, int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int accumulate) {
-    __shared__ float As[16][65], Bs[16][65];
+    __shared__ __attribute__((aligned(16))) float As[16][68], Bs[16][68];
     const float* __restrict__ A = t.A[blockIdx.z];
     const float* __restrict__ Bm = t.B[blockIdx.z];
     float* __restrict__ Cm = t.C[blockIdx.z];
     const float* __restrict__ bias = t.bias[blockIdx.z];
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // thread -> outputs (m0 + ty + 16 i, n0 + tx + 16 j)
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // thread -> outputs (m0 + 4 ty + i, n0 + 4 tx + j)
     float acc[4][4] = {};
     for (int k0 = 0; k0 < K; k0 += 16) {
         for (int e = threadIdx.x; e < 1024; e += 256) {
@@ -564,27 +566,36 @@ __global__ __launch_bounds__(256) void k_gemm_small_b(const SmallBatch t, int M,
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty + 16 * i]; b[i] = Bs[kk][tx + 16 * i]; }
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&As[kk][4 * ty]), bv = *reinterpret_cast<const f32x4*>(&Bs[kk][4 * tx]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
         }
         __syncthreads();
     }
+    const int n = n0 + 4 * tx;
+    const bool vec = n + 3 < N && (ldc & 3) == 0 && (reinterpret_cast<size_t>(Cm) & 15) == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * ty + i;
+        if (m >= M) continue;
+        float* p = Cm + (size_t)m * ldc + n;
+        if (vec) {
+            f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
-            if (m < M && n < N) {
-                float v = acc[i][j] + (bias ? bias[n] : 0.f);
-                float* p = Cm + (size_t)m * ldc + n;
-                *p = accumulate ? *p + v : v;
-            }
+            for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + (bias ? bias[n + j] : 0.f);
+            if (accumulate) { const f32x4 o = ld4(p); v = f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]}; }
+            st4(p, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < N) {
+                    const float v = acc[i][j] + (bias ? bias[n + j] : 0.f);
+                    p[j] = accumulate ? p[j] + v : v;
+                }
         }
+    }
 }
 
 // the Linear-forward shape of the same path:  C[m][n] = sum_k A[m*lda + k] * B[n*ldb + k] (+ bias[n]) with BOTH operands k-contiguous and
@@ -812,6 +823,14 @@ struct dsvc_trainer {
     DevBuf dOh, dyh;                               // planes of dO [rows][2 C2p] and of dy [TGUARD + rows + TGUARD][2 C2p]
     DevBuf oT_t, dT_t;                             // W_o^T and the flipped W_d^T, rows = input channels of the layer
     size_t oT_halfs = 0, dT_halfs = 0;
+    // round 5: the residual layers' weight gradients are contracted straight from these frame-major planes (wgrad.h: wgrad_fm_kernel) instead of
+    // channel-major copies a k_split_t pass writes -- which needs layer l's x / g planes alive in the backward pass: every layer gets its own
+    // (2 x 270 MB at the 64 x 128 batch).  fm = the architecture fits the kernel's tiles (C % 128, H % 128: the shipped configs; others keep k_split_t)
+    bool fm = false;
+    size_t xh_layer = 0, gh_layer = 0;             // halfs between the layers' planes in xhP / ghP (0: one buffer all layers share)
+    DevBuf wbias;                                  // partial column sums (bias gradients) of one wgrad_fm launch: [slices][k tiles][O_pad]
+    int wgrad_fm(const _Float16* a, int a_ld, int a_lo, int O, const WgradFmSeg* segs, int n_seg, const WgradSegs& rsegs, float scale, float* bias_dst,
+                 hipStream_t st);
     DevBuf t_gate_rm, t_gate_rs, t_out_rm;         // packed row -> source channel (+ the gate rows' pre-scale)
     std::vector<TPackDesc> tpack_q;
     DevBuf tpack_dev;
@@ -823,7 +842,7 @@ struct dsvc_trainer {
         for (DevBuf* b : {&sa, &sb, &spec_min, &spec_max, &xt, &xs, &sig, &tau, &g, &skip, &ypre, &s2pre, &eps, &deps, &condT, &tstep,
                           &clipid, &iotaB, &e0, &e1pre, &e1, &e2, &filmB, &dfilm, &de2, &de1, &de1pre, &dx, &dxin, &dO, &dy, &ds2pre,
                           &dh0, &loss, &AT, &BT, &wpart, &pack_dev, &bin_count, &bin_cursor, &bin_segs, &bin_nsegs, &bin_order, &bin_S,
-                          &xhP, &ghP, &condHP, &gate_t, &out_t, &cproj_t, &t_gate_rm, &t_gate_rs, &t_out_rm, &tpack_dev, &dOh, &dyh, &oT_t, &dT_t})
+                          &xhP, &ghP, &condHP, &gate_t, &out_t, &cproj_t, &t_gate_rm, &t_gate_rs, &t_out_rm, &tpack_dev, &dOh, &dyh, &oT_t, &dT_t, &wbias})
             b->release();
         if (step_err) (void)hipHostFree(step_err);
         auto rel = [](Packed& p) { p.w.release(); };
@@ -1010,7 +1029,13 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     {   // operands of the residual layers' GEMMs on the tgemm engine (channels % 64 == 0, hidden % 16 == 0, dilations <= TGUARD: checked at create)
         Cp = round_up(C, 128); Hp = round_up(H, 128);
         const int mpl = C / 16;
-        DSVC_TRY(z(xhP, (r + 2 * TGUARD) * 2 * Cp * 2)); DSVC_TRY(z(ghP, r * 2 * Cp * 2)); DSVC_TRY(z(condHP, r * 2 * Hp * 2));
+        // (every row of [0, rows) of these planes is rewritten by the producing epilogue each step, zeros on gap rows included; the guard rows
+        //  are what has to be zero, and a layout change moves them: cleared whole here, 0.5 GB = 0.1 ms with per-layer planes)
+        fm = C % 128 == 0 && (2 * C) % 256 == 0 && H % 128 == 0 && max_dil <= TGUARD;
+        xh_layer = fm ? (r + 2 * TGUARD) * 2 * Cp : 0; gh_layer = fm ? r * 2 * Cp : 0;
+        const size_t nl = fm ? (size_t)L : 1;
+        DSVC_TRY(z(xhP, nl * (r + 2 * TGUARD) * 2 * Cp * 2)); DSVC_TRY(z(ghP, nl * r * 2 * Cp * 2)); DSVC_TRY(z(condHP, r * 2 * Hp * 2));
+        if (fm) DSVC_TRY(wbias.alloc((size_t)WGRAD_MAX_TILES * 256 * 4));
         gate_halfs = tpacked_halfs(mpl, 3, Cp, 2, 1); out_halfs = tpacked_halfs(mpl, 1, Cp, 2, 1); cproj_halfs = tpacked_halfs(mpl, 1, Hp, 2, 1);
         DSVC_TRY(gate_t.alloc(gate_halfs * L * 2)); DSVC_TRY(out_t.alloc(out_halfs * L * 2)); DSVC_TRY(cproj_t.alloc(cproj_halfs * L * 2));
         C2p = round_up(2 * C, 128);
@@ -1091,6 +1116,40 @@ int dsvc_trainer::wgrad_nt(int O, int K_pad, int b_row0, const WgradSegs& segs, 
     hipLaunchKernelGGL(wgrad_nt_kernel, dim3(tiles * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, a);
     DSVC_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_wgrad_nt_reduce, dim3(ceil_div(K_pad, 1024), O), dim3(256), 0, st, wpart.as<float>(), S, O_pad, K_pad, O, segs, scale);
+    DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+// dW[o][k] = sum_n A[n][o] * B_seg[n + shift][k] over ALL rows of the workspace (gap rows are zero in every plane), the k axis = the segments'
+// 128-column tiles in order; bias_dst != nullptr: + the column sums of A.  Slices, XCD placement and the fixed-order reduction as wgrad_nt.
+int dsvc_trainer::wgrad_fm(const _Float16* a, int a_ld, int a_lo, int O, const WgradFmSeg* segs, int n_seg, const WgradSegs& rsegs, float scale,
+                           float* bias_dst, hipStream_t st) {
+    if (O % 256 || n_seg < 1 || n_seg > 4 || rows % 32) return fail(DSVC_EINVAL, "wgrad_fm: %d output rows, %d segments, %d frames", O, n_seg, rows);
+    int kt = 0;
+    for (int s = 0; s < n_seg; ++s) kt += segs[s].k_tiles;
+    const int K_pad = kt * 128, tiles = (O / 256) * kt;
+    int per_xcd = tiles <= 32 ? 32 / tiles : 1;
+    int S = 8 * per_xcd, xcd_map = 1;
+    if (S > rows / 128) { S = rows / 128 < 1 ? 1 : rows / 128; xcd_map = S % 8 == 0; }      // at least four 32-frame stages per slice
+    if ((long long)S * tiles > WGRAD_MAX_TILES) return fail(DSVC_EINVAL, "wgrad_fm: %d slices x %d output tiles exceed the partial-tile scratch", S, tiles);
+    WgradFmArgs w{};
+    w.a = a; w.a_ld = a_ld; w.a_lo = a_lo; w.n_seg = n_seg;
+    for (int s = 0; s < n_seg; ++s) w.seg[s] = segs[s];
+    w.n_total = rows; w.slice_len = round_up(ceil_div(rows, S), 32);
+    w.part = wpart.as<float>(); w.O_pad = O; w.K_pad = K_pad; w.tiles = tiles; w.xcd_map = xcd_map;
+    w.bias_part = bias_dst ? wbias.as<float>() : nullptr;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DSVC_HIP(hipFuncSetAttribute((const void*)wgrad_fm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_STAGES * WG_STAGE_BYTES));
+        DSVC_HIP(hipFuncSetAttribute((const void*)wgrad_fm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_STAGES * WG_STAGE_BYTES));
+        attr_set = true;
+    }
+    if (bias_dst) hipLaunchKernelGGL(wgrad_fm_kernel<true>, dim3(tiles * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, w);
+    else hipLaunchKernelGGL(wgrad_fm_kernel<false>, dim3(tiles * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, w);
+    DSVC_HIP(hipGetLastError());
+    // (the bias column sums are reduced by one more column of blocks of the same launch)
+    hipLaunchKernelGGL(k_wgrad_nt_reduce, dim3(ceil_div(K_pad, 1024) + (bias_dst ? 1 : 0), O), dim3(256), 0, st, wpart.as<float>(), S, O, K_pad, O, rsegs, scale,
+                       (const float*)w.bias_part, S * kt, bias_dst);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
@@ -1185,10 +1244,10 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
     {
         // the residual layers on the tgemm engine (epilogues above): operands as fp16 [hi | lo] row planes, every layer's stores as fp32 rows
         const int mpl = C / 16;
-        _Float16* xh = xhP.as<_Float16>() + (size_t)TGUARD * 2 * Cp;
+        _Float16* xh0 = xhP.as<_Float16>() + (size_t)TGUARD * 2 * Cp;      // layer l's planes: xh0 + l * xh_layer (fm: kept for the weight gradients)
         const size_t tslab = r * 2 * C;                                    // one layer of the accumulator-tiled conditioner projection (in ypre)
         const RowInfo ri_all{Tp, Tp, nr};
-        hipLaunchKernelGGL(k_rows_to_planes, dim3(2048), dim3(256), 0, st, xs.as<float>(), C, C, filmB.as<float>(), L * C, xh, Cp, ri, rows);
+        hipLaunchKernelGGL(k_rows_to_planes, dim3(2048), dim3(256), 0, st, xs.as<float>(), C, C, filmB.as<float>(), L * C, xh0, Cp, ri, rows);
         hipLaunchKernelGGL(k_rows_to_planes, dim3(2048), dim3(256), 0, st, condT.as<float>(), H, H, (const float*)nullptr, 0, condHP.as<_Float16>(), Hp, ri_all, rows);
         {
             const std::string q0 = "denoise_fn.residual_layers.0.", q1 = "denoise_fn.residual_layers.1.";
@@ -1200,16 +1259,18 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
             const int d = 1 << (l % cfg.dilation_cycle);
             float* xl = xs.as<float>() + (size_t)l * slab;
+            _Float16* xh = xh0 + (size_t)l * xh_layer;
+            _Float16* gh = ghP.as<_Float16>() + (size_t)l * gh_layer;
             {
                 TEpiGateT::Args e{ypre.as<float>() + (size_t)l * tslab, sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab,
-                                  g.as<float>() + (size_t)l * slab, ghP.as<_Float16>(), C, Cp, ri};
+                                  fm ? nullptr : g.as<float>() + (size_t)l * slab, gh, C, Cp, ri};
                 if (tgemm_smem<2>(3, d, 2 * Cp) <= 160 * 1024) DSVC_TRY(tg<TEpiGateT>(xh, Cp, 3, d, gate_t.as<_Float16>() + (size_t)l * gate_halfs, mpl, e, st));
                 else DSVC_TRY((tg<TEpiGateT, 1>(xh, Cp, 3, d, gate_t.as<_Float16>() + (size_t)l * gate_halfs, mpl, e, st, 128)));      // wide halos: streamed K
             }
             {
-                TEpiResSkipT::Args e{xl, xs.as<float>() + (size_t)(l + 1) * slab, skip.as<float>(), l + 1 < L ? xh : nullptr, P(q + "output_projection.bias"),
+                TEpiResSkipT::Args e{xl, xs.as<float>() + (size_t)(l + 1) * slab, skip.as<float>(), l + 1 < L ? xh + xh_layer : nullptr, P(q + "output_projection.bias"),
                                      filmB.as<float>() + (size_t)(l + 1 < L ? l + 1 : l) * C, L * C, C, Cp, l == 0 ? 1 : 0, ri};
-                DSVC_TRY(tg<TEpiResSkipT>(ghP.as<_Float16>(), Cp, 1, 1, out_t.as<_Float16>() + (size_t)l * out_halfs, mpl, e, st));
+                DSVC_TRY(tg<TEpiResSkipT>(gh, Cp, 1, 1, out_t.as<_Float16>() + (size_t)l * out_halfs, mpl, e, st));
             }
         }
     }
@@ -1269,9 +1330,14 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
         const int d = 1 << (l % cfg.dilation_cycle);
         const float* xl = xs.as<float>() + (size_t)l * slab;
         const float* gl = g.as<float>() + (size_t)l * slab;
-        DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias")));
-        DSVC_TRY(split_t(false, 0, gl, C, C, nullptr, 0, 0, st));
-        DSVC_TRY(wgrad_nt(2 * C, cp128, 0, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
+        if (fm) {   // dW_o[o][c] = sum_n dO[n][o] g[n][c] from the planes dg = W_o^T dO reads and the forward pass left (wgrad.h: wgrad_fm_kernel)
+            const WgradFmSeg sg{ghP.as<_Float16>() + (size_t)l * gh_layer, 2 * Cp, Cp, 0, C / 128};
+            DSVC_TRY(wgrad_fm(dOh.as<_Float16>(), 2 * C2p, C2p, 2 * C, &sg, 1, seg1(G(q + "output_projection.weight"), C, C), 1.0f, G(q + "output_projection.bias"), st));
+        } else {
+            DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias")));
+            DSVC_TRY(split_t(false, 0, gl, C, C, nullptr, 0, 0, st));
+            DSVC_TRY(wgrad_nt(2 * C, cp128, 0, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
+        }
         {   // dg = W_o^T dO -> dy, K = 2C streamed in phases of 256 (128 where 2C is not a multiple of 256) channels
             TEpiGateBwdT::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(),
                                  dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p, C, C2p, ri};
@@ -1279,13 +1345,22 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
         }
         // dW_d[o][c][tap] = sum_n dy[n][o] (x^l + film)[n + (tap-1) d][c]  and  dW_c[o][h] = sum_n dy[n][o] cond[n][h]  share dy^T: ONE
         // contraction over the k axis [tap 0 | tap 1 | tap 2 | cond]
-        DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "dilated_conv.bias")));
-        DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
-        DSVC_TRY(split_t(false, 0, xl, C, C, filmB.as<float>() + (size_t)l * C, L * C, d, st));
-        {
-            WgradSegs sg{};
-            sg.n = 3;
-            for (int tap = 0; tap < 3; ++tap) sg.s[tap] = WgradSeg{G(q + "dilated_conv.weight"), tap * cp128, C, (long long)C * 3, 3, tap};
+        WgradSegs sg{};
+        sg.n = 3;
+        for (int tap = 0; tap < 3; ++tap) sg.s[tap] = WgradSeg{G(q + "dilated_conv.weight"), tap * cp128, C, (long long)C * 3, 3, tap};
+        if (fm) {   // the three taps are row offsets of ONE copy of (x^l + film_l): the planes the forward gate conv read, guard rows included
+            const _Float16* xh = xhP.as<_Float16>() + (size_t)TGUARD * 2 * Cp + (size_t)l * xh_layer;
+            const _Float16* dyp = dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p;
+            WgradFmSeg taps[3];
+            for (int tap = 0; tap < 3; ++tap) taps[tap] = WgradFmSeg{xh, 2 * Cp, Cp, (tap - 1) * d, C / 128};
+            DSVC_TRY(wgrad_fm(dyp, 2 * C2p, C2p, 2 * C, taps, 3, sg, 1.0f, G(q + "dilated_conv.bias"), st));
+            DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
+            const WgradFmSeg cs{condHP.as<_Float16>(), 2 * Hp, Hp, 0, H / 128};
+            DSVC_TRY(wgrad_fm(dyp, 2 * C2p, C2p, 2 * C, &cs, 1, seg1(G(q + "conditioner_projection.weight"), H, H), 1.0f, nullptr, st));
+        } else {
+            DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "dilated_conv.bias")));
+            DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
+            DSVC_TRY(split_t(false, 0, xl, C, C, filmB.as<float>() + (size_t)l * C, L * C, d, st));
             DSVC_TRY(wgrad_nt(2 * C, 3 * cp128, 0, sg, 1.0f, st));
             // (one launch over [taps | cond] is 33 tiles at C = 384: one more than an XCD has CUs)
             DSVC_TRY(wgrad_nt(2 * C, hp128, 3 * cp128, seg1(G(q + "conditioner_projection.weight"), H, H), 1.0f, st));
@@ -1295,7 +1370,7 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
                                bin_order.as<int>(), bin_segs.as<int>(), bin_nsegs.as<int>(), T, Tp,
                                bin_S.as<float>() + (size_t)l * cfg.pitch_vocab * 2 * C, 2 * C);
         {   // dxin = convT(dy); dx <- dx / sqrt 2 + dxin; the residual half of dO (rows and planes) <- dx / sqrt 2
-            TEpiDxT::Args e{dx.as<float>(), dxin.as<float>(), dO.as<float>(), dOh.as<_Float16>(), C, C2p, ri};
+            TEpiDxT::Args e{dx.as<float>(), dxin.as<float>(), fm ? nullptr : dO.as<float>(), dOh.as<_Float16>(), C, C2p, ri};
             DSVC_TRY((tg<TEpiDxT, 1>(dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p, C2p, 3, d, dT_t.as<_Float16>() + (size_t)l * dT_halfs, C / 32, e, st, (C2p % 256 == 0 && (64 + 2 * d) * 2048 <= 160 * 1024) ? 256 : 128)));      // (two phase buffers of 64 + 2d rows in LDS)
         }
         hipLaunchKernelGGL(k_clip_colsum, dim3(ceil_div(C, 64), B), dim3(256), 0, st, dxin.as<float>(), dfilm.as<float>() + (size_t)l * C, T, C, Tp, L * C);

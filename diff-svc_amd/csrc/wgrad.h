@@ -207,6 +207,224 @@ wgrad_nt_kernel(const WgradNtArgs a) {
             }
 }
 
+// ---- round 5: the same contraction straight from the FRAME-MAJOR planes the layer kernels already write ------------------------------------
+// k_split_t is a pure layout pass: it re-reads the fp32 rows a producing epilogue wrote and writes them again, channel-major, once per operand and
+// conv tap (87 launches, 3.7 GB of HBM traffic and 10.6 % of the training step at the 64 x 128-frame batch, profiles/r5F_kernel_stats_train.csv).
+// Every operand of the residual layers' weight gradients ALSO exists as fp16 [hi | lo] row planes -- the tgemm layer kernels write them for their
+// own contractions (train.hip: TEpiGateT -> g, TEpiResSkipT -> x + film, TEpiGateBwdT -> dy, TEpiDxT -> dO), frame-major, zero on every gap row.
+// wgrad_fm_kernel contracts THOSE: a 32-frame stage of the A planes [32][256 channels] and of the B planes [32][128] is DMA'd into LDS as it
+// lies in memory (512 B / 256 B contiguous per frame), and gfx950's transposing LDS read (ds_read_b64_tr_b16) hands each lane the four
+// consecutive FRAMES of its channel that an MFMA fragment wants: within a 16-lane group, lane s supplies the address of 4 consecutive channels of
+// frame (s >> 2) and lane i receives channel i of the four frames.  Two such reads (frames f .. f+3, f+4 .. f+7) make one half8 fragment, at the
+// LDS cost of the one ds_read_b128 of the fragment-tiled planes.  A conv tap is a row offset of the B source (the planes carry guard rows), so the
+// three taps of a dilated conv read ONE copy of x.  The contraction runs over all rows, gap rows included: their products are zero (both operands
+// are), 6 % more MFMAs at 8 gap rows per 128-frame clip.
+// LDS image of a stage (48 KB): A hi [32 frames][512 B] | A lo | B hi [32][256 B] | B lo.  A frame's 64-byte blocks (32 channels) are XOR-swizzled
+// by (frame & 3) on the SOURCE side of the DMA, so the 4 frames x 64 B that 32 lanes of a transposing read touch cover all 64 banks once.
+// BIAS: the column sums of A (a bias gradient) ride along as MFMAs against a fragment of ones; the stages are dealt round-robin to the k tiles of
+// an output row block, each wave sums one 32-row tile: 2 more MFMAs per k16 step in one stage out of (k tiles).
+struct WgradFmSeg {
+    const _Float16* b;      // B planes, row 0 (guard rows precede where shift < 0): [n][ld] halfs, hi at column 0, lo `lo` halfs further
+    int ld, lo;
+    int shift;              // rows added to the frame index (a conv tap: (tap - 1) * dil)
+    int k_tiles;            // 128-column tiles of this segment on the k axis
+};
+struct WgradFmArgs {
+    const _Float16* a;      // A planes, row 0: [n][a_ld] halfs, hi at column 0, lo a_lo halfs further
+    int a_ld, a_lo;
+    WgradFmSeg seg[4];
+    int n_seg;
+    int n_total;            // rows to contract (% 32 == 0)
+    int slice_len;          // rows per slice (% 32 == 0)
+    float* part;            // [slices][O_pad][K_pad] partial tiles (as wgrad_nt_kernel)
+    int O_pad, K_pad, tiles, xcd_map;
+    float* bias_part;       // BIAS: [slices][K_pad / 128][O_pad] partial column sums of A
+};
+
+typedef short wg_short4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short wg_short8 __attribute__((__vector_size__(8 * sizeof(short))));
+
+// The transposing read as inline asm: through the builtin (__builtin_amdgcn_ds_read_tr16_b64_v4i16) hipcc puts an s_waitcnt vmcnt(0) in front of
+// the first read of every stage -- it cannot tell the read from the LDS-DMA pieces in flight for the stages after it, and the three-stage
+// pipeline collapses into load / wait / compute.  An asm read is invisible to that pass; its lgkmcnt wait is ours to place (wg_frags_wait ties the
+// registers to the wait so that no MFMA moves above it).
+template <int OFF>
+__device__ __forceinline__ void wg_tr_read(wg_short4& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+// the 8 fragments of one k16 step: A [i = 32-row tile][p = hi | lo], B [q][p]; each two 64-bit reads (frames f .. f+3 | f+4 .. f+7)
+struct WgFrags { wg_short4 a[2][2][2], b[2][2][2]; };
+template <int J>
+__device__ __forceinline__ void wg_frags_read(WgFrags& f, const unsigned (&adA)[2], const unsigned (&adB)[2]) {
+#define WG_RA(i, p, h) wg_tr_read<16384 * (p) + 8192 * J + 2048 * (h)>(f.a[i][p][h], adA[i])
+#define WG_RB(i, p, h) wg_tr_read<8192 * (p) + 4096 * J + 1024 * (h)>(f.b[i][p][h], adB[i])
+    WG_RA(0, 0, 0); WG_RA(0, 0, 1); WG_RB(0, 0, 0); WG_RB(0, 0, 1); WG_RB(1, 0, 0); WG_RB(1, 0, 1); WG_RA(1, 0, 0); WG_RA(1, 0, 1);
+    WG_RA(0, 1, 0); WG_RA(0, 1, 1); WG_RA(1, 1, 0); WG_RA(1, 1, 1); WG_RB(0, 1, 0); WG_RB(0, 1, 1); WG_RB(1, 1, 0); WG_RB(1, 1, 1);
+#undef WG_RA
+#undef WG_RB
+}
+__device__ __forceinline__ void wg_frags_wait(WgFrags& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.a[0][0][0]), "+v"(f.a[0][0][1]), "+v"(f.a[0][1][0]), "+v"(f.a[0][1][1]), "+v"(f.a[1][0][0]), "+v"(f.a[1][0][1]), "+v"(f.a[1][1][0]),
+                   "+v"(f.a[1][1][1])
+                 :: "memory");
+    asm volatile("" : "+v"(f.b[0][0][0]), "+v"(f.b[0][0][1]), "+v"(f.b[0][1][0]), "+v"(f.b[0][1][1]), "+v"(f.b[1][0][0]), "+v"(f.b[1][0][1]), "+v"(f.b[1][1][0]),
+                 "+v"(f.b[1][1][1]));
+}
+__device__ __forceinline__ half8 wg_frag(const wg_short4 (&v)[2]) {
+    const wg_short8 w = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(half8, w);
+}
+
+template <bool BIAS>
+__global__ void __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad_fm_kernel(const WgradFmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave >> 1, wk = wave & 1;                 // this wave's 64 x 64 corner of the 256 x 128 tile
+    int slice, tile;
+    if (a.xcd_map) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        slice = xcd + 8 * (j / a.tiles); tile = j % a.tiles;
+    } else {
+        slice = blockIdx.x / a.tiles; tile = blockIdx.x % a.tiles;
+    }
+    const int kt = a.K_pad >> 7;
+    const int ot = tile / kt, kti = tile - ot * kt;
+    const int o0 = ot * 256;
+    // the B source of this k tile (wave-uniform)
+    const _Float16* bsrc = a.seg[0].b;
+    int b_ld = a.seg[0].ld, b_lo = a.seg[0].lo, shift = a.seg[0].shift, kc0 = 0;
+    {
+        int ks = kti;
+        bool found = false;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (!found && s < a.n_seg) {
+                if (ks < a.seg[s].k_tiles) { bsrc = a.seg[s].b; b_ld = a.seg[s].ld; b_lo = a.seg[s].lo; shift = a.seg[s].shift; kc0 = ks * 128; found = true; }
+                else ks -= a.seg[s].k_tiles;
+            }
+        }
+    }
+    const int n_begin = slice * a.slice_len;
+    int n_end = n_begin + a.slice_len;
+    if (n_end > a.n_total) n_end = a.n_total;
+    const int stages = n_end > n_begin ? (n_end - n_begin) >> 5 : 0;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    auto dma = [&](int s) {
+        char* dst = smem + (s % WG_STAGES) * WG_STAGE_BYTES;
+        const long long n = n_begin + s * 32;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int pc = wave + 8 * i;                       // KiB pieces 0..15: A hi (2 frames each), 16..31: A lo, 32..39: B hi (4 frames each), 40..47: B lo
+            const _Float16* src;
+            if (i < 4) {
+                const int p = i >> 1, fr = 2 * (pc & 15) + (lane >> 5);
+                const int c = (lane & 31) ^ ((fr & 3) << 2);   // 16-byte chunk of the source row that lands in LDS chunk (lane & 31)
+                src = a.a + (n + fr) * (long long)a.a_ld + (long long)p * a.a_lo + o0 + c * 8;
+            } else {
+                const int p = i - 4, fr = 4 * (pc & 7) + (lane >> 4);
+                const int c = (lane & 15) ^ ((fr & 3) << 2);
+                src = bsrc + (n + fr + shift) * (long long)b_ld + (long long)p * b_lo + kc0 + c * 8;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+
+    // fragment addresses: lane (i = lane & 15, g = lane >> 4) supplies frame 8 (g >> 1) + (i >> 2) [+ 4 for the second read], channels
+    // 16 (g & 1) + 4 (i & 3) .. + 3 of a 32-channel block; block b of frame f sits at b ^ (f & 3)
+    const int li = lane & 15, lg = lane >> 4;
+    const unsigned fr_l = 8u * (unsigned)(lg >> 1) + (unsigned)(li >> 2);
+    const unsigned inblk = 32u * (unsigned)(lg & 1) + 8u * (unsigned)(li & 3);
+    unsigned baseA[2], baseB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        baseA[i] = lds0 + fr_l * 512u + ((((unsigned)(2 * wo + i)) ^ (unsigned)(li >> 2)) << 6) + inblk;
+        baseB[i] = lds0 + 32768u + fr_l * 256u + ((((unsigned)(2 * wk + i)) ^ (unsigned)(li >> 2)) << 6) + inblk;
+    }
+
+    f32x16 acc[2][2], accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    half8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
+
+    auto products = [&](const WgFrags& f, bool bias_stage) {
+        half8 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) { fa[i][p] = wg_frag(f.a[i][p]); fb[i][p] = wg_frag(f.b[i][p]); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[q][0], acc[i][q], 0, 0, 0);
+                acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[q][0], acc[i][q], 0, 0, 0);
+                acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[q][1], acc[i][q], 0, 0, 0);
+            }
+        if constexpr (BIAS) {
+            if (bias_stage) {
+                const half8 ah = wk ? fa[1][0] : fa[0][0], al = wk ? fa[1][1] : fa[0][1];
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ones, accb, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ones, accb, 0, 0, 0);
+            }
+        }
+    };
+
+    if (stages > 0) dma(0);
+    if (stages > 1) dma(1);
+    for (int s = 0; s < stages; ++s) {
+        // (as wgrad_nt_kernel: this wave's only vector-memory traffic is its 6 DMA pieces per stage)
+        if (s + 1 < stages) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 2 < stages) dma(s + 2);
+        const unsigned sb = (unsigned)(s % WG_STAGES) * WG_STAGE_BYTES;
+        const bool bias_stage = BIAS && (((n_begin >> 5) + s) % kt) == kti;
+        const unsigned adA[2] = {baseA[0] + sb, baseA[1] + sb}, adB[2] = {baseB[0] + sb, baseB[1] + sb};
+        WgFrags f0, f1;
+        wg_frags_read<0>(f0, adA, adB);
+        wg_frags_wait(f0);
+        wg_frags_read<1>(f1, adA, adB);                        // the second k16 step's reads fly under the first one's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        products(f0, bias_stage);
+        __builtin_amdgcn_sched_barrier(0);
+        wg_frags_wait(f1);
+        products(f1, bias_stage);
+    }
+    // partial tile: accumulator register r of lane l = row 8 (r >> 2) + 4 (l >> 5) + (r & 3), column l & 31
+    float* out = a.part + ((size_t)slice * a.O_pad + o0 + wo * 64) * a.K_pad + kti * 128 + wk * 64 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                out[(size_t)row * a.K_pad + q * 32] = acc[i][q][r];
+            }
+    if constexpr (BIAS) {
+        if ((lane & 31) == 0) {                                // every column of accb holds the row sums: take column 0
+            float* bp = a.bias_part + ((size_t)slice * kt + kti) * a.O_pad + o0 + wo * 64 + wk * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bp[8 * (r >> 2) + (r & 3)] = accb[r];
+        }
+    }
+}
+
 // ---- slice reduction + scatter into the parameter gradients -----------------------------------------------------------------------
 // The k axis of a launch may concatenate several operands (the three taps of a dilated conv and its conditioner projection share dY):
 // segment s covers columns [k_begin, k_begin + k_len) and lands at dst[o * stride_o + (k - k_begin) * stride_k + off].
@@ -214,7 +432,22 @@ struct WgradSeg { float* dst; int k_begin, k_len; long long stride_o, stride_k, 
 struct WgradSegs { WgradSeg s[4]; int n; };
 
 __global__ __launch_bounds__(256) void k_wgrad_nt_reduce(const float* __restrict__ part, int n_slices, int O_pad, int K_pad, int n_o, WgradSegs segs,
-                                                         float scale) {
+                                                         float scale, const float* __restrict__ bias_part = nullptr, int n_bias = 0,
+                                                         float* __restrict__ bias_dst = nullptr) {
+    if (bias_part && blockIdx.x == gridDim.x - 1) {
+        // wgrad_fm_kernel<BIAS>'s partial column sums [n_bias][O_pad] ride on this launch (grid.x has one more column): block y sums 64 outputs,
+        // four threads per output walk the partials, thread group 0 adds the four in a fixed order
+        __shared__ float red[4][64];
+        const int o = blockIdx.y * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
+        if (blockIdx.y * 64 >= n_o) return;
+        float v = 0.f;
+        if (o < n_o)
+            for (int z = zl; z < n_bias; z += 4) v += bias_part[(size_t)z * O_pad + o];
+        red[zl][threadIdx.x & 63] = v;
+        __syncthreads();
+        if (zl == 0 && o < n_o) bias_dst[o] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * scale;
+        return;
+    }
     const int k = (blockIdx.x * 256 + threadIdx.x) * 4;           // four adjacent columns per thread (segments begin at multiples of 128, lengths % 4 == 0)
     const int o = blockIdx.y;
     if (k >= K_pad || o >= n_o) return;
@@ -226,6 +459,7 @@ __global__ __launch_bounds__(256) void k_wgrad_nt_reduce(const float* __restrict
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t slice = (size_t)O_pad * K_pad;
     const float* p = part + (size_t)o * K_pad + k;
+#pragma unroll 8
     for (int z = 0; z < n_slices; ++z) {
         const float4 x = *reinterpret_cast<const float4*>(p + z * slice);
         v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
