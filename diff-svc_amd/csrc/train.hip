@@ -829,8 +829,13 @@ struct dsvc_trainer {
     bool fm = false;
     size_t xh_layer = 0, gh_layer = 0;             // halfs between the layers' planes in xhP / ghP (0: one buffer all layers share)
     DevBuf wbias;                                  // partial column sums (bias gradients) of one wgrad_fm launch: [slices][k tiles][O_pad]
-    int wgrad_fm(const _Float16* a, int a_ld, int a_lo, int O, const WgradFmSeg* segs, int n_seg, const WgradSegs& rsegs, float scale, float* bias_dst,
-                 hipStream_t st);
+    struct FmProb {                                // one contraction: dW[o][k] = sum_n A[n][o] * B_seg[n + shift][k]; bias_dst (and bias_dst2) <- column sums of A
+        const _Float16* a; int a_ld, a_lo, O;
+        const WgradFmSeg* segs; int n_seg;
+        WgradSegs rsegs; float scale;
+        float* bias_dst; float* bias_dst2;
+    };
+    int wgrad_fm(const FmProb* probs, int n_prob, hipStream_t st);
     DevBuf t_gate_rm, t_gate_rs, t_out_rm;         // packed row -> source channel (+ the gate rows' pre-scale)
     std::vector<TPackDesc> tpack_q;
     DevBuf tpack_dev;
@@ -1120,36 +1125,63 @@ int dsvc_trainer::wgrad_nt(int O, int K_pad, int b_row0, const WgradSegs& segs, 
     return DSVC_OK;
 }
 
-// dW[o][k] = sum_n A[n][o] * B_seg[n + shift][k] over ALL rows of the workspace (gap rows are zero in every plane), the k axis = the segments'
+// One or two contractions dW[o][k] = sum_n A[n][o] * B_seg[n + shift][k] in one launch (wgrad.h: wgrad_fm_kernel), the k axis = the segments'
 // 128-column tiles in order; bias_dst != nullptr: + the column sums of A.  Slices, XCD placement and the fixed-order reduction as wgrad_nt.
-int dsvc_trainer::wgrad_fm(const _Float16* a, int a_ld, int a_lo, int O, const WgradFmSeg* segs, int n_seg, const WgradSegs& rsegs, float scale,
-                           float* bias_dst, hipStream_t st) {
-    if (O % 256 || n_seg < 1 || n_seg > 4 || rows % 32) return fail(DSVC_EINVAL, "wgrad_fm: %d output rows, %d segments, %d frames", O, n_seg, rows);
-    int kt = 0;
-    for (int s = 0; s < n_seg; ++s) kt += segs[s].k_tiles;
-    const int K_pad = kt * 128, tiles = (O / 256) * kt;
-    int per_xcd = tiles <= 32 ? 32 / tiles : 1;
+// Two contractions share the launch when their output tiles fit an XCD together (the output projection's 9 and the conditioner projection's 6):
+// 2 x 8 slices each and 240 workgroups instead of 24 / 40 thin slices in two launches that each leave the chip waiting for its last workgroups.
+int dsvc_trainer::wgrad_fm(const FmProb* probs, int n_prob, hipStream_t st) {
+    if (n_prob < 1 || n_prob > 2 || rows % 32) return fail(DSVC_EINVAL, "wgrad_fm: %d contractions over %d rows", n_prob, rows);
+    int tiles[2] = {0, 0}, kts[2] = {0, 0};
+    for (int i = 0; i < n_prob; ++i) {
+        if (probs[i].O % 256 || probs[i].n_seg < 1 || probs[i].n_seg > 4) return fail(DSVC_EINVAL, "wgrad_fm: %d output rows, %d segments", probs[i].O, probs[i].n_seg);
+        for (int s = 0; s < probs[i].n_seg; ++s) kts[i] += probs[i].segs[s].k_tiles;
+        tiles[i] = (probs[i].O / 256) * kts[i];
+    }
+    if (n_prob == 2 && tiles[0] + tiles[1] > 32) {          // no room for a slice of each on an XCD: two launches
+        DSVC_TRY(wgrad_fm(probs, 1, st));
+        return wgrad_fm(probs + 1, 1, st);
+    }
+    // gap rows are zero in every plane: with whole 32-row stages per clip they are skipped
+    const int spc = wsT % 32 == 0 ? wsT / 32 : 0;
+    const int n_stages = spc ? wsB * spc : rows / 32;
+    const int tsum = tiles[0] + tiles[1];
+    int per_xcd = tsum <= 32 ? 32 / tsum : 1;
     int S = 8 * per_xcd, xcd_map = 1;
-    if (S > rows / 128) { S = rows / 128 < 1 ? 1 : rows / 128; xcd_map = S % 8 == 0; }      // at least four 32-frame stages per slice
-    if ((long long)S * tiles > WGRAD_MAX_TILES) return fail(DSVC_EINVAL, "wgrad_fm: %d slices x %d output tiles exceed the partial-tile scratch", S, tiles);
+    if (S > n_stages / 4) {                                 // at least four stages per slice
+        if (n_prob == 2) { DSVC_TRY(wgrad_fm(probs, 1, st)); return wgrad_fm(probs + 1, 1, st); }
+        S = n_stages / 4 < 1 ? 1 : n_stages / 4; xcd_map = S % 8 == 0;
+    }
+    if ((long long)S * tsum > WGRAD_MAX_TILES) return fail(DSVC_EINVAL, "wgrad_fm: %d slices x %d output tiles exceed the partial-tile scratch", S, tsum);
     WgradFmArgs w{};
-    w.a = a; w.a_ld = a_ld; w.a_lo = a_lo; w.n_seg = n_seg;
-    for (int s = 0; s < n_seg; ++s) w.seg[s] = segs[s];
-    w.n_total = rows; w.slice_len = round_up(ceil_div(rows, S), 32);
-    w.part = wpart.as<float>(); w.O_pad = O; w.K_pad = K_pad; w.tiles = tiles; w.xcd_map = xcd_map;
-    w.bias_part = bias_dst ? wbias.as<float>() : nullptr;
+    w.n_prob = n_prob; w.wgs0 = S * tiles[0]; w.n_stages = n_stages; w.clip_rows = Tp; w.spc = spc; w.xcd_map = xcd_map;
+    float* part = wpart.as<float>();
+    float* bpart = wbias.as<float>();
+    bool any_bias = false;
+    for (int i = 0; i < n_prob; ++i) {
+        WgradFmProb& q = w.p[i];
+        q.a = probs[i].a; q.a_ld = probs[i].a_ld; q.a_lo = probs[i].a_lo; q.n_seg = probs[i].n_seg;
+        for (int s = 0; s < probs[i].n_seg; ++s) q.seg[s] = probs[i].segs[s];
+        q.slices = S; q.slice_stages = ceil_div(n_stages, S);
+        q.part = part; q.O_pad = probs[i].O; q.K_pad = kts[i] * 128; q.tiles = tiles[i];
+        q.bias_part = probs[i].bias_dst ? bpart : nullptr;
+        any_bias = any_bias || probs[i].bias_dst;
+        part += (size_t)S * tiles[i] * 256 * 128;
+        bpart += (size_t)S * tiles[i] * 256;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         DSVC_HIP(hipFuncSetAttribute((const void*)wgrad_fm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_STAGES * WG_STAGE_BYTES));
         DSVC_HIP(hipFuncSetAttribute((const void*)wgrad_fm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_STAGES * WG_STAGE_BYTES));
         attr_set = true;
     }
-    if (bias_dst) hipLaunchKernelGGL(wgrad_fm_kernel<true>, dim3(tiles * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, w);
-    else hipLaunchKernelGGL(wgrad_fm_kernel<false>, dim3(tiles * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, w);
+    if (any_bias) hipLaunchKernelGGL(wgrad_fm_kernel<true>, dim3(S * tsum), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, w);
+    else hipLaunchKernelGGL(wgrad_fm_kernel<false>, dim3(S * tsum), dim3(512), WG_STAGES * WG_STAGE_BYTES, st, w);
     DSVC_HIP(hipGetLastError());
-    // (the bias column sums are reduced by one more column of blocks of the same launch)
-    hipLaunchKernelGGL(k_wgrad_nt_reduce, dim3(ceil_div(K_pad, 1024) + (bias_dst ? 1 : 0), O), dim3(256), 0, st, wpart.as<float>(), S, O, K_pad, O, rsegs, scale,
-                       (const float*)w.bias_part, S * kt, bias_dst);
+    for (int i = 0; i < n_prob; ++i) {      // (the bias column sums are reduced by one more column of blocks of the same launch)
+        const WgradFmProb& q = w.p[i];
+        hipLaunchKernelGGL(k_wgrad_nt_reduce, dim3(ceil_div(q.K_pad, 1024) + (q.bias_part ? 1 : 0), q.O_pad), dim3(256), 0, st, q.part, S, q.O_pad, q.K_pad,
+                           q.O_pad, probs[i].rsegs, probs[i].scale, (const float*)q.bias_part, S * kts[i], probs[i].bias_dst, probs[i].bias_dst2);
+    }
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
@@ -1330,14 +1362,11 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
         const int d = 1 << (l % cfg.dilation_cycle);
         const float* xl = xs.as<float>() + (size_t)l * slab;
         const float* gl = g.as<float>() + (size_t)l * slab;
-        if (fm) {   // dW_o[o][c] = sum_n dO[n][o] g[n][c] from the planes dg = W_o^T dO reads and the forward pass left (wgrad.h: wgrad_fm_kernel)
-            const WgradFmSeg sg{ghP.as<_Float16>() + (size_t)l * gh_layer, 2 * Cp, Cp, 0, C / 128};
-            DSVC_TRY(wgrad_fm(dOh.as<_Float16>(), 2 * C2p, C2p, 2 * C, &sg, 1, seg1(G(q + "output_projection.weight"), C, C), 1.0f, G(q + "output_projection.bias"), st));
-        } else {
+        if (!fm) {
             DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias")));
             DSVC_TRY(split_t(false, 0, gl, C, C, nullptr, 0, 0, st));
             DSVC_TRY(wgrad_nt(2 * C, cp128, 0, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
-        }
+        }   // (fm: dW_o shares a launch with the conditioner projection's gradient below -- dOh is intact until this layer's TEpiDxT)
         {   // dg = W_o^T dO -> dy, K = 2C streamed in phases of 256 (128 where 2C is not a multiple of 256) channels
             TEpiGateBwdT::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(),
                                  dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p, C, C2p, ri};
@@ -1353,10 +1382,13 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             const _Float16* dyp = dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p;
             WgradFmSeg taps[3];
             for (int tap = 0; tap < 3; ++tap) taps[tap] = WgradFmSeg{xh, 2 * Cp, Cp, (tap - 1) * d, C / 128};
-            DSVC_TRY(wgrad_fm(dyp, 2 * C2p, C2p, 2 * C, taps, 3, sg, 1.0f, G(q + "dilated_conv.bias"), st));
-            DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));
-            const WgradFmSeg cs{condHP.as<_Float16>(), 2 * Hp, Hp, 0, H / 128};
-            DSVC_TRY(wgrad_fm(dyp, 2 * C2p, C2p, 2 * C, &cs, 1, seg1(G(q + "conditioner_projection.weight"), H, H), 1.0f, nullptr, st));
+            const FmProb conv{dyp, 2 * C2p, C2p, 2 * C, taps, 3, sg, 1.0f, G(q + "dilated_conv.bias"), G(q + "conditioner_projection.bias")};
+            DSVC_TRY(wgrad_fm(&conv, 1, st));
+            // dW_o[o][c] = sum_n dO[n][o] g[n][c] (the planes dg = W_o^T dO read and the forward pass left) and dW_c[o][h] = sum_n dy[n][o] cond[n][h]: one launch
+            const WgradFmSeg gs{ghP.as<_Float16>() + (size_t)l * gh_layer, 2 * Cp, Cp, 0, C / 128}, cs{condHP.as<_Float16>(), 2 * Hp, Hp, 0, H / 128};
+            const FmProb two[2] = {{dOh.as<_Float16>(), 2 * C2p, C2p, 2 * C, &gs, 1, seg1(G(q + "output_projection.weight"), C, C), 1.0f, G(q + "output_projection.bias"), nullptr},
+                                   {dyp, 2 * C2p, C2p, 2 * C, &cs, 1, seg1(G(q + "conditioner_projection.weight"), H, H), 1.0f, nullptr, nullptr}};
+            DSVC_TRY(wgrad_fm(two, 2, st));
         } else {
             DSVC_TRY(split_t(true, 0, dy.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "dilated_conv.bias")));
             DSVC_HIP(hipMemcpyAsync(G(q + "conditioner_projection.bias"), G(q + "dilated_conv.bias"), (size_t)2 * C * 4, hipMemcpyDeviceToDevice, st));

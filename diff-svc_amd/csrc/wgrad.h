@@ -229,16 +229,29 @@ struct WgradFmSeg {
     int shift;              // rows added to the frame index (a conv tap: (tap - 1) * dil)
     int k_tiles;            // 128-column tiles of this segment on the k axis
 };
-struct WgradFmArgs {
+// one contraction of a launch
+struct WgradFmProb {
     const _Float16* a;      // A planes, row 0: [n][a_ld] halfs, hi at column 0, lo a_lo halfs further
     int a_ld, a_lo;
     WgradFmSeg seg[4];
     int n_seg;
-    int n_total;            // rows to contract (% 32 == 0)
-    int slice_len;          // rows per slice (% 32 == 0)
-    float* part;            // [slices][O_pad][K_pad] partial tiles (as wgrad_nt_kernel)
-    int O_pad, K_pad, tiles, xcd_map;
-    float* bias_part;       // BIAS: [slices][K_pad / 128][O_pad] partial column sums of A
+    int slices;             // frame slices (blockIdx -> slice, tile as wgrad_nt_kernel; xcd_map: a multiple of 8, every XCD gets whole slices)
+    int slice_stages;       // 32-row stages per slice
+    float* part;            // [slices][O_pad][K_pad] partial tiles
+    int O_pad, K_pad, tiles;
+    float* bias_part;       // BIAS: [slices][K_pad / 128][O_pad] partial column sums of A, or null
+};
+// A launch runs ONE or TWO contractions (`n_prob`): two that would each leave CUs idle or need many thin slices to fill the chip -- a layer's output
+// projection (9 output tiles) and its conditioner projection (6) -- share a grid: workgroups [0, wgs0) belong to p[0], the rest to p[1] (with
+// xcd_map per XCD: the first wgs0 / 8 workgroups of an XCD).
+// Rows: stage t covers rows 32 t .. 32 t + 31 of the workspace -- or, with spc > 0 (every clip holds spc whole stages: T % 32 == 0), the rows
+// clip_rows * (t / spc) + 32 * (t % spc) ..: the gap rows between clips (zeros in every plane: 6 % of the rows at 128 + 8) are not contracted.
+struct WgradFmArgs {
+    WgradFmProb p[2];
+    int n_prob, wgs0;
+    int n_stages;           // stages in all
+    int clip_rows, spc;
+    int xcd_map;
 };
 
 typedef short wg_short4 __attribute__((__vector_size__(4 * sizeof(short))));
@@ -284,39 +297,54 @@ wgrad_fm_kernel(const WgradFmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave >> 1, wk = wave & 1;                 // this wave's 64 x 64 corner of the 256 x 128 tile
-    int slice, tile;
+    // which contraction, which slice, which output tile
+    int prob = 0, slice, tile;
     if (a.xcd_map) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        slice = xcd + 8 * (j / a.tiles); tile = j % a.tiles;
+        const int xcd = blockIdx.x & 7;
+        int j = blockIdx.x >> 3;
+        const int per0 = a.wgs0 >> 3;
+        if (a.n_prob > 1 && j >= per0) { prob = 1; j -= per0; }
+        const int tl = a.p[prob].tiles;
+        slice = xcd + 8 * (j / tl); tile = j % tl;
     } else {
-        slice = blockIdx.x / a.tiles; tile = blockIdx.x % a.tiles;
+        int j = blockIdx.x;
+        if (a.n_prob > 1 && j >= a.wgs0) { prob = 1; j -= a.wgs0; }
+        const int tl = a.p[prob].tiles;
+        slice = j / tl; tile = j % tl;
     }
-    const int kt = a.K_pad >> 7;
+    const WgradFmProb& P = a.p[prob];
+    const int kt = P.K_pad >> 7;
     const int ot = tile / kt, kti = tile - ot * kt;
     const int o0 = ot * 256;
     // the B source of this k tile (wave-uniform)
-    const _Float16* bsrc = a.seg[0].b;
-    int b_ld = a.seg[0].ld, b_lo = a.seg[0].lo, shift = a.seg[0].shift, kc0 = 0;
+    const _Float16* bsrc = P.seg[0].b;
+    int b_ld = P.seg[0].ld, b_lo = P.seg[0].lo, shift = P.seg[0].shift, kc0 = 0;
     {
         int ks = kti;
         bool found = false;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            if (!found && s < a.n_seg) {
-                if (ks < a.seg[s].k_tiles) { bsrc = a.seg[s].b; b_ld = a.seg[s].ld; b_lo = a.seg[s].lo; shift = a.seg[s].shift; kc0 = ks * 128; found = true; }
-                else ks -= a.seg[s].k_tiles;
+            if (!found && s < P.n_seg) {
+                if (ks < P.seg[s].k_tiles) { bsrc = P.seg[s].b; b_ld = P.seg[s].ld; b_lo = P.seg[s].lo; shift = P.seg[s].shift; kc0 = ks * 128; found = true; }
+                else ks -= P.seg[s].k_tiles;
             }
         }
     }
-    const int n_begin = slice * a.slice_len;
-    int n_end = n_begin + a.slice_len;
-    if (n_end > a.n_total) n_end = a.n_total;
-    const int stages = n_end > n_begin ? (n_end - n_begin) >> 5 : 0;
+    const _Float16* asrc = P.a;
+    const int a_ld = P.a_ld, a_lo = P.a_lo;
+    const int st_begin = slice * P.slice_stages;
+    int st_end = st_begin + P.slice_stages;
+    if (st_end > a.n_stages) st_end = a.n_stages;
+    const int stages = st_end > st_begin ? st_end - st_begin : 0;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // row of the next stage to DMA (stages are DMA'd in order): one division here, then increments
+    int dma_c = 0;
+    long long dma_row = (long long)st_begin * 32;
+    if (a.spc > 0) { const int cl = st_begin / a.spc; dma_c = st_begin - cl * a.spc; dma_row = (long long)cl * a.clip_rows + (long long)dma_c * 32; }
 
     auto dma = [&](int s) {
         char* dst = smem + (s % WG_STAGES) * WG_STAGE_BYTES;
-        const long long n = n_begin + s * 32;
+        const long long n = dma_row;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int pc = wave + 8 * i;                       // KiB pieces 0..15: A hi (2 frames each), 16..31: A lo, 32..39: B hi (4 frames each), 40..47: B lo
@@ -324,7 +352,7 @@ wgrad_fm_kernel(const WgradFmArgs a) {
             if (i < 4) {
                 const int p = i >> 1, fr = 2 * (pc & 15) + (lane >> 5);
                 const int c = (lane & 31) ^ ((fr & 3) << 2);   // 16-byte chunk of the source row that lands in LDS chunk (lane & 31)
-                src = a.a + (n + fr) * (long long)a.a_ld + (long long)p * a.a_lo + o0 + c * 8;
+                src = asrc + (n + fr) * (long long)a_ld + (long long)p * a_lo + o0 + c * 8;
             } else {
                 const int p = i - 4, fr = 4 * (pc & 7) + (lane >> 4);
                 const int c = (lane & 15) ^ ((fr & 3) << 2);
@@ -333,6 +361,8 @@ wgrad_fm_kernel(const WgradFmArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
         }
+        dma_row += 32;
+        if (a.spc > 0 && ++dma_c == a.spc) { dma_c = 0; dma_row += a.clip_rows - 32 * a.spc; }
     };
 
     // fragment addresses: lane (i = lane & 15, g = lane >> 4) supplies frame 8 (g >> 1) + (i >> 2) [+ 4 for the second read], channels
@@ -393,7 +423,7 @@ wgrad_fm_kernel(const WgradFmArgs a) {
         asm volatile("" ::: "memory");
         if (s + 2 < stages) dma(s + 2);
         const unsigned sb = (unsigned)(s % WG_STAGES) * WG_STAGE_BYTES;
-        const bool bias_stage = BIAS && (((n_begin >> 5) + s) % kt) == kti;
+        const bool bias_stage = BIAS && P.bias_part && ((st_begin + s) % kt) == kti;
         const unsigned adA[2] = {baseA[0] + sb, baseA[1] + sb}, adB[2] = {baseB[0] + sb, baseB[1] + sb};
         WgFrags f0, f1;
         wg_frags_read<0>(f0, adA, adB);
@@ -406,7 +436,7 @@ wgrad_fm_kernel(const WgradFmArgs a) {
         products(f1, bias_stage);
     }
     // partial tile: accumulator register r of lane l = row 8 (r >> 2) + 4 (l >> 5) + (r & 3), column l & 31
-    float* out = a.part + ((size_t)slice * a.O_pad + o0 + wo * 64) * a.K_pad + kti * 128 + wk * 64 + (lane & 31);
+    float* out = P.part + ((size_t)slice * P.O_pad + o0 + wo * 64) * P.K_pad + kti * 128 + wk * 64 + (lane & 31);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -414,11 +444,11 @@ wgrad_fm_kernel(const WgradFmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                out[(size_t)row * a.K_pad + q * 32] = acc[i][q][r];
+                out[(size_t)row * P.K_pad + q * 32] = acc[i][q][r];
             }
     if constexpr (BIAS) {
-        if ((lane & 31) == 0) {                                // every column of accb holds the row sums: take column 0
-            float* bp = a.bias_part + ((size_t)slice * kt + kti) * a.O_pad + o0 + wo * 64 + wk * 32 + 4 * (lane >> 5);
+        if (P.bias_part && (lane & 31) == 0) {                                // every column of accb holds the row sums: take column 0
+            float* bp = P.bias_part + ((size_t)slice * kt + kti) * P.O_pad + o0 + wo * 64 + wk * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int r = 0; r < 16; ++r) bp[8 * (r >> 2) + (r & 3)] = accb[r];
         }
@@ -433,7 +463,7 @@ struct WgradSegs { WgradSeg s[4]; int n; };
 
 __global__ __launch_bounds__(256) void k_wgrad_nt_reduce(const float* __restrict__ part, int n_slices, int O_pad, int K_pad, int n_o, WgradSegs segs,
                                                          float scale, const float* __restrict__ bias_part = nullptr, int n_bias = 0,
-                                                         float* __restrict__ bias_dst = nullptr) {
+                                                         float* __restrict__ bias_dst = nullptr, float* __restrict__ bias_dst2 = nullptr) {
     if (bias_part && blockIdx.x == gridDim.x - 1) {
         // wgrad_fm_kernel<BIAS>'s partial column sums [n_bias][O_pad] ride on this launch (grid.x has one more column): block y sums 64 outputs,
         // four threads per output walk the partials, thread group 0 adds the four in a fixed order
@@ -445,7 +475,11 @@ __global__ __launch_bounds__(256) void k_wgrad_nt_reduce(const float* __restrict
             for (int z = zl; z < n_bias; z += 4) v += bias_part[(size_t)z * O_pad + o];
         red[zl][threadIdx.x & 63] = v;
         __syncthreads();
-        if (zl == 0 && o < n_o) bias_dst[o] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * scale;
+        if (zl == 0 && o < n_o) {
+            const float r = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * scale;
+            bias_dst[o] = r;
+            if (bias_dst2) bias_dst2[o] = r;                   // (a second tensor with the same gradient: the conditioner projection's bias)
+        }
         return;
     }
     const int k = (blockIdx.x * 256 + threadIdx.x) * 4;           // four adjacent columns per thread (segments begin at multiples of 128, lengths % 4 == 0)

@@ -63,7 +63,10 @@ int main() {
     const int a_ld = 2 * O, a_lo = O, x_ld = 2 * C, x_lo = C, c_ld = 2 * H, c_lo = H;
     std::vector<_Float16> ha((size_t)rows * a_ld), hx((size_t)(rows + 2 * GUARD) * x_ld), hc((size_t)rows * c_ld);
     srand(7);
-    for (size_t i = 0; i < ha.size(); ++i) { const bool lo = (i % a_ld) >= (size_t)a_lo; ha[i] = (_Float16)(frand() * (lo ? 4e-4f : 1.0f)); }
+    for (size_t i = 0; i < ha.size(); ++i) {
+        const bool lo = (i % a_ld) >= (size_t)a_lo, gap = (i / a_ld) % 136 >= 128;         // clips of 128 frames, 136 rows apart; gap rows are zero as in the trainer's planes
+        ha[i] = gap ? (_Float16)0.f : (_Float16)(frand() * (lo ? 4e-4f : 1.0f));
+    }
     for (size_t i = 0; i < hx.size(); ++i) { const bool lo = (i % x_ld) >= (size_t)x_lo; hx[i] = (_Float16)(frand() * (lo ? 4e-4f : 1.0f)); }
     for (size_t i = 0; i < hc.size(); ++i) { const bool lo = (i % c_ld) >= (size_t)c_lo; hc[i] = (_Float16)(frand() * (lo ? 4e-4f : 1.0f)); }
     _Float16 *da, *dx, *dc;
@@ -74,51 +77,68 @@ int main() {
     CK(hipFuncSetAttribute((const void*)wgrad_fm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_STAGES * WG_STAGE_BYTES));
     CK(hipFuncSetAttribute((const void*)wgrad_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_STAGES * WG_STAGE_BYTES));
 
-    auto run_case = [&](const char* name, int n_seg, const WgradFmSeg* segs, int n_rows, int S, bool with_bias, int reps) -> int {
-        int kt = 0;
-        for (int s = 0; s < n_seg; ++s) kt += segs[s].k_tiles;
-        const int K_pad = kt * 128, O_pad = 768, tiles = (O_pad / 256) * kt;
+    // one launch of one or two contractions (the second, if any: the conditioner-like source `cond2` against the same A), checked against float64
+    auto run_case = [&](const char* name, int n_seg, const WgradFmSeg* segs, int n_rows, int S, bool with_bias, int reps, int spc = 0, int clip_rows = 0,
+                        const WgradFmSeg* second = nullptr) -> int {
+        const int n_prob = second ? 2 : 1;
+        const WgradFmSeg* sgs[2] = {segs, second};
+        const int nsg[2] = {n_seg, 1};
+        int kt[2] = {0, 0}, tiles[2] = {0, 0};
+        for (int q = 0; q < n_prob; ++q) { for (int s = 0; s < nsg[q]; ++s) kt[q] += sgs[q][s].k_tiles; tiles[q] = 3 * kt[q]; }
+        const int O_pad = 768, tsum = tiles[0] + tiles[1];
         WgradFmArgs a{};
-        a.a = da; a.a_ld = a_ld; a.a_lo = a_lo; a.n_seg = n_seg;
-        for (int s = 0; s < n_seg; ++s) a.seg[s] = segs[s];
-        a.n_total = n_rows; a.slice_len = round_up(ceil_div(n_rows, S), 32);
-        a.O_pad = O_pad; a.K_pad = K_pad; a.tiles = tiles; a.xcd_map = S % 8 == 0;
-        float *part, *bpart, *dw, *db;
-        CK(hipMalloc(&part, (size_t)S * O_pad * K_pad * 4)); CK(hipMalloc(&bpart, (size_t)S * kt * O_pad * 4));
-        CK(hipMalloc(&dw, (size_t)O * K_pad * 4)); CK(hipMalloc(&db, O * 4));
-        a.part = part; a.bias_part = with_bias ? bpart : nullptr;
-        WgradSegs rs{}; rs.n = 1; rs.s[0] = WgradSeg{dw, 0, K_pad, (long long)K_pad, 1, 0};
+        a.n_prob = n_prob; a.wgs0 = S * tiles[0]; a.n_stages = spc ? (n_rows / clip_rows) * spc : n_rows / 32; a.clip_rows = clip_rows; a.spc = spc; a.xcd_map = S % 8 == 0;
+        float *part, *bpart, *dw[2], *db;
+        CK(hipMalloc(&part, (size_t)S * tsum * 256 * 128 * 4)); CK(hipMalloc(&bpart, (size_t)S * tsum * 256 * 4)); CK(hipMalloc(&db, O * 4));
+        float* pp = part; float* bp = bpart;
+        for (int q = 0; q < n_prob; ++q) {
+            WgradFmProb& P = a.p[q];
+            P.a = da; P.a_ld = a_ld; P.a_lo = a_lo; P.n_seg = nsg[q];
+            for (int s = 0; s < nsg[q]; ++s) P.seg[s] = sgs[q][s];
+            P.slices = S; P.slice_stages = ceil_div(a.n_stages, S); P.part = pp; P.O_pad = O_pad; P.K_pad = kt[q] * 128; P.tiles = tiles[q];
+            P.bias_part = (with_bias && q == 0) ? bp : nullptr;
+            pp += (size_t)S * tiles[q] * 256 * 128; bp += (size_t)S * tiles[q] * 256;
+            CK(hipMalloc(&dw[q], (size_t)O * P.K_pad * 4));
+        }
         auto launch = [&]() {
-            if (with_bias) hipLaunchKernelGGL(wgrad_fm_kernel<true>, dim3(tiles * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, 0, a);
-            else hipLaunchKernelGGL(wgrad_fm_kernel<false>, dim3(tiles * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, 0, a);
+            if (with_bias) hipLaunchKernelGGL(wgrad_fm_kernel<true>, dim3(tsum * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, 0, a);
+            else hipLaunchKernelGGL(wgrad_fm_kernel<false>, dim3(tsum * S), dim3(512), WG_STAGES * WG_STAGE_BYTES, 0, a);
         };
         launch();
-        hipLaunchKernelGGL(k_wgrad_nt_reduce, dim3(ceil_div(K_pad, 1024) + (with_bias ? 1 : 0), O), dim3(256), 0, 0, part, S, O_pad, K_pad, O, rs, 1.0f,
-                           (const float*)a.bias_part, S * kt, db);
+        for (int q = 0; q < n_prob; ++q) {
+            const WgradFmProb& P = a.p[q];
+            WgradSegs rs{}; rs.n = 1; rs.s[0] = WgradSeg{dw[q], 0, P.K_pad, (long long)P.K_pad, 1, 0};
+            hipLaunchKernelGGL(k_wgrad_nt_reduce, dim3(ceil_div(P.K_pad, 1024) + (P.bias_part ? 1 : 0), O), dim3(256), 0, 0, P.part, S, O_pad, P.K_pad, O, rs, 1.0f,
+                               (const float*)P.bias_part, S * kt[q], db, (float*)nullptr);
+        }
         CK(hipDeviceSynchronize());
         int rc = 0;
-        if (n_rows <= 4096) {            // float64 check
-            double *rw, *rb;
-            CK(hipMalloc(&rw, (size_t)O * K_pad * 8)); CK(hipMalloc(&rb, O * 8));
-            int kb = 0;
-            for (int s = 0; s < n_seg; ++s) {
-                hipLaunchKernelGGL(k_ref, dim3(ceil_div(segs[s].k_tiles * 128, 128), O), dim3(128), 0, 0, da, a_ld, a_lo, segs[s], kb, n_rows, O, rw, K_pad, rb);
-                kb += segs[s].k_tiles * 128;
+        if (n_rows <= 4096) {            // float64 check (the gap rows of A are zero, so the sum over all rows is the sum over the clips' frames)
+            for (int q = 0; q < n_prob; ++q) {
+                const int K_pad = a.p[q].K_pad;
+                double *rw, *rb;
+                CK(hipMalloc(&rw, (size_t)O * K_pad * 8)); CK(hipMalloc(&rb, O * 8));
+                int kb = 0;
+                for (int s = 0; s < nsg[q]; ++s) {
+                    hipLaunchKernelGGL(k_ref, dim3(ceil_div(sgs[q][s].k_tiles * 128, 128), O), dim3(128), 0, 0, da, a_ld, a_lo, sgs[q][s], kb, n_rows, O, rw, K_pad, rb);
+                    kb += sgs[q][s].k_tiles * 128;
+                }
+                CK(hipDeviceSynchronize());
+                std::vector<float> w((size_t)O * K_pad), b(O);
+                std::vector<double> w64((size_t)O * K_pad), b64(O);
+                CK(hipMemcpy(w.data(), dw[q], w.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(w64.data(), rw, w64.size() * 8, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(b.data(), db, O * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b64.data(), rb, O * 8, hipMemcpyDeviceToHost));
+                const bool chk_bias = with_bias && q == 0;
+                double num = 0, den = 0, worst = 0, bnum = 0, bden = 0;
+                for (size_t i = 0; i < w.size(); ++i) { const double d = w[i] - w64[i]; num += d * d; den += w64[i] * w64[i]; if (fabs(d) > worst) worst = fabs(d); }
+                if (chk_bias) for (int o = 0; o < O; ++o) { const double d = b[o] - b64[o]; bnum += d * d; bden += b64[o] * b64[o]; }
+                const double rel = sqrt(num / den), brel = chk_bias ? sqrt(bnum / bden) : 0.0;
+                printf("%s [%d]: %d rows (%d stages), %d slices, K_pad %d: rel-L2 vs float64 %.3e (worst |d| %.3e at rms %.3e)\n", name, q, n_rows, a.n_stages, S, K_pad, rel,
+                       worst, sqrt(den / w.size()));
+                if (chk_bias) printf("    bias column sums: rel-L2 %.3e\n", brel);
+                if (!(rel < 2e-6) || (chk_bias && !(brel < 2e-6))) { printf("    FAILED\n"); rc = 1; }
+                CK(hipFree(rw)); CK(hipFree(rb));
             }
-            CK(hipDeviceSynchronize());
-            std::vector<float> w((size_t)O * K_pad), b(O);
-            std::vector<double> w64((size_t)O * K_pad), b64(O);
-            CK(hipMemcpy(w.data(), dw, w.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(w64.data(), rw, w64.size() * 8, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(b.data(), db, O * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b64.data(), rb, O * 8, hipMemcpyDeviceToHost));
-            double num = 0, den = 0, worst = 0, bnum = 0, bden = 0;
-            for (size_t i = 0; i < w.size(); ++i) { const double d = w[i] - w64[i]; num += d * d; den += w64[i] * w64[i]; if (fabs(d) > worst) worst = fabs(d); }
-            if (with_bias) for (int o = 0; o < O; ++o) { const double d = b[o] - b64[o]; bnum += d * d; bden += b64[o] * b64[o]; }
-            const double rel = sqrt(num / den), brel = with_bias ? sqrt(bnum / bden) : 0.0;
-            printf("%s: %d rows, %d slices, K_pad %d: rel-L2 vs float64 %.3e (worst |d| %.3e at rms %.3e)%s\n", name, n_rows, S, K_pad, rel, worst,
-                   sqrt(den / w.size()), "");
-            if (with_bias) printf("    bias column sums: rel-L2 %.3e\n", brel);
-            if (!(rel < 2e-6) || (with_bias && !(brel < 2e-6))) { printf("    FAILED\n"); rc = 1; }
-            CK(hipFree(rw)); CK(hipFree(rb));
         }
         if (reps > 0) {
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -127,10 +147,11 @@ int main() {
             for (int i = 0; i < reps; ++i) launch();
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            const double flop = 2.0 * n_rows * O_pad * K_pad * 3;
-            printf("%s: wgrad_fm_kernel %.1f us per launch (%d workgroups), %.0f TFLOP/s MFMA-equivalent\n", name, ms * 1000 / reps, tiles * S, flop / (ms / reps * 1e-3) / 1e12);
+            const double flop = 2.0 * a.n_stages * 32 * O_pad * (kt[0] + kt[1]) * 128 * 3;
+            printf("%s: wgrad_fm_kernel %.1f us per launch (%d workgroups), %.0f TFLOP/s MFMA-equivalent\n", name, ms * 1000 / reps, tsum * S, flop / (ms / reps * 1e-3) / 1e12);
         }
-        CK(hipFree(part)); CK(hipFree(bpart)); CK(hipFree(dw)); CK(hipFree(db));
+        CK(hipFree(part)); CK(hipFree(bpart)); CK(hipFree(db));
+        for (int q = 0; q < n_prob; ++q) CK(hipFree(dw[q]));
         return rc;
     };
     int rc = 0;
@@ -143,6 +164,9 @@ int main() {
     rc |= run_case("cond (256)", 1, cond, rows, 40, false, 0);
     rc |= run_case("out projection (384), bias", 1, outp, rows, 24, true, 0);
     rc |= run_case("two sources, ragged slices", 2, mixed, rows - 64, 5, true, 0);
+    rc |= run_case("conv taps, gap rows skipped", 3, taps, rows, 8, true, 0, 4, 136);
+    rc |= run_case("out projection + cond in one launch, gap rows skipped", 1, outp, rows, 16, true, 0, 4, 136, cond);
+    rc |= run_case("out projection + cond in one launch, 3 slices each", 1, outp, rows, 3, true, 0, 0, 0, cond);
     // ---- (3) time at the benchmarked size (64 clips x 136 rows) ----
     {
         const int big = 8704;
@@ -154,9 +178,10 @@ int main() {
         WgradFmSeg c1[1] = {{dc, c_ld, c_lo, 0, 2}};
         WgradFmSeg o1[1] = {{xb, x_ld, x_lo, 0, 3}};
         run_case("conv taps @ 8704 rows", 3, t3, big, 8, true, 50);
-        run_case("conv taps @ 8704 rows, no bias", 3, t3, big, 8, false, 50);
+        run_case("conv taps @ 8192 frames of 8704 rows", 3, t3, big, 8, true, 50, 4, 136);
         run_case("cond @ 8704 rows", 1, c1, big, 40, false, 50);
         run_case("out projection @ 8704 rows", 1, o1, big, 24, true, 50);
+        run_case("out projection + cond @ 8192 frames, one launch", 1, o1, big, 16, true, 50, 4, 136, c1);
         // wgrad_nt_kernel on fragment-tiled planes of the same problem (8192 real frames), for the kernel-to-kernel comparison
         const int ldT = 8192, a_rows = 768, b_rows = 3 * 384 + 256;
         _Float16 *at, *bt; float* part;
