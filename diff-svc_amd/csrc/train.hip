@@ -250,11 +250,13 @@ struct TEpiGateBwdT {
                     db[4 * q + i] = ok ? v * s[i] * (1.0f - t[i] * t[i]) : 0.f;
                 }
             }
-            float* pa = e.dy + (size_t)frame * (2 * e.C) + cb;
+            if (e.dy) {      // (null: every reader takes the planes -- wgrad_fm_kernel, k_bin_sums)
+                float* pa = e.dy + (size_t)frame * (2 * e.C) + cb;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                st4(pa + 4 * q, f32x4{da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]});
-                st4(pa + e.C + 4 * q, f32x4{db[4 * q], db[4 * q + 1], db[4 * q + 2], db[4 * q + 3]});
+                for (int q = 0; q < 4; ++q) {
+                    st4(pa + 4 * q, f32x4{da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]});
+                    st4(pa + e.C + 4 * q, f32x4{db[4 * q], db[4 * q + 1], db[4 * q + 2], db[4 * q + 3]});
+                }
             }
             _Float16* ph = e.dyh + (size_t)frame * (2 * e.C2p) + cb;
             store_hi_lo16(ph, e.C2p, da);
@@ -464,7 +466,10 @@ __global__ void k_loss(const float* __restrict__ eps, float* __restrict__ deps, 
 
 // dst[c] += sum over rows of src[row][c]   (bias gradients); grid (ceil(C/256), row chunks): a thread owns four adjacent columns (one
 // 16-byte load per row) and every fourth row of the chunk, four loads in flight; C, ld % 4 == 0
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld, int rows_per_block) {
+// blockIdx.z walks a batch of independent sums src + z * src_z -> dst + z * dst_z (the layers' diffusion-projection biases in one launch)
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ld, int rows_per_block,
+                                                long long src_z = 0, long long dst_z = 0) {
+    src += (long long)blockIdx.z * src_z; dst += (long long)blockIdx.z * dst_z;
     const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
     const int sub = threadIdx.x >> 6;                        // 4 row phases
     const int r0 = blockIdx.y * rows_per_block;
@@ -495,18 +500,24 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ src, f
     }
 }
 
-// dst[clip][c] = sum_t src[clip*stride + t][c]   (FiLM gradient); grid (ceil(C/64), B)
-__global__ void k_clip_colsum(const float* __restrict__ src, float* __restrict__ dst, int T, int C, int stride, int dst_ld) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sub = threadIdx.x >> 6;
+// dst[clip][c] = sum_t src[clip*stride + t][c]   (FiLM gradient); grid (ceil(C/128), B): a thread owns 4 columns and every eighth frame, 16-byte
+// loads (round 5; one column and every fourth frame, 4-byte loads before: 10 us for 13 MB)
+__global__ __launch_bounds__(256) void k_clip_colsum(const float* __restrict__ src, float* __restrict__ dst, int T, int C, int stride, int dst_ld) {
+    const int c = blockIdx.x * 128 + (threadIdx.x & 31) * 4;
+    const int sub = threadIdx.x >> 5;
     const int b = blockIdx.y;
-    float s = 0.f;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (c < C)
-        for (int t = sub; t < T; t += 4) s += src[((size_t)b * stride + t) * C + c];
-    __shared__ float red[4][64];
-    red[sub][threadIdx.x & 63] = s;
+        for (int t = sub; t < T; t += 8) { const f32x4 v = ld4(src + ((size_t)b * stride + t) * C + c); s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+    __shared__ f32x4 red[8][32];
+    red[sub][threadIdx.x & 31] = s;
     __syncthreads();
-    if (sub == 0 && c < C) dst[(size_t)b * dst_ld + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (sub == 0 && c < C) {
+        f32x4 r = red[0][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { const f32x4 v = red[q][threadIdx.x]; r[0] += v[0]; r[1] += v[1]; r[2] += v[2]; r[3] += v[3]; }
+        st4(dst + (size_t)b * dst_ld + c, r);
+    }
 }
 
 // dst[row][off + c] = src[row][c] * scale
@@ -544,7 +555,10 @@ struct SmallBatch { const float* A[32]; const float* B[32]; float* C[32]; const 
 // (round 5: a thread's 4 x 4 outputs are ADJACENT rows / columns -- one ds_read_b128 per operand and k instead of four ds_read_b32, 16-byte
 //  stores; the k order of every output's fp32 chain is unchanged)
 __global__ __launch_bounds__(256) void k_gemm_small_b(const SmallBatch t, int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int accumulate) {
-    __shared__ __attribute__((aligned(16))) float As[16][68], Bs[16][68];
+    // 64-deep k chunks (round 5; 16 before): a chunk is one round trip to memory and two barriers, and the K = 384 ... 768 problems of the
+    // step-embedding / pitch-embedding path -- a few hundred workgroups -- spent their time waiting for 24 ... 48 of them
+    constexpr int KC = 64;
+    __shared__ __attribute__((aligned(16))) float As[KC][68], Bs[KC][68];
     const float* __restrict__ A = t.A[blockIdx.z];
     const float* __restrict__ Bm = t.B[blockIdx.z];
     float* __restrict__ Cm = t.C[blockIdx.z];
@@ -552,20 +566,38 @@ __global__ __launch_bounds__(256) void k_gemm_small_b(const SmallBatch t, int M,
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // thread -> outputs (m0 + 4 ty + i, n0 + 4 tx + j)
     float acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        for (int e = threadIdx.x; e < 1024; e += 256) {
-            int kk, mm;
-            if (ta) { mm = e & 63; kk = e >> 6; } else { kk = e & 15; mm = e >> 4; }       // fastest index = the contiguous one
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        // a chunk's 2 x 16 loads per thread go out together (addresses clamped, values selected: no branch between them) and are parked in LDS
+        // afterwards -- one memory round trip per chunk.  The index that is contiguous in memory runs fastest across the lanes; where that is k,
+        // a wave takes 16 k x 4 rows, so that its LDS column stores spread over all banks
+        float ra[16], rb[16];
+        const int tq = threadIdx.x;
+        const int kq = (tq & 15) + 16 * ((tq >> 6) & 3), rq0 = (tq >> 4) & 3;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int kk = ta ? (tq >> 6) + 4 * it : kq, mm = ta ? (tq & 63) : rq0 + 4 * it;
             const int m = m0 + mm, k = k0 + kk;
-            As[kk][mm] = (m < M && k < K) ? (ta ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]) : 0.f;
-            int kb, nn;
-            if (tb) { kb = e & 15; nn = e >> 4; } else { nn = e & 63; kb = e >> 6; }
+            const bool oka = m < M && k < K;
+            const size_t ia = oka ? (ta ? (size_t)k * lda + m : (size_t)m * lda + k) : 0;
+            const float va = A[ia];
+            ra[it] = oka ? va : 0.f;
+            const int kb = tb ? kq : (tq >> 6) + 4 * it, nn = tb ? rq0 + 4 * it : (tq & 63);
             const int n = n0 + nn, k2 = k0 + kb;
-            Bs[kb][nn] = (n < N && k2 < K) ? (tb ? Bm[(size_t)n * ldb + k2] : Bm[(size_t)k2 * ldb + n]) : 0.f;
+            const bool okb = n < N && k2 < K;
+            const size_t ib = okb ? (tb ? (size_t)n * ldb + k2 : (size_t)k2 * ldb + n) : 0;
+            const float vb = Bm[ib];
+            rb[it] = okb ? vb : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int kk = ta ? (tq >> 6) + 4 * it : kq, mm = ta ? (tq & 63) : rq0 + 4 * it;
+            As[kk][mm] = ra[it];
+            const int kb = tb ? kq : (tq >> 6) + 4 * it, nn = tb ? rq0 + 4 * it : (tq & 63);
+            Bs[kb][nn] = rb[it];
         }
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll 16
+        for (int kk = 0; kk < KC; ++kk) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(&As[kk][4 * ty]), bv = *reinterpret_cast<const f32x4*>(&Bs[kk][4 * tx]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -709,9 +741,12 @@ __global__ void k_bin_scatter(const int* __restrict__ pitch, const int* __restri
     int p;
     if (i < n && bin_ok(pitch, mel2ph, i, vocab, p)) order[atomicAdd(cursor + p, 1)] = i;
 }
-// S[bin][c] += sum over the segment's frames of src[row(frame)][c]; grid (max segments, ceil(C / 256)), 64 threads x 4 columns
-__global__ __launch_bounds__(64) void k_bin_sums(const float* __restrict__ src, int ld, const int* __restrict__ order, const int* __restrict__ segs,
+// S[bin][c] += sum over the segment's frames of src[row(frame)][c]; grid (max segments, ceil(C / 256)), 64 threads x 4 columns.  src = the fp16
+// [hi | lo] row planes of dy (TEpiGateBwdT writes them for the transposed conv; round 5: the fp32 rows are no longer written): ld halfs per row,
+// lo plane `lo` halfs in; hi + lo is dy to 2^-22
+__global__ __launch_bounds__(64) void k_bin_sums(const _Float16* __restrict__ src, int ld, int lo, const int* __restrict__ order, const int* __restrict__ segs,
                                                  const int* __restrict__ n_segs, int T, int stride, float* __restrict__ S, int C) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     if ((int)blockIdx.x >= *n_segs) return;
     const int bin = segs[3 * blockIdx.x], first = segs[3 * blockIdx.x + 1], len = segs[3 * blockIdx.x + 2];
     const int c = blockIdx.y * 256 + threadIdx.x * 4;
@@ -719,8 +754,9 @@ __global__ __launch_bounds__(64) void k_bin_sums(const float* __restrict__ src, 
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = 0; i < len; ++i) {
         const int bt = order[first + i], b = bt / T, t = bt - b * T;
-        const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)b * stride + t) * ld + c);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        const _Float16* p = src + ((size_t)b * stride + t) * ld + c;
+        const h4 vh = *reinterpret_cast<const h4*>(p), vl = *reinterpret_cast<const h4*>(p + lo);
+        s.x += (float)vh[0] + (float)vl[0]; s.y += (float)vh[1] + (float)vl[1]; s.z += (float)vh[2] + (float)vl[2]; s.w += (float)vh[3] + (float)vl[3];
     }
     float* d = S + (size_t)bin * C + c;
     atomicAdd(d, s.x); atomicAdd(d + 1, s.y); atomicAdd(d + 2, s.z); atomicAdd(d + 3, s.w);
@@ -1368,7 +1404,7 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             DSVC_TRY(wgrad_nt(2 * C, cp128, 0, seg1(G(q + "output_projection.weight"), C, C), 1.0f, st));
         }   // (fm: dW_o shares a launch with the conditioner projection's gradient below -- dOh is intact until this layer's TEpiDxT)
         {   // dg = W_o^T dO -> dy, K = 2C streamed in phases of 256 (128 where 2C is not a multiple of 256) channels
-            TEpiGateBwdT::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, dy.as<float>(),
+            TEpiGateBwdT::Args e{sig.as<float>() + (size_t)l * slab, tau.as<float>() + (size_t)l * slab, fm ? nullptr : dy.as<float>(),
                                  dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p, C, C2p, ri};
             DSVC_TRY((tg<TEpiGateBwdT, 1>(dOh.as<_Float16>(), C2p, 1, 1, oT_t.as<_Float16>() + (size_t)l * oT_halfs, C / 32, e, st, C2p % 256 == 0 ? 256 : 128)));
         }
@@ -1398,14 +1434,14 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             DSVC_TRY(wgrad_nt(2 * C, hp128, 3 * cp128, seg1(G(q + "conditioner_projection.weight"), H, H), 1.0f, st));
         }
         if (ta->pitch)     // S_l[bin] = sum of this layer's dy rows per pitch bin (instead of dcond += W_c^T dy: see k_bin_sums)
-            hipLaunchKernelGGL(k_bin_sums, dim3(ceil_div(B * T, 32) + cfg.pitch_vocab, ceil_div(2 * C, 256)), dim3(64), 0, st, dy.as<float>(), 2 * C,
-                               bin_order.as<int>(), bin_segs.as<int>(), bin_nsegs.as<int>(), T, Tp,
+            hipLaunchKernelGGL(k_bin_sums, dim3(ceil_div(B * T, 32) + cfg.pitch_vocab, ceil_div(2 * C, 256)), dim3(64), 0, st,
+                               (const _Float16*)(dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p), 2 * C2p, C2p, bin_order.as<int>(), bin_segs.as<int>(), bin_nsegs.as<int>(), T, Tp,
                                bin_S.as<float>() + (size_t)l * cfg.pitch_vocab * 2 * C, 2 * C);
         {   // dxin = convT(dy); dx <- dx / sqrt 2 + dxin; the residual half of dO (rows and planes) <- dx / sqrt 2
             TEpiDxT::Args e{dx.as<float>(), dxin.as<float>(), fm ? nullptr : dO.as<float>(), dOh.as<_Float16>(), C, C2p, ri};
             DSVC_TRY((tg<TEpiDxT, 1>(dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p, C2p, 3, d, dT_t.as<_Float16>() + (size_t)l * dT_halfs, C / 32, e, st, (C2p % 256 == 0 && (64 + 2 * d) * 2048 <= 160 * 1024) ? 256 : 128)));      // (two phase buffers of 64 + 2d rows in LDS)
         }
-        hipLaunchKernelGGL(k_clip_colsum, dim3(ceil_div(C, 64), B), dim3(256), 0, st, dxin.as<float>(), dfilm.as<float>() + (size_t)l * C, T, C, Tp, L * C);
+        hipLaunchKernelGGL(k_clip_colsum, dim3(ceil_div(C, 128), B), dim3(256), 0, st, dxin.as<float>(), dfilm.as<float>() + (size_t)l * C, T, C, Tp, L * C);
     }
     // the step-embedding side of these layers: d diffusion_projection from dfilm_l (the FiLM gradient) -- with them the layers' gradients are final
     if (batched_small) {
@@ -1415,7 +1451,12 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".diffusion_projection.";
             const float* df = dfilm.as<float>() + (size_t)l * C;
             dw.A[l - l_lo] = df; dw.B[l - l_lo] = e2.as<float>(); dw.C[l - l_lo] = G(q + "weight");     // dWp[o][i] = sum_b dfilm[b][o] e2[b][i]
-            hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, df, G(q + "bias"), B, C, L * C, B);   // dbp = sum_b dfilm[b]
+        }
+        {   // dbp_l = sum_b dfilm_l[b], all layers of the range in one launch (the layers' parameters sit a constant stride apart)
+            const std::string b0 = "denoise_fn.residual_layers." + std::to_string(l_lo) + ".diffusion_projection.bias";
+            const long long lstride = l_hi - l_lo > 1 ? index.at("denoise_fn.residual_layers." + std::to_string(l_lo + 1) + ".diffusion_projection.bias").first - index.at(b0).first : 0;
+            hipLaunchKernelGGL(k_colsum, dim3(ceil_div(C, 256), 1, l_hi - l_lo), dim3(256), 0, st, dfilm.as<float>() + (size_t)l_lo * C, G(b0), B, C, L * C, B,
+                               (long long)C, lstride);
         }
         small_b(dw, C, C, B, L * C, C, C, 1, 0, 0);
     } else for (int l = l_lo; l < l_hi; ++l) {
