@@ -53,6 +53,8 @@ struct ConvGemmArgs {
     float in_slope;        // leaky-relu slope applied to the staged input (1 = identity)
     int k_slices;          // > 1: the reduction (cin) is cut into k_slices ranges of k_slice_len channels over blockIdx.y; every slice
     int k_slice_len;       //      runs its own epilogue (which tells slices apart by blockIdx.y): weight-gradient GEMMs (train.hip)
+    int nz;                // > 1: blockIdx.z walks nz independent problems of one shape -- x += z * x_z floats, w += z * w_z halfs; the epilogue tells
+    long long x_z, w_z;    //      them apart by blockIdx.z (hubert.hip: the heads of an attention layer, the groups of the positional conv, in ONE launch)
 };
 
 // number of halfs of one packed [lane 64][8] fragment
@@ -129,7 +131,7 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
     half8 bring[PF][2][NW];
     const int wpl = a.w_planes;
     const size_t tile_halfs = (size_t)a.taps * nk16 * wpl * FRAG_HALFS;
-    const _Float16* wbase = a.w + (size_t)ct0 * tile_halfs + lane * 8;
+    const _Float16* wbase = a.w + (size_t)blockIdx.z * a.w_z + (size_t)ct0 * tile_halfs + lane * 8;
     auto wload = [&](half8 (&dst)[2][NW], int c0, int tap, int ks) {
         const int k16 = ((c0 + kz * KCW) >> 4) + ks;
         const _Float16* p = wbase + ((size_t)tap * nk16 + k16) * (wpl * FRAG_HALFS);
@@ -172,7 +174,7 @@ conv_gemm_kernel(const ConvGemmArgs a, const typename Epi::Args ea) {
                     valid = (r - clip * a.clip_stride) < (a.clip_lens ? a.clip_lens[clip] : a.clip_len);
                 }
                 if (valid) {
-                    const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)r * a.ldx + c0 + c8);
+                    const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)blockIdx.z * a.x_z + (size_t)r * a.ldx + c0 + c8);
                     sr[u][0] = src[0];
                     sr[u][1] = src[1];
                     vmask |= 1u << u;
@@ -378,7 +380,8 @@ inline int conv_gemm_launch(const ConvGemmArgs& a, const typename Epi::Args& ea,
     const int ncg = ceil_div(a.n_ctiles, 2 * WAVES_N);
     const int nrt = ceil_div(a.n_rows, 32 * WM_TILES * WAVES_M);
     const int grid = round_up(nrt, 8) * ncg;
-    hipLaunchKernelGGL(kern, dim3(grid, a.k_slices > 1 ? a.k_slices : 1), dim3(64 * WAVES_N * WAVES_K * WAVES_M), smem, stream, a, ea);
+    if (a.nz > 1 && (a.x_z % 4 != 0 || a.w_z % 8 != 0)) return fail(DSVC_EINVAL, "conv_gemm: batch strides %lld / %lld break the 16-byte accesses", a.x_z, a.w_z);
+    hipLaunchKernelGGL(kern, dim3(grid, a.k_slices > 1 ? a.k_slices : 1, a.nz > 1 ? a.nz : 1), dim3(64 * WAVES_N * WAVES_K * WAVES_M), smem, stream, a, ea);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }

@@ -30,16 +30,19 @@ constexpr int HB_C0 = 512, HB_D = 768, HB_FF = 3072, HB_HEADS = 12, HB_HD = 64, 
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// out[row][col_off + col] = act(acc * scale + bias[col]) + res[row][col]   on rows < n_valid (others 0)
+// out[row][col_off + col] = act(acc * scale + bias[col]) + res[row][col]   on rows < n_valid (others 0).  In a batched launch (ConvGemmArgs::nz)
+// problem z = blockIdx.z writes out + z * out_z at columns col_off + z * col_z (bias and residual columns move with them): the heads of an
+// attention layer land in their own score matrices / their own 64 columns of the context, the groups of the positional conv in their 48
 struct EpLin {
     static constexpr bool PAIRED = false;
-    struct Args { float* out; int ld; const float* bias; int cout; int act; const float* res; int ldres; int col_off; int n_valid; float scale; };
+    struct Args { float* out; int ld; const float* bias; int cout; int act; const float* res; int ldres; int col_off; int n_valid; float scale; long long out_z; int col_z; };
     __device__ __forceinline__ void one(const Args& e, int row, int col, float v) const {
         if (col >= e.cout) return;
-        v = v * e.scale + (e.bias ? e.bias[col] : 0.f);
+        const int z = blockIdx.z, co = e.col_off + z * e.col_z + col;
+        v = v * e.scale + (e.bias ? e.bias[z * e.col_z + col] : 0.f);
         if (e.act == 1) v = gelu_exact(v);
-        if (e.res) v += e.res[(size_t)row * e.ldres + e.col_off + col];
-        e.out[(size_t)row * e.ld + e.col_off + col] = row < e.n_valid ? v : 0.f;
+        if (e.res) v += e.res[(size_t)row * e.ldres + co];
+        e.out[(size_t)z * e.out_z + (size_t)row * e.ld + co] = row < e.n_valid ? v : 0.f;
     }
 };
 
@@ -96,11 +99,12 @@ __global__ void k_gn_apply_gelu(float* __restrict__ x, const double* __restrict_
 }
 
 // row softmax over the first n columns of [rows][ld]; columns n..ld-1 are zeroed (they are K padding of the next GEMM)
-__global__ void k_softmax_rows(float* __restrict__ s, int rows, int n, int ld) {
+// (blockIdx.y walks matrices z_stride floats apart: the heads of a layer in one launch)
+__global__ void k_softmax_rows(float* __restrict__ s, int rows, int n, int ld, long long z_stride) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
-    float* p = s + (size_t)row * ld;
+    float* p = s + (size_t)blockIdx.y * z_stride + (size_t)row * ld;
     float m = -INFINITY;
     for (int c = lane; c < n; c += 64) m = fmaxf(m, p[c]);
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -129,10 +133,14 @@ struct dsvc_hubert {
     long long wsN = -1;
     int L[7] = {0, 0, 0, 0, 0, 0, 0};
     DevBuf wavp, c[2], gsum, h, h2, posb, qkv, S, attn, ffb, packK, packV;
+    // round 5: the 12 heads of a layer and the 16 groups of the positional conv run as ONE batched launch each (conv_gemm.h: ConvGemmArgs::nz)
+    DevBuf pos_all;                                // the groups' packed weights, pos_halfs apart
+    size_t pos_halfs = 0, packK_halfs = 0, packV_halfs = 0;      // per group / per head
+    DevBuf head_packs;                             // 2 x HB_HEADS PackDesc: K_h and V_h^T of every head out of the qkv buffer (k_pack_w_batch)
 
     ~dsvc_hubert() {
         for (DevBuf* b : {&conv0_w, &gn_g, &gn_b, &fp_ln_g, &fp_ln_b, &fp_b, &pos_w, &pos_b, &ln_g, &ln_b, &proj_b, &wavp, &c[0], &c[1], &gsum, &h, &h2,
-                          &posb, &qkv, &S, &attn, &ffb, &packK, &packV})
+                          &posb, &qkv, &S, &attn, &ffb, &packK, &packV, &pos_all, &head_packs})
             b->release();
         for (auto& p : fe) p.w.release();
         fp_w.w.release(); proj_w.w.release();
@@ -225,6 +233,13 @@ int dsvc_hubert::finalize() {
         for (size_t i = 0; i < v->size(); ++i) w[i] = (float)((double)(*g)[i % HB_PK] * (double)(*v)[i] / sqrt(nrm[i % HB_PK]));
         for (int gi = 0; gi < HB_GROUPS; ++gi)      // group gi: W(col = o_local, tap = k, ci = c) = w[(gc*gi + o_local)][c][k]
             DSVC_TRY(pack(pos[gi], w.data() + (size_t)gi * gc * gc * HB_PK, (size_t)gc * gc * HB_PK, gc, HB_PK, gc, (long long)gc * HB_PK, HB_PK, 1));
+        // ... side by side, so that one batched launch walks the groups
+        pos_halfs = packed_halfs(pos[0].n_ctiles, pos[0].taps, pos[0].cin_pad, 2);
+        DSVC_TRY(pos_all.alloc(pos_halfs * 2 * HB_GROUPS));
+        for (int gi = 0; gi < HB_GROUPS; ++gi) {
+            DSVC_HIP(hipMemcpy(pos_all.as<_Float16>() + (size_t)gi * pos_halfs, pos[gi].w.p, pos_halfs * 2, hipMemcpyDeviceToDevice));
+            pos[gi].w.release();
+        }
         DSVC_TRY(up(pos_b, "positional_embedding.conv.bias", HB_D));
     }
     DSVC_TRY(up(ln_g, "norm.weight", HB_D)); DSVC_TRY(up(ln_b, "norm.bias", HB_D));
@@ -268,11 +283,25 @@ int dsvc_hubert::ensure_ws(long long n, hipStream_t st) {
     DSVC_TRY(gsum.alloc(2 * HB_C0 * 8));
     const size_t Tr = (size_t)round_up((int)T, 32), Tp = Tr;
     DSVC_TRY(h.alloc(Tr * HB_D * 4)); DSVC_TRY(h2.alloc(Tr * HB_D * 4)); DSVC_TRY(posb.alloc(Tr * HB_D * 4)); DSVC_TRY(qkv.alloc(Tr * 3 * HB_D * 4));
-    DSVC_TRY(S.alloc(Tr * Tp * 4)); DSVC_TRY(attn.alloc(Tr * HB_D * 4)); DSVC_TRY(ffb.alloc(Tr * HB_FF * 4));
-    DSVC_TRY(packK.alloc(packed_halfs(round_up(ceil_div((int)T, 32), 2), 1, HB_HD, 2) * 2));
-    DSVC_TRY(packV.alloc(packed_halfs(2, 1, round_up((int)T, 16), 2) * 2));
+    DSVC_TRY(S.alloc(Tr * Tp * 4 * HB_HEADS)); DSVC_TRY(attn.alloc(Tr * HB_D * 4)); DSVC_TRY(ffb.alloc(Tr * HB_FF * 4));
+    const int nctK = round_up(ceil_div((int)T, 32), 2), Tk = round_up((int)T, 16);
+    packK_halfs = packed_halfs(nctK, 1, HB_HD, 2); packV_halfs = packed_halfs(2, 1, Tk, 2);
+    DSVC_TRY(packK.alloc(packK_halfs * 2 * HB_HEADS));
+    DSVC_TRY(packV.alloc(packV_halfs * 2 * HB_HEADS));
+    {   // K_h as the weights of scores = Q_h K_h^T: W(col = j, ci = d) = K[j][d]; V_h^T as those of out = P V_h: W(col = d, ci = j) = V[j][d] -- the
+        // qkv buffer is the same for every layer, so the 24 descriptors are built once per utterance length
+        std::vector<PackDesc> pd(2 * HB_HEADS);
+        for (int hd = 0; hd < HB_HEADS; ++hd) {
+            const float* K = qkv.as<float>() + HB_D + hd * HB_HD;
+            const float* V = qkv.as<float>() + 2 * HB_D + hd * HB_HD;
+            pd[hd] = PackDesc{K, nullptr, packK.as<_Float16>() + (size_t)hd * packK_halfs, nctK, 1, HB_HD, (int)T, HB_HD, (long long)3 * HB_D, 1LL, 0LL, 0, 1.0f};
+            pd[HB_HEADS + hd] = PackDesc{V, nullptr, packV.as<_Float16>() + (size_t)hd * packV_halfs, 2, 1, Tk, HB_HD, (int)T, 1LL, (long long)3 * HB_D, 0LL, 0, 1.0f};
+        }
+        DSVC_TRY(head_packs.alloc(pd.size() * sizeof(PackDesc)));
+        DSVC_HIP(hipMemcpyAsync(head_packs.p, pd.data(), pd.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+        DSVC_HIP(hipStreamSynchronize(st));                // (pd is a host temporary)
+    }
     wsN = n;
-    (void)st;
     return DSVC_OK;
 }
 
@@ -310,10 +339,15 @@ int dsvc_hubert::units(const float* wav, long long n, float* out, hipStream_t st
         DSVC_TRY(gemm(c[cur ^ 1].as<float>(), HB_C0, T, HB_C0, fp_w, 1, e));
     }
     // ---- x + positional conv embedding (grouped k=128 conv, GELU), then LayerNorm(768)  (hubert_model.py:48-49,119-137) ----
-    for (int gi = 0; gi < HB_GROUPS; ++gi) {
+    {   // the 16 groups are 16 problems of one launch: group z reads / writes columns 48 z .. 48 z + 47 (16 launches of 16 workgroups each took
+        // 3.5 of HuBERT's 10.4 ms, profiles/r5h_kernel_stats_hubert.csv)
         const int gc = HB_D / HB_GROUPS;
-        EpLin::Args e{posb.as<float>(), HB_D, pos_b.as<float>() + gi * gc, gc, 1, h.as<float>(), HB_D, gi * gc, T, 1.0f};
-        DSVC_TRY(gemm(h.as<float>() + gi * gc, HB_D, T, gc, pos[gi], HB_PK, e));
+        ConvGemmArgs a{};
+        a.x = h.as<float>(); a.ldx = HB_D; a.n_rows = T; a.clip_stride = T < 32 ? 32 : T; a.clip_len = T;
+        a.cin = gc; a.taps = HB_PK; a.dil = 1; a.w = pos_all.as<_Float16>(); a.n_ctiles = pos[0].n_ctiles; a.w_planes = 2; a.in_slope = 1.0f;
+        a.nz = HB_GROUPS; a.x_z = gc; a.w_z = (long long)pos_halfs;
+        EpLin::Args e{posb.as<float>(), HB_D, pos_b.as<float>(), gc, 1, h.as<float>(), HB_D, 0, T, 1.0f, 0LL, gc};
+        DSVC_TRY(launch<EpLin>(a, e, st));
     }
     hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(T, 4)), dim3(256), 0, st, posb.as<float>(), h.as<float>(), ln_g.as<float>(), ln_b.as<float>(), T, HB_D, 1e-5f);
     // ---- 12 post-LN transformer encoder layers (nn.TransformerEncoderLayer(768, 12, 3072, gelu, batch_first)) ----
@@ -325,30 +359,25 @@ int dsvc_hubert::units(const float* wav, long long n, float* out, hipStream_t st
             EpLin::Args e{qkv.as<float>(), 3 * HB_D, y.in_b.as<float>(), 3 * HB_D, 0, nullptr, 0, 0, T, 1.0f};
             DSVC_TRY(gemm(h.as<float>(), HB_D, T, HB_D, y.in_w, 1, e));
         }
-        for (int hd = 0; hd < HB_HEADS; ++hd) {
-            const float* Q = qkv.as<float>() + hd * HB_HD;
-            const float* K = qkv.as<float>() + HB_D + hd * HB_HD;
-            const float* V = qkv.as<float>() + 2 * HB_D + hd * HB_HD;
-            {   // scores[t][j] = Q_h[t] . K_h[j] / sqrt(64): K_h as weights W(col = j, ci = d) = K[j][d]
-                const long long tot = (long long)nctK * (HB_HD / 16) * 512;
-                hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, K, (const int*)nullptr, packK.as<_Float16>(), nctK, 1, HB_HD, T,
-                                   HB_HD, (long long)3 * HB_D, 1LL, 0LL, 0, 1.0f);
-                Packed pk; pk.n_ctiles = nctK;
+        {   // all 12 heads at once (5 launches per layer instead of 60): K_h / V_h^T of every head packed as "weights" by one launch, then
+            // scores_h = Q_h K_h^T / 8 -> softmax -> out_h = P_h V_h as batched launches (blockIdx.z = head; head h's scores in S + h * Tp * Tp)
+            const long long sz = (long long)Tp * Tp;
+            hipLaunchKernelGGL(k_pack_w_batch, dim3(128, 2 * HB_HEADS), dim3(256), 0, st, (const PackDesc*)head_packs.p);
+            {
                 ConvGemmArgs a{};
-                a.x = Q; a.ldx = 3 * HB_D; a.n_rows = T; a.clip_stride = T < 32 ? 32 : T; a.clip_len = T; a.cin = HB_HD; a.taps = 1; a.dil = 1;
+                a.x = qkv.as<float>(); a.ldx = 3 * HB_D; a.n_rows = T; a.clip_stride = T < 32 ? 32 : T; a.clip_len = T; a.cin = HB_HD; a.taps = 1; a.dil = 1;
                 a.w = packK.as<_Float16>(); a.n_ctiles = nctK; a.w_planes = 2; a.in_slope = 1.0f;
-                EpLin::Args e{S.as<float>(), Tp, nullptr, Tp, 0, nullptr, 0, 0, T, 0.125f};
+                a.nz = HB_HEADS; a.x_z = HB_HD; a.w_z = (long long)packK_halfs;
+                EpLin::Args e{S.as<float>(), Tp, nullptr, Tp, 0, nullptr, 0, 0, T, 0.125f, sz, 0};
                 DSVC_TRY(launch<EpLin>(a, e, st));
             }
-            hipLaunchKernelGGL(k_softmax_rows, dim3(ceil_div(T, 4)), dim3(256), 0, st, S.as<float>(), T, T, Tp);
-            {   // out[t][d] = sum_j P[t][j] V_h[j][d]: V_h^T as weights W(col = d, ci = j) = V[j][d]
-                const long long tot = (long long)2 * (Tk / 16) * 512;
-                hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, V, (const int*)nullptr, packV.as<_Float16>(), 2, 1, Tk, HB_HD,
-                                   T, 1LL, (long long)3 * HB_D, 0LL, 0, 1.0f);
+            hipLaunchKernelGGL(k_softmax_rows, dim3(ceil_div(T, 4), HB_HEADS), dim3(256), 0, st, S.as<float>(), T, T, Tp, sz);
+            {
                 ConvGemmArgs a{};
                 a.x = S.as<float>(); a.ldx = Tp; a.n_rows = T; a.clip_stride = T < 32 ? 32 : T; a.clip_len = T; a.cin = Tk; a.taps = 1; a.dil = 1;
                 a.w = packV.as<_Float16>(); a.n_ctiles = 2; a.w_planes = 2; a.in_slope = 1.0f;
-                EpLin::Args e{attn.as<float>(), HB_D, nullptr, HB_HD, 0, nullptr, 0, hd * HB_HD, T, 1.0f};
+                a.nz = HB_HEADS; a.x_z = sz; a.w_z = (long long)packV_halfs;
+                EpLin::Args e{attn.as<float>(), HB_D, nullptr, HB_HD, 0, nullptr, 0, 0, T, 1.0f, 0LL, HB_HD};
                 DSVC_TRY(launch<EpLin>(a, e, st));
             }
         }
