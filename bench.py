@@ -512,7 +512,8 @@ def main():
                               **same_workload_fields(world * Bt * Tt / (ms * 1e-3), None if solo_ms is None else Bt * Tt / (solo_ms * 1e-3), world,
                                                      "rank 0 alone, %d x %d-frame batch, forward + backward + clip + AdamW without the all-reduce" % (Bt, Tt)),
                               "roofline": {"bound": "mfma", "scope": "whole step per GPU (forward + backward + clip + AdamW), not one kernel: the largest kernels are "
-                                           "wgrad_nt_kernel (16 %) and the transposed conv on the tgemm engine (14 %), profiles/r4u_kernel_stats_train.csv",
+                                           "wgrad_fm_kernel (20 %: the weight gradients, contracted from the frame-major planes through the transposing LDS read) "
+                                           "and the transposed conv on the tgemm engine (17 %), profiles/r5G_kernel_stats_train.csv",
                                            "algorithmic_tflop_per_step": train_step_flops(hp, Bt * Tt) / 1e12,
                                            "achieved": train_step_flops(hp, Bt * Tt) / (ms * 1e-3) / 1e12, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                                            "frac": train_step_flops(hp, Bt * Tt) / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_F16, "mfma_per_product": 3, "traffic": load_train_traffic()[0], "traffic_source": load_train_traffic()[1],
@@ -727,8 +728,12 @@ def main():
                 mel24 = torch.from_numpy(synth.mel_like(1, 1, 1875, 80)).to(dev)
                 stages["pitch_extractor_ms"] = timed(lambda: pe(mel24))
                 del pe
+                # north_star's chain starts at the content encoder: the same clip with HuBERT-soft's time added (`value` itself starts at the units,
+                # where the reference's encoder wrapper finds them cached beside the wav: preprocessing/hubertinfer.py:35-38)
+                stages["value_with_hubert"] = result["value"] * (elapsed / args.steps) / (elapsed / args.steps + stages["hubert_soft_ms"] * 1e-3 * B)
                 stages["note"] = ("one 10 s clip: NSF-HiFiGAN alone (inside `value`), HuBERT-soft on 160 000 samples at 16 kHz and the 24 kHz pitch "
-                                  "extractor on 1875 frames (outside `value`: upstream / config B), D2H of mel + f0 + PCM")
+                                  "extractor on 1875 frames (outside `value`: upstream / config B; `value_with_hubert` = `value` with the encoder's "
+                                  "time per clip added), D2H of mel + f0 + PCM")
                 result["stages"] = stages
             except Exception as ex:
                 result["stages"] = {"error": repr(ex)[:300]}
@@ -761,8 +766,8 @@ def main():
                                         "ms_per_step": ms_t, "value": 64 * 128 / (ms_t * 1e-3), "unit": "frames/s", "final_loss": loss_t,
                                         "precision": "split fp16 operands (fp32-class), fp32 master weights",
                                         "roofline": {"bound": "mfma", "scope": "whole step (forward + backward + clip + AdamW), not one kernel: the largest "
-                                                     "kernels are wgrad_nt_kernel (16 %) and the transposed conv on the tgemm engine (14 %) "
-                                                     "(profiles/r4u_kernel_stats_train.csv)",
+                                                     "kernels are wgrad_fm_kernel (20 %: the weight gradients, contracted from the frame-major planes through the "
+                                                     "transposing LDS read) and the transposed conv on the tgemm engine (17 %) (profiles/r5G_kernel_stats_train.csv)",
                                                      "algorithmic_tflop_per_step": train_step_flops(hp, 64 * 128) / 1e12, "achieved": tfl,
                                                      "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": tfl / PEAK_TFLOPS_F16, "mfma_per_product": 3,
                                                      "pipe_frac": 3 * tfl / PEAK_TFLOPS_F16, "traffic": load_train_traffic()[0],

@@ -1071,11 +1071,25 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
         Cp = round_up(C, 128); Hp = round_up(H, 128);
         const int mpl = C / 16;
         // (every row of [0, rows) of these planes is rewritten by the producing epilogue each step, zeros on gap rows included; the guard rows
-        //  are what has to be zero, and a layout change moves them: cleared whole here, 0.5 GB = 0.1 ms with per-layer planes)
+        //  are what has to be zero, and a layout change moves them)
         fm = C % 128 == 0 && (2 * C) % 256 == 0 && H % 128 == 0 && max_dil <= TGUARD;
         xh_layer = fm ? (r + 2 * TGUARD) * 2 * Cp : 0; gh_layer = fm ? r * 2 * Cp : 0;
         const size_t nl = fm ? (size_t)L : 1;
-        DSVC_TRY(z(xhP, nl * (r + 2 * TGUARD) * 2 * Cp * 2)); DSVC_TRY(z(ghP, nl * r * 2 * Cp * 2)); DSVC_TRY(z(condHP, r * 2 * Hp * 2));
+        {   // a re-used allocation only needs its guard rows cleared (they move with the layout); a fresh one is cleared whole
+            const size_t row_b = (size_t)2 * Cp * 2, layer_b = (r + 2 * TGUARD) * row_b, guard_b = (size_t)TGUARD * row_b;
+            const void* was = xhP.p;
+            const bool reused = xhP.p && nl * layer_b <= xhP.bytes;
+            DSVC_TRY(xhP.alloc(nl * layer_b));
+            if (!reused || xhP.p != was) DSVC_HIP(hipMemsetAsync(xhP.p, 0, nl * layer_b, st));
+            else {
+                DSVC_HIP(hipMemset2DAsync(xhP.p, layer_b, 0, guard_b, nl, st));
+                DSVC_HIP(hipMemset2DAsync((char*)xhP.p + guard_b + r * row_b, layer_b, 0, guard_b, nl, st));
+            }
+            const bool g_reused = ghP.p && nl * r * row_b <= ghP.bytes;
+            DSVC_TRY(ghP.alloc(nl * r * row_b));
+            if (!g_reused) DSVC_HIP(hipMemsetAsync(ghP.p, 0, nl * r * row_b, st));       // (no guard rows: every row of [0, rows) is rewritten each step)
+        }
+        DSVC_TRY(z(condHP, r * 2 * Hp * 2));
         if (fm) DSVC_TRY(wbias.alloc((size_t)WGRAD_MAX_TILES * 256 * 4));
         gate_halfs = tpacked_halfs(mpl, 3, Cp, 2, 1); out_halfs = tpacked_halfs(mpl, 1, Cp, 2, 1); cproj_halfs = tpacked_halfs(mpl, 1, Hp, 2, 1);
         DSVC_TRY(gate_t.alloc(gate_halfs * L * 2)); DSVC_TRY(out_t.alloc(out_halfs * L * 2)); DSVC_TRY(cproj_t.alloc(cproj_halfs * L * 2));
