@@ -146,6 +146,7 @@ SYMBOLS = [
     ("dsvc_trainer_step", ctypes.c_int, [_VP, ctypes.POINTER(TrainArgs), _VP, _VP]),
     ("dsvc_trainer_step_begin", ctypes.c_int, [_VP, ctypes.POINTER(TrainArgs), _VP]),
     ("dsvc_trainer_check", ctypes.c_int, [_VP, _VP]),
+    ("dsvc_trainer_debug_set", ctypes.c_int, [_VP, ctypes.c_char_p, ctypes.c_int32]),
     ("dsvc_trainer_step_layers", ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, _VP]),
     ("dsvc_trainer_step_end", ctypes.c_int, [_VP, _VP, _VP]),
     ("dsvc_adamw_step", ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,

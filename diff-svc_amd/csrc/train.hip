@@ -863,6 +863,7 @@ struct dsvc_trainer {
     // channel-major copies a k_split_t pass writes -- which needs layer l's x / g planes alive in the backward pass: every layer gets its own
     // (2 x 270 MB at the 64 x 128 batch).  fm = the architecture fits the kernel's tiles (C % 128, H % 128: the shipped configs; others keep k_split_t)
     bool fm = false;
+    bool fm_off = false;                           // test support (dsvc_trainer_debug_set "wgrad_fm" 0): keep the k_split_t path where fm would apply
     size_t xh_layer = 0, gh_layer = 0;             // halfs between the layers' planes in xhP / ghP (0: one buffer all layers share)
     DevBuf wbias;                                  // partial column sums (bias gradients) of one wgrad_fm launch: [slices][k tiles][O_pad]
     struct FmProb {                                // one contraction: dW[o][k] = sum_n A[n][o] * B_seg[n + shift][k]; bias_dst (and bias_dst2) <- column sums of A
@@ -1072,7 +1073,7 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
         const int mpl = C / 16;
         // (every row of [0, rows) of these planes is rewritten by the producing epilogue each step, zeros on gap rows included; the guard rows
         //  are what has to be zero, and a layout change moves them)
-        fm = C % 128 == 0 && (2 * C) % 256 == 0 && H % 128 == 0 && max_dil <= TGUARD;
+        fm = !fm_off && C % 128 == 0 && (2 * C) % 256 == 0 && H % 128 == 0 && max_dil <= TGUARD;
         xh_layer = fm ? (r + 2 * TGUARD) * 2 * Cp : 0; gh_layer = fm ? r * 2 * Cp : 0;
         const size_t nl = fm ? (size_t)L : 1;
         {   // a re-used allocation only needs its guard rows cleared (they move with the layout); a fresh one is cleared whole
@@ -1600,6 +1601,13 @@ int dsvc_trainer_check(dsvc_trainer* t, void* stream) {
         return fail(DSVC_EINVAL, "a training step was given a diffusion step outside [0, %d): it ran at the clamped step", t->cfg.timesteps);
     }
     return DSVC_OK;
+}
+
+int dsvc_trainer_debug_set(dsvc_trainer* t, const char* key, int32_t value) {
+    if (!t || !key) return fail(DSVC_EINVAL, "null argument");
+    if (t->next_layer >= 0) return fail(DSVC_ESTATE, "trainer: a step is in flight");
+    if (std::string(key) == "wgrad_fm") { t->fm_off = value == 0; t->wsB = t->wsT = 0; return DSVC_OK; }      // (the next step lays the workspace out again)
+    return fail(DSVC_EINVAL, "trainer: unknown debug key '%s'", key);
 }
 
 int dsvc_trainer_step_begin(dsvc_trainer* t, const dsvc_train_args* a, void* stream) {

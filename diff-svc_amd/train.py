@@ -41,6 +41,10 @@ class TrainerHandle:
         clamped on the device; the reference's extract() would raise an IndexError)."""
         check(lib().dsvc_trainer_check(self._h, stream_ptr()))
 
+    def debug_set(self, key, value):
+        """Test support (include/dsvc_debug.h: dsvc_trainer_debug_set), e.g. ``("wgrad_fm", 0)``: the k_split_t weight-gradient path."""
+        check(lib().dsvc_trainer_debug_set(self._h, key.encode(), int(value)))
+
     def bind(self, params, grads):
         assert params.is_cuda and grads.is_cuda and params.numel() == self.n_floats == grads.numel()
         self._keep = (params, grads)

@@ -51,6 +51,12 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
 int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters,
                                      float* avg_us, int64_t* rows, int32_t* kind, void* stream);
 
+/* test support for the trainer, as dsvc_denoiser_debug_set: "wgrad_fm" = 0 makes the residual layers' weight gradients take the k_split_t +
+ * wgrad_nt_kernel path (channel-major copies of every operand) where the architecture would let them be contracted straight from the
+ * frame-major operand planes (csrc/wgrad.h: wgrad_fm_kernel, the default since round 5); 1 = automatic.  Both paths compute the same products;
+ * tests/test_gpu_train.py holds them to each other.  Not for a deployment. */
+int dsvc_trainer_debug_set(dsvc_trainer* t, const char* key, int32_t value);
+
 #ifdef __cplusplus
 }
 #endif
