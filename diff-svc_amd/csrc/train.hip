@@ -744,20 +744,28 @@ __global__ void k_bin_scatter(const int* __restrict__ pitch, const int* __restri
 // S[bin][c] += sum over the segment's frames of src[row(frame)][c]; grid (max segments, ceil(C / 256)), 64 threads x 4 columns.  src = the fp16
 // [hi | lo] row planes of dy (TEpiGateBwdT writes them for the transposed conv; round 5: the fp32 rows are no longer written): ld halfs per row,
 // lo plane `lo` halfs in; hi + lo is dy to 2^-22
-__global__ __launch_bounds__(64) void k_bin_sums(const _Float16* __restrict__ src, int ld, int lo, const int* __restrict__ order, const int* __restrict__ segs,
-                                                 const int* __restrict__ n_segs, int T, int stride, float* __restrict__ S, int C) {
+__global__ __launch_bounds__(256) void k_bin_sums(const _Float16* __restrict__ src, int ld, int lo, const int* __restrict__ order, const int* __restrict__ segs,
+                                                  const int* __restrict__ n_segs, int T, int stride, float* __restrict__ S, int C) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     if ((int)blockIdx.x >= *n_segs) return;
     const int bin = segs[3 * blockIdx.x], first = segs[3 * blockIdx.x + 1], len = segs[3 * blockIdx.x + 2];
-    const int c = blockIdx.y * 256 + threadIdx.x * 4;
-    if (c >= C) return;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;          // four waves walk every fourth frame of the segment (round 5: one wave, <= 32 dependent row loads)
+    const int c = blockIdx.y * 256 + lane * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = 0; i < len; ++i) {
-        const int bt = order[first + i], b = bt / T, t = bt - b * T;
-        const _Float16* p = src + ((size_t)b * stride + t) * ld + c;
-        const h4 vh = *reinterpret_cast<const h4*>(p), vl = *reinterpret_cast<const h4*>(p + lo);
-        s.x += (float)vh[0] + (float)vl[0]; s.y += (float)vh[1] + (float)vl[1]; s.z += (float)vh[2] + (float)vl[2]; s.w += (float)vh[3] + (float)vl[3];
-    }
+    if (c < C)
+        for (int i = sub; i < len; i += 4) {
+            const int bt = order[first + i], b = bt / T, t = bt - b * T;
+            const _Float16* p = src + ((size_t)b * stride + t) * ld + c;
+            const h4 vh = *reinterpret_cast<const h4*>(p), vl = *reinterpret_cast<const h4*>(p + lo);
+            s.x += (float)vh[0] + (float)vl[0]; s.y += (float)vh[1] + (float)vl[1]; s.z += (float)vh[2] + (float)vl[2]; s.w += (float)vh[3] + (float)vl[3];
+        }
+    __shared__ float4 red[4][64];
+    red[sub][lane] = s;
+    __syncthreads();
+    if (sub || c >= C) return;
+    s = red[0][lane];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) { s.x += red[q][lane].x; s.y += red[q][lane].y; s.z += red[q][lane].z; s.w += red[q][lane].w; }
     float* d = S + (size_t)bin * C + c;
     atomicAdd(d, s.x); atomicAdd(d + 1, s.y); atomicAdd(d + 2, s.z); atomicAdd(d + 3, s.w);
 }
@@ -1449,7 +1457,7 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
             DSVC_TRY(wgrad_nt(2 * C, hp128, 3 * cp128, seg1(G(q + "conditioner_projection.weight"), H, H), 1.0f, st));
         }
         if (ta->pitch)     // S_l[bin] = sum of this layer's dy rows per pitch bin (instead of dcond += W_c^T dy: see k_bin_sums)
-            hipLaunchKernelGGL(k_bin_sums, dim3(ceil_div(B * T, 32) + cfg.pitch_vocab, ceil_div(2 * C, 256)), dim3(64), 0, st,
+            hipLaunchKernelGGL(k_bin_sums, dim3(ceil_div(B * T, 32) + cfg.pitch_vocab, ceil_div(2 * C, 256)), dim3(256), 0, st,
                                (const _Float16*)(dyh.as<_Float16>() + (size_t)TGUARD * 2 * C2p), 2 * C2p, C2p, bin_order.as<int>(), bin_segs.as<int>(), bin_nsegs.as<int>(), T, Tp,
                                bin_S.as<float>() + (size_t)l * cfg.pitch_vocab * 2 * C, 2 * C);
         {   // dxin = convT(dy); dx <- dx / sqrt 2 + dxin; the residual half of dO (rows and planes) <- dx / sqrt 2
