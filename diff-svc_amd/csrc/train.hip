@@ -8,13 +8,15 @@
 // 93 % of the FLOPs -- run on the sampler's tgemm engine (tgemm.h; round 4): activations as fp16 [hi | lo] row planes written by the producing
 // epilogue and DMA'd straight into LDS, weights re-packed per step into fragment order (k_tpack_batch); the data gradients' 2C-channel
 // operands are streamed through LDS in K phases (tgemm.h KP).  The small projections at both ends stay on conv_gemm.h, the weight gradients
-// on wgrad.h.  Layout: fp32 frame-major rows (row = clip*Tp + t, gap rows zero = the convs' zero padding) for everything the backward
-// pass re-reads.
+// on wgrad.h.  Layout: fp32 frame-major rows (row = clip*Tp + t, gap rows zero = the convs' zero padding) for what the backward pass
+// re-reads as fp32 (x, sigma, tau), fp16 [hi | lo] row planes -- one set per layer for x + film and g -- for what it contracts.
 //   forward   y = conv_dil(x + film) + W_c cond + b ;  g = sigmoid(y_a) tanh(y_b) ;  [r; s] = W_o g + b ;  x' = (x + r)/sqrt2 ; skip += s
 //             (sigma, tau, g and every layer's x are kept: ~1.3 GB for the 64 x 128-frame batch)
 //   backward  dO = [dx/sqrt2 ; dskip] ;  dg = W_o^T dO ;  dy = dg (tau sigma(1-sigma) ; sigma(1-tau^2)) ;  dx = dx/sqrt2 + convT(dy) ;
-//             (the conditioner's data gradient is never formed: k_bin_sums) ;  weight gradients dW[o][k] = sum_n A[n][o] B[n][k] on channel-major fp16 hi|lo planes of both
-//             operands (wgrad.h: k_split_t + wgrad_nt_kernel; the contraction index is the frame index).
+//             (the conditioner's data gradient is never formed: k_bin_sums) ;  weight gradients dW[o][k] = sum_n A[n][o] B[n][k], the contraction index is
+//             the frame index: round 5 contracts the residual layers' straight from those frame-major planes (wgrad.h: wgrad_fm_kernel, transposing LDS
+//             reads; conv taps = row offsets, bias sums = MFMAs against ones); the three projections at both ends, and architectures whose channel
+//             counts are not multiples of 128, go through channel-major copies (k_split_t + wgrad_nt_kernel).
 //   loss scaling: d loss / d eps is ~1/(B M T) ~ 1e-6, inside fp16's SUBNORMAL range where a hi + lo split keeps 4 bits; the backward
 //             pass is linear in it, so it runs on deps * 2^k (k chosen from 1/(B M T): operands in fp16's normal range) and the flat
 //             gradient buffer is multiplied by 2^-k once at the end -- exact, powers of two.

@@ -5,7 +5,7 @@
 // Both operands are produced frame-major ([n][channel] fp32) by the forward / data-gradient kernels, but an MFMA fragment wants the
 // contraction index contiguous per lane.  Round 2 ran this contraction on the conv engine: dY^T repacked into weight fragments
 // (k_pack_w), X^T as an fp32 transposed copy, fp32 -> hi|lo conversion at staging, 32 x 64 output tiles: 41 % of the training step.
-// Here:
+// Round 3 (still the path of the small projections at both ends of the network and of channel counts that are not multiples of 128):
 //   * k_split_t  writes an operand ONCE as channel-major fp16 planes  T[plane hi|lo][channel][n]  (v = hi + lo, fp32-class), with the
 //                validity mask, the FiLM shift of the dilated conv's input and the conv tap's frame shift folded in.
 //   * wgrad_nt_kernel  is then a plain "NT" GEMM on those planes: a 256 (o) x 128 (k) output tile per workgroup, 8 waves of 64 x 64,
@@ -15,6 +15,9 @@
 //                piece loads row (l & 31), frames 8 (l >> 5) .. +7 and the DMA drops it at piece + 16 l -- exactly what ds_read_b128 at
 //                lane*16 hands to the MFMA, so there is no swizzle and no bank conflict.  Three stages (144 KB) in flight, one bare
 //                s_barrier per stage, counted vmcnt.
+// Round 5 (the residual layers, 97 % of the weight-gradient FLOPs):
+//   * wgrad_fm_kernel  contracts the frame-major fp16 [hi | lo] planes the layer kernels write anyway -- no k_split_t pass, no copies: the
+//                stage is DMA'd as the planes lie and ds_read_b64_tr_b16 transposes on the way out of LDS (further down).
 #pragma once
 #include "conv_gemm.h"
 
