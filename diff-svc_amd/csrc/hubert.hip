@@ -27,6 +27,7 @@ using namespace dsvc;
 namespace {
 
 constexpr int HB_C0 = 512, HB_D = 768, HB_FF = 3072, HB_HEADS = 12, HB_HD = 64, HB_LAYERS = 12, HB_OUT = 256, HB_GROUPS = 16, HB_PK = 128;
+constexpr size_t HB_SCORE_BYTES = (size_t)4 << 30;      // budget of the heads' score matrices [heads in a launch][T][T] fp32 (12 heads fit up to T = 9 400 frames = 3 min)
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -137,6 +138,7 @@ struct dsvc_hubert {
     DevBuf pos_all;                                // the groups' packed weights, pos_halfs apart
     size_t pos_halfs = 0, packK_halfs = 0, packV_halfs = 0;      // per group / per head
     DevBuf head_packs;                             // 2 x HB_HEADS PackDesc: K_h and V_h^T of every head out of the qkv buffer (k_pack_w_batch)
+    int head_batch = HB_HEADS;                     // heads per batched launch: all 12 unless their score matrices would not fit HB_SCORE_BYTES (minutes-long utterances)
 
     ~dsvc_hubert() {
         for (DevBuf* b : {&conv0_w, &gn_g, &gn_b, &fp_ln_g, &fp_ln_b, &fp_b, &pos_w, &pos_b, &ln_g, &ln_b, &proj_b, &wavp, &c[0], &c[1], &gsum, &h, &h2,
@@ -283,7 +285,9 @@ int dsvc_hubert::ensure_ws(long long n, hipStream_t st) {
     DSVC_TRY(gsum.alloc(2 * HB_C0 * 8));
     const size_t Tr = (size_t)round_up((int)T, 32), Tp = Tr;
     DSVC_TRY(h.alloc(Tr * HB_D * 4)); DSVC_TRY(h2.alloc(Tr * HB_D * 4)); DSVC_TRY(posb.alloc(Tr * HB_D * 4)); DSVC_TRY(qkv.alloc(Tr * 3 * HB_D * 4));
-    DSVC_TRY(S.alloc(Tr * Tp * 4 * HB_HEADS)); DSVC_TRY(attn.alloc(Tr * HB_D * 4)); DSVC_TRY(ffb.alloc(Tr * HB_FF * 4));
+    head_batch = (int)(HB_SCORE_BYTES / (Tr * Tp * 4));
+    head_batch = head_batch < 1 ? 1 : (head_batch > HB_HEADS ? HB_HEADS : head_batch);
+    DSVC_TRY(S.alloc(Tr * Tp * 4 * head_batch)); DSVC_TRY(attn.alloc(Tr * HB_D * 4)); DSVC_TRY(ffb.alloc(Tr * HB_FF * 4));
     const int nctK = round_up(ceil_div((int)T, 32), 2), Tk = round_up((int)T, 16);
     packK_halfs = packed_halfs(nctK, 1, HB_HD, 2); packV_halfs = packed_halfs(2, 1, Tk, 2);
     DSVC_TRY(packK.alloc(packK_halfs * 2 * HB_HEADS));
@@ -363,22 +367,25 @@ int dsvc_hubert::units(const float* wav, long long n, float* out, hipStream_t st
             // scores_h = Q_h K_h^T / 8 -> softmax -> out_h = P_h V_h as batched launches (blockIdx.z = head; head h's scores in S + h * Tp * Tp)
             const long long sz = (long long)Tp * Tp;
             hipLaunchKernelGGL(k_pack_w_batch, dim3(128, 2 * HB_HEADS), dim3(256), 0, st, (const PackDesc*)head_packs.p);
-            {
-                ConvGemmArgs a{};
-                a.x = qkv.as<float>(); a.ldx = 3 * HB_D; a.n_rows = T; a.clip_stride = T < 32 ? 32 : T; a.clip_len = T; a.cin = HB_HD; a.taps = 1; a.dil = 1;
-                a.w = packK.as<_Float16>(); a.n_ctiles = nctK; a.w_planes = 2; a.in_slope = 1.0f;
-                a.nz = HB_HEADS; a.x_z = HB_HD; a.w_z = (long long)packK_halfs;
-                EpLin::Args e{S.as<float>(), Tp, nullptr, Tp, 0, nullptr, 0, 0, T, 0.125f, sz, 0};
-                DSVC_TRY(launch<EpLin>(a, e, st));
-            }
-            hipLaunchKernelGGL(k_softmax_rows, dim3(ceil_div(T, 4), HB_HEADS), dim3(256), 0, st, S.as<float>(), T, T, Tp, sz);
-            {
-                ConvGemmArgs a{};
-                a.x = S.as<float>(); a.ldx = Tp; a.n_rows = T; a.clip_stride = T < 32 ? 32 : T; a.clip_len = T; a.cin = Tk; a.taps = 1; a.dil = 1;
-                a.w = packV.as<_Float16>(); a.n_ctiles = 2; a.w_planes = 2; a.in_slope = 1.0f;
-                a.nz = HB_HEADS; a.x_z = sz; a.w_z = (long long)packV_halfs;
-                EpLin::Args e{attn.as<float>(), HB_D, nullptr, HB_HD, 0, nullptr, 0, 0, T, 1.0f, 0LL, HB_HD};
-                DSVC_TRY(launch<EpLin>(a, e, st));
+            for (int h0 = 0; h0 < HB_HEADS; h0 += head_batch) {      // (one round unless the utterance is minutes long: head_batch)
+                const int nb = HB_HEADS - h0 < head_batch ? HB_HEADS - h0 : head_batch;
+                {
+                    ConvGemmArgs a{};
+                    a.x = qkv.as<float>() + h0 * HB_HD; a.ldx = 3 * HB_D; a.n_rows = T; a.clip_stride = T < 32 ? 32 : T; a.clip_len = T; a.cin = HB_HD; a.taps = 1; a.dil = 1;
+                    a.w = packK.as<_Float16>() + (size_t)h0 * packK_halfs; a.n_ctiles = nctK; a.w_planes = 2; a.in_slope = 1.0f;
+                    a.nz = nb; a.x_z = HB_HD; a.w_z = (long long)packK_halfs;
+                    EpLin::Args e{S.as<float>(), Tp, nullptr, Tp, 0, nullptr, 0, 0, T, 0.125f, sz, 0};
+                    DSVC_TRY(launch<EpLin>(a, e, st));
+                }
+                hipLaunchKernelGGL(k_softmax_rows, dim3(ceil_div(T, 4), nb), dim3(256), 0, st, S.as<float>(), T, T, Tp, sz);
+                {
+                    ConvGemmArgs a{};
+                    a.x = S.as<float>(); a.ldx = Tp; a.n_rows = T; a.clip_stride = T < 32 ? 32 : T; a.clip_len = T; a.cin = Tk; a.taps = 1; a.dil = 1;
+                    a.w = packV.as<_Float16>() + (size_t)h0 * packV_halfs; a.n_ctiles = 2; a.w_planes = 2; a.in_slope = 1.0f;
+                    a.nz = nb; a.x_z = sz; a.w_z = (long long)packV_halfs;
+                    EpLin::Args e{attn.as<float>(), HB_D, nullptr, HB_HD, 0, nullptr, 0, h0 * HB_HD, T, 1.0f, 0LL, HB_HD};
+                    DSVC_TRY(launch<EpLin>(a, e, st));
+                }
             }
         }
         {   // x = LayerNorm1(x + out_proj(attn))
