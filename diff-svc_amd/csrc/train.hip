@@ -1064,14 +1064,19 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
         DSVC_HIP(hipGetLastError());
         return DSVC_OK;
     };
+    // (round 5) fm: the residual layers' weight gradients are contracted from the layers' fp16 operand planes (wgrad.h: wgrad_fm_kernel) -- then
+    // g and dy are never stored as fp32 rows and their buffers (0.3 GB at the 64 x 128 batch) are not allocated
+    fm = !fm_off && C % 128 == 0 && (2 * C) % 256 == 0 && H % 128 == 0 && max_dil <= TGUARD;
     DSVC_TRY(z(xt, r * M * 4)); DSVC_TRY(zg(xs, C, L + 1)); DSVC_TRY(zg(sig, C, L)); DSVC_TRY(zg(tau, C, L));
-    DSVC_TRY(zg(g, C, L)); DSVC_TRY(z(skip, r * C * 4)); DSVC_TRY(zg(ypre, round_up(2 * C, 128), L)); DSVC_TRY(z(s2pre, r * C * 4));
+    if (!fm) DSVC_TRY(zg(g, C, L));
+    DSVC_TRY(z(skip, r * C * 4)); DSVC_TRY(zg(ypre, round_up(2 * C, 128), L)); DSVC_TRY(z(s2pre, r * C * 4));
     DSVC_TRY(z(eps, r * M * 4)); DSVC_TRY(z(deps, r * M * 4)); DSVC_TRY(z(condT, r * H * 4));
     DSVC_TRY(z(tstep, (size_t)B * 4)); DSVC_TRY(z(clipid, (size_t)B * 4)); DSVC_TRY(z(iotaB, (size_t)B * 4));
     DSVC_TRY(z(e0, (size_t)B * C * 4)); DSVC_TRY(z(e1pre, (size_t)B * 4 * C * 4)); DSVC_TRY(z(e1, (size_t)B * 4 * C * 4)); DSVC_TRY(z(e2, (size_t)B * C * 4));
     DSVC_TRY(z(filmB, (size_t)B * L * C * 4)); DSVC_TRY(z(dfilm, (size_t)B * L * C * 4)); DSVC_TRY(z(de2, (size_t)B * C * 4));
     DSVC_TRY(z(de1, (size_t)B * 4 * C * 4)); DSVC_TRY(z(de1pre, (size_t)B * 4 * C * 4));
-    DSVC_TRY(z(dx, r * C * 4)); DSVC_TRY(z(dxin, r * C * 4)); DSVC_TRY(z(dO, r * 2 * C * 4)); DSVC_TRY(z(dy, r * 2 * C * 4));
+    DSVC_TRY(z(dx, r * C * 4)); DSVC_TRY(z(dxin, r * C * 4)); DSVC_TRY(z(dO, r * 2 * C * 4));
+    if (!fm) DSVC_TRY(z(dy, r * 2 * C * 4));
     DSVC_TRY(z(ds2pre, r * C * 4)); DSVC_TRY(z(dh0, r * C * 4)); DSVC_TRY(z(loss, 16));
     {   // pitch-bin bookkeeping (k_bin_*): at most ceil(B T / 32) + vocab segments of <= 32 frames
         const int V = cfg.pitch_vocab, max_segs = ceil_div(B * T, 32) + V;
@@ -1083,7 +1088,6 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
         const int mpl = C / 16;
         // (every row of [0, rows) of these planes is rewritten by the producing epilogue each step, zeros on gap rows included; the guard rows
         //  are what has to be zero, and a layout change moves them)
-        fm = !fm_off && C % 128 == 0 && (2 * C) % 256 == 0 && H % 128 == 0 && max_dil <= TGUARD;
         xh_layer = fm ? (r + 2 * TGUARD) * 2 * Cp : 0; gh_layer = fm ? r * 2 * Cp : 0;
         const size_t nl = fm ? (size_t)L : 1;
         {   // a re-used allocation only needs its guard rows cleared (they move with the layout); a fresh one is cleared whole
@@ -1422,7 +1426,7 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
         const std::string q = "denoise_fn.residual_layers." + std::to_string(l) + ".";
         const int d = 1 << (l % cfg.dilation_cycle);
         const float* xl = xs.as<float>() + (size_t)l * slab;
-        const float* gl = g.as<float>() + (size_t)l * slab;
+        const float* gl = fm ? nullptr : g.as<float>() + (size_t)l * slab;
         if (!fm) {
             DSVC_TRY(split_t(true, 0, dO.as<float>(), 2 * C, 2 * C, nullptr, 0, 0, st, G(q + "output_projection.bias")));
             DSVC_TRY(split_t(false, 0, gl, C, C, nullptr, 0, 0, st));
