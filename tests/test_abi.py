@@ -63,6 +63,10 @@ def test_hot_kernels_do_not_spill():
     tr = build.kernel_resources("train.hip")
     tk = {k: v for k, v in tr.items() if "tgemm_kernelILi2ELi8ELi2ELi4ELi2E" in k}
     assert len(tk) == 6 and all(v["spill"] == 0 and v["scratch"] == 0 for v in tk.values()), tk
+    # round 5: the weight-gradient kernel on the frame-major planes (wgrad.h) -- both instantiations (with / without the bias column sums) keep their
+    # two fragment sets, four accumulator tiles and the dynamically indexed problem descriptor in registers / SGPRs (no scratch), two waves per SIMD
+    wk = {k: v for k, v in tr.items() if "wgrad_fm_kernel" in k}
+    assert len(wk) == 2 and all(v["spill"] == 0 and v["scratch"] == 0 and v["vgprs"] <= 256 for v in wk.values()), wk
     # the vocoder's wide-stage kernels (round 4: tgemm with split activations; 128 channels as two frame sub-tiles per workgroup)
     vk = {k: v for k, v in build.kernel_resources("vocoder.hip").items() if "tgemm_kernel" in k}
     assert len(vk) == 6 and all(v["spill"] == 0 and v["scratch"] == 0 for v in vk.values()), vk
