@@ -61,17 +61,37 @@ __global__ void k_pe_stage_mel(const float* __restrict__ mel, float* __restrict_
 
 // GroupNorm moments per (clip, group) over T frames x gs channels: sums[clip][G][2] doubles; grid (chunks, B), 256 threads
 __global__ void k_pe_gn_stats(const float* __restrict__ y, double* __restrict__ sums, int T, int Ts, int C, int gs, int rows_per_block) {
+    // per-channel partial moments of this block's rows, added up per GROUP in LDS before they go out: one pair of double atomics per group and block
+    // (round 5; one pair per CHANNEL and block before -- 15 000 atomics on 16 addresses, 78 us for a 1.9 MB tensor, profiles/r5p_kernel_stats_pe.csv)
+    __shared__ double sh[2][512];
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * rows_per_block;
     const int G = C / gs;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0.0, q = 0.0;
-        for (int t = t0; t < t0 + rows_per_block && t < T; ++t) {
-            const double v = (double)y[((size_t)b * Ts + t) * C + c];
-            s += v; q += v * v;
+    for (int c0 = 0; c0 < C; c0 += 512) {
+        for (int c = c0 + threadIdx.x; c < C && c < c0 + 512; c += blockDim.x) {
+            double s = 0.0, q = 0.0;
+            for (int t = t0; t < t0 + rows_per_block && t < T; ++t) {
+                const double v = (double)y[((size_t)b * Ts + t) * C + c];
+                s += v; q += v * v;
+            }
+            sh[0][c - c0] = s; sh[1][c - c0] = q;
         }
-        atomicAdd(sums + ((size_t)b * G + c / gs) * 2, s);
-        atomicAdd(sums + ((size_t)b * G + c / gs) * 2 + 1, q);
+        __syncthreads();
+        const int c_hi = C < c0 + 512 ? C : c0 + 512;
+        if (gs <= 512 && c0 % gs == 0 && 512 % gs == 0) {
+            for (int g = c0 / gs + threadIdx.x; g * gs < c_hi; g += blockDim.x) {      // whole groups inside this 512-channel chunk
+                double s = 0.0, q = 0.0;
+                for (int c = g * gs; c < (g + 1) * gs; ++c) { s += sh[0][c - c0]; q += sh[1][c - c0]; }
+                atomicAdd(sums + ((size_t)b * G + g) * 2, s);
+                atomicAdd(sums + ((size_t)b * G + g) * 2 + 1, q);
+            }
+        } else {
+            for (int c = c0 + threadIdx.x; c < c_hi; c += blockDim.x) {
+                atomicAdd(sums + ((size_t)b * G + c / gs) * 2, sh[0][c - c0]);
+                atomicAdd(sums + ((size_t)b * G + c / gs) * 2 + 1, sh[1][c - c0]);
+            }
+        }
+        __syncthreads();
     }
 }
 // x <- x + relu((y - mean) * rstd * gamma + beta)   (ConvBlock :69-78 + the residual of ConvStacks :108-110; biased variance, eps 1e-5)
