@@ -55,21 +55,16 @@ __global__ void k_pad_wav(const float* __restrict__ wav, float* __restrict__ dst
 }
 
 // conv0: Conv1d(1, 512, 10, stride 5, no bias)  (hubert_model.py:85)  out[t][c] = sum_j w[c][j] x[5t + j]
-__global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int L) {
-    // a thread owns ONE channel (its ten weights in registers) and walks 64 frames: the samples are wave-uniform loads, the stores run along the
-    // channels (round 5; one thread per output re-read its 40 weight bytes for each of the 32 000 frames: 62 us for a 65 MB output)
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    const int t0 = blockIdx.x * 64, t1 = t0 + 64 < L ? t0 + 64 : L;
-    float wr[10];
+__global__ void k_conv0(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int L) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)L * HB_C0) return;
+    const int t = (int)(i / HB_C0), c = (int)(i - (long long)t * HB_C0);
+    const float* xp = x + (long long)t * 5;
+    const float* wp = w + c * 10;
+    float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) wr[j] = w[c * 10 + j];
-    for (int t = t0; t < t1; ++t) {
-        const float* xp = x + (long long)t * 5;
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) s = fmaf(wr[j], xp[j], s);
-        out[(size_t)t * HB_C0 + c] = s;
-    }
+    for (int j = 0; j < 10; ++j) s = fmaf(wp[j], xp[j], s);
+    out[i] = s;
 }
 
 // GroupNorm(512, 512): per-channel moments over time; grid (C/64, chunks), double atomics into sums[2][C]
@@ -327,9 +322,9 @@ int dsvc_hubert::units(const float* wav, long long n, float* out, hipStream_t st
     hipLaunchKernelGGL(k_pad_wav, dim3((unsigned)((n + 80 + 255) / 256)), dim3(256), 0, st, wav, wavp.as<float>(), n, 40);
     DSVC_HIP(hipMemsetAsync(c[0].p, 0, c[0].bytes, st));
     DSVC_HIP(hipMemsetAsync(c[1].p, 0, c[1].bytes, st));
-    hipLaunchKernelGGL(k_conv0, dim3(ceil_div(L[0], 64), HB_C0 / 256), dim3(256), 0, st, wavp.as<float>(), conv0_w.as<float>(), c[0].as<float>(), L[0]);
+    hipLaunchKernelGGL(k_conv0, dim3((unsigned)(((long long)L[0] * HB_C0 + 255) / 256)), dim3(256), 0, st, wavp.as<float>(), conv0_w.as<float>(), c[0].as<float>(), L[0]);
     DSVC_HIP(hipMemsetAsync(gsum.p, 0, 2 * HB_C0 * 8, st));
-    hipLaunchKernelGGL(k_gn_stats, dim3(HB_C0 / 64, ceil_div(L[0], 256)), dim3(256), 0, st, c[0].as<float>(), gsum.as<double>(), L[0], HB_C0, 256);      // (256 rows per block: 1 000 blocks; 1024 rows left each thread a chain of 256 loads)
+    hipLaunchKernelGGL(k_gn_stats, dim3(HB_C0 / 64, ceil_div(L[0], 1024)), dim3(256), 0, st, c[0].as<float>(), gsum.as<double>(), L[0], HB_C0, 1024);
     hipLaunchKernelGGL(k_gn_apply_gelu, dim3(4096), dim3(256), 0, st, c[0].as<float>(), gsum.as<double>(), gn_g.as<float>(), gn_b.as<float>(), L[0], HB_C0);
     int cur = 0;
     for (int i = 1; i <= 6; ++i) {
