@@ -23,3 +23,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs (a kernel that never returns) must fail the run, not sit until the visit's time limit takes the box with it: every
+    ``gpu`` test gets a 300 s limit (the longest takes 19 s, profiles/r5H_pytest_gpu.txt) through pytest-timeout's THREAD method, which ends the
+    process even while the main thread is blocked inside a HIP call.  Without the plugin nothing changes."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for it in items:
+        if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
+            it.add_marker(pytest.mark.timeout(300, method="thread"))
