@@ -14,7 +14,7 @@ PREC_F16_X3T = 4
 PREC_F16_W6 = 5
 PREC_F16_W6N = 6
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3, "f16_x3t": PREC_F16_X3T}
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def parse_precision(p):
@@ -23,7 +23,7 @@ def parse_precision(p):
     if isinstance(p, (tuple, list)):
         return int(p[0]), int(p[1])
     if isinstance(p, int):
-        return p, 0                                      # (0 = the scheme's default number of dithered roundings, chosen by the library: 64 for the 6-bit schemes)
+        return p, -1                                     # (DSVC_VARIANTS_DEFAULT: the scheme's default number of dithered roundings, chosen by the library: 64 for the 6-bit schemes)
     if p == "f16_x3t":                                   # (64 dithered roundings of the fp6 w_lo codes its small tilings use since round 4)
         return PREC_F16_X3T, 64
     if p in PRECISIONS:
@@ -110,6 +110,7 @@ SYMBOLS = [
     ("dsvc_sampler_finalize", ctypes.c_int, [_VP]),
     ("dsvc_sampler_destroy", None, [_VP]),
     ("dsvc_sample", ctypes.c_int, [_VP, ctypes.POINTER(SampleArgs), _VP]),
+    ("dsvc_sampler_stats", ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32]),
     ("dsvc_sampler_profile_gate_kernel", ctypes.c_int,
      [_VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64), c_i32p, _VP]),
     ("dsvc_vocoder_create", ctypes.c_int, [ctypes.POINTER(VocoderCfg), ctypes.POINTER(_VP)]),
@@ -154,39 +155,64 @@ SYMBOLS = [
     ("dsvc_grad_clip_coef", ctypes.c_int, [_VP, ctypes.c_int64, ctypes.c_float, _VP, _VP, _VP]),
 ]
 
-_lib = None
+_libs = {}                      # path -> loaded library (product, test-hooks and profiling builds can coexist: every internal is hidden)
+HOOKS_PATH = os.path.join(HERE, "libdsvc_hip_hooks.so")
 
 
 def use_profiling_build():
     """Profiling tools only (tools/): bind to libdsvc_hip_prof.so, the -DDSVC_PROFILING build whose kernels carry the ablation knobs
     (``python -m diffsvc_amd.build --profiling``).  Must be called before the first ``lib()``."""
     global LIB_PATH
-    if _lib is not None:
+    if _libs:
         raise RuntimeError("the library is already loaded")
     LIB_PATH = os.path.join(HERE, "libdsvc_hip_prof.so")
 
 
-def lib():
-    """Load the HIP library (once).  Raises if it is missing -- build it with diffsvc_amd.build.build()."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("libdsvc_hip.so not found at %s: build it with `python -m diffsvc_amd.build` "
-                               "(there is no CPU fallback)" % LIB_PATH)
-        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+def _load(path):
+    handle = _libs.get(path)
+    if handle is None:
+        if not os.path.exists(path):
+            raise RuntimeError("%s not found at %s: build it with `python -m diffsvc_amd.build` "
+                               "(there is no CPU fallback)" % (os.path.basename(path), path))
+        handle = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
         for name, res, args in SYMBOLS:
             fn = getattr(handle, name)          # AttributeError if the ABI symbol is missing
             fn.restype = res
             fn.argtypes = args
         if handle.dsvc_abi_version() != ABI_VERSION:
-            raise RuntimeError("libdsvc_hip.so ABI version mismatch")
-        _lib = handle
-    return _lib
+            raise RuntimeError("%s ABI version mismatch" % os.path.basename(path))
+        _libs[path] = handle
+    return handle
 
 
-def check(rc):
+def lib():
+    """Load the HIP library (once).  Raises if it is missing -- build it with diffsvc_amd.build.build()."""
+    return _load(LIB_PATH)
+
+
+class hooks_build:
+    """``with _lib.hooks_build(): ...`` -- handles created inside bind to libdsvc_hip_hooks.so, the TEST-HOOKS build: the product library plus the
+    ``dsvc_*_debug_set`` keys that change which kernel computes a result (per-layer taps, the A/B partners of the fused kernels and of the
+    6-bit products).  Same sources, same kernels; only csrc/diffnet.hip and csrc/train.hip are compiled a second time with -DDSVC_TEST_HOOKS,
+    which switches on branches of those two host functions and nothing else.  The product library refuses those keys.  A handle keeps the
+    library it was created in for its lifetime (``DenoiserHandle._L``), so hooks handles and product handles coexist in one process."""
+
+    def __enter__(self):
+        global LIB_PATH
+        self._prev = LIB_PATH
+        if not LIB_PATH.endswith("_prof.so"):              # (the profiling build carries the hooks as well)
+            LIB_PATH = HOOKS_PATH
+        return lib()
+
+    def __exit__(self, *exc):
+        global LIB_PATH
+        LIB_PATH = self._prev
+        return False
+
+
+def check(rc, L=None):
     if rc != 0:
-        msg = lib().dsvc_last_error()
+        msg = (L or lib()).dsvc_last_error()
         raise RuntimeError("dsvc error %d: %s" % (rc, msg.decode() if msg else "?"))
 
 

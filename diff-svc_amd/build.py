@@ -15,7 +15,10 @@ OUT = os.path.join(HERE, "libdsvc_hip.so")
 OUT_PROF = os.path.join(HERE, "libdsvc_hip_prof.so")
 SOURCES = ["common.hip", "diffnet.hip", "vocoder.hip", "melspec.hip", "train.hip", "hubert.hip", "pe.hip", "cond.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-fvisibility=hidden", "-fvisibility-inlines-hidden",      # the entry points (DSVC_API in include/dsvc.h) are the ONLY dynamic symbols
          "-Rpass-analysis=kernel-resource-usage"]       # the per-kernel register / scratch report is kept next to the object
+OUT_HOOKS = os.path.join(HERE, "libdsvc_hip_hooks.so")
+HOOK_SOURCES = ["diffnet.hip", "train.hip"]             # the two units that hold dsvc_*_debug_set: compiled a second time with -DDSVC_TEST_HOOKS
 
 
 def _hipcc():
@@ -33,45 +36,64 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True, profiling=False):
-    """profiling=True compiles a SEPARATE library, libdsvc_hip_prof.so, with -DDSVC_PROFILING: the ablation / A-B knobs of the kernels
+    """Builds libdsvc_hip.so (the product) and libdsvc_hip_hooks.so (the TEST-HOOKS build: the same objects except csrc/diffnet.hip and
+    csrc/train.hip, compiled with -DDSVC_TEST_HOOKS, which lets dsvc_*_debug_set accept the keys that change which kernel computes a result --
+    per-layer taps and A/B partners for the parity tests; the product library refuses them).
+    profiling=True compiles a SEPARATE library, libdsvc_hip_prof.so, with -DDSVC_PROFILING: the ablation / A-B knobs of the kernels
     (environment variables DSVC_TG_DEBUG, DSVC_TG_STAMPS, DSVC_PROFILE_KERNEL, ... -- several of them give WRONG results by design) exist
     only there.  The product library reads no environment variable; tools load the other one with _lib.use_profiling_build()."""
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build_prof" if profiling else "build")
+    hookdir = os.path.join(HERE, "build_hooks")
     out = OUT_PROF if profiling else OUT
     flags = FLAGS + (["-DDSVC_PROFILING"] if profiling else [])
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "dsvc.h"))
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "dsvc_debug.h"))
     missing = [s for s in SOURCES if not os.path.exists(os.path.join(CSRC, s))]
     if missing:
         raise RuntimeError("HIP sources missing from %s: %s" % (CSRC, ", ".join(missing)))
     srcs = list(SOURCES)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
+    jobs = [(s, o, flags) for s, o in zip(srcs, objs)]
+    hook_objs = []
+    if not profiling:
+        os.makedirs(hookdir, exist_ok=True)
+        hook_objs = [os.path.join(hookdir, s.replace(".hip", ".o")) for s in HOOK_SOURCES]
+        jobs += [(s, o, flags + ["-DDSVC_TEST_HOOKS"]) for s, o in zip(HOOK_SOURCES, hook_objs)]
 
-    def compile_one(pair):
-        src, obj = pair
+    def compile_one(job):
+        src, obj, fl = job
         if not force and not _stale(obj, [os.path.join(CSRC, src)] + headers):
             return None
-        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + fl + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-8000:]))
         with open(obj.replace(".o", ".resources.txt"), "w") as f:
             f.write(r.stderr)
-        return src
+        return obj
 
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        built = [b for b in ex.map(compile_one, zip(srcs, objs)) if b]
-    if built or force or _stale(out, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        built = [b for b in ex.map(compile_one, jobs) if b]
+
+    def link(target, objects):
+        if not (built or force or _stale(target, objects + [os.path.join(CSRC, "exports.map")])):
+            if verbose:
+                print("up to date: %s" % target)
+            return
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", target] + objects
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-8000:])
         if verbose:
-            print("built %s (%s)" % (out, ", ".join(built) if built else "relink"))
-    elif verbose:
-        print("up to date: %s" % out)
+            print("built %s (%s)" % (target, ", ".join(os.path.relpath(b, HERE) for b in built) if built else "relink"))
+
+    link(out, objs)
+    if hook_objs:
+        swap = {os.path.basename(o): o for o in hook_objs}
+        link(OUT_HOOKS, [swap.get(os.path.basename(o), o) for o in objs])
     return out
 
 

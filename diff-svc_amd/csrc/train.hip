@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../../include/dsvc.h"
+#include "../../include/dsvc_debug.h"
 #include "cg_util.h"
 #include "wgrad.h"
 #include "tepi_util.h"
@@ -1620,8 +1621,11 @@ int dsvc_trainer_check(dsvc_trainer* t, void* stream) {
 int dsvc_trainer_debug_set(dsvc_trainer* t, const char* key, int32_t value) {
     if (!t || !key) return fail(DSVC_EINVAL, "null argument");
     if (t->next_layer >= 0) return fail(DSVC_ESTATE, "trainer: a step is in flight");
+#if defined(DSVC_TEST_HOOKS) || defined(DSVC_PROFILING)       // (the test-hooks build only: see dsvc_denoiser_debug_set)
     if (std::string(key) == "wgrad_fm") { t->fm_off = value == 0; t->wsB = t->wsT = 0; return DSVC_OK; }      // (the next step lays the workspace out again)
-    return fail(DSVC_EINVAL, "trainer: unknown debug key '%s'", key);
+#endif
+    (void)value;
+    return fail(DSVC_EINVAL, "trainer: unknown debug key '%s' (test hooks live in libdsvc_hip_hooks.so, not in the product library)", key);
 }
 
 int dsvc_trainer_step_begin(dsvc_trainer* t, const dsvc_train_args* a, void* stream) {

@@ -99,11 +99,10 @@ class DiffNetHip(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.precision,)
 
     def workspace_tiles(self, clips, T):
-        """128-row tiles of the C workspace for a [clips, T] call (csrc/diffnet.hip: ensure_ws -- a clip occupies round_up(T + largest
-        dilation, 32) rows, the batch is rounded up to whole tiles)."""
+        """128-row tiles of the C workspace for a [clips, T] call (csrc/diffnet.hip: bucket_rows -- a clip occupies round_up(T + largest
+        dilation, 128) rows: the BUCKET every T up to that size shares, workspace and captured graphs included)."""
         max_dil = 2 ** min(self.dilation_cycle - 1, self.n_layers - 1)
-        tp = (T + max_dil + 31) // 32 * 32
-        return (clips * tp + 127) // 128
+        return clips * ((T + max_dil + 127) // 128)
 
     def precision_for(self, use, speedup=1, frames=None, clips=None):
         """The operand precision used for ``use`` in {'ddpm', 'plms', 'forward'} (PLMS: also by its step interval; DDPM: also by the

@@ -32,20 +32,24 @@ class DenoiserHandle:
     def __init__(self, state, mel_bins, hidden, channels, layers, dilation_cycle, max_steps,
                  precision="f16_d64", prefix=""):
         self._h = ctypes.c_void_p(0)
+        self._L = lib()                                  # the library this handle lives in (product, or the test-hooks build: _lib.hooks_build)
         prec, variants = parse_precision(precision)
         self.cfg = _lib.DenoiserCfg(mel_bins, hidden, channels, layers, dilation_cycle, max_steps, prec, variants)
         self.mel_bins, self.hidden = mel_bins, hidden
-        check(lib().dsvc_denoiser_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
+        self._ck(self._L.dsvc_denoiser_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
         n = 0
         for k, v in state.items():
             if not k.startswith(prefix):
                 continue
             h, p = host_f32(v)
-            check(lib().dsvc_denoiser_load_tensor(self._h, k[len(prefix):].encode(), p, h.numel()))
+            self._ck(self._L.dsvc_denoiser_load_tensor(self._h, k[len(prefix):].encode(), p, h.numel()))
             n += 1
         if n == 0:
             raise RuntimeError("no tensors with prefix '%s' in the state dict" % prefix)
-        check(lib().dsvc_denoiser_finalize(self._h))
+        self._ck(self._L.dsvc_denoiser_finalize(self._h))
+
+    def _ck(self, rc):
+        check(rc, self._L)
 
     def forward(self, spec, t, cond, cond_changed=True):
         """DiffNet.forward: spec [B,1,M,T], t [B] (any int dtype), cond [B,H,T] -> [B,1,M,T]."""
@@ -62,30 +66,30 @@ class DenoiserHandle:
         # Steps outside the table are clamped ON THE DEVICE and raise a sticky flag (no device-to-host check on this 1000-calls-per-
         # clip seam): check() raises (later, valid calls are executed normally).  (The sampler never leaves the range; this guards direct callers.)
         out = torch.empty_like(spec)
-        check(lib().dsvc_denoiser_forward(self._h, ptr(spec), ptr(t32), ptr(cond), ptr(out), B, T,
+        self._ck(self._L.dsvc_denoiser_forward(self._h, ptr(spec), ptr(t32), ptr(cond), ptr(out), B, T,
                                           1 if cond_changed else 0, stream_ptr()))
         return out
 
     def check(self):
         """Wait for the current stream and raise if any forward() since the last check saw a diffusion step outside the schedule."""
-        check(lib().dsvc_denoiser_check(self._h, stream_ptr()))
+        self._ck(self._L.dsvc_denoiser_check(self._h, stream_ptr()))
 
     def debug_set(self, key, value):
         """Test support: 'stop_after_layers' (n >= 0, -1 = off) / 'two_launch_layer' (0 / 1) -- see include/dsvc.h."""
-        check(lib().dsvc_denoiser_debug_set(self._h, key.encode(), int(value)))
+        self._ck(self._L.dsvc_denoiser_debug_set(self._h, key.encode(), int(value)))
 
     def debug_buffer(self, name):
         """Copy of an internal frame-major buffer as a [rows, ld] tensor (parity-test aid)."""
         rows, ld = ctypes.c_int32(0), ctypes.c_int32(0)
-        check(lib().dsvc_denoiser_debug_buffer(self._h, name.encode(), None, 0, ctypes.byref(rows), ctypes.byref(ld)))
+        self._ck(self._L.dsvc_denoiser_debug_buffer(self._h, name.encode(), None, 0, ctypes.byref(rows), ctypes.byref(ld)))
         out = torch.empty(rows.value, ld.value, device="cuda", dtype=torch.float32)
-        check(lib().dsvc_denoiser_debug_buffer(self._h, name.encode(), ptr(out), out.numel(), None, None))
+        self._ck(self._L.dsvc_denoiser_debug_buffer(self._h, name.encode(), ptr(out), out.numel(), None, None))
         return out
 
     def __del__(self):
         try:
             if self._h:
-                lib().dsvc_denoiser_destroy(self._h)
+                self._L.dsvc_denoiser_destroy(self._h)
                 self._h = ctypes.c_void_p(0)
         except Exception:
             pass
@@ -96,14 +100,25 @@ class SamplerHandle:
 
     def __init__(self, denoiser, state):
         self._h = ctypes.c_void_p(0)
+        self._L = denoiser._L
         self.den = denoiser
-        check(lib().dsvc_sampler_create(denoiser._h, ctypes.byref(self._h)))
+        self._ck(self._L.dsvc_sampler_create(denoiser._h, ctypes.byref(self._h)))
         for k in SCHEDULE_KEYS:
             if k not in state:
                 raise KeyError("schedule buffer '%s' missing from the checkpoint state dict" % k)
             h, p = host_f32(state[k].reshape(-1))
-            check(lib().dsvc_sampler_load_tensor(self._h, k.encode(), p, h.numel()))
-        check(lib().dsvc_sampler_finalize(self._h))
+            self._ck(self._L.dsvc_sampler_load_tensor(self._h, k.encode(), p, h.numel()))
+        self._ck(self._L.dsvc_sampler_finalize(self._h))
+
+    def _ck(self, rc):
+        check(rc, self._L)
+
+    def stats(self):
+        """dsvc_sampler_stats: {'capture_ddpm', 'capture_plms', 'graph_launches', 'buckets_allocated', 'bucket_reuses', 'graphs_alive'} since the
+        handle was created -- how often a variable-length call sequence had to build a workspace bucket or capture a chain."""
+        out = (ctypes.c_int64 * 6)()
+        self._ck(self._L.dsvc_sampler_stats(self._h, out, 6))
+        return dict(zip(("capture_ddpm", "capture_plms", "graph_launches", "buckets_allocated", "bucket_reuses", "graphs_alive"), [int(v) for v in out]))
 
     def sample(self, cond, t_start, speedup=1, x_init=None, mel2ph=None, seed=0, first_clip=0, t_stop=0,
                use_graph=True, return_x=False, ref_mel=None, clip_ids=None, clip_lens=None):
@@ -144,7 +159,7 @@ class SamplerHandle:
                             ids.data_ptr() if ids is not None else None, lens.data_ptr() if lens is not None else None,
                             t_start, t_stop,
                             int(speedup), 1 if use_graph else 0, mel.data_ptr(), xo.data_ptr() if xo is not None else None)
-        check(lib().dsvc_sample(self._h, ctypes.byref(a), stream_ptr()))
+        self._ck(self._L.dsvc_sample(self._h, ctypes.byref(a), stream_ptr()))
         return (mel, xo) if return_x else mel
 
     def profile_gate_kernel(self, B, T, iters=5):
@@ -153,13 +168,13 @@ class SamplerHandle:
         us = ctypes.c_float(0)
         rows = ctypes.c_int64(0)
         kind = ctypes.c_int32(0)
-        check(lib().dsvc_sampler_profile_gate_kernel(self._h, B, T, iters, ctypes.byref(us), ctypes.byref(rows), ctypes.byref(kind), stream_ptr()))
+        self._ck(self._L.dsvc_sampler_profile_gate_kernel(self._h, B, T, iters, ctypes.byref(us), ctypes.byref(rows), ctypes.byref(kind), stream_ptr()))
         return us.value, rows.value, kind.value
 
     def __del__(self):
         try:
             if self._h:
-                lib().dsvc_sampler_destroy(self._h)
+                self._L.dsvc_sampler_destroy(self._h)
                 self._h = ctypes.c_void_p(0)
         except Exception:
             pass

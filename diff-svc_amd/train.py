@@ -23,37 +23,41 @@ from .cond import CondBuilder
 class TrainerHandle:
     def __init__(self, hp, loss_type="l2", pitch_vocab=300):
         self._h = ctypes.c_void_p(0)
+        self._L = lib()                                    # the library this handle lives in (product, or the test-hooks build: _lib.hooks_build)
         self._inflight = None                              # tensors of the step between step_begin() and step_end()
         self.cfg = _lib.TrainerCfg(hp["audio_num_mel_bins"], hp["hidden_size"], hp["residual_channels"], hp["residual_layers"],
                                    hp["dilation_cycle_length"], int(hp.get("timesteps", 1000)), 1 if loss_type == "l1" else 0, pitch_vocab)
-        check(lib().dsvc_trainer_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
+        self._ck(self._L.dsvc_trainer_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
         nt, nf = ctypes.c_int64(0), ctypes.c_int64(0)
-        check(lib().dsvc_trainer_param_count(self._h, ctypes.byref(nt), ctypes.byref(nf)))
+        self._ck(self._L.dsvc_trainer_param_count(self._h, ctypes.byref(nt), ctypes.byref(nf)))
         self.n_floats = nf.value
         self.layout = []                                   # (name, offset, numel) in flat order
         for i in range(nt.value):
             name, off, n = ctypes.c_char_p(), ctypes.c_int64(0), ctypes.c_int64(0)
-            check(lib().dsvc_trainer_param_info(self._h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(n)))
+            self._ck(self._L.dsvc_trainer_param_info(self._h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(n)))
             self.layout.append((name.value.decode(), off.value, n.value))
+
+    def _ck(self, rc):
+        check(rc, self._L)
 
     def check(self):
         """Wait for the current stream and raise if a step since the last check was given a diffusion step outside [0, timesteps) (steps are
         clamped on the device; the reference's extract() would raise an IndexError)."""
-        check(lib().dsvc_trainer_check(self._h, stream_ptr()))
+        self._ck(self._L.dsvc_trainer_check(self._h, stream_ptr()))
 
     def debug_set(self, key, value):
         """Test support (include/dsvc_debug.h: dsvc_trainer_debug_set), e.g. ``("wgrad_fm", 0)``: the k_split_t weight-gradient path."""
-        check(lib().dsvc_trainer_debug_set(self._h, key.encode(), int(value)))
+        self._ck(self._L.dsvc_trainer_debug_set(self._h, key.encode(), int(value)))
 
     def bind(self, params, grads):
         assert params.is_cuda and grads.is_cuda and params.numel() == self.n_floats == grads.numel()
         self._keep = (params, grads)
-        check(lib().dsvc_trainer_bind(self._h, ptr(params), ptr(grads)))
+        self._ck(self._L.dsvc_trainer_bind(self._h, ptr(params), ptr(grads)))
 
     def set_schedule(self, sqrt_ac, sqrt_1mac, spec_min, spec_max):
         a, b = sqrt_ac.detach().cpu().float().contiguous(), sqrt_1mac.detach().cpu().float().contiguous()
         lo, hi = spec_min.detach().cpu().float().reshape(-1).contiguous(), spec_max.detach().cpu().float().reshape(-1).contiguous()
-        check(lib().dsvc_trainer_set_schedule(self._h, ptr(a), ptr(b), a.numel(), ptr(lo), ptr(hi), lo.numel()))
+        self._ck(self._L.dsvc_trainer_set_schedule(self._h, ptr(a), ptr(b), a.numel(), ptr(lo), ptr(hi), lo.numel()))
 
     def _args(self, mel, cond, t, pitch, mel2ph, seed, first_clip, clip_ids):
         B, T, M = mel.shape
@@ -75,29 +79,29 @@ class TrainerHandle:
     def step(self, mel, cond, t, pitch=None, mel2ph=None, seed=0, first_clip=0, clip_ids=None, loss_out=None):
         a, keep = self._args(mel, cond, t, pitch, mel2ph, seed, first_clip, clip_ids)
         loss = loss_out if loss_out is not None else torch.empty(1, device=mel.device, dtype=torch.float32)
-        check(lib().dsvc_trainer_step(self._h, ctypes.byref(a), ptr(loss), stream_ptr()))
+        self._ck(self._L.dsvc_trainer_step(self._h, ctypes.byref(a), ptr(loss), stream_ptr()))
         return loss
 
     # the same step in phases (include/dsvc.h): after each call a contiguous slice of the gradient buffer is final
     def step_begin(self, mel, cond, t, pitch=None, mel2ph=None, seed=0, first_clip=0, clip_ids=None):
         a, self._inflight = self._args(mel, cond, t, pitch, mel2ph, seed, first_clip, clip_ids)
-        check(lib().dsvc_trainer_step_begin(self._h, ctypes.byref(a), stream_ptr()))
+        self._ck(self._L.dsvc_trainer_step_begin(self._h, ctypes.byref(a), stream_ptr()))
 
     def step_layers(self, l_hi, l_lo):
-        check(lib().dsvc_trainer_step_layers(self._h, int(l_hi), int(l_lo), stream_ptr()))
+        self._ck(self._L.dsvc_trainer_step_layers(self._h, int(l_hi), int(l_lo), stream_ptr()))
 
     def step_end(self, loss_out=None):
         if self._inflight is None:
             raise RuntimeError("diffsvc_amd: step_end() without a step in flight (call step_begin first)")
         loss = loss_out if loss_out is not None else torch.empty(1, device=self._inflight[0].device, dtype=torch.float32)
-        check(lib().dsvc_trainer_step_end(self._h, ptr(loss), stream_ptr()))
+        self._ck(self._L.dsvc_trainer_step_end(self._h, ptr(loss), stream_ptr()))
         self._inflight = None
         return loss
 
     def __del__(self):
         try:
             if self._h:
-                lib().dsvc_trainer_destroy(self._h)
+                self._L.dsvc_trainer_destroy(self._h)
                 self._h = ctypes.c_void_p(0)
         except Exception:
             pass

@@ -22,8 +22,17 @@
 extern "C" {
 #endif
 
-#define DSVC_ABI_VERSION 7
+#define DSVC_ABI_VERSION 8
 
+/* The library is built with -fvisibility=hidden: the entry points below (and those of dsvc_debug.h) are its ONLY dynamic symbols -- no C++
+ * internal, kernel stub or runtime template can interpose with (or be interposed by) another HIP library of the host process. */
+#if defined(__GNUC__) || defined(__clang__)
+#define DSVC_API __attribute__((visibility("default")))
+#else
+#define DSVC_API
+#endif
+
+#define DSVC_VARIANTS_DEFAULT (-1)
 enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM = 4 };
 
 /* Operand precision of the two big per-layer MFMA contractions (fp32 accumulate everywhere):
@@ -58,8 +67,8 @@ enum { DSVC_OK = 0, DSVC_EINVAL = 1, DSVC_EHIP = 2, DSVC_ESTATE = 3, DSVC_ENOMEM
 enum { DSVC_PREC_F16 = 0, DSVC_PREC_F16_W2 = 1, DSVC_PREC_F16_X3 = 2, DSVC_PREC_F16_MIX = 3, DSVC_PREC_F16_X3T = 4, DSVC_PREC_F16_W6 = 5,
        DSVC_PREC_F16_W6N = 6 };
 
-int dsvc_abi_version(void);
-const char* dsvc_last_error(void);
+DSVC_API int dsvc_abi_version(void);
+DSVC_API const char* dsvc_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Denoiser -- replaces network/diff/net.py:86-135 (class DiffNet), selected through the DIFF_DECODERS
@@ -75,23 +84,25 @@ typedef struct {
     int32_t dilation_cycle;  /* dilation_cycle_length                             (net.py:94)  */
     int32_t max_steps;       /* number of integer diffusion steps to tabulate (timesteps)      */
     int32_t precision;       /* DSVC_PREC_* for the two big per-layer contractions              */
-    int32_t weight_variants; /* DSVC_PREC_F16 / F16_MIX / F16_W6 / F16_W6N / F16_X3T: number of dithered weight roundings; 1 = one nearest rounding,
-                              * 0 = the scheme's default (64 for the three 6-bit schemes, 1 otherwise) */
+    int32_t weight_variants; /* DSVC_PREC_F16 / F16_MIX / F16_W6 / F16_W6N / F16_X3T: number of dithered weight roundings; 0 or 1 = one nearest rounding
+                              * (what a zero-initialised cfg has always meant), DSVC_VARIANTS_DEFAULT (-1) = the scheme's default: 64 for the
+                              * three 6-bit schemes (64x the fp6 code-plane memory: 0.4 GB for F16_W6, 1.1 GB for F16_X3T at the 44.1 kHz
+                              * architecture), 1 otherwise */
 } dsvc_denoiser_cfg;
 
-int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out);
+DSVC_API int dsvc_denoiser_create(const dsvc_denoiser_cfg* cfg, dsvc_denoiser** out);
 /* name = state_dict key of DiffNet (e.g. "residual_layers.3.dilated_conv.weight"); host fp32 data in the
  * checkpoint's own layout (Conv1d [out,in,k], Linear [out,in]).  Replaces load_state_dict for this module
  * (utils/__init__.py:178-209). */
-int dsvc_denoiser_load_tensor(dsvc_denoiser* d, const char* name, const float* host, int64_t numel);
+DSVC_API int dsvc_denoiser_load_tensor(dsvc_denoiser* d, const char* name, const float* host, int64_t numel);
 /* packs weights into MFMA fragment order on the device and builds the step-embedding / FiLM tables */
-int dsvc_denoiser_finalize(dsvc_denoiser* d);
-void dsvc_denoiser_destroy(dsvc_denoiser* d);
+DSVC_API int dsvc_denoiser_finalize(dsvc_denoiser* d);
+DSVC_API void dsvc_denoiser_destroy(dsvc_denoiser* d);
 
 /* DiffNet.forward(spec, diffusion_step, cond)  (net.py:112-135)
  *   spec [B,1,M,T] device, t [B] int32 device (one step per clip), cond [B,H,T] device -> out [B,1,M,T] device.
  * cond_changed != 0 recomputes the hoisted conditioner projections (they depend on cond only). */
-int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t, const float* cond,
+DSVC_API int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t, const float* cond,
                           float* out, int32_t B, int32_t T, int32_t cond_changed, void* stream);
 
 /* dsvc_denoiser_forward clamps diffusion steps outside [0, max_steps) on the device (the step embedding is tabulated for the integer
@@ -99,7 +110,7 @@ int dsvc_denoiser_forward(dsvc_denoiser* d, const float* spec, const int32_t* t,
  * denoiser seam; the flag is reported by this function ONLY (it first waits for `stream`, then clears the flag): later, valid forward calls are
  * executed, not rejected for a predecessor's argument.  The host wrappers call it where they synchronise anyway (DiffNetHip.check(), the
  * trainer every 100 steps, SvcPipeline.check()). */
-int dsvc_denoiser_check(dsvc_denoiser* d, void* stream);
+DSVC_API int dsvc_denoiser_check(dsvc_denoiser* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampler -- replaces GaussianDiffusion.forward(infer=True) from the initial x to mel_out
@@ -107,15 +118,15 @@ int dsvc_denoiser_check(dsvc_denoiser* d, void* stream);
  * ---------------------------------------------------------------------------------------------- */
 typedef struct dsvc_sampler dsvc_sampler;
 
-int dsvc_sampler_create(dsvc_denoiser* d, dsvc_sampler** out);
+DSVC_API int dsvc_sampler_create(dsvc_denoiser* d, dsvc_sampler** out);
 /* the registered buffers of GaussianDiffusion (diffusion.py:100-123): "alphas_cumprod",
  * "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
  * "posterior_mean_coef2", "posterior_log_variance_clipped", "sqrt_alphas_cumprod",
  * "sqrt_one_minus_alphas_cumprod", "spec_min", "spec_max".  Taken from the checkpoint, never recomputed
  * (SURVEY.md 0.8). */
-int dsvc_sampler_load_tensor(dsvc_sampler* s, const char* name, const float* host, int64_t numel);
-int dsvc_sampler_finalize(dsvc_sampler* s);
-void dsvc_sampler_destroy(dsvc_sampler* s);
+DSVC_API int dsvc_sampler_load_tensor(dsvc_sampler* s, const char* name, const float* host, int64_t numel);
+DSVC_API int dsvc_sampler_finalize(dsvc_sampler* s);
+DSVC_API void dsvc_sampler_destroy(dsvc_sampler* s);
 
 typedef struct {
     int32_t B, T;              /* clips, mel frames per clip                                               */
@@ -140,7 +151,14 @@ typedef struct {
     float* x_out;              /* [B,1,M,T] device or NULL: final normalised state (for tests)              */
 } dsvc_sample_args;
 
-int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream);
+DSVC_API int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream);
+
+/* Serving telemetry.  The reference's driver calls the model chunk by chunk, every chunk with its own T (infer.py:44-67,
+ * infer_tools/infer_tool.py:155-159,276).  dsvc_sample lays a call out in a BUCKET -- a clip occupies round_up(T + largest dilation, 128) rows --
+ * and keeps the buckets it has seen (workspace zeroed once, captured DDPM / PLMS chains) in an LRU, so a chunk whose bucket exists costs no
+ * allocation, no clearing and no graph capture.  out[0..n) (n <= 6) receives: DDPM periods captured, PLMS chains captured, graph launches,
+ * buckets allocated, calls served by an existing bucket, captured chains alive -- all since the handle was created. */
+DSVC_API int dsvc_sampler_stats(dsvc_sampler* s, int64_t* out, int32_t n);
 
 /* ------------------------------------------------------------------------------------------------
  * Vocoder -- replaces modules/nsf_hifigan/models.py:325-387 (Generator.forward) + :14-30 (load_model),
@@ -169,17 +187,17 @@ typedef struct {
     int32_t n_dilations;           /* entries used of resblock_dilations[j] (ResBlock1: 3); 0 means 3 */
 } dsvc_vocoder_cfg;
 
-int dsvc_vocoder_create(const dsvc_vocoder_cfg* cfg, dsvc_vocoder** out);
+DSVC_API int dsvc_vocoder_create(const dsvc_vocoder_cfg* cfg, dsvc_vocoder** out);
 /* name = key of the checkpoint's 'generator' dict, weight-norm pairs included
  * ("ups.0.weight_g", "ups.0.weight_v", ...); folded here like remove_weight_norm (models.py:28,389-396). */
-int dsvc_vocoder_load_tensor(dsvc_vocoder* v, const char* name, const float* host, int64_t numel);
-int dsvc_vocoder_finalize(dsvc_vocoder* v);
-void dsvc_vocoder_destroy(dsvc_vocoder* v);
+DSVC_API int dsvc_vocoder_load_tensor(dsvc_vocoder* v, const char* name, const float* host, int64_t numel);
+DSVC_API int dsvc_vocoder_finalize(dsvc_vocoder* v);
+DSVC_API void dsvc_vocoder_destroy(dsvc_vocoder* v);
 
 /* Generator.forward(mel_scale * mel^T, f0)   mel [B,T,M] device, f0 [B,T] Hz device (NULL iff use_source == 0) -> wav [B, T*hop] device.
  * The source module's random draws (models.py:192,271) come from Philox(seed, clip id), clip id = clip_ids[b] (device [B]) or,
  * when clip_ids is NULL, first_clip + b. */
-int dsvc_vocode(dsvc_vocoder* v, const float* mel, const float* f0, float* wav, int32_t B, int32_t T,
+DSVC_API int dsvc_vocode(dsvc_vocoder* v, const float* mel, const float* f0, float* wav, int32_t B, int32_t T,
                 uint64_t seed, int32_t first_clip, const int32_t* clip_ids, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -197,11 +215,11 @@ typedef struct {
 } dsvc_melspec_cfg;
 
 /* mel_basis: host [n_mels][n_fft/2+1] fp32 (librosa.filters.mel, built by the Python host) */
-int dsvc_melspec_create(const dsvc_melspec_cfg* cfg, const float* mel_basis, dsvc_melspec** out);
-void dsvc_melspec_destroy(dsvc_melspec* m);
+DSVC_API int dsvc_melspec_create(const dsvc_melspec_cfg* cfg, const float* mel_basis, dsvc_melspec** out);
+DSVC_API void dsvc_melspec_destroy(dsvc_melspec* m);
 /* wav [B,N] device -> mel [B,T,n_mels] log10 device, T = (N - hop) / hop + 1 ... see dsvc_melspec_frames */
-int dsvc_melspec_frames(const dsvc_melspec* m, int64_t n_samples, int32_t* frames);
-int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, int64_t n_samples, void* stream);
+DSVC_API int dsvc_melspec_frames(const dsvc_melspec* m, int64_t n_samples, int32_t* frames);
+DSVC_API int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, int64_t n_samples, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pitch index work of the condition builder -- replaces the host arithmetic of add_pitch (modules/fastspeech/fs2.py:229-237):
@@ -210,7 +228,7 @@ int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, i
  * thresholds: the ascending fp32 values of the NORMALISED pitch at which the reference's own expression steps to the next bin
  * (found by bisection with that expression, diff-svc_amd/cond.py), n = B*T elements, all pointers device; uv may be NULL.
  * ---------------------------------------------------------------------------------------------- */
-int dsvc_pitch_coarse(const float* f0_log2, const int64_t* mel2ph, const float* uv, const float* thresholds, int32_t n_thresholds,
+DSVC_API int dsvc_pitch_coarse(const float* f0_log2, const int64_t* mel2ph, const float* uv, const float* thresholds, int32_t n_thresholds,
                       int64_t n, float* f0_denorm, int64_t* coarse, void* stream);
 
 /* The whole condition builder of the no_fs2 configuration in one launch -- replaces FastSpeech2.forward's no_fs2 branch
@@ -220,7 +238,7 @@ int dsvc_pitch_coarse(const float* f0_log2, const int64_t* mel2ph, const float* 
  *   hubert [B,N,H], mel2ph [B,T] int64 (0 = padding, else 1-based unit index), f0_log2 [B,T] (IN/OUT: zeroed where mel2ph == 0, as the
  *   reference mutates its argument, fs2.py:231), uv [B,T] or NULL, pitch_embed [vocab,H]  ->  decoder_inp [B,T,H], cond_bht [B,H,T],
  *   f0_denorm [B,T], coarse [B,T] int64.  All pointers device.  Values are bit-identical to the reference's fp32 expression. */
-int dsvc_cond_build(const float* hubert, const int64_t* mel2ph, float* f0_log2, const float* uv, const float* thresholds,
+DSVC_API int dsvc_cond_build(const float* hubert, const int64_t* mel2ph, float* f0_log2, const float* uv, const float* thresholds,
                     int32_t n_thresholds, const float* pitch_embed, int32_t B, int32_t N, int32_t T, int32_t H,
                     float* decoder_inp, float* cond_bht, float* f0_denorm, int64_t* coarse, void* stream);
 
@@ -232,17 +250,17 @@ int dsvc_cond_build(const float* hubert, const int64_t* mel2ph, float* f0_log2, 
  * ---------------------------------------------------------------------------------------------- */
 typedef struct dsvc_hubert dsvc_hubert;
 
-int dsvc_hubert_create(dsvc_hubert** out);
+DSVC_API int dsvc_hubert_create(dsvc_hubert** out);
 /* name = key of HubertSoft.state_dict() ("feature_extractor.conv0.weight", "positional_embedding.conv.weight_g",
  * "encoder.layers.3.self_attn.in_proj_weight", ...); host fp32 in the checkpoint's layout.  Keys the inference path does not use
  * (masked_spec_embed, label_embedding.weight) are accepted and ignored. */
-int dsvc_hubert_load_tensor(dsvc_hubert* h, const char* name, const float* host, int64_t numel);
-int dsvc_hubert_finalize(dsvc_hubert* h);
-void dsvc_hubert_destroy(dsvc_hubert* h);
+DSVC_API int dsvc_hubert_load_tensor(dsvc_hubert* h, const char* name, const float* host, int64_t numel);
+DSVC_API int dsvc_hubert_finalize(dsvc_hubert* h);
+DSVC_API void dsvc_hubert_destroy(dsvc_hubert* h);
 /* frames produced for n_samples of 16 kHz audio: seven valid convolutions of total stride 320 over n_samples + 80 */
-int dsvc_hubert_frames(int64_t n_samples, int32_t* frames);
+DSVC_API int dsvc_hubert_frames(int64_t n_samples, int32_t* frames);
 /* wav [n_samples] device fp32 in [-1, 1] at 16 kHz (one utterance) -> units [frames][256] device */
-int dsvc_hubert_units(dsvc_hubert* h, const float* wav, int64_t n_samples, float* units, void* stream);
+DSVC_API int dsvc_hubert_units(dsvc_hubert* h, const float* wav, int64_t n_samples, float* units, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pitch extractor (mel -> f0) -- replaces modules/fastspeech/pe.py:120-148 (PitchExtractor.forward: Prenet :7-42 -> ConvStacks
@@ -266,18 +284,18 @@ typedef struct {
     float f0_mean, f0_std;
 } dsvc_pe_cfg;
 
-int dsvc_pe_create(const dsvc_pe_cfg* cfg, dsvc_pe** out);
+DSVC_API int dsvc_pe_create(const dsvc_pe_cfg* cfg, dsvc_pe** out);
 /* name = key of PitchExtractor.state_dict() ("mel_prenet.layers.0.0.weight", "mel_prenet.layers.0.2.running_var",
  * "mel_encoder.conv.1.norm.weight", "pitch_predictor.conv.4.3.bias", "pitch_predictor.pos_embed_alpha", ...); host fp32 in the
  * checkpoint's layout.  Keys the forward does not read (num_batches_tracked, embed_positions._float_tensor) are accepted and ignored. */
-int dsvc_pe_load_tensor(dsvc_pe* p, const char* name, const float* host, int64_t numel);
-int dsvc_pe_finalize(dsvc_pe* p);
+DSVC_API int dsvc_pe_load_tensor(dsvc_pe* p, const char* name, const float* host, int64_t numel);
+DSVC_API int dsvc_pe_finalize(dsvc_pe* p);
 /* the sinusoidal table SinusoidalPositionalEmbedding.weights [n_rows][hidden] (common_layers.py:105-122; a constructor constant, not
  * in the state dict); a run over T frames needs n_rows >= T + 1 */
-int dsvc_pe_set_positions(dsvc_pe* p, const float* host_table, int32_t n_rows);
-void dsvc_pe_destroy(dsvc_pe* p);
+DSVC_API int dsvc_pe_set_positions(dsvc_pe* p, const float* host_table, int32_t n_rows);
+DSVC_API void dsvc_pe_destroy(dsvc_pe* p);
 /* mel [B][T][n_mel] device fp32 (all-zero rows are padding) -> pitch_pred [B][T][2] (may be NULL), f0 [B][T] (Hz) device */
-int dsvc_pe_run(dsvc_pe* p, const float* mel, int32_t B, int32_t T, float* pitch_pred, float* f0, void* stream);
+DSVC_API int dsvc_pe_run(dsvc_pe* p, const float* mel, int32_t B, int32_t T, float* pitch_pred, float* f0, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training step -- replaces GaussianDiffusion.forward(infer=False) -> p_losses (network/diff/diffusion.py:200-225,237-241;
@@ -307,18 +325,18 @@ typedef struct {
     const int32_t* clip_ids;  /* ... or explicit ids [B] device */
 } dsvc_train_args;
 
-int dsvc_trainer_create(const dsvc_trainer_cfg* cfg, dsvc_trainer** out);
-void dsvc_trainer_destroy(dsvc_trainer* t);
+DSVC_API int dsvc_trainer_create(const dsvc_trainer_cfg* cfg, dsvc_trainer** out);
+DSVC_API void dsvc_trainer_destroy(dsvc_trainer* t);
 /* the flat layout: number of tensors / of floats; tensor i's state-dict name ("denoise_fn.*" in DiffNet.state_dict() order, then
  * "fs2.pitch_embed.weight"), offset and size in floats.  Tensors keep the checkpoint's own layouts (Conv1d [out,in,k], Linear [out,in]). */
-int dsvc_trainer_param_count(const dsvc_trainer* t, int64_t* n_tensors, int64_t* n_floats);
-int dsvc_trainer_param_info(const dsvc_trainer* t, int64_t i, const char** name, int64_t* offset, int64_t* numel);
-int dsvc_trainer_bind(dsvc_trainer* t, float* params, float* grads);          /* device, n_floats each; retained until destroy */
+DSVC_API int dsvc_trainer_param_count(const dsvc_trainer* t, int64_t* n_tensors, int64_t* n_floats);
+DSVC_API int dsvc_trainer_param_info(const dsvc_trainer* t, int64_t i, const char** name, int64_t* offset, int64_t* numel);
+DSVC_API int dsvc_trainer_bind(dsvc_trainer* t, float* params, float* grads);          /* device, n_floats each; retained until destroy */
 /* registered buffers of GaussianDiffusion the loss needs (diffusion.py:107-108,122-123), host pointers */
-int dsvc_trainer_set_schedule(dsvc_trainer* t, const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod, int32_t K,
+DSVC_API int dsvc_trainer_set_schedule(dsvc_trainer* t, const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod, int32_t K,
                               const float* spec_min, const float* spec_max, int32_t n_spec);
 /* forward + backward of one batch: grads <- d loss / d params (overwritten), *loss_out (device float, may be NULL) <- the loss */
-int dsvc_trainer_step(dsvc_trainer* t, const dsvc_train_args* a, float* loss_out, void* stream);
+DSVC_API int dsvc_trainer_step(dsvc_trainer* t, const dsvc_train_args* a, float* loss_out, void* stream);
 /* The same step in three phases, for a data-parallel host that all-reduces finished gradient slices while the backward pass of the
  * earlier layers still runs (what the reference's DDP reducer does bucket by bucket, utils/pl_utils.py:187-221):
  *   begin              inputs, forward, loss, backward of the tail.  Final afterwards: the contiguous slice
@@ -329,19 +347,19 @@ int dsvc_trainer_step(dsvc_trainer* t, const dsvc_train_args* a, float* loss_out
  *   end                input projection, step-embedding MLP, pitch embedding; *loss_out.  Final afterwards: everything
  *                      ([denoise_fn.input_projection.weight .. denoise_fn.mlp.2.bias] and fs2.pitch_embed.weight were the missing slices).
  * dsvc_trainer_step == begin; layers(residual_layers, 0); end.  All three enqueue on `stream` and return. */
-int dsvc_trainer_step_begin(dsvc_trainer* t, const dsvc_train_args* a, void* stream);
+DSVC_API int dsvc_trainer_step_begin(dsvc_trainer* t, const dsvc_train_args* a, void* stream);
 /* Diffusion steps outside [0, timesteps) are clamped on the device (the reference's extract() would raise an IndexError, diffusion.py:22-25,
  * but a device-to-host check per step is not what a training loop wants): a sticky flag records it, and this call -- which waits for
  * `stream` -- returns DSVC_EINVAL once and clears it.  Same contract as dsvc_denoiser_check. */
-int dsvc_trainer_check(dsvc_trainer* t, void* stream);
-int dsvc_trainer_step_layers(dsvc_trainer* t, int32_t l_hi, int32_t l_lo, void* stream);
-int dsvc_trainer_step_end(dsvc_trainer* t, float* loss_out, void* stream);
+DSVC_API int dsvc_trainer_check(dsvc_trainer* t, void* stream);
+DSVC_API int dsvc_trainer_step_layers(dsvc_trainer* t, int32_t l_hi, int32_t l_lo, void* stream);
+DSVC_API int dsvc_trainer_step_end(dsvc_trainer* t, float* loss_out, void* stream);
 /* torch.optim.AdamW update of a flat buffer.  The gradient is multiplied by *grad_scale_dev (device, e.g. the clip coefficient)
  * when that pointer is not NULL, else by grad_scale. */
-int dsvc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+DSVC_API int dsvc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int64_t step, const float* grad_scale_dev, float grad_scale, void* stream);
 /* clip_grad_norm_: *sqnorm_dev <- ||g||^2, *coef_dev <- min(1, max_norm / (||g|| + 1e-6)) */
-int dsvc_grad_clip_coef(const float* grads, int64_t n, float max_norm, float* sqnorm_dev, float* coef_dev, void* stream);
+DSVC_API int dsvc_grad_clip_coef(const float* grads, int64_t n, float max_norm, float* sqnorm_dev, float* coef_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,14 +15,14 @@ extern "C" {
 
 /* measurement aid for bench.py: the dense fp16 MFMA rate (TFLOP/s) and shader clock (GHz) this chip sustains right now on a
  * register-resident loop with random (1) or zero (0) operands -- the rate a roofline fraction can actually approach. */
-int dsvc_probe_mfma(int32_t random_data, float* tflops, float* clock_ghz, void* stream);
+DSVC_API int dsvc_probe_mfma(int32_t random_data, float* tflops, float* clock_ghz, void* stream);
 /* the same probe in detail: out4 = { TFLOP/s over the kernel's wall time (HIP events), TFLOP/s over the 4 ms in-kernel window every wave
  * issues MFMAs for, mean shader clock over all waves [GHz], lowest clock any wave saw [GHz] } */
-int dsvc_probe_mfma_detail(int32_t random_data, float* out4, void* stream);
+DSVC_API int dsvc_probe_mfma_detail(int32_t random_data, float* out4, void* stream);
 
 /* debugging aid for the parity tests: copy an internal frame-major buffer ("xres", "g", "skip", "s2", "eps",
  * "condT", "cproj", "film", "xin", "xh") to a device pointer as fp32; rows/ld receive its logical shape. */
-int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, int64_t numel, int32_t* rows, int32_t* ld);
+DSVC_API int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, int64_t numel, int32_t* rows, int32_t* ld);
 
 /* test support (explicit handle state; the library reads no environment variable): "stop_after_layers" = n >= 0 makes an evaluation
  * return after n residual layers so that dsvc_denoiser_debug_buffer taps layer n-1 (-1 = off); "two_launch_layer" = 1 runs a residual
@@ -40,7 +40,7 @@ int dsvc_denoiser_debug_buffer(dsvc_denoiser* d, const char* name, float* dst, i
  * NONE of these is part of the supported surface: they exist for the parity tests and the bench's roofline entries, they change which kernel
  * computes a result (never to an unsupported precision), and a deployment should not call this function.  Pure tuning knobs of variants that
  * were measured and not kept ("layer_prio", "tail_tiling") exist in the -DDSVC_PROFILING build only. */
-int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
+DSVC_API int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
 
 /* per-kernel timing for bench.py's roofline: average duration in microseconds of the dominant kernel at this batch size,
  * measured with HIP events on the launch stream over back-to-back launches of all layers (a different dither variant per round:
@@ -48,14 +48,14 @@ int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t value);
  * kind (may be NULL) receives which kernel that is: 0 = the gate kernel (dilated conv + conditioner projection + gate: small
  * batches run a layer as two launches), > 0 = the fused residual-layer kernel (gate GEMM + output projection) and the number of
  * 32-frame N-tiles a workgroup covers: 4 = the throughput tiling, 2 / 1 = the mid-size tilings of f16_w6 / f16_w6n (round 5). */
-int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters,
+DSVC_API int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters,
                                      float* avg_us, int64_t* rows, int32_t* kind, void* stream);
 
 /* test support for the trainer, as dsvc_denoiser_debug_set: "wgrad_fm" = 0 makes the residual layers' weight gradients take the k_split_t +
  * wgrad_nt_kernel path (channel-major copies of every operand) where the architecture would let them be contracted straight from the
  * frame-major operand planes (csrc/wgrad.h: wgrad_fm_kernel, the default since round 5); 1 = automatic.  Both paths compute the same products;
  * tests/test_gpu_train.py holds them to each other.  Not for a deployment. */
-int dsvc_trainer_debug_set(dsvc_trainer* t, const char* key, int32_t value);
+DSVC_API int dsvc_trainer_debug_set(dsvc_trainer* t, const char* key, int32_t value);
 
 #ifdef __cplusplus
 }

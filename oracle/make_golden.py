@@ -503,6 +503,12 @@ def main():
         return golden_train_bench_f64()
     if "--plms-only" in sys.argv:
         return golden_plms_conditioned()
+    if "--plms-t861-more" in sys.argv:
+        return golden_plms_t861_more()
+    if "--long-only" in sys.argv:
+        return golden_long()
+    if "--long-1000" in sys.argv:
+        return golden_long_1000()
     if "--hifigan-only" in sys.argv:
         return golden_hifigan_24k()
     if "--hubert-only" in sys.argv:
@@ -538,6 +544,60 @@ def main():
     golden_slicer_demo_input()
     golden_schedule()
     golden_cond_energy()
+    golden_plms_t861_more()
+    golden_long()
+    golden_long_1000()
+
+
+# Round 6: BASELINE configs[2] at the benchmarked size rested on ONE (clip, noise) pair.  Five more, same conditioned
+# checkpoint, 51 evaluations of the REAL reference each.
+PLMS_T861_MORE = ((1, 85), (2, 86), (3, 87), (4, 88), (7, 89))         # (clip, seed); (5, 88) left the data range on the reference itself (mel max +0.078): not a well-conditioned probe
+
+
+def golden_plms_t861_more():
+    full = dict(synth.HPARAMS_44K)
+    for clip, seed in PLMS_T861_MORE:
+        golden_sampler("plmsc_44k_T861_s20_c%d" % clip, full, 0, clips=[clip], T=861, n_units=500, speedup=20, seed=seed,
+                       conditioned=(1.5, 0.07), store_cond=False)
+
+
+# Round 6: the sampler beyond T = 861.  The reference accepts max_frames 42000 (training/config_nsf.yaml:82) and
+# its slicer hands out chunks of 5 ... 30 s and more; T = 2600 (30 s) is 82 frame tiles of 32 on the small tilings, T = 7000 (81 s) crosses
+# the fused-layer threshold with ONE clip.  20-step DDPM (K_step 20 of the 1000-step schedule) and 20-iteration PLMS (pndm_speedup 50) of the
+# REAL reference at both lengths, both architectures; three clips of different lengths run one by one (the reference is B = 1) that the
+# drop-in runs as ONE ragged batch.
+LONG_RAGGED = ((0, 2000, 1161), (1, 1500, 871), (2, 1111, 645))         # (clip, T, n_units)
+
+
+def golden_long():
+    full, k24 = dict(synth.HPARAMS_44K), dict(synth.HPARAMS_24K)
+    for T, nu in ((2600, 1510), (7000, 4065)):
+        golden_sampler("ddpm_44k_k20_T%d" % T, dict(full, K_step=20), 0, clips=[0], T=T, n_units=nu, speedup=1, seed=101, store_cond=False)
+        golden_sampler("plmsc_44k_s50_T%d" % T, full, 0, clips=[1], T=T, n_units=nu, speedup=50, seed=102, conditioned=(1.5, 0.07), store_cond=False)
+        golden_sampler("ddpm_24k_k20_T%d" % T, dict(k24, K_step=20), 2, clips=[2], T=T, n_units=nu, speedup=1, seed=103, store_cond=False)
+    golden_sampler("plmsc_24k_s50_T2600", k24, 2, clips=[3], T=2600, n_units=1510, speedup=50, seed=104, conditioned=(1.35, 0.05), store_cond=False)
+    hp = dict(full, K_step=20)
+    sd = synth.acoustic_state(hp, 0)
+    model = build_reference_model(hp, sd)
+    out = {}
+    for clip, T, nu in LONG_RAGGED:
+        hub, m2p, f0 = clip_batch(hp, [clip], T, nu)
+        ret = run_reference_sampler(model, hp, hub, m2p, f0, [clip], 1, 105)
+        out["mel_c%d" % clip] = ret["mel_out"].numpy()[0]
+    np.savez_compressed(os.path.join(OUT, "ddpm_44k_k20_ragged3.npz"), wseed=0, seed=105, K_step=20, clips=np.array([c for c, _, _ in LONG_RAGGED]),
+                        T=np.array([t for _, t, _ in LONG_RAGGED]), n_units=np.array([n for _, _, n in LONG_RAGGED]), **out)
+    print("ddpm_44k_k20_ragged3", {k: v.shape for k, v in out.items()})
+
+
+def golden_long_1000():
+    """The full 1000-step DDPM chain of the REAL reference on ONE clip of T = 2600 (f16_x3t on 82 small tiles) and ONE of T = 7000 (the fused
+    f16_w6 layer kernel with a single clip): ~4 and ~11 minutes on 8 cores."""
+    for T, nu, clip in ((2600, 1510, 0), (7000, 4065, 1)):
+        name = "e2e_44k_T%d_k1000" % T
+        if os.path.exists(os.path.join(OUT, name + ".npz")) and "--force" not in sys.argv:
+            print(name, "exists")
+            continue
+        golden_headline(name=name, clips=(clip,), T=T, n_units=nu, seed=2027, with_wav=False)
 
 
 def golden_plms_conditioned():

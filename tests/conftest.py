@@ -20,6 +20,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def hooks():
+    """Handles created inside a test that takes this fixture live in libdsvc_hip_hooks.so -- the product library plus the dsvc_*_debug_set keys
+    that change which kernel computes a result (per-layer taps, A/B partners; csrc/diffnet.hip and csrc/train.hip compiled with -DDSVC_TEST_HOOKS,
+    every other object shared with the product).  The product library refuses those keys (tests/test_abi.py), and every test WITHOUT this
+    fixture -- the parity tests proper -- runs on libdsvc_hip.so."""
+    from diffsvc_amd import _lib
+    with _lib.hooks_build() as lib:
+        yield lib
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -211,7 +211,7 @@ def _tap_errors(den, sd, spec, t, cond, rows_of):
 @pytest.mark.parametrize("precision,B,T,fused", [("f16_w2", 1, 45, True), ("f16_d64", 1, 45, True), ("f16_d64", 2, 861, True),
                                                  ("f16_w2", 8, 861, True), ("f16_d64", 8, 861, True), ("f16_d64", 8, 861, False),
                                                  ("f16_m64", 1, 45, True), ("f16_m64", 8, 861, True)])
-def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused):
+def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused, hooks):
     """Per-layer localisation on the PRODUCT engine (tgemm): after every residual block the residual stream x_l, the gate
     output g_l and the running skip sum are compared with the oracle -- for the split-K single-clip tiling (T=45 and T=861), the
     small-batch tiling (B=2) and the 128-frame throughput tiling (B=8 x 861).  The throughput tiling runs a layer as ONE fused
@@ -258,7 +258,7 @@ def test_end_to_end_waveform_vs_reference(precision):
 
 
 @pytest.mark.parametrize("precision", ["f16_m64", "f16_d64", "f16_w2"])
-def test_fused_layer_kernel_equals_the_two_launch_layer_bit_for_bit(precision):
+def test_fused_layer_kernel_equals_the_two_launch_layer_bit_for_bit(precision, hooks):
     """The throughput tiling runs a residual layer as ONE kernel (tlayer.h: gate GEMM -> g in LDS -> output projection).  It issues
     the same MFMAs on the same operands in the same order as the two tgemm launches it replaces (debug_set two_launch_layer), so a
     20-step DDPM chain at B=8 x T=861 must come out bit-identical -- layer geometry, g hand-off through LDS, the alternating xh
@@ -442,7 +442,7 @@ def test_mid_batch_auto_every_clip_with_a_golden(B):
 
 
 @pytest.mark.parametrize("precision", ["f16_w6", "f16_w6n"])
-def test_mid_size_tilings_of_the_fused_layer_kernel_equal_the_128_frame_tiling_bit_for_bit(precision):
+def test_mid_size_tilings_of_the_fused_layer_kernel_equal_the_128_frame_tiling_bit_for_bit(precision, hooks):
     """The fused layer kernel on 64- and 32-frame tiles (round 5: tlayer_kernel<..., NT = 2 / 1>) issues the same products in the same order
     for every accumulator as on 128-frame tiles -- a frame's K loops do not depend on which workgroup holds it -- so a 20-step DDPM chain at
     8 x T=861 comes out bit-identical on all three (tile DMA and halo, g blocks and 6-bit code rows in LDS scaled by NT / 4, the output
@@ -466,7 +466,7 @@ def test_mid_size_tilings_of_the_fused_layer_kernel_equal_the_128_frame_tiling_b
 
 
 @pytest.mark.parametrize("arch", ["44k", "24k"])
-def test_fused_step_tail_vs_the_three_launches_and_across_graph_replays(arch):
+def test_fused_step_tail_vs_the_three_launches_and_across_graph_replays(arch, hooks):
     """The tail of a batched DDPM step as ONE kernel (round 5, csrc/ttail.h: skip projection -> output projection + posterior step -> the NEXT
     evaluation's input projection; the default of the f16_w6 fused-layer path) against the three tgemm launches it replaces (debug_set
     'fused_tail' 0).  Same operands and split scheme, but the fused kernel walks K in plain order and leaves out W_lo x_lo (2^-22 of a
@@ -509,7 +509,7 @@ def test_fused_step_tail_vs_the_three_launches_and_across_graph_replays(arch):
 
 
 @pytest.mark.parametrize("precision", ["f16_w2", "f16_m64"])
-def test_deferred_skip_contraction_taps_and_equivalence(precision):
+def test_deferred_skip_contraction_taps_and_equivalence(precision, hooks):
     """The deferred skip path (debug_set 'defer_skip' 1; not the default: time-neutral, design/tlayer.md): the layer kernels write the gate
     output g to HBM and compute only the residual half of the 1x1; ONE [C x L*C] contraction per evaluation (tskip.h) produces
     relu(skip_projection(sum of skips / sqrt(L))) from all layers' g with weights composed at load time.  Checked at 8 x 861: (1) per-layer residual stream x_l and gate output g_l against the oracle
@@ -563,7 +563,7 @@ def test_deferred_skip_contraction_taps_and_equivalence(precision):
 
 
 @pytest.mark.parametrize("precision", ["f16_w6", "f16_w6n", "f16_w2", "f16_w6/2", "f16_w6/1", "f16_w6n/1"])
-def test_fused_layer_kernels_on_the_24k_architecture(precision):
+def test_fused_layer_kernels_on_the_24k_architecture(precision, hooks):
     """The fused layer kernel's two-block instantiations (C = 256: the 24 kHz demo architecture, BASELINE configs[0]'s shapes) -- every other test of
     the batched path runs the three-block 44.1 kHz ones.  8 clips x T = 861 on the fused kernel (forced: the automatic choice needs >= 120 tiles), a
     30-step DDPM chain, every clip against the oracle's chain from the same Philox noise: f16_w6 / f16_w6n (the 6-bit correction products and the

@@ -58,7 +58,7 @@ def test_train_step_loss_and_gradients_vs_autograd(arch, loss_type):
 
 
 @pytest.mark.parametrize("T", [64, 75])
-def test_weight_gradients_from_the_operand_planes_equal_the_split_path(T):
+def test_weight_gradients_from_the_operand_planes_equal_the_split_path(T, hooks):
     """Round 5: the residual layers' weight gradients are contracted straight from the frame-major fp16 planes the layer kernels write
     (csrc/wgrad.h: wgrad_fm_kernel -- transposing LDS reads, conv taps as row offsets, bias sums as MFMAs against ones, two contractions per
     launch) instead of channel-major copies written by k_split_t.  Same products, another order of the fp32 sums over the frames: every gradient

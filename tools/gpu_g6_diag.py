@@ -8,6 +8,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np, torch
 import diffsvc_amd
+from diffsvc_amd import _lib as _dsvc_lib
+_dsvc_lib.hooks_build().__enter__()      # this tool sets dsvc_*_debug_set keys: they exist in the test-hooks build only (round 6)
 from diffsvc_amd import synth
 from diffsvc_amd.engine import DenoiserHandle
 import dsvc_oracle as O

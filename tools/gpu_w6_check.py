@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import diffsvc_amd
+from diffsvc_amd import _lib as _dsvc_lib
+_dsvc_lib.hooks_build().__enter__()      # this tool sets dsvc_*_debug_set keys: they exist in the test-hooks build only (round 6)
 from diffsvc_amd import synth
 from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
 

@@ -4,6 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import diffsvc_amd
+if os.environ.get("DSVC_PROF_KNOBS"):       # knobs are dsvc_denoiser_debug_set keys: they exist in the test-hooks build only (round 6); without
+    from diffsvc_amd import _lib as _dsvc_lib     # them this workload runs on the product library (what the PMC traffic passes profile)
+    _dsvc_lib.hooks_build().__enter__()
 from diffsvc_amd import synth
 from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
 B, steps, prec = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
