@@ -563,19 +563,28 @@ def golden_plms_t861_more():
 
 # Round 6: the sampler beyond T = 861.  The reference accepts max_frames 42000 (training/config_nsf.yaml:82) and
 # its slicer hands out chunks of 5 ... 30 s and more; T = 2600 (30 s) is 82 frame tiles of 32 on the small tilings, T = 7000 (81 s) crosses
-# the fused-layer threshold with ONE clip.  20-step DDPM (K_step 20 of the 1000-step schedule) and 20-iteration PLMS (pndm_speedup 50) of the
-# REAL reference at both lengths, both architectures; three clips of different lengths run one by one (the reference is B = 1) that the
+# the fused-layer threshold with ONE clip.  20-step DDPM (K_step 20 of the 1000-step schedule) and 50-iteration PLMS of the
+# REAL reference at both lengths, both architectures (PLMS: pndm_speedup 20 -- at 50 the conditioned synthetic checkpoint's own chain leaves the data range); three clips of different lengths run one by one (the reference is B = 1) that the
 # drop-in runs as ONE ragged batch.
 LONG_RAGGED = ((0, 2000, 1161), (1, 1500, 871), (2, 1111, 645))         # (clip, T, n_units)
 
 
 def golden_long():
     full, k24 = dict(synth.HPARAMS_44K), dict(synth.HPARAMS_24K)
+
+    def once(name, *a, **kw):
+        if os.path.exists(os.path.join(OUT, name + ".npz")) and "--force" not in sys.argv:
+            print(name, "exists")
+            return
+        golden_sampler(name, *a, **kw)
+
     for T, nu in ((2600, 1510), (7000, 4065)):
-        golden_sampler("ddpm_44k_k20_T%d" % T, dict(full, K_step=20), 0, clips=[0], T=T, n_units=nu, speedup=1, seed=101, store_cond=False)
-        golden_sampler("plmsc_44k_s50_T%d" % T, full, 0, clips=[1], T=T, n_units=nu, speedup=50, seed=102, conditioned=(1.5, 0.07), store_cond=False)
-        golden_sampler("ddpm_24k_k20_T%d" % T, dict(k24, K_step=20), 2, clips=[2], T=T, n_units=nu, speedup=1, seed=103, store_cond=False)
-    golden_sampler("plmsc_24k_s50_T2600", k24, 2, clips=[3], T=2600, n_units=1510, speedup=50, seed=104, conditioned=(1.35, 0.05), store_cond=False)
+        once("ddpm_44k_k20_T%d" % T, dict(full, K_step=20), 0, clips=[0], T=T, n_units=nu, speedup=1, seed=101, store_cond=False)
+        once("plmsc_44k_s20_T%d" % T, full, 0, clips=[1], T=T, n_units=nu, speedup=20, seed=102, conditioned=(1.5, 0.07), store_cond=False)
+        once("ddpm_24k_k20_T%d" % T, dict(k24, K_step=20), 2, clips=[2], T=T, n_units=nu, speedup=1, seed=103, store_cond=False)
+    once("plmsc_24k_s20_T2600", k24, 2, clips=[3], T=2600, n_units=1510, speedup=20, seed=104, conditioned=(1.35, 0.05), store_cond=False)
+    if os.path.exists(os.path.join(OUT, "ddpm_44k_k20_ragged3.npz")) and "--force" not in sys.argv:
+        return
     hp = dict(full, K_step=20)
     sd = synth.acoustic_state(hp, 0)
     model = build_reference_model(hp, sd)

@@ -127,6 +127,36 @@ def test_plms_50_iterations_T861_vs_reference(precision):
                                                             # with one at 1.08e-3 (profiles/r2w_precision_spread.txt): not shipped
 
 
+def test_plms_50_iterations_T861_six_goldens_at_the_shipped_precision():
+    """BASELINE configs[2] at the benchmarked size rested on ONE (clip, noise) pair.  Five more runs of the REAL reference
+    (oracle/make_golden.py::golden_plms_t861_more: 51 evaluations each, same conditioned checkpoint, clips 1, 2, 3, 4, 7 with their own noise)
+    beside the first; the shipped PLMS precision (DiffNetHip.AUTO['plms'] = f16_x3t), the captured-graph path bench.py times, ONE sampler for
+    all six (the chain's graph is captured once): every one within 1e-4 of the reference."""
+    from diffsvc_amd.denoiser import DiffNetHip
+    from diffsvc_amd.engine import DenoiserHandle, SamplerHandle
+    from make_golden import PLMS_T861_MORE
+    hp = dict(synth.HPARAMS_44K)
+    names = ["plmsc_44k_T861_s20"] + ["plmsc_44k_T861_s20_c%d" % c for c, _ in PLMS_T861_MORE]
+    precision = DiffNetHip.AUTO["plms"]
+    smp, sd, errs = None, None, []
+    for name in names:
+        g = load_golden(name)
+        if smp is None:
+            sd = golden_state(g, hp)
+            den = DenoiserHandle(sd, 128, 256, 384, 20, 4, 1000, precision=precision, prefix="denoise_fn.")
+            smp = SamplerHandle(den, sd)
+        clips = [int(c) for c in g["clips"]]
+        hub, m2p, f0 = clip_batch(hp, clips, int(g["T"]), int(g["n_units"]))
+        cond, f0_denorm, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+        assert np.array_equal(f0_denorm.numpy(), g["f0_denorm"])
+        mel = smp.sample(cond.transpose(1, 2).contiguous().cuda(), int(g["K_step"]), speedup=int(g["speedup"]), mel2ph=m2p.cuda(),
+                         seed=int(g["seed"]), first_clip=clips[0], use_graph=True)
+        errs.append((clips[0], (mel.cpu() - torch.from_numpy(g["mel_out"])).abs().max().item()))
+    print("PLMS-50 T=861 %s, six (clip, noise) pairs: mel max-abs err %s" % (precision, ["%d: %.2e" % e for e in errs]))
+    assert smp.stats()["capture_plms"] == 1
+    assert max(e[1] for e in errs) < 1e-4, errs
+
+
 @pytest.mark.parametrize("precision", ["f16_m64", "f16_d64"])
 def test_throughput_tiling_full_chain_vs_reference(precision):
     """The batched number's kernels over the FULL chain: 8 clips x T=861 (7168 rows -> the 128-frame tgemm tiling with the
@@ -223,7 +253,7 @@ def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused, hooks):
     spec = torch.from_numpy(g.standard_normal((B, 1, 128, T)).astype(np.float32))
     cond = torch.from_numpy((g.standard_normal((B, 256, T)) * 0.5).astype(np.float32))
     t = torch.from_numpy(g.integers(0, 1000, size=(B,)))
-    Tp = (T + 8 + 31) // 32 * 32
+    Tp = (T + 8 + 127) // 128 * 128          # csrc/diffnet.hip: bucket_rows
     den.debug_set("two_launch_layer", -1 if fused else 1)        # -1: the fused kernel wherever it is supported (auto takes it from ~18 clips)
     worst = _tap_errors(den, sd, spec, t, cond, lambda b: slice(b * Tp, b * Tp + T))
     print("tgemm taps %s B=%d T=%d fused=%d: worst |err| x %.2e (layer %d), g %.2e (layer %d), skip-sum %.2e (layer %d)"
@@ -525,7 +555,7 @@ def test_deferred_skip_contraction_taps_and_equivalence(precision, hooks):
     spec = torch.from_numpy(g.standard_normal((B, 1, 128, T)).astype(np.float32))
     cond = torch.from_numpy((g.standard_normal((B, 256, T)) * 0.5).astype(np.float32))
     t = torch.from_numpy(g.integers(0, 1000, size=(B,)))
-    Tp = (T + 8 + 31) // 32 * 32
+    Tp = (T + 8 + 127) // 128 * 128          # csrc/diffnet.hip: bucket_rows
     taps = {}
     with torch.no_grad():
         ref_out = O.diffnet_forward(sd, spec, t, cond, 4, taps=taps)

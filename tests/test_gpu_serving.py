@@ -1,0 +1,139 @@
+"""GPU: the variable-length serving path (round 6; VERDICT r5 missing 4 / weak 10).
+
+The reference's driver calls the model chunk by chunk, every chunk with its own T (infer.py:44-67, infer_tools/infer_tool.py:155-159,276).
+``dsvc_sample`` lays a call out in a BUCKET -- a clip occupies round_up(T + largest dilation, 128) rows -- and keeps the buckets it has seen
+(workspace zeroed once, captured DDPM / PLMS chains) in an LRU, so that a chunk whose bucket exists costs no allocation, no clearing and no
+graph capture.  Held here:
+
+  * a chunk run in a re-used bucket (after longer and shorter chunks of the same bucket, after other buckets) equals the same chunk on a
+    FRESH handle bit for bit -- nothing of an earlier chunk leaks through the workspace;
+  * the counters of dsvc_sampler_stats: one bucket and one capture per distinct bucket, none on the second pass;
+  * more buckets than the LRU holds: eviction, re-allocation and re-capture keep the results.
+"""
+import numpy as np
+import pytest
+import torch
+
+from diffsvc_amd import synth
+import dsvc_oracle as O
+from util import clip_batch
+from test_gpu_diffnet import make_handles
+
+pytestmark = pytest.mark.gpu
+
+
+def _chunk(hp, sd, clip, T):
+    n_units = max(2, (T * 500) // 861)
+    hub, m2p, f0 = clip_batch(hp, [clip], T, n_units)
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    return cond.transpose(1, 2).contiguous().cuda(), m2p.cuda()
+
+
+def _bucket(T, max_dil=8):
+    return (T + max_dil + 127) // 128
+
+
+def _run(smp, cond, m2p, clip, kind, K):
+    if kind == "plms":
+        return smp.sample(cond, K, speedup=K // 50, mel2ph=m2p, seed=7, first_clip=clip, use_graph=True)
+    # DDPM: 150 steps of the schedule -- an eager walk to the dither-period boundary, two graph replays, an eager rest
+    return smp.sample(cond, K, mel2ph=m2p, seed=7, first_clip=clip, t_stop=K - 150, use_graph=True)
+
+
+@pytest.mark.parametrize("kind", ["ddpm", "plms"])
+def test_chunks_in_a_reused_bucket_equal_a_fresh_handle_bit_for_bit_44k(kind):
+    """The 44.1 kHz architecture at the shipped single-clip precision (f16_x3t): seven chunks over three buckets on ONE sampler, every one
+    compared with the same chunk on a handle that has seen nothing else."""
+    hp = dict(synth.HPARAMS_44K)
+    sd, den, smp = make_handles(hp, 0, "f16_x3t")
+    chunks = [(0, 700), (1, 861), (2, 650), (3, 888), (4, 430), (5, 861), (6, 1300)]      # (clip, T): buckets 6, 7, 6, 7, 4, 7, 11 tiles
+    got = {}
+    for clip, T in chunks:
+        cond, m2p = _chunk(hp, sd, clip, T)
+        got[(clip, T)] = _run(smp, cond, m2p, clip, kind, 1000).clone()
+    st = smp.stats()
+    n_buckets = len({_bucket(T) for _, T in chunks})
+    assert st["buckets_allocated"] == n_buckets, st
+    assert st["capture_" + kind] == n_buckets and st["capture_" + ("plms" if kind == "ddpm" else "ddpm")] == 0, st
+    # second pass: nothing is built again, and the results are the first pass's
+    for clip, T in chunks:
+        cond, m2p = _chunk(hp, sd, clip, T)
+        assert torch.equal(_run(smp, cond, m2p, clip, kind, 1000), got[(clip, T)]), (clip, T)
+    st2 = smp.stats()
+    assert st2["buckets_allocated"] == n_buckets and st2["capture_" + kind] == n_buckets, st2
+    assert st2["graph_launches"] > st["graph_launches"]
+    del smp, den
+    for clip, T in ((2, 650), (3, 888), (6, 1300)):           # fresh handles: three packed weight sets one after the other
+        _, den1, smp1 = make_handles(hp, 0, "f16_x3t", sd=sd)
+        cond, m2p = _chunk(hp, sd, clip, T)
+        fresh = _run(smp1, cond, m2p, clip, kind, 1000)
+        assert torch.isfinite(fresh).all()
+        assert torch.equal(fresh, got[(clip, T)]), (kind, clip, T, (fresh - got[(clip, T)]).abs().max().item())
+        del smp1, den1
+
+
+@pytest.mark.parametrize("precision", ["f16_x3t", "f16_w2", "f16_x3"])
+def test_more_buckets_than_the_lru_holds_tiny(precision):
+    """Twelve buckets (the denoiser keeps 8 parked beside the active one), walked twice in different orders, PLMS and DDPM interleaved, on
+    the tiny architecture: every result equals a fresh handle's; evicted buckets are rebuilt, their graphs re-captured.  f16_x3 is the
+    conv_gemm engine, whose kernels take the call's T by value: its graphs are keyed on T as well."""
+    hp = synth.tiny_hparams(K=100)
+    sd, den, smp = make_handles(hp, 4, precision)
+    Ts = [40 + 128 * i for i in range(12)]
+    order = Ts + Ts[::-1] + [Ts[3], Ts[3] - 17, Ts[3] + 5]
+    got = {}
+    for n, T in enumerate(order):
+        cond, m2p = _chunk(hp, sd, 1, T)
+        kind = "plms" if n % 2 else "ddpm"
+        if kind == "plms":
+            mel = smp.sample(cond, 100, speedup=5, mel2ph=m2p, seed=3, first_clip=1, use_graph=True)
+        else:
+            mel = smp.sample(cond, 100, mel2ph=m2p, seed=3, first_clip=1, use_graph=True)
+        assert torch.isfinite(mel).all()
+        if (kind, T) in got:
+            assert torch.equal(mel, got[(kind, T)]), (kind, T)
+        got[(kind, T)] = mel.clone()
+    st = smp.stats()
+    assert st["buckets_allocated"] > 12 and st["graphs_alive"] <= 12, st         # buckets were evicted and rebuilt
+    del smp, den
+    _, den1, smp1 = make_handles(hp, 4, precision, sd=sd)
+    for (kind, T), mel in list(got.items())[::5]:
+        cond, m2p = _chunk(hp, sd, 1, T)
+        fresh = (smp1.sample(cond, 100, speedup=5, mel2ph=m2p, seed=3, first_clip=1, use_graph=False) if kind == "plms"
+                 else smp1.sample(cond, 100, mel2ph=m2p, seed=3, first_clip=1, use_graph=False))
+        assert torch.equal(fresh, mel), (precision, kind, T)
+
+
+def test_denoiser_forward_seam_across_chunk_lengths():
+    """DiffNet.forward (the denoiser seam the reference's own sampler loop calls) with a new T every call: the bucket's workspace is re-used,
+    the hoisted conditioner projections are recomputed for the new chunk, results equal a fresh handle's."""
+    hp = dict(synth.HPARAMS_44K)
+    sd, den, _ = make_handles(hp, 0, "f16_x3t")
+    g = np.random.Generator(np.random.PCG64(21))
+    outs = {}
+    for T in (300, 250, 300, 380, 120):
+        spec = torch.from_numpy(g.standard_normal((1, 1, 128, T)).astype(np.float32)).cuda()
+        cond = torch.from_numpy((g.standard_normal((1, 256, T)) * 0.5).astype(np.float32)).cuda()
+        t = torch.tensor([int(g.integers(0, 1000))], device="cuda")
+        outs[T] = (spec, cond, t, den.forward(spec, t, cond, cond_changed=False).clone())      # (cond_changed False: a new T must recompute anyway)
+    del den
+    _, den1, _ = make_handles(hp, 0, "f16_x3t", sd=sd)
+    for T, (spec, cond, t, out) in outs.items():
+        assert torch.equal(den1.forward(spec, t, cond), out), T
+
+
+def test_the_product_library_refuses_the_test_hooks():
+    """dsvc_denoiser_debug_set of libdsvc_hip.so knows one measurement key; every key that changes which kernel computes a result exists in
+    libdsvc_hip_hooks.so only."""
+    from diffsvc_amd import _lib
+    hp = synth.tiny_hparams(K=12)
+    sd, den, smp = make_handles(hp, 4, "f16_w2")
+    den.debug_set("profile_kernel", 0)
+    for key in ("two_launch_layer", "stop_after_layers", "fused_nt", "w6_off", "defer_skip"):
+        with pytest.raises(RuntimeError, match="hooks"):
+            den.debug_set(key, 1)
+    with _lib.hooks_build():
+        _, den_h, _ = make_handles(hp, 4, "f16_w2", sd=sd)
+    assert den_h._L is not den._L
+    den_h.debug_set("two_launch_layer", 1)
+    den_h.debug_set("two_launch_layer", 0)

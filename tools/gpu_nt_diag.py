@@ -17,7 +17,7 @@ g = np.random.Generator(np.random.PCG64(23))
 spec = torch.from_numpy(g.standard_normal((B, 1, 128, T)).astype(np.float32))
 cond = torch.from_numpy((g.standard_normal((B, 256, T)) * 0.5).astype(np.float32))
 t = torch.full((B,), 417, dtype=torch.long)
-Tp = (T + 8 + 31) // 32 * 32
+Tp = (T + 8 + 127) // 128 * 128          # csrc/diffnet.hip: bucket_rows
 taps = {}
 with torch.no_grad():
     O.diffnet_forward(sd, spec, t, cond, 4, taps=taps)

@@ -19,7 +19,7 @@ g = np.random.Generator(np.random.PCG64(23))
 spec = torch.from_numpy(g.standard_normal((B, 1, M, T)).astype(np.float32)).cuda()
 cond = torch.from_numpy((g.standard_normal((B, 256, T)) * 0.5).astype(np.float32)).cuda()
 t = torch.from_numpy(g.integers(0, 1000, size=(B,))).cuda()
-Tp = (T + 8 + 31) // 32 * 32
+Tp = (T + 8 + 127) // 128 * 128          # csrc/diffnet.hip: bucket_rows
 den.debug_set("two_launch_layer", -1)
 den.debug_set("defer_skip", 1)
 out_d = den.forward(spec, t, cond).cpu()
