@@ -289,6 +289,104 @@ def cpu_baseline(hp, sd, vs, h, budget_s=20.0):
                       % (n, per_step, t_voc)}
 
 
+def time_job(pipe, n_clips, cpb, dev, ddpm_steps, overlap=True, warm=True):
+    """One whole job of n_clips fixed-length 10 s clips on ONE device, `cpb` clips per batch through one SvcPipeline (SvcPipeline.infer_job:
+    the reference's sequential loop, batch.py:25-43, as batches; the vocoder of batch k on a second stream under the sampler of batch k+1).
+    This is the 1-GPU side of north_star's ">= 6x at 8 GPUs vs 1 GPU on the batched config": the WHOLE 256-clip job on one device, not one
+    rank's 32-clip share (that one is `same_workload_1gpu` of the N > 1 lines: weak scaling)."""
+    hub, m2p, f0 = make_inputs(list(range(n_clips)), dev)
+    if warm:                                                  # bucket + graph of this batch size on a short chain
+        pipe.model.K_step = 130
+        pipe.infer_job(hub[:cpb], m2p[:cpb], f0[:cpb], clips_per_batch=cpb, seed=1, overlap=overlap)
+        pipe.model.K_step = ddpm_steps
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    wav = pipe.infer_job(hub, m2p, f0, clips_per_batch=cpb, seed=2, overlap=overlap)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    return {"clips": n_clips, "clips_per_batch": cpb, "batches": -(-n_clips // cpb), "value": n_clips * CLIP_SECONDS / dt, "unit": "audio-sec/wall-sec",
+            "s_per_job": dt, "vocoder_overlapped": bool(overlap), "finite_output": bool(torch.isfinite(wav).all().item())}
+
+
+RAGGED_T = (430, 700, 861, 1200, 1600, 2100, 2600)          # 5 ... 30 s chunks, as the reference's slicer hands them out (infer_tools/slicer.py)
+
+
+def time_ragged(pipe, dev, speedup, ddpm_steps):
+    """Variable-length serving (VERDICT r5 missing 4): the reference's driver calls the model chunk by chunk, every chunk with its own T
+    (infer.py:44-67, infer_tool.py:155-159,276).  Seven chunks of 5 ... 30 s through ONE pipeline: the first pass builds a workspace bucket and
+    captures a chain per bucket (`first_call_ms`); the second, timed pass must build nothing (`recapture_count`, `buckets_built`: the deltas of
+    dsvc_sampler_stats over it) and run within 5 % of the same chunks each repeated at a fixed T (`fixed_T_value`)."""
+    chunks = []
+    for i, T in enumerate(RAGGED_T):
+        n_units = max(2, T * N_UNITS // T_FRAMES)
+        a, b, c, _ = synth.clip_inputs(100 + i, T=T, n_units=n_units, H=256)
+        chunks.append(tuple(torch.from_numpy(v[None]).to(dev) for v in (a, b, c)))
+    audio = sum(RAGGED_T) * 512 / 44100.0
+    run = lambda ch, i: pipe.infer(*ch, speedup=speedup, seed=40 + i, first_clip=100 + i, full_length=True)
+    smp = pipe.model._handle("plms" if speedup > 1 else "ddpm", speedup, frames=RAGGED_T[0], clips=1)
+    first = []
+    for i, ch in enumerate(chunks):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        run(ch, i)
+        torch.cuda.synchronize(); first.append((time.perf_counter() - t0) * 1e3)
+    s0 = smp.stats()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i, ch in enumerate(chunks[::-1]):                        # another order than the first pass
+        run(ch, i)
+    torch.cuda.synchronize(); mixed = time.perf_counter() - t0
+    s1 = smp.stats()
+    fixed = 0.0
+    for i, ch in enumerate(chunks):                              # each chunk again, back to back at ITS fixed T (second of two calls timed)
+        run(ch, i)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        run(ch, i)
+        torch.cuda.synchronize(); fixed += time.perf_counter() - t0
+    return {"workload": "%d chunks of one utterance, T = %s mel frames (%.0f s of audio), B = 1, %s + NSF-HiFiGAN, one pipeline"
+                        % (len(chunks), list(RAGGED_T), audio, "%d-step DDPM" % ddpm_steps if speedup <= 1 else "PLMS (pndm_speedup %d)" % speedup),
+            "value": audio / mixed, "unit": "audio-sec/wall-sec", "s_per_pass": mixed,
+            "fixed_T_value": audio / fixed, "vs_fixed_T": fixed / mixed,
+            "first_call_ms": [round(v, 2) for v in first], "steady_call_ms_total": mixed * 1e3,
+            "recapture_count": (s1["capture_ddpm"] + s1["capture_plms"]) - (s0["capture_ddpm"] + s0["capture_plms"]),
+            "buckets_built": s1["buckets_allocated"] - s0["buckets_allocated"], "graphs_alive": s1["graphs_alive"],
+            "buckets": sorted({(T + 8 + 127) // 128 for T in RAGGED_T})}
+
+
+def plms_breakdown(pipe, hub, m2p, f0, n=5):
+    """Where one PLMS-50 clip's wall time goes (2 ms of 25 were outside both the evaluations and the vocoder): HIP events at
+    the phase boundaries inside dsvc_sample (dsvc_sampler_phase_times) + events around the condition builder and the vocoder, mean of n clips."""
+    smp = pipe.model._handle("plms", 20, frames=T_FRAMES, clips=1)
+    smp.phase_timing(True)
+    acc = {}
+    try:
+        for i in range(n + 1):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            hpx = dict(pipe.hp, pndm_speedup=20)
+            pipe.model.hp = hpx; pipe.model.fs2.hp = hpx
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ev[0].record()
+            ret = pipe.model.fs2(hub, m2p, None, None, f0.clone(), None, None, skip_decoder=True, infer=True)
+            cond = ret.pop("cond_bht", None)
+            if cond is None:
+                cond = ret["decoder_inp"].transpose(1, 2).contiguous()
+            ev[1].record()
+            mel = smp.sample(cond, pipe.model.K_step, speedup=20, mel2ph=m2p, seed=60 + i, first_clip=0)
+            ev[2].record()
+            mel_c = torch.clamp(mel, hpx["mel_vmin"], hpx["mel_vmax"])
+            pipe.vocoder.vocode(mel_c, ret["f0_denorm"], seed=60 + i, first_clip=0)
+            ev[3].record()
+            torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
+            if i == 0:
+                continue
+            ph = smp.phase_times()
+            parts = {"cond_build": ev[0].elapsed_time(ev[1]), "prepare_cond": ph["prepare"], "x_init": ph["init"], "sampler_chain": ph["chain"],
+                     "finish": ph["finish"], "vocoder": ev[2].elapsed_time(ev[3])}
+            parts["other"] = wall - sum(parts.values())
+            parts["wall"] = wall
+            for k, v in parts.items():
+                acc[k] = acc.get(k, 0.0) + v / n
+    finally:
+        smp.phase_timing(False)
+    return {k: round(v, 3) for k, v in acc.items()}
+
+
 def spawn_ranks(n):
     """Re-run this command line as n ranks on this node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n (rendezvous on
     127.0.0.1, a free port).  Returns the launcher's exit code; rank 0 of the child job prints the JSON line."""
@@ -423,6 +521,11 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="measure BASELINE configs[4] instead: the training step (diffusion loss fwd+bwd + AdamW) on a 64 x 128-frame mel "
                          "batch per GPU, gradients all-reduced over the ranks (weak scaling)")
+    ap.add_argument("--job-clips", type=int, default=0,
+                    help="--gpus 1 only: time ONE job of this many clips on the one device (batches of --clips-per-batch through one pipeline, the "
+                         "vocoder of batch k under the sampler of batch k+1) and print it as `value`: north_star's 1-GPU denominator for the 8-GPU job")
+    ap.add_argument("--clips-per-batch", type=int, default=32)
+    ap.add_argument("--no-overlap", action="store_true", help="--job-clips: run the vocoder on the sampler's stream (A/B of the overlap)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the sampler steps eagerly (rocprofv3 --pmc segfaults on hipGraph replays on this stack)")
     args = ap.parse_args()
@@ -525,6 +628,19 @@ def main():
         return
     pipe = SvcPipeline(hp, sd, vs, h, precision=args.precision, vocoder_precision="f16_x3")
 
+    if args.job_clips > 0:
+        if world != 1:
+            print("bench.py: --job-clips is the ONE-device job (use --gpus 1)", file=sys.stderr)
+            sys.exit(2)
+        job = time_job(pipe, args.job_clips, args.clips_per_batch, dev, args.ddpm_steps, overlap=not args.no_overlap)
+        print(json.dumps({"metric": "audio-sec/wall-sec (RTF) end-to-end 44.1kHz %d-step DDPM + NSF-HiFiGAN" % args.ddpm_steps, "value": job["value"],
+                          "unit": "audio-sec/wall-sec", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": job["s_per_job"] * 1e3, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[3] on ONE device: the whole %d-clip job (10 s clips, 44.1 kHz, %d-step DDPM + NSF-HiFiGAN) "
+                                                 "as %d batches of %d" % (args.job_clips, args.ddpm_steps, job["batches"], args.clips_per_batch),
+                                     "precision": pipe.model.denoise_fn.precision_for("ddpm", 1, frames=args.clips_per_batch * T_FRAMES, clips=args.clips_per_batch)},
+                          "job": job, "cpu_baseline": None}))
+        return
     B = args.clips_per_gpu if args.clips_per_gpu > 0 else (1 if world == 1 else 32)
     # what the timed chain runs at: precision="auto" picks by sampler and by the size of the call (DiffNetHip.precision_for)
     prec = pipe.model.denoise_fn.precision_for("plms" if args.speedup > 1 else "ddpm", args.speedup, frames=B * T_FRAMES, clips=B)
@@ -618,6 +734,14 @@ def main():
             result["plms_50"] = {"workload": "BASELINE configs[2]: single 10 s clip, 50-iteration PLMS (pndm_speedup=20) + NSF-HiFiGAN",
                                  "precision": pipe.model.denoise_fn.precision_for("plms", 20),
                                  "value": CLIP_SECONDS / tpl, "unit": "audio-sec/wall-sec", "ms_per_clip": tpl * 1e3}
+            try:
+                result["plms_50"]["breakdown_ms"] = plms_breakdown(pipe, hub, m2p, f0)
+            except Exception as ex:
+                result["plms_50"]["breakdown_ms"] = {"error": repr(ex)[:200]}
+            try:    # the reference's driver: chunk after chunk, a new T every call (one pipeline, buckets + captured chains re-used)
+                result["ragged"] = {"plms_50": time_ragged(pipe, dev, 20, args.ddpm_steps), "ddpm": time_ragged(pipe, dev, 1, args.ddpm_steps)}
+            except Exception as ex:
+                result["ragged"] = {"error": repr(ex)[:300]}
             try:    # the same chain with fp16 activations and exact weights: faster, but 1 of 10 (clip, noise) pairs measured over the mel bar
                 pw = SvcPipeline(hp, sd, vs, h, precision="f16_w2", vocoder_precision="f16_x3")
                 pw.infer(hub, m2p, f0, speedup=20, seed=7)
@@ -665,6 +789,17 @@ def main():
                     r_["pipe_frac_of_sustained"] = r_["pipe_tflops"] / sustained["cold"]["tflops"]
                 if r_["bound"] == "hbm":
                     r_["frac_of_stream_copy"] = r_["achieved"] / 6290.0               # against the 6.29 TB/s a float4 copy reaches (MI355X_MICROARCH.md)
+            try:    # north_star's 1-GPU denominator: the WHOLE 256-clip job on this one device (8 batches of 32, vocoder under the next batch's DDPM),
+                    # and a job of chip-filling batches (36 clips = 252 frame tiles on 256 CUs; 32 clips leave 32 CUs without a workgroup)
+                result["job_256"] = time_job(pipe, 256, 32, dev, args.ddpm_steps, overlap=True)
+                result["job_256"]["no_overlap"] = {k: v for k, v in time_job(pipe, 64, 32, dev, args.ddpm_steps, overlap=False, warm=False).items()
+                                                   if k in ("clips", "value", "s_per_job")}
+                result["job_256"]["chip_filling_batches"] = time_job(pipe, 252, 36, dev, args.ddpm_steps, overlap=True)
+                result["job_256"]["note"] = ("256 clips need 8 batches at any batch size <= 36, so the 256-clip job runs 8 x 32; `chip_filling_batches` is a "
+                                             "252-clip job as 7 x 36 (252 of 256 CUs hold a frame tile); `no_overlap` = 64 clips as 2 x 32 with the vocoder on "
+                                             "the sampler's stream")
+            except Exception as ex:
+                result["job_256"] = {"error": repr(ex)[:300]}
             if FAST_SIDE and precb != FAST_SIDE:
                 # other operand schemes beside the shipped ones (design/precision.md): f16_w2 -- round 3's batched default, and what a single clip runs
                 # at when the fp32-class f16_x3t is not asked for -- and f16_w6n (f16_w6 without the gate-output correction: f16_w2's error class)

@@ -111,6 +111,7 @@ SYMBOLS = [
     ("dsvc_sampler_destroy", None, [_VP]),
     ("dsvc_sample", ctypes.c_int, [_VP, ctypes.POINTER(SampleArgs), _VP]),
     ("dsvc_sampler_stats", ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32]),
+    ("dsvc_sampler_phase_times", ctypes.c_int, [_VP, ctypes.c_int32, c_f32p]),
     ("dsvc_sampler_profile_gate_kernel", ctypes.c_int,
      [_VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64), c_i32p, _VP]),
     ("dsvc_vocoder_create", ctypes.c_int, [ctypes.POINTER(VocoderCfg), ctypes.POINTER(_VP)]),

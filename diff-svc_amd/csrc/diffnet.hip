@@ -1023,12 +1023,16 @@ struct dsvc_sampler : SmpWs {
     std::vector<SmpGraph> graphs;
     unsigned long long clock = 0;
     long long stat_capture_ddpm = 0, stat_capture_plms = 0, stat_graph_launch = 0;
+    bool timing = false;            // dsvc_sampler_phase_times: HIP events at the phase boundaries of dsvc_sample (bench.py's plms_50.breakdown_ms)
+    hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool tev_valid = false;
     hipStream_t cap_stream = nullptr;
     SmpWs& active() { return *this; }
 
     ~dsvc_sampler() {
         for (SmpGraph& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        for (hipEvent_t e : tev) if (e) (void)hipEventDestroy(e);
         for (DevBuf* b : {&alphas_cumprod, &sqrt_recip, &sqrt_recipm1, &coef1, &coef2, &sigma, &spec_min, &spec_max, &step_dev})
             b->release();
         for (SmpWs& w : ws_cache) w.release_all();
@@ -1500,10 +1504,14 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
     dsvc_denoiser* d = s->den;
     const int B = a->B, T = a->T, M = d->cfg.mel_bins;
     if ((T * M) % 4) return fail(DSVC_EINVAL, "T*mel_bins must be a multiple of 4");
+    auto stamp = [&](int i) { if (s->timing && s->tev[i]) (void)hipEventRecord(s->tev[i], st); };
+    s->tev_valid = false;
+    stamp(0);
     DSVC_TRY(s->ensure_ws(B, T, st));
     d->tail_fused_last = false;                           // a new chain: nothing of a previous call's tail applies
     DSVC_TRY(d->set_clip_meta(a->clip_ids, a->first_clip, a->clip_lens, st));
     DSVC_TRY(d->prepare_cond(a->cond, B, T, st));
+    stamp(1);
     float* xs = s->xstate.as<float>();
     if (a->ref_mel) {
         // use_gt_mel start (diffusion.py:255-261): x = q_sample(norm_spec(ref_mel), t_start - 1, noise)   (:200-205, :286-287)
@@ -1521,6 +1529,7 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
     if (d->tpath)      // fp16 copy of the state for the first input projection; every DDPM tail refreshes it afterwards
         hipLaunchKernelGGL(k_rows_to_half, dim3(ceil_div(d->rows * (M / 4), 256) < 2048 ? ceil_div(d->rows * (M / 4), 256) : 2048), dim3(256), 0, st,
                            xs, d->xsh.as<_Float16>(), M, d->Mp, d->rowmap(), d->rows);
+    stamp(2);
     if (a->speedup > 1) DSVC_TRY(s->run_plms(a, st));
     else {
         DSVC_TRY(s->den->ensure_x3t_codes());
@@ -1529,13 +1538,28 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
         s->den->ddpm_chain = false;
         if (rc_chain != DSVC_OK) return rc_chain;
     }
+    stamp(3);
     const size_t n = (size_t)B * T * M;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_finish_mel, dim3(blocks), dim3(256), 0, st, xs, a->mel_out, a->mel2ph, d->lens.as<int>(), s->spec_min.as<float>(),
                        s->spec_max.as<float>(), s->n_spec, B, T, M, d->Tp);
     if (a->x_out)
         hipLaunchKernelGGL(k_from_frame_major, dim3(ceil_div(T, 32), ceil_div(M, 32), B), dim3(256), 0, st, xs, a->x_out, B, M, T, d->Tp);
+    stamp(4);
+    s->tev_valid = s->timing;
     DSVC_HIP(hipGetLastError());
+    return DSVC_OK;
+}
+
+int dsvc_sampler_phase_times(dsvc_sampler* s, int32_t enable, float* out_ms) {
+    if (!s) return fail(DSVC_EINVAL, "null handle");
+    if (out_ms) {
+        if (!s->tev_valid) return fail(DSVC_ESTATE, "sampler: no timed dsvc_sample call to report (enable the phase timing first)");
+        DSVC_HIP(hipEventSynchronize(s->tev[4]));
+        for (int i = 0; i < 4; ++i) DSVC_HIP(hipEventElapsedTime(&out_ms[i], s->tev[i], s->tev[i + 1]));
+    }
+    s->timing = enable != 0;
+    if (s->timing) for (hipEvent_t& e : s->tev) if (!e) DSVC_HIP(hipEventCreate(&e));
     return DSVC_OK;
 }
 

@@ -120,6 +120,16 @@ class SamplerHandle:
         self._ck(self._L.dsvc_sampler_stats(self._h, out, 6))
         return dict(zip(("capture_ddpm", "capture_plms", "graph_launches", "buckets_allocated", "bucket_reuses", "graphs_alive"), [int(v) for v in out]))
 
+    def phase_timing(self, enable=True):
+        """Measurement aid (include/dsvc_debug.h: dsvc_sampler_phase_times): record HIP events at the phase boundaries of every later sample()."""
+        self._ck(self._L.dsvc_sampler_phase_times(self._h, 1 if enable else 0, None))
+
+    def phase_times(self):
+        """{'prepare', 'init', 'chain', 'finish'} in ms of the last sample() call made with phase_timing on (waits for it)."""
+        out = (ctypes.c_float * 4)()
+        self._ck(self._L.dsvc_sampler_phase_times(self._h, 1, out))
+        return dict(zip(("prepare", "init", "chain", "finish"), [float(v) for v in out]))
+
     def sample(self, cond, t_start, speedup=1, x_init=None, mel2ph=None, seed=0, first_clip=0, t_stop=0,
                use_graph=True, return_x=False, ref_mel=None, clip_ids=None, clip_lens=None):
         """cond [B,H,T] -> mel_out [B,T,M] (denormalised, masked).  See dsvc_sample_args.

@@ -110,6 +110,51 @@ class SvcPipeline:
             out += (lens,)
         return out if len(out) > 1 else wav
 
+    @torch.no_grad()
+    def infer_job(self, hubert, mel2ph, f0, clips_per_batch=32, speedup=1, seed=0, first_clip=0, clip_ids=None, use_graph=True, overlap=True):
+        """A job of MANY fixed-length clips on ONE device -- the reference's sequential loop over its inputs (batch.py:25-43) as batches of
+        ``clips_per_batch`` through the same sampler and vocoder: the 1-GPU side of north_star's "speed-up at 8 GPUs vs 1 GPU on the batched
+        config" (the whole 256-clip job on one device, not one rank's share).  hubert [N,n,H], mel2ph [N,T], f0 [N,T] on the device, no padding
+        frames (``full_length``); returns PCM [N, T*hop].
+
+        ``overlap``: the vocoder of batch k runs on a second stream while the sampler of batch k+1 has the main stream -- a fused layer launch
+        of 32 ten-second clips holds 224 of the 256 CUs for the whole DDPM loop, the generator's kernels fit beside it.  Every clip's noise
+        streams are keyed by its global id, and neither the sampler nor the vocoder mixes clips or batches: the job is BIT-IDENTICAL to
+        separate ``infer`` calls per batch (tests/test_gpu_pipeline.py), overlapped or not."""
+        N, T = mel2ph.shape
+        hop = self.vocoder.hop
+        hp = dict(self.hp, pndm_speedup=speedup)
+        self.model.hp = hp
+        self.model.fs2.hp = hp
+        if clip_ids is None:
+            clip_ids = torch.arange(first_clip, first_clip + N, dtype=torch.int32, device=mel2ph.device)
+        out = torch.empty(N, T * hop, device=mel2ph.device, dtype=torch.float32)
+        main = torch.cuda.current_stream()
+        if overlap and getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        keep = []                                                    # tensors the side stream still reads
+        for lo in range(0, N, clips_per_batch):
+            hi = min(N, lo + clips_per_batch)
+            ids = clip_ids[lo:hi].contiguous()
+            ret = self.model(hubert[lo:hi], mel2ph=mel2ph[lo:hi], f0=f0[lo:hi].clone(), infer=True, seed=seed, clip_ids=ids, use_graph=use_graph)
+            mel_c = torch.clamp(ret["mel_out"], hp["mel_vmin"], hp["mel_vmax"])
+            f0_hz = ret["f0_denorm"]
+            if not overlap:
+                out[lo:hi] = self.vocoder.vocode(mel_c, f0_hz, seed=seed, clip_ids=ids)
+                continue
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                out[lo:hi] = self.vocoder.vocode(mel_c, f0_hz, seed=seed, clip_ids=ids)      # (stream_ptr(): the side stream)
+            keep.append((mel_c, f0_hz, ids))
+        if overlap:
+            main.wait_stream(self._side)
+            for group in keep:
+                for t in group:
+                    t.record_stream(self._side)
+        return out
+
     def check(self):
         """The deferred argument checks of the device path, at a point where the caller synchronises anyway (after the PCM has been read, at the
         end of a job): mel2ph entries outside [0, content frames] -- the reference's torch.gather raises an IndexError at once (fs2.py:100-102),
@@ -158,11 +203,14 @@ def pcm16(wav):
     return torch.clamp(torch.round(wav * 32767.0), -32768.0, 32767.0).to(torch.int16)
 
 
-def gather_pcm(local_wav, clip_ids, n_clips, group=None, as_int16=False):
+def gather_pcm(local_wav, clip_ids, n_clips, group=None, as_int16=False, root=None):
     """The one collective of the sharded job: every rank contributes its finished PCM [n_local, L]; rank order
     is undone so the result is indexed by clip id.  Equal counts per rank are required (pad the batch).
     ``as_int16``: convert to the 16-bit PCM the reference writes BEFORE the exchange -- half the bytes on the xGMI links (226 MB
-    instead of 451 MB for 256 clips); the result is int16."""
+    instead of 451 MB for 256 clips); the result is int16.
+    ``root``: None = ``all_gather`` (every rank ends up with the whole job's PCM); an int = north_star's "final gather" -- ``dist.gather`` to that
+    rank only (one eighth of the bytes on the links: each peer sends its 56 MB share once, over its own xGMI link to the root); the root gets
+    the [n_clips, L] tensor, every other rank None."""
     import torch.distributed as dist
     if as_int16:
         local_wav = pcm16(local_wav)
@@ -176,8 +224,15 @@ def gather_pcm(local_wav, clip_ids, n_clips, group=None, as_int16=False):
     wire = local_wav.contiguous()
     if dtype == torch.int16:                                        # neither RCCL nor gloo has a 16-bit integer type: the gather only moves bytes
         wire = wire.view(torch.uint8)
-    out = [torch.empty_like(wire) for _ in range(world)]
-    dist.all_gather(out, wire, group=group)
+    if root is not None:
+        me = dist.get_rank(group)
+        out = [torch.empty_like(wire) for _ in range(world)] if me == root else None
+        dist.gather(wire, out, dst=root, group=group)
+        if me != root:
+            return None
+    else:
+        out = [torch.empty_like(wire) for _ in range(world)]
+        dist.all_gather(out, wire, group=group)
     full = torch.empty(n_clips, local_wav.shape[1], dtype=dtype, device=dev)
     for r in range(world):
         ids = shard_clips(n_clips, r, world)

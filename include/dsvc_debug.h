@@ -51,6 +51,13 @@ DSVC_API int dsvc_denoiser_debug_set(dsvc_denoiser* d, const char* key, int32_t 
 DSVC_API int dsvc_sampler_profile_gate_kernel(dsvc_sampler* s, int32_t B, int32_t T, int32_t iters,
                                      float* avg_us, int64_t* rows, int32_t* kind, void* stream);
 
+/* measurement aid for bench.py's `plms_50.breakdown_ms` / `ragged`: enable != 0 makes every later dsvc_sample call record HIP events at its
+ * phase boundaries on the caller's stream (four extra event records per call).  out_ms (may be NULL; else float[4]) receives the phases of the
+ * LAST timed call, in ms, after waiting for it: [0] workspace bucket + clip metadata + the L hoisted conditioner projections, [1] the initial
+ * state (x_T noise / q_sample of the reference mel) and its fp16 planes, [2] the sampling chain (eager evaluations, graph capture if the
+ * bucket had none, graph replays), [3] denormalisation + mask. */
+DSVC_API int dsvc_sampler_phase_times(dsvc_sampler* s, int32_t enable, float* out_ms);
+
 /* test support for the trainer, as dsvc_denoiser_debug_set: "wgrad_fm" = 0 makes the residual layers' weight gradients take the k_split_t +
  * wgrad_nt_kernel path (channel-major copies of every operand) where the architecture would let them be contracted straight from the
  * frame-major operand planes (csrc/wgrad.h: wgrad_fm_kernel, the default since round 5); 1 = automatic.  Both paths compute the same products;

@@ -484,3 +484,29 @@ def test_cond_builder_energy_branch_on_the_device_vs_real_fastspeech2():
     assert np.array_equal(ret["decoder_inp"].cpu().numpy(), g["decoder_inp"])
     assert torch.equal(ret["cond_bht"], ret["decoder_inp"].transpose(1, 2))
     assert np.array_equal(ret["pitch_pred"].cpu().numpy(), g["pitch"])
+
+
+@pytest.mark.parametrize("arch", ["tiny", "44k"])
+def test_pipelined_job_equals_separate_batches_bit_for_bit(arch):
+    """SvcPipeline.infer_job (round 6: north_star's 1-GPU denominator, the whole job on one device -- batch.py:25-43's loop as batches, the
+    vocoder of batch k on a second stream under the sampler of batch k+1): the PCM equals what separate ``infer`` calls per batch return,
+    bit for bit, overlapped or not, ragged last batch included.  44k: the batched precision on the fused layer kernel (8 clips per batch)."""
+    if arch == "tiny":
+        pipe, hp, h, sd, vs = tiny_pipeline(K=30, precision="auto")
+        N, cpb, T, n_units = 10, 4, 40, 23
+    else:
+        from diffsvc_amd.pipeline import SvcPipeline
+        hp = dict(synth.HPARAMS_44K, K_step=20)
+        h = dict(synth.VOCODER_44K)
+        sd, vs = synth.acoustic_state(hp, 0), synth.vocoder_state(h, 1)
+        pipe = SvcPipeline(hp, sd, vs, h, precision="auto", vocoder_precision="f16_x3")
+        N, cpb, T, n_units = 20, 8, 861, 500
+    hub, m2p, f0 = (t.cuda() for t in clip_batch(hp, list(range(N)), T, n_units))
+    ids = torch.arange(100, 100 + N, dtype=torch.int32, device="cuda")
+    ref = torch.cat([pipe.infer(hub[lo:lo + cpb], m2p[lo:lo + cpb], f0[lo:lo + cpb], seed=9, clip_ids=ids[lo:lo + cpb], full_length=True)
+                     for lo in range(0, N, cpb)])
+    for overlap in (True, False, True):
+        job = pipe.infer_job(hub, m2p, f0, clips_per_batch=cpb, seed=9, clip_ids=ids, overlap=overlap)
+        torch.cuda.synchronize()
+        assert torch.isfinite(job).all()
+        assert torch.equal(job, ref), (arch, overlap, (job - ref).abs().max().item())

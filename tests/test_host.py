@@ -106,8 +106,12 @@ def _gather_worker(rank, world, port, n_clips, L, q):
     local = torch.stack([torch.full((L,), float(i)) + torch.arange(L) * 1e-3 for i in ids])
     full = gather_pcm(local, ids, n_clips)
     full16 = gather_pcm(local / 8.0, ids, n_clips, as_int16=True)
+    rooted = gather_pcm(local, ids, n_clips, root=0)           # north_star's "final gather": to rank 0 only
+    rooted16 = gather_pcm(local / 8.0, ids, n_clips, as_int16=True, root=0)
+    assert (rooted is None) == (rank != 0) and (rooted16 is None) == (rank != 0)
     dist.barrier()
     if rank == 0:
+        assert torch.equal(rooted, full) and torch.equal(rooted16, full16)
         q.put((full.numpy(), full16.numpy()))
     dist.destroy_process_group()
 
