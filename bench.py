@@ -715,6 +715,16 @@ def main():
             "roofline": roof,
         }
         if world == 1 and B == 1 and args.speedup <= 1 and roof["bound"] == "mfma":
+            # the single clip is frozen, with the evidence on the line
+            roof["frozen_since"] = "r4"
+            roof["target_feasibility"] = {
+                "target_x_rt": 200.0, "ceiling_x_rt": 55.0,
+                "why": "20 000 serially dependent layer evaluations per clip, two launches each: at the stated latency floors (gate 4.9 us + res/skip 3.5 us per "
+                       "layer + 43 graph-node boundaries per step) a 1000-step clip cannot go below ~0.18 s = 55x RT; both kernels have sat at 44-48 % of those "
+                       "floors for two rounds (r4: 10.3 / 7.7 us, r5: 10.3 / 7.7 us, r6: unchanged) with everything in design/tgemm.md tried (XCD-major placement "
+                       "-12 %, split-K variants, 6-bit lo plane +7.5 %); one frame tile's eight slices already share two XCDs, so the all-to-all hand-off of a "
+                       "persistent layer costs 26-28 us (tools/micro/handoff.hip) against 18 us for the two launches",
+                "what_serves_the_target_instead": "batching: 32 clips per GPU run at 122x RT per GPU (`batched`), 36 at 127x (`job_256.chip_filling_batches`)"}
             try:        # the single clip's second layer kernel (39 % of its GPU time), priced the same way
                 result["roofline_res_skip"] = res_skip_roofline(pipe.model._handle("ddpm", 1, frames=B * T_FRAMES, clips=B), prec)
             except Exception as ex:
@@ -769,6 +779,22 @@ def main():
             result["batched"] = {"workload": "BASELINE configs[3] per-GPU share: 32 x 10 s clips in one batch, 1000-step DDPM + NSF-HiFiGAN",
                                  "clips_per_gpu": Bb, "precision": precb, "value": Bb * CLIP_SECONDS / tb, "unit": "audio-sec/wall-sec",
                                  "s_per_batch": tb, "roofline": broof}
+            # where the two kernels stand against the 200x target, with the evidence (profiles/r6c_layer_ablations.txt)
+            result["batched"]["target_feasibility"] = {
+                "target_x_rt": 200.0, "ceiling_x_rt": 136.0,
+                "why": "the fused layer's two phases sit on different roofs and do not overlap on this part (gate phase: matrix pipe at 70-90 % of its issue "
+                       "rate at the 1.5-1.6 GHz the chip holds; output phase: 193 MB at the 5.4 TB/s streaming rate; dedicated memory waves starve beside "
+                       "MFMA waves, de-phased half batches gain nothing: design/tlayer.md).  Serial-phase model: 57 us matrix + 56 us HBM per layer -> "
+                       "136x; 200x needs 75 us per layer.",
+                "levers_measured_r6": {
+                    "cproj_compressed": "ablation reading HALF of cproj (1536 of 3072 B per frame, an upper bound on fp16-hi + 6-bit-lo codes at 2112 B): "
+                                        "-2.5 % per DDPM step -> the real scheme <= -1.5 %: not built",
+                    "persistent_launch_neighbour_flags": "the hand-off protocol (poll i-1 / i+1 + agent acquire; drain + agent release + flag) as pure overhead "
+                                                         "inside the real kernel: +3.1 % per step (+4 us per layer); it could hide at most the 1.75 us boundary "
+                                                         "and the neighbour-independent part of the 9 us prologue: net < 1 %: not built",
+                    "chip_filling_batch": "36 clips per batch (252 of 256 CUs hold a tile): +4.3 % per clip (`job_256.chip_filling_batches`)",
+                    "vocoder_under_next_batch": "second stream: +0.1 % (`job_256` vs `job_256.no_overlap`): the layer kernels leave no CU a co-resident workgroup fits on"},
+                "source": "profiles/r6c_layer_ablations.txt, profiles/r6b_bench.json (same-box A/B, profiling build for the ablations)"}
             fit, why = load_error_fit(precb)
             if fit:
                 import math

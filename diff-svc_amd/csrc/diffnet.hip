@@ -1236,68 +1236,70 @@ int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
     const size_t n = (size_t)den->rows * den->cfg.mel_bins;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     int* sdev = step_dev.as<int>();                      // sdev[0] = t, sdev[1] = predictions stored so far
-    PlmsArgs p{};
-    p.x = xstate.as<float>(); p.eps = den->eps.as<float>(); p.hist = hist.as<float>(); p.x_pred = xpred.as<float>();
-    p.alphas_cumprod = alphas_cumprod.as<float>(); p.n = n; p.interval = interval;
-    int i = ((a->t_start - 1) / interval) * interval;
-    if (i < a->t_stop) return DSVC_OK;
-    {   // first iteration: no history yet -> improved Euler with a second evaluation at t_prev (diffusion.py:184-187)
-        const int t_prev = i - interval > 0 ? i - interval : 0;
-        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, sdev, i);
-        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, st, i));
-        p.t = i; p.t_prev = t_prev; p.n_hist = 0; p.phase = 0;
-        hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, sdev, t_prev);
-        DSVC_TRY(den->eval(xpred.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, st, t_prev));
-        p.phase = 1;
-        hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, st, p);
-        i -= interval;
-    }
-    if (i < a->t_stop) { DSVC_HIP(hipGetLastError()); return DSVC_OK; }
-    // remaining iterations: eps = denoiser(x, t); x = x_pred(x, AB(eps, history), t); one body, state on the device
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, sdev, i);
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, sdev + 1, 1);
-    p.phase = 2; p.state_dev = sdev;
-    // t of every iteration is known on the host, so each evaluation gets its weight variant by value (see run_ddpm); the
-    // Adams-Bashforth kernel keeps reading t / the history count from the device, which lets one body serve all iterations
-    auto body = [&](hipStream_t s2, int t_host) -> int {
-        DSVC_TRY(den->eval(xstate.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, s2, t_host));
-        hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, s2, p);
-        hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s2, sdev, -interval);
-        hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s2, sdev + 1, 1);
+    PlmsArgs p0{};
+    p0.x = xstate.as<float>(); p0.eps = den->eps.as<float>(); p0.hist = hist.as<float>(); p0.x_pred = xpred.as<float>();
+    p0.alphas_cumprod = alphas_cumprod.as<float>(); p0.n = n; p0.interval = interval;
+    const int i_first = ((a->t_start - 1) / interval) * interval;
+    if (i_first < a->t_stop) return DSVC_OK;
+    const int i_body = i_first - interval;               // first iteration of the Adams-Bashforth body
+    const int iters = i_body >= a->t_stop ? (i_body - a->t_stop) / interval + 1 : 0;
+    // the whole chain as a sequence of launches on one stream.  t of every evaluation is known on the host, so each one gets its weight variant
+    // by value (see run_ddpm); the Adams-Bashforth kernel reads t / the history count from the device, which lets one body serve all iterations
+    auto chain = [&](hipStream_t s2) -> int {
+        PlmsArgs p = p0;
+        {   // first iteration: no history yet -> improved Euler with a second evaluation at t_prev (diffusion.py:184-187)
+            const int t_prev = i_first - interval > 0 ? i_first - interval : 0;
+            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s2, sdev, i_first);
+            DSVC_TRY(den->eval(xstate.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, s2, i_first));
+            p.t = i_first; p.t_prev = t_prev; p.n_hist = 0; p.phase = 0;
+            hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, s2, p);
+            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s2, sdev, t_prev);
+            DSVC_TRY(den->eval(xpred.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, s2, t_prev));
+            p.phase = 1;
+            hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, s2, p);
+        }
+        if (iters < 1) return DSVC_OK;
+        // remaining iterations: eps = denoiser(x, t); x = x_pred(x, AB(eps, history), t); state on the device
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s2, sdev, i_body);
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s2, sdev + 1, 1);
+        p.phase = 2; p.state_dev = sdev;
+        for (int k = 0; k < iters; ++k) {
+            DSVC_TRY(den->eval(xstate.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, s2, i_body - k * interval));
+            hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, s2, p);
+            hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s2, sdev, -interval);
+            hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s2, sdev + 1, 1);
+        }
         return DSVC_OK;
     };
-    int iters = (i - a->t_stop) / interval + 1;
-    if (a->use_graph && iters >= 4) {
-        // the whole remaining chain is ONE graph (51 evaluations for pndm_speedup = 20: ~2300 nodes), keyed by its schedule
-        DSVC_TRY(body(st, i));                           // first of them eagerly: sets every function attribute outside a capture
-        iters -= 1; i -= interval;
+    if (a->use_graph && iters >= 3) {
+        // Round 6: the WHOLE chain is one graph -- the improved-Euler head included (until round 5 its two evaluations and the first body
+        // iteration were launched eagerly on every call: 3 x 43 host launches, 2.4 ms of a 26 ms clip, bench.py plms_50.breakdown_ms) -- 52
+        // evaluations / ~2400 nodes for pndm_speedup = 20, keyed by its schedule and its bucket.  The call that finds no graph runs the chain
+        // eagerly (that also sets every function attribute outside a capture) and records the graph for the calls after it.
         SmpGraph want{};
         want.kind = 1; want.ws_id = den->ws_id; want.gen = den->ws_gen; want.prec = den->cfg.precision; want.interval = interval;
-        want.first = i + interval; want.iters = iters; want.T = den->tpath ? 0 : a->T;
-        SmpGraph* gr = find_graph(want);
-        if (!gr) {
-            if (!cap_stream) DSVC_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
-            DSVC_HIP(hipStreamSynchronize(st));
-            DSVC_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
-            int rc = DSVC_OK;
-            for (int k = 0; k < iters && rc == DSVC_OK; ++k) rc = body(cap_stream, i - k * interval);
-            hipGraph_t graph = nullptr;
-            hipError_t ce = hipStreamEndCapture(cap_stream, &graph);
-            if (rc != DSVC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            if (ce != hipSuccess) return fail(DSVC_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-            ce = hipGraphInstantiate(&want.exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (ce != hipSuccess) return fail(DSVC_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ce));
-            ++stat_capture_plms;
-            DSVC_TRY(keep_graph(want));
-            gr = &graphs.back();
+        want.first = i_first; want.iters = iters; want.T = den->tpath ? 0 : a->T;
+        if (SmpGraph* gr = find_graph(want)) {
+            DSVC_HIP(hipGraphLaunch(gr->exec, st));
+            ++stat_graph_launch;
+            return DSVC_OK;
         }
-        DSVC_HIP(hipGraphLaunch(gr->exec, st));
-        ++stat_graph_launch;
-        iters = 0;
+        DSVC_TRY(chain(st));
+        if (!cap_stream) DSVC_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+        DSVC_HIP(hipStreamSynchronize(st));
+        DSVC_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = chain(cap_stream);
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(cap_stream, &graph);
+        if (rc != DSVC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ce != hipSuccess) return fail(DSVC_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        const hipError_t ie = hipGraphInstantiate(&want.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) return fail(DSVC_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+        ++stat_capture_plms;
+        return keep_graph(want);
     }
-    for (; iters > 0; --iters, i -= interval) DSVC_TRY(body(st, i));
+    DSVC_TRY(chain(st));
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }

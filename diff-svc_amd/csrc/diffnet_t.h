@@ -41,6 +41,10 @@ struct TEpiGate {
         _Float16* g;            // [rows][ldg] fp16
         int C, ldg;
         int lo_off;             // > 0: also store the lo plane fp16(g - fp16(g)) lo_off halfs into the row (split activations, tgemm NA = 2)
+#ifdef DSVC_PROFILING
+        int abl;                // profiling build, round 6 (tools/gpu_r6_ablate.py; WRONG results): 1 = the accumulator init reads HALF of cproj's bytes
+                                // (1536 instead of 3072 B per frame): an upper bound on what ANY compressed cproj (fp16 hi + 6-bit lo: 2112 B) can buy
+#endif
     };
     template <int NT_N>
     __device__ __forceinline__ void init(const Args& e, int mt, int row0, int lane, f32x16 (&acc)[NT_N]) const {
@@ -48,6 +52,14 @@ struct TEpiGate {
 #pragma unroll
         for (int nt = 0; nt < NT_N; ++nt) {
             const float* p = e.cproj + tiled_lane_base(row0 + 32 * nt, n_mt, mt, lane);
+#ifdef DSVC_PROFILING
+            if (e.abl & 1) {
+                const f32x4 h0 = ld4_nt(p), h1 = ld4_nt(p + 256);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[nt][i] = h0[i]; acc[nt][4 + i] = h1[i]; acc[nt][8 + i] = h0[i]; acc[nt][12 + i] = h1[i]; }
+                continue;
+            }
+#endif
             const f32x4 v0 = ld4_nt(p), v1 = ld4_nt(p + 256), v2 = ld4_nt(p + 512), v3 = ld4_nt(p + 768);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc[nt][i] = v0[i]; acc[nt][4 + i] = v1[i]; acc[nt][8 + i] = v2[i]; acc[nt][12 + i] = v3[i]; }

@@ -54,6 +54,11 @@ struct TLayerArgs {
     int sc6b;
 #ifdef DSVC_PROFILING
     unsigned long long* stamps; // profiling build: 16 s_memrealtime stamps per wave of the LAST launch (tools/gpu_layer_stamps.py)
+    int abl;                    // round-6 ablations (env DSVC_TL_ABL, tools/gpu_r6_ablate.py): 1 = half of cproj's bytes (WRONG results; TEpiGate::Args::abl);
+                                // 2 = the neighbour hand-off protocol a persistent per-evaluation launch would need, as PURE OVERHEAD inside the real
+                                // kernel (results unchanged): before its tile DMA a workgroup polls the flags of tiles i-1 / i+1 (set by the previous
+                                // launch) and takes one agent-scope acquire; after its last store it drains, releases at agent scope and sets its flag
+    unsigned* flags;            // abl & 2: one word per frame tile
 #endif
 };
 
@@ -242,6 +247,17 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     TL_STAMP(0);
     const int row0 = blockIdx.x * TN;
+#ifdef DSVC_PROFILING
+    if (ga.abl & 2) {                                     // consumer side of the hand-off (MI355X_MICROARCH.md: ONE relaxed poll -> ONE agent acquire -> barrier -> plain loads)
+        if (tid == 0) {
+            const unsigned lo = blockIdx.x > 0 ? blockIdx.x - 1 : 0, hi = blockIdx.x + 1 < gridDim.x ? blockIdx.x + 1 : blockIdx.x;
+            while (__hip_atomic_load(ga.flags + lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+            while (__hip_atomic_load(ga.flags + hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+#endif
     const int halo = ga.dil;                              // taps == 3
     const int rows_lds = TN + 2 * halo;
     const int chunks = ga.cin >> 3;
@@ -304,7 +320,11 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
 
     TEpiGate gepi;
     TEpiResSkip oepi;
+#ifdef DSVC_PROFILING
+    const TEpiGate::Args ge{cproj, nullptr, ga.cin, ga.cin, 0, ga.abl & 1};
+#else
     const TEpiGate::Args ge{cproj, nullptr, ga.cin, ga.cin};
+#endif
     f32x16 acc[NT], nxt[NT];
     half8 ringA[KG * NW], ringB[KG * NW];
     v6i_t gmid6 = {};                                     // G6: the middle pass's g_lo codes
@@ -597,6 +617,15 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
     }
 #ifdef DSVC_PROFILING
     if (ga.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TL_STAMP(14); }      // every store acknowledged
+    if (ga.abl & 2) {                                     // producer side: plain stores -> drain -> barrier -> lane-0 agent release -> drain -> relaxed agent flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(ga.flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #endif
 }
 
@@ -659,6 +688,13 @@ inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs
     a.gvar = g.variant_halfs; a.ovar = o.n_variants == g.n_variants ? o.variant_halfs : 0; a.n_variants = g.n_variants;
     a.step_ptr = g.step_ptr; a.step_off = g.step_off;
 #ifdef DSVC_PROFILING
+    a.abl = getenv("DSVC_TL_ABL") ? atoi(getenv("DSVC_TL_ABL")) : 0;
+    if (a.abl & 2) {
+        static unsigned* flags = nullptr;
+        if (!flags) { DSVC_HIP(hipMalloc(&flags, 4096 * 4)); DSVC_HIP(hipMemset(flags, 0xff, 4096 * 4)); }       // "every neighbour has arrived": the poll never waits
+        if (n_rows / (32 * nt) > 4096) return fail(DSVC_EINVAL, "tlayer: DSVC_TL_ABL=2 covers 4096 tiles");
+        a.flags = flags;
+    }
     if (getenv("DSVC_TL_STAMPS")) {
         if (!tl_stamp_buffer()) { DSVC_HIP(hipMalloc(&tl_stamp_buffer(), (size_t)4096 * 8 * 16 * 8)); }
         if (nt == 4 && n_rows / TL_TN <= 4096) { a.stamps = tl_stamp_buffer(); tl_stamp_groups() = n_rows / TL_TN; }

@@ -94,7 +94,7 @@ def golden_diffnet(name, hp, wseed, B, T):
     print(name, "out std %.3f" % out.std().item())
 
 
-def golden_sampler(name, hp, wseed, clips, T, n_units, speedup, seed, conditioned=None, store_cond=True):
+def golden_sampler(name, hp, wseed, clips, T, n_units, speedup, seed, conditioned=None, store_cond=True, slack=0.0):
     """conditioned = (lam, rho): synth.acoustic_state_conditioned -- a checkpoint whose noise prediction tracks its input like a
     trained model's, so that the unclamped PNDM chain contracts; the reference's own mel must then stay inside
     [spec_min, spec_max] (asserted here: a golden outside the data range is an ill-conditioned parity probe)."""
@@ -103,8 +103,9 @@ def golden_sampler(name, hp, wseed, clips, T, n_units, speedup, seed, conditione
     hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
     ret = run_reference_sampler(model, hp, hub, m2p, f0, clips, speedup, seed)
     lo, hi = ret["mel_out"].min().item(), ret["mel_out"].max().item()
-    if conditioned:
-        assert min(hp["spec_min"]) <= lo and hi <= max(hp["spec_max"]), (name, lo, hi)
+    if conditioned:     # (slack: a clip of thousands of frames reaches further into the tail of its own distribution -- T = 7000 leaves [-5, 0] by half a unit
+        #  on a handful of frames in the reference itself; still a contracting chain)
+        assert min(hp["spec_min"]) - slack <= lo and hi <= max(hp["spec_max"]) + slack, (name, lo, hi)
     extra = dict(decoder_inp=ret["decoder_inp"].numpy()) if store_cond else {}
     np.savez_compressed(os.path.join(OUT, name + ".npz"), mel_out=ret["mel_out"].numpy(),
                         f0_denorm=ret["f0_denorm"].numpy(),
@@ -212,7 +213,7 @@ def golden_vocoder_rb2():
 
 
 def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500, seed=2026, wseed=0, vseed=1, K=1000, speedup=1, with_wav=True,
-                    conditioned=None):
+                    conditioned=None, assert_clamp=True):
     """The BENCHMARKED configuration (BASELINE configs[1]: 10 s clip, T=861, 44.1 kHz architecture, full 1000-step DDPM) through
     the REAL reference end to end: GaussianDiffusion.forward(infer=True) (diffusion.py:227-284) -> the host glue of
     Svc.after_infer (clip to [mel_vmin, mel_vmax], infer_tool.py:177-183) -> Generator.forward (models.py:361-387) for the first
@@ -233,7 +234,7 @@ def golden_headline(name="e2e_44k_T861_k1000", clips=(0, 1), T=861, n_units=500,
     mel = ret["mel_out"].numpy()
     on_clamp = float(((mel <= min(hp["spec_min"])) | (mel >= max(hp["spec_max"]))).mean())
     print(name, "sampler %.0f s, mel range %.3f..%.3f, %.2f %% of the mel on spec_min/spec_max" % (time.time() - t0, mel.min(), mel.max(), 100 * on_clamp))
-    if conditioned:
+    if conditioned and assert_clamp:
         assert on_clamp < 0.01, (name, on_clamp)
     extra = {}
     if with_wav:
@@ -290,6 +291,24 @@ def golden_headline_spread(only=None):
             print(name, "exists")
             continue
         golden_headline(name=name, clips=(clip,), seed=seed, with_wav=False, conditioned=cond)
+
+
+# Round 6: the shipped batched precision f16_w6 measures 4.0e-4 ... 6.1e-4 on the random-init checkpoint and 1.3e-4 ... 1.6e-4
+# on the two conditioned ones -- how does its 1000-step error move BETWEEN them?  Three more checkpoints on the line from `ca` (eps tracks x,
+# like a trained model: lam 1.5, rho 0.07) to random-init (lam 0, rho 1), eight clips each (clips 0..7, seed 2026: one batch of 8 on the GPU).
+# The fraction of the reference's own mel that sits on p_sample's clamp is stored with every golden (`on_clamp`), not asserted.
+WSTAT_CKPTS = (("w1", (1.0, 0.3)), ("w2", (0.6, 0.55)), ("w3", (0.25, 0.8)))
+WSTAT_CLIPS = tuple(range(8))
+
+
+def golden_weight_statistics():
+    for tag, par in WSTAT_CKPTS:
+        for c in WSTAT_CLIPS:
+            name = "e2e_44k_T861_k1000_%s_c%d" % (tag, c)
+            if os.path.exists(os.path.join(OUT, name + ".npz")) and "--force" not in sys.argv:
+                print(name, "exists")
+                continue
+            golden_headline(name=name, clips=(c,), seed=SPREAD_SEED, with_wav=False, conditioned=par, assert_clamp=False)
 
 
 def golden_headline_extra():
@@ -509,6 +528,8 @@ def main():
         return golden_long()
     if "--long-1000" in sys.argv:
         return golden_long_1000()
+    if "--weight-statistics" in sys.argv:
+        return golden_weight_statistics()
     if "--hifigan-only" in sys.argv:
         return golden_hifigan_24k()
     if "--hubert-only" in sys.argv:
@@ -547,6 +568,7 @@ def main():
     golden_plms_t861_more()
     golden_long()
     golden_long_1000()
+    golden_weight_statistics()
 
 
 # Round 6: BASELINE configs[2] at the benchmarked size rested on ONE (clip, noise) pair.  Five more, same conditioned
@@ -580,7 +602,7 @@ def golden_long():
 
     for T, nu in ((2600, 1510), (7000, 4065)):
         once("ddpm_44k_k20_T%d" % T, dict(full, K_step=20), 0, clips=[0], T=T, n_units=nu, speedup=1, seed=101, store_cond=False)
-        once("plmsc_44k_s20_T%d" % T, full, 0, clips=[1], T=T, n_units=nu, speedup=20, seed=102, conditioned=(1.5, 0.07), store_cond=False)
+        once("plmsc_44k_s20_T%d" % T, full, 0, clips=[1], T=T, n_units=nu, speedup=20, seed=102, conditioned=(1.5, 0.07), store_cond=False, slack=0.75)
         once("ddpm_24k_k20_T%d" % T, dict(k24, K_step=20), 2, clips=[2], T=T, n_units=nu, speedup=1, seed=103, store_cond=False)
     once("plmsc_24k_s20_T2600", k24, 2, clips=[3], T=2600, n_units=1510, speedup=20, seed=104, conditioned=(1.35, 0.05), store_cond=False)
     if os.path.exists(os.path.join(OUT, "ddpm_44k_k20_ragged3.npz")) and "--force" not in sys.argv:
