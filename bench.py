@@ -223,6 +223,23 @@ def load_train_traffic():
     return tj.get("bytes_per_step"), tj.get("source")
 
 
+def load_train_kernels():
+    """The per-kernel roofline of the training step and the step's algorithmic bytes (profiles/train_kernels.json: tools/train_roofline.py over
+    the rocprofv3 kernel stats of `bench.py --train` and the PMC pass), or {'missing': why} when absent or measured on other trainer sources."""
+    path = os.path.join(ROOT, "profiles", "train_kernels.json")
+    if not os.path.exists(path):
+        return {"missing": "no profiles/train_kernels.json (tools/train_roofline.py)"}
+    with open(path) as f:
+        tk = json.load(f)
+    if tk.get("csrc_sha16") != kernel_sources_sha(TRAIN_SOURCES):
+        return {"missing": "stale: train_kernels.json was derived on trainer sources %s, this tree is %s" % (tk.get("csrc_sha16"), kernel_sources_sha(TRAIN_SOURCES))}
+    keep = ("kernel", "launches_per_step", "avg_us", "algorithmic_bytes_per_launch", "pmc_bytes_per_launch", "pmc_over_algorithmic", "achieved_tflops", "mfma_frac",
+            "pipe_frac", "hbm_frac", "bound")
+    return {"algorithmic_bytes": tk["algorithmic_bytes_per_step"], "algorithmic_bytes_note": tk["algorithmic_bytes_note"],
+            "traffic_over_algorithmic": tk.get("pmc_over_algorithmic"), "per_kernel_source": "profiles/train_kernels.json <- profiles/" + tk["source"],
+            "per_kernel": [{k: e[k] for k in keep if k in e} for e in tk["kernels"][:6]]}
+
+
 def load_traffic(name, precision):
     """(bytes_per_launch, source) of a committed PMC measurement, or (None, why) when it is missing, was taken on other kernel
     sources (tools/rocprof_traffic.py stamps the file with kernel_sources_sha()) or at another operand precision."""
@@ -620,7 +637,7 @@ def main():
                                            "algorithmic_tflop_per_step": train_step_flops(hp, Bt * Tt) / 1e12,
                                            "achieved": train_step_flops(hp, Bt * Tt) / (ms * 1e-3) / 1e12, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                                            "frac": train_step_flops(hp, Bt * Tt) / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_F16, "mfma_per_product": 3, "traffic": load_train_traffic()[0], "traffic_source": load_train_traffic()[1],
-                                           "traffic_unit": "HBM bytes per step (PMC)"},
+                                           "traffic_unit": "HBM bytes per step (PMC)", **load_train_kernels()},
                               "cpu_baseline": None}))
         if world > 1:
             dist.barrier()
@@ -932,7 +949,7 @@ def main():
                                                      "algorithmic_tflop_per_step": train_step_flops(hp, 64 * 128) / 1e12, "achieved": tfl,
                                                      "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": tfl / PEAK_TFLOPS_F16, "mfma_per_product": 3,
                                                      "pipe_frac": 3 * tfl / PEAK_TFLOPS_F16, "traffic": load_train_traffic()[0],
-                                                     "traffic_source": load_train_traffic()[1], "traffic_unit": "HBM bytes per step (PMC)"}}
+                                                     "traffic_source": load_train_traffic()[1], "traffic_unit": "HBM bytes per step (PMC)", **load_train_kernels()}}
                 # the reference's max_tokens loader changes (B, T) every step (training/task/tts.py:60-88): ONE trainer alternating through five
                 # batch shapes of about the benchmarked size (8 192 frames each; only the gap rows are cleared on a shape change, design/training.md)
                 try:

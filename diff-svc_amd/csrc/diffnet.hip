@@ -1080,6 +1080,7 @@ int dsvc_sampler::finalize() {
         return fail(DSVC_EINVAL, "sampler: spec_min/spec_max must have 1 or mel_bins entries");
     DSVC_TRY(upload(spec_min, smin->data(), n_spec * 4)); DSVC_TRY(upload(spec_max, smax->data(), n_spec * 4));
     DSVC_TRY(step_dev.alloc(64));
+    DSVC_HIP(hipMemset(step_dev.p, 0, 64));              // word 4 stays 0: the PLMS chain's by-value steps (run_plms)
     host.clear();
     finalized = true;
     return DSVC_OK;
@@ -1235,39 +1236,39 @@ int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
     const int interval = a->speedup;
     const size_t n = (size_t)den->rows * den->cfg.mel_bins;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    int* sdev = step_dev.as<int>();                      // sdev[0] = t, sdev[1] = predictions stored so far
+    const int* zero = step_dev.as<int>() + 4;            // a constant 0 on the device: StepRef{zero, -t, 0}.get() == t -- the step BY VALUE.
+    // Round 6: every launch of the chain knows its diffusion step on the host (the schedule is fixed by t_start / interval), so the device-side
+    // step counter and history count of round 2 (k_set_int / two k_add_int launches per iteration) are gone, and k_plms leaves the fp16 planes the
+    // next input projection reads (no k_rows_to_half in front of every evaluation): 44 instead of 47 launches per evaluation.  Same arithmetic.
     PlmsArgs p0{};
     p0.x = xstate.as<float>(); p0.eps = den->eps.as<float>(); p0.hist = hist.as<float>(); p0.x_pred = xpred.as<float>();
-    p0.alphas_cumprod = alphas_cumprod.as<float>(); p0.n = n; p0.interval = interval;
+    p0.alphas_cumprod = alphas_cumprod.as<float>(); p0.n = n; p0.interval = interval; p0.state_dev = nullptr;
+    const bool planes = den->tpath;                      // (dsvc_sample has converted the initial state already)
+    if (planes) { p0.xsh = den->xsh.as<_Float16>(); p0.rowclip = den->rowclip.as<int>(); p0.M = den->cfg.mel_bins; p0.ldh = den->Mp; }
     const int i_first = ((a->t_start - 1) / interval) * interval;
     if (i_first < a->t_stop) return DSVC_OK;
     const int i_body = i_first - interval;               // first iteration of the Adams-Bashforth body
     const int iters = i_body >= a->t_stop ? (i_body - a->t_stop) / interval + 1 : 0;
-    // the whole chain as a sequence of launches on one stream.  t of every evaluation is known on the host, so each one gets its weight variant
-    // by value (see run_ddpm); the Adams-Bashforth kernel reads t / the history count from the device, which lets one body serve all iterations
+    auto at = [&](int t) { return StepRef{zero, -t, 0}; };
+    // the whole chain as a sequence of launches on one stream; each evaluation also gets its weight variant by value (see run_ddpm)
     auto chain = [&](hipStream_t s2) -> int {
         PlmsArgs p = p0;
         {   // first iteration: no history yet -> improved Euler with a second evaluation at t_prev (diffusion.py:184-187)
             const int t_prev = i_first - interval > 0 ? i_first - interval : 0;
-            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s2, sdev, i_first);
-            DSVC_TRY(den->eval(xstate.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, s2, i_first));
+            DSVC_TRY(den->eval(xstate.as<float>(), at(i_first), dsvc_denoiser::TAIL_EPS, nullptr, planes, s2, i_first));
             p.t = i_first; p.t_prev = t_prev; p.n_hist = 0; p.phase = 0;
             hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, s2, p);
-            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s2, sdev, t_prev);
-            DSVC_TRY(den->eval(xpred.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, s2, t_prev));
+            DSVC_TRY(den->eval(xpred.as<float>(), at(t_prev), dsvc_denoiser::TAIL_EPS, nullptr, planes, s2, t_prev));
             p.phase = 1;
             hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, s2, p);
         }
-        if (iters < 1) return DSVC_OK;
-        // remaining iterations: eps = denoiser(x, t); x = x_pred(x, AB(eps, history), t); state on the device
-        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s2, sdev, i_body);
-        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s2, sdev + 1, 1);
-        p.phase = 2; p.state_dev = sdev;
+        // remaining iterations: eps = denoiser(x, t); x = x_pred(x, AB(eps, history), t)
+        p.phase = 2;
         for (int k = 0; k < iters; ++k) {
-            DSVC_TRY(den->eval(xstate.as<float>(), StepRef{sdev, 0, 0}, dsvc_denoiser::TAIL_EPS, nullptr, false, s2, i_body - k * interval));
+            const int t = i_body - k * interval;
+            DSVC_TRY(den->eval(xstate.as<float>(), at(t), dsvc_denoiser::TAIL_EPS, nullptr, planes, s2, t));
+            p.t = t; p.t_prev = t - interval > 0 ? t - interval : 0; p.n_hist = 1 + k;
             hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, s2, p);
-            hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s2, sdev, -interval);
-            hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s2, sdev + 1, 1);
         }
         return DSVC_OK;
     };

@@ -271,6 +271,11 @@ struct PlmsArgs {
     int phase;               // 0: x_pred = xpred(x, eps, t)                 (first iteration, before the 2nd eval)
                              // 1: eps' = (hist[0] + eps)/2 ; x = xpred(x, eps', t)   (first iteration, after the 2nd eval; hist[0] holds eps_0)
                              // 2: eps' = AB(eps, hist); x = xpred(x, eps', t); push eps
+    // round 6: the fp16 [hi | lo] planes of the value the NEXT evaluation's input projection reads (x_pred in phase 0, the new x otherwise), written
+    // here instead of by a k_rows_to_half launch in front of every evaluation; null on the conv_gemm engine
+    _Float16* xsh;           // [rows][2 * ldh]
+    const int* rowclip;      // [rows]: < 0 on gap / padded rows (left alone, as k_rows_to_half leaves them)
+    int M, ldh;
 };
 
 __device__ __forceinline__ float plms_xpred(float x, float e, float a_t, float a_p) {
@@ -288,12 +293,15 @@ __global__ void k_plms(const PlmsArgs a) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
         const float e = a.eps[i];
         const float x = a.x[i];
+        float xn;                                            // what the next evaluation reads
         if (a.phase == 0) {
-            a.x_pred[i] = plms_xpred(x, e, a_t, a_p);
+            xn = plms_xpred(x, e, a_t, a_p);
+            a.x_pred[i] = xn;
             a.hist[i] = e;                                   // slot 0 <- eps_0
         } else if (a.phase == 1) {
             const float ep = (a.hist[i] + e) / 2.0f;
-            a.x[i] = plms_xpred(x, ep, a_t, a_p);
+            xn = plms_xpred(x, ep, a_t, a_p);
+            a.x[i] = xn;
         } else {
             const int nh = n_hist;
             const float h1 = a.hist[(size_t)((nh - 1) & 3) * a.n + i];
@@ -308,8 +316,19 @@ __global__ void k_plms(const PlmsArgs a) {
                 const float h3 = a.hist[(size_t)((nh - 3) & 3) * a.n + i];
                 ep = (55.0f * e - 59.0f * h1 + 37.0f * h2 - 9.0f * h3) / 24.0f;
             }
-            a.x[i] = plms_xpred(x, ep, a_t, a_p);
+            xn = plms_xpred(x, ep, a_t, a_p);
+            a.x[i] = xn;
             a.hist[(size_t)(nh & 3) * a.n + i] = e;
+        }
+        if (a.xsh) {
+            const size_t row = i / (size_t)a.M;
+            if (a.rowclip[row] >= 0) {
+                const int c = (int)(i - row * (size_t)a.M);
+                const _Float16 h = (_Float16)xn;
+                _Float16* q = a.xsh + row * (size_t)(2 * a.ldh) + c;
+                q[0] = h;
+                q[a.ldh] = (_Float16)(xn - (float)h);
+            }
         }
     }
 }
