@@ -27,7 +27,8 @@ using namespace dsvc;
 namespace {
 
 constexpr int HB_C0 = 512, HB_D = 768, HB_FF = 3072, HB_HEADS = 12, HB_HD = 64, HB_LAYERS = 12, HB_OUT = 256, HB_GROUPS = 16, HB_PK = 128;
-constexpr size_t HB_SCORE_BYTES = (size_t)4 << 30;      // budget of the heads' score matrices [heads in a launch][T][T] fp32 (12 heads fit up to T = 9 400 frames = 3 min)
+constexpr size_t HB_SCORE_BYTES = (size_t)1 << 30;      // budget of the heads' score matrices [heads in a launch][T][T] fp32: 12 heads fit up to T = 4 700 frames (94 s);
+                                                        // longer utterances run the heads in groups (head_batch).  (4 GB held next to the denoiser / vocoder workspaces, grow-only)
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
