@@ -240,6 +240,23 @@ def load_train_kernels():
             "per_kernel": [{k: e[k] for k in keep if k in e} for e in tk["kernels"][:6]]}
 
 
+def load_voc_kernels():
+    """Per-kernel roofline entries of the generator (profiles/voc_kernels.json: tools/voc_roofline.py over the rocprofv3 stats of tools/prof_vocoder.py)."""
+    path = os.path.join(ROOT, "profiles", "voc_kernels.json")
+    if not os.path.exists(path):
+        return {"per_kernel_missing": "no profiles/voc_kernels.json (tools/voc_roofline.py)"}
+    with open(path) as f:
+        vk = json.load(f)
+    h = hashlib.sha256()
+    for name in ("common.h", "common.hip", "tgemm.h", "conv_gemm.h", "cg_util.h", "vocoder.hip"):
+        with open(os.path.join(ROOT, "diff-svc_amd", "csrc", name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    if vk.get("csrc_sha16") != h.hexdigest()[:16]:
+        return {"per_kernel_missing": "stale: voc_kernels.json was derived on other vocoder sources"}
+    keep = ("kernel", "launches_per_clip", "avg_us", "achieved_tflops", "mfma_frac", "pipe_frac", "hbm_frac", "bound")
+    return {"per_kernel_source": "profiles/voc_kernels.json <- profiles/" + vk["source"], "per_kernel": [{k: e[k] for k in keep} for e in vk["kernels"]]}
+
+
 def load_traffic(name, precision):
     """(bytes_per_launch, source) of a committed PMC measurement, or (None, why) when it is missing, was taken on other kernel
     sources (tools/rocprof_traffic.py stamps the file with kernel_sources_sha()) or at another operand precision."""
@@ -891,7 +908,7 @@ def main():
                 stages["vocoder_roofline"] = {"bound": "mfma", "algorithmic_gflop_per_clip": VOCODER_FLOP_PER_FRAME * T_FRAMES / 1e9, "achieved": vtf,
                                               "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": vtf / PEAK_TFLOPS_F16, "mfma_per_product": 3,
                                               "pipe_frac": 3 * vtf / PEAK_TFLOPS_F16,
-                                              "scope": "the whole generator for one 10 s clip (29 launches), split fp16 operands (f16_x3)"}
+                                              "scope": "the whole generator for one 10 s clip (29 launches), split fp16 operands (f16_x3)", **load_voc_kernels()}
                 # what the reference's host glue adds around the device path (infer_tool.py:174,200: mel / f0 to numpy, PCM to numpy)
                 stages["host_round_trip_ms"] = timed(lambda: (mel1.cpu().numpy(), f01.cpu().numpy(), wav[:1].cpu().numpy()))
                 from diffsvc_amd.hubert import HubertSoftHip
