@@ -274,10 +274,16 @@ struct DenWs {
         for (DevBuf* b : {&xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps, &lens, &clipid, &rowclip, &xh, &xh2, &gh, &skiph, &s2h, &xsh, &gall}) b->release();
         wsB = wsT = Tp = rows = rows_alloc = 0; cond_ready = false; ws_id = 0;
     }
+    size_t bytes() const {
+        size_t n = 0;
+        for (const DevBuf* b : {&xin, &xres, &g, &skip, &s2, &eps, &condT, &cproj, &tsteps, &lens, &clipid, &rowclip, &xh, &xh2, &gh, &skiph, &s2h, &xsh, &gall}) n += b->bytes;
+        return n;
+    }
 };
 
 struct dsvc_denoiser : DenWs {
-    static constexpr int WS_CACHE = 8;          // buckets kept alive beside the active one (B = 1, T = 2600: 0.23 GB each at the 44.1 kHz architecture)
+    static constexpr int WS_CACHE = 8;          // buckets kept alive beside the active one (B = 1, T = 2600: 0.23 GB each at the 44.1 kHz architecture) ...
+    static constexpr size_t WS_CACHE_BYTES = (size_t)32 << 30;      // ... as long as the parked ones hold no more than this (a 32-clip batch of 10 s clips is 2.5 GB)
     std::vector<DenWs> ws_cache;                // inactive buckets (their buffers are owned here until evicted)
     unsigned ws_next_id = 1;
     unsigned long long ws_clock = 0;
@@ -672,7 +678,9 @@ int dsvc_denoiser::ensure_ws(int B, int T, hipStream_t st) {
             return DSVC_OK;
         }
     }
-    while ((int)ws_cache.size() >= WS_CACHE) {              // evict the least recently used bucket (its graphs die with their ws_id: dsvc_sampler prunes them)
+    auto parked_bytes = [&]() { size_t n = 0; for (const DenWs& w : ws_cache) n += w.bytes(); return n; };
+    while (!ws_cache.empty() && ((int)ws_cache.size() >= WS_CACHE || parked_bytes() > WS_CACHE_BYTES)) {
+        // evict the least recently used bucket (its graphs die with their ws_id: dsvc_sampler prunes them)
         size_t lru = 0;
         for (size_t i = 1; i < ws_cache.size(); ++i) if (ws_cache[i].last_use < ws_cache[lru].last_use) lru = i;
         DSVC_HIP(hipStreamSynchronize(st));                 // (work that still reads it was enqueued on the caller's stream)

@@ -1068,6 +1068,13 @@ int dsvc_trainer::ensure_ws(int B, int T, hipStream_t st) {
     // (round 5) fm: the residual layers' weight gradients are contracted from the layers' fp16 operand planes (wgrad.h: wgrad_fm_kernel) -- then
     // g and dy are never stored as fp32 rows and their buffers (0.3 GB at the 64 x 128 batch) are not allocated
     fm = !fm_off && C % 128 == 0 && (2 * C) % 256 == 0 && H % 128 == 0 && max_dil <= TGUARD;
+    if (fm) {   //  the per-layer operand planes fm keeps for the backward pass (L x rows x 2 Cp halfs, x and g: 2 x 270 MB at 64 x 128 frames,
+        // growing with the frames per step) must fit beside everything else: if the device cannot hold them, take the k_split_t path instead of failing
+        const size_t cp = (size_t)round_up(C, 128), want = (size_t)L * ((r + 2 * TGUARD) + r) * 2 * cp * 2;
+        const size_t have_planes = xhP.bytes + ghP.bytes;
+        size_t free_b = 0, total_b = 0;
+        if (want > have_planes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < (want - have_planes) + ((size_t)2 << 30)) fm = false;
+    }
     DSVC_TRY(z(xt, r * M * 4)); DSVC_TRY(zg(xs, C, L + 1)); DSVC_TRY(zg(sig, C, L)); DSVC_TRY(zg(tau, C, L));
     if (!fm) DSVC_TRY(zg(g, C, L));
     DSVC_TRY(z(skip, r * C * 4)); DSVC_TRY(zg(ypre, round_up(2 * C, 128), L)); DSVC_TRY(z(s2pre, r * C * 4));
@@ -1409,7 +1416,7 @@ int dsvc_trainer::run(int phases, int l_hi, int l_lo, const dsvc_train_args* ta_
     // dO as the operand planes of the top layer's dg = W_o^T dO (the layers' epilogues refresh the residual half; the skip half is the same for all)
         hipLaunchKernelGGL(k_rows_to_planes, dim3(2048), dim3(256), 0, st, dO.as<float>(), 2 * C, 2 * C, (const float*)nullptr, 0, dOh.as<_Float16>(), C2p, ri, rows);
     // cond^T planes once (weight gradients of every conditioner projection): the last segment of the layers' k axis, which nothing else writes
-    DSVC_TRY(split_t(false, 3 * cp128, condT.as<float>(), H, H, nullptr, 0, 0, st));
+    if (!fm) DSVC_TRY(split_t(false, 3 * cp128, condT.as<float>(), H, H, nullptr, 0, 0, st));      // (fm reads the frame-major planes of cond the forward pass left)
     if (ta->pitch) {   // frames by pitch bin, once per step (the pitch-embedding gradient: k_bin_sums per layer, one product at the end)
         const int V = cfg.pitch_vocab, n = B * T;
         DSVC_HIP(hipMemsetAsync(bin_count.p, 0, (size_t)V * 4, st));

@@ -450,3 +450,21 @@ def test_resblock_geometry_follows_the_reference_constructors():
         VocoderHandle({}, h2)
     sd = synth.vocoder_state(dict(synth.tiny_vocoder(rds=((1, 3, 5), (2, 4, 7))), resblock="2"), 7)
     assert not any(".convs.2." in k for k in sd) and any(".convs.1." in k for k in sd)
+
+
+def test_auto_precision_follows_the_workspace_buckets():
+    """`DiffNetHip.precision_for` mirrors the C library's layout rule (csrc/diffnet.hip: bucket_rows -- a clip occupies round_up(T + largest
+    dilation, 128) rows since round 6) and its 48-tile threshold for the fused layer kernel: what `auto` picks for a call is what the handle
+    will really run (f16_w6 only where the fused kernel takes the call).  Host logic only."""
+    hp = dict(synth.HPARAMS_44K)
+    net = DiffNetHip(128, hparams=hp)
+    assert net.workspace_tiles(1, 861) == 7 and net.workspace_tiles(32, 861) == 224 and net.workspace_tiles(36, 861) == 252
+    assert net.workspace_tiles(1, 888) == 7 and net.workspace_tiles(1, 889) == 8              # 888 + 8 = 896: the bucket's last frame
+    assert net.precision_for("ddpm", 1, frames=861, clips=1) == "f16_x3t"
+    assert net.precision_for("ddpm", 1, frames=6 * 861, clips=6) == "f16_x3t" and net.precision_for("ddpm", 1, frames=7 * 861, clips=7) == "f16_w6"
+    assert net.precision_for("ddpm", 1, frames=2600, clips=1) == "f16_x3t"                    # 21 tiles
+    assert net.precision_for("ddpm", 1, frames=6000, clips=1) == "f16_x3t" and net.precision_for("ddpm", 1, frames=6100, clips=1) == "f16_w6"   # 47 / 48 tiles
+    assert net.precision_for("ddpm", 1, frames=3 * 2000, clips=3) == "f16_w6"                 # 3 x 16 tiles
+    assert net.precision_for("plms", 20, frames=7000, clips=1) == "f16_x3t" and net.precision_for("forward") == "f16_x3t"
+    tiny = DiffNetHip(16, hparams=synth.tiny_hparams())
+    assert tiny.precision_for("ddpm", 1, frames=100000, clips=100) == "f16_x3t"               # 64 channels: no fused layer kernel for this architecture
