@@ -758,7 +758,7 @@ def main():
                        "floors for two rounds (r4: 10.3 / 7.7 us, r5: 10.3 / 7.7 us, r6: unchanged) with everything in design/tgemm.md tried (XCD-major placement "
                        "-12 %, split-K variants, 6-bit lo plane +7.5 %); one frame tile's eight slices already share two XCDs, so the all-to-all hand-off of a "
                        "persistent layer costs 26-28 us (tools/micro/handoff.hip) against 18 us for the two launches",
-                "what_serves_the_target_instead": "batching: 32 clips per GPU run at 122x RT per GPU (`batched`), 36 at 127x (`job_256.chip_filling_batches`)"}
+                "what_serves_the_target_instead": "batching: 32 clips per GPU run at 123-125x RT per GPU (`batched`), 36 at 129-131x (`job_256.chip_filling_batches`)"}
             try:        # the single clip's second layer kernel (39 % of its GPU time), priced the same way
                 result["roofline_res_skip"] = res_skip_roofline(pipe.model._handle("ddpm", 1, frames=B * T_FRAMES, clips=B), prec)
             except Exception as ex:
@@ -826,8 +826,8 @@ def main():
                     "persistent_launch_neighbour_flags": "the hand-off protocol (poll i-1 / i+1 + agent acquire; drain + agent release + flag) as pure overhead "
                                                          "inside the real kernel: +3.1 % per step (+4 us per layer); it could hide at most the 1.75 us boundary "
                                                          "and the neighbour-independent part of the 9 us prologue: net < 1 %: not built",
-                    "chip_filling_batch": "36 clips per batch (252 of 256 CUs hold a tile): +4.3 % per clip (`job_256.chip_filling_batches`)",
-                    "vocoder_under_next_batch": "second stream: +0.1 % (`job_256` vs `job_256.no_overlap`): the layer kernels leave no CU a co-resident workgroup fits on"},
+                    "chip_filling_batch": "36 clips per batch (252 of 256 CUs hold a tile): +4 ... 5 % per clip (`job_256.chip_filling_batches` on this line)",
+                    "vocoder_under_next_batch": "second stream: +-0.1 % (`job_256` vs `job_256.no_overlap` on this line): the layer kernels leave no CU a co-resident workgroup fits on"},
                 "source": "profiles/r6c_layer_ablations.txt, profiles/r6b_bench.json (same-box A/B, profiling build for the ablations)"}
             fit, why = load_error_fit(precb)
             if fit:
