@@ -1274,6 +1274,10 @@ int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
         p.phase = 2;
         for (int k = 0; k < iters; ++k) {
             const int t = i_body - k * interval;
+            // the iteration at t = 0 is dead work in the reference itself: t_prev = max(t - interval, 0) = t, so alphas_cumprod[t_prev] == alphas_cumprod[t]
+            // and get_x_pred returns x + 0 * (...) = x (diffusion.py:171-179,186; SURVEY 8(a): "the last denoiser eval is computed then multiplied by
+            // 0") -- the state is final after the iteration before it.  Skipping it is bit-identical and saves one of the 51 evaluations.
+            if (t == 0) break;
             DSVC_TRY(den->eval(xstate.as<float>(), at(t), dsvc_denoiser::TAIL_EPS, nullptr, planes, s2, t));
             p.t = t; p.t_prev = t - interval > 0 ? t - interval : 0; p.n_hist = 1 + k;
             hipLaunchKernelGGL(k_plms, dim3(blocks), dim3(256), 0, s2, p);

@@ -56,6 +56,21 @@ def test_the_libraries_export_the_c_abi_and_nothing_else():
     assert b"profile_kernel\0" in blob           # the one measurement key the product library keeps (which kernel the bench's timer times)
 
 
+def test_hooks_build_is_a_second_library_bound_per_handle():
+    """`_lib.hooks_build()` binds to libdsvc_hip_hooks.so for its duration and restores the product library afterwards; both carry the whole ABI
+    (same version, every symbol); the product library's debug_set refuses a hook key with the message that says where it lives, the hooks
+    library gets past the key check (it then fails on the null handle -- no device call is made here)."""
+    from diffsvc_amd import build
+    build.build(verbose=False)
+    prod = _lib.lib()
+    with _lib.hooks_build() as hooks:
+        assert hooks is not prod and _lib.lib() is hooks and hooks.dsvc_abi_version() == prod.dsvc_abi_version() == _lib.ABI_VERSION
+        for name, _, _ in _lib.SYMBOLS:
+            assert hasattr(hooks, name), name
+    assert _lib.lib() is prod
+    assert prod.dsvc_denoiser_debug_set(None, b"two_launch_layer", 1) != 0 and b"null" in prod.dsvc_last_error()
+
+
 def test_error_convention_without_gpu():
     import ctypes
     lib = _lib.lib()
