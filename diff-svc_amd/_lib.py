@@ -123,6 +123,7 @@ SYMBOLS = [
     ("dsvc_melspec_destroy", None, [_VP]),
     ("dsvc_melspec_frames", ctypes.c_int, [_VP, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]),
     ("dsvc_melspec_run", ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int32, ctypes.c_int64, _VP]),
+    ("dsvc_melspec_run_linear", ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_float, ctypes.c_int32, ctypes.c_int64, _VP]),
     ("dsvc_pitch_coarse", ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int64, _VP, _VP, _VP]),
     ("dsvc_cond_build", ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, ctypes.c_int32, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_int32, _VP, _VP, _VP, _VP, _VP]),

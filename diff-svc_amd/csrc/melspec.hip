@@ -24,9 +24,12 @@ struct dsvc_melspec {
 
 namespace {
 
+// linear (may be null): the normalised linear spectrogram process_utterance(return_linear=True) returns beside the mel
+// (preprocessing/data_gen_utils.py:144-149: audio.normalize(audio.amp_to_db(|X|)) = (20 log10(max(1e-5, |X|)) - min_level_db) / -min_level_db,
+// utils/audio.py:51-56), [B][n_frames][n_fft / 2 + 1]
 __global__ void k_melspec(const float* __restrict__ wav, float* __restrict__ mel, const float* __restrict__ basis,
                           const int* __restrict__ range, int n_samples, int n_frames, int n_fft, int log2n, int win,
-                          int hop, int n_mels, float clip_val, int mode) {
+                          int hop, int n_mels, float clip_val, int mode, float* __restrict__ linear, float min_level_db) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* buf = reinterpret_cast<float2*>(smem);                 // [n_fft] complex
     float2* tw = buf + n_fft;                                      // [n_fft/2] twiddles e^{-2 pi i k / n_fft}
@@ -78,6 +81,7 @@ __global__ void k_melspec(const float* __restrict__ wav, float* __restrict__ mel
     for (int k = tid; k < n_bins; k += nt) {
         const float2 v = buf[k];
         mag[k] = sqrtf(v.x * v.x + v.y * v.y + (mode == 1 ? 0.f : 1e-9f));
+        if (linear) linear[((size_t)b * n_frames + t) * n_bins + k] = (20.0f * log10f(fmaxf(1e-5f, mag[k])) - min_level_db) / -min_level_db;
     }
     __syncthreads();
     for (int m = tid; m < n_mels; m += nt) {
@@ -146,7 +150,21 @@ int dsvc_melspec_frames(const dsvc_melspec* m, int64_t n_samples, int32_t* frame
     return DSVC_OK;
 }
 
+static int melspec_launch(dsvc_melspec* m, const float* wav, float* mel, float* linear, float min_level_db, int32_t B, int64_t n_samples, void* stream);
+
 int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, int64_t n_samples, void* stream) {
+    return melspec_launch(m, wav, mel, nullptr, -100.0f, B, n_samples, stream);
+}
+
+int dsvc_melspec_run_linear(dsvc_melspec* m, const float* wav, float* mel, float* linear, float min_level_db, int32_t B, int64_t n_samples, void* stream) {
+    if (!linear) return fail(DSVC_EINVAL, "melspec: null output for the linear spectrogram");
+    if (!(min_level_db < 0.f)) return fail(DSVC_EINVAL, "melspec: min_level_db must be negative (audio.normalize divides by it)");
+    return melspec_launch(m, wav, mel, linear, min_level_db, B, n_samples, stream);
+}
+
+}  // extern "C"
+
+static int melspec_launch(dsvc_melspec* m, const float* wav, float* mel, float* linear, float min_level_db, int32_t B, int64_t n_samples, void* stream) {
     if (!m || !wav || !mel || B < 1) return fail(DSVC_EINVAL, "bad argument");
     int32_t T = 0;
     DSVC_TRY(dsvc_melspec_frames(m, n_samples, &T));
@@ -154,9 +172,7 @@ int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, i
     const size_t smem = (size_t)m->cfg.n_fft * 8 + (size_t)m->cfg.n_fft * 4;
     hipLaunchKernelGGL(k_melspec, dim3(T, B), dim3(256), smem, (hipStream_t)stream, wav, mel, (const float*)m->basis,
                        (const int*)m->range, (int)n_samples, T, m->cfg.n_fft, m->log2n, m->cfg.win_size, m->cfg.hop,
-                       m->cfg.n_mels, m->cfg.clip_val, m->cfg.mode);
+                       m->cfg.n_mels, m->cfg.clip_val, m->cfg.mode, linear, min_level_db);
     DSVC_HIP(hipGetLastError());
     return DSVC_OK;
 }
-
-}  // extern "C"

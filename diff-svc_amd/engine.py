@@ -276,6 +276,7 @@ class MelspecHandle:
         from .melfb import mel_filterbank
         self._h = ctypes.c_void_p(0)
         self.n_mels = n_mels
+        self.n_fft = n_fft
         basis = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax)).contiguous()
         cfg = _lib.MelspecCfg(n_fft, win_size, hop, n_mels, clip_val, mode)
         check(lib().dsvc_melspec_create(ctypes.byref(cfg), ctypes.c_void_p(basis.data_ptr()), ctypes.byref(self._h)))
@@ -293,6 +294,17 @@ class MelspecHandle:
         out = torch.empty(B, self.frames(N), self.n_mels, device=wav.device, dtype=torch.float32)
         check(lib().dsvc_melspec_run(self._h, ptr(wav), ptr(out), B, N, stream_ptr()))
         return out
+
+    def mel_and_linear(self, wav, min_level_db):
+        """wav [B,N] -> (mel [B,T,n_mels] log10, linear [B,T,n_fft/2+1]): process_utterance(return_linear=True)'s normalised dB spectrogram."""
+        _need_cuda(wav)
+        wav = wav.contiguous().float()
+        B, N = wav.shape
+        T = self.frames(N)
+        mel = torch.empty(B, T, self.n_mels, device=wav.device, dtype=torch.float32)
+        lin = torch.empty(B, T, self.n_fft // 2 + 1, device=wav.device, dtype=torch.float32)
+        check(lib().dsvc_melspec_run_linear(self._h, ptr(wav), ptr(mel), ptr(lin), float(min_level_db), B, N, stream_ptr()))
+        return mel, lin
 
     def __del__(self):
         try:

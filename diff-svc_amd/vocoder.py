@@ -215,10 +215,9 @@ class HifiGANHip(BaseVocoder):
     def wav2spec(wav_fn, return_linear=False):
         """PWG.wav2spec (network/vocoders/pwg.py:106-122) -> process_utterance (preprocessing/data_gen_utils.py:96-145): the file at the
         model's rate, a centred zero-padded STFT, |X| through the mel filterbank, log10(max(eps, .)); the waveform comes back
-        zero-padded to frames * hop.  Returns (wav [T*hop], mel [T, num_mels])."""
+        zero-padded to frames * hop.  Returns (wav [T*hop], mel [T, num_mels]) -- and, ``return_linear=True``, the normalised dB spectrogram
+        [T, fft_size / 2 + 1] as third element (data_gen_utils.py:144-149: audio.normalize(audio.amp_to_db(|X|)) with hparams['min_level_db'])."""
         hp = get_hparams()
-        if return_linear:
-            raise NotImplementedError("return_linear (the normalised linear spectrogram) is not part of this path")
         if hp.get("loud_norm"):
             raise NotImplementedError("loud_norm (pyloudnorm BS.1770 normalisation) is not part of this path")
         sr, hop = hp["audio_sample_rate"], hp["hop_size"]
@@ -229,7 +228,12 @@ class HifiGANHip(BaseVocoder):
         if key not in _melspec_cache:
             _melspec_cache[key] = MelspecHandle(sr, hp["fft_size"], hp["win_size"], hop, hp["audio_num_mel_bins"], fmin, fmax, clip_val=eps, mode=1)
         wav = read_wav(wav_fn, sr, mono="mean")                                  # librosa.core.load(wav_path, sr=...) averages channels
-        mel = _melspec_cache[key].mel(torch.from_numpy(wav)[None].cuda())[0].cpu().numpy()
+        lin = None
+        if return_linear:
+            mel, lin = _melspec_cache[key].mel_and_linear(torch.from_numpy(wav)[None].cuda(), hp.get("min_level_db", -100))      # (process_utterance's default)
+            mel, lin = mel[0].cpu().numpy(), lin[0].cpu().numpy()
+        else:
+            mel = _melspec_cache[key].mel(torch.from_numpy(wav)[None].cuda())[0].cpu().numpy()
         n = mel.shape[0] * hop                                                   # librosa_pad_lr(..., 1) then wav[:T * hop]
         wav = np.pad(wav, (0, max(0, n - len(wav))))[:n]
-        return wav, mel
+        return (wav, mel, lin) if return_linear else (wav, mel)

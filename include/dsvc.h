@@ -220,6 +220,11 @@ DSVC_API void dsvc_melspec_destroy(dsvc_melspec* m);
 /* wav [B,N] device -> mel [B,T,n_mels] log10 device, T = (N - hop) / hop + 1 ... see dsvc_melspec_frames */
 DSVC_API int dsvc_melspec_frames(const dsvc_melspec* m, int64_t n_samples, int32_t* frames);
 DSVC_API int dsvc_melspec_run(dsvc_melspec* m, const float* wav, float* mel, int32_t B, int64_t n_samples, void* stream);
+/* process_utterance(..., return_linear=True) (preprocessing/data_gen_utils.py:144-149; PWG.wav2spec(return_linear=True), network/vocoders/pwg.py:
+ * 106-122): the mel as above AND the normalised linear spectrogram audio.normalize(audio.amp_to_db(|X|)) = (20 log10(max(1e-5, |X|)) - min_level_db)
+ * / -min_level_db (utils/audio.py:51-56; hparams['min_level_db'], -120 in training/config.yaml:90), linear [B, frames, n_fft / 2 + 1] device. */
+DSVC_API int dsvc_melspec_run_linear(dsvc_melspec* m, const float* wav, float* mel, float* linear, float min_level_db, int32_t B, int64_t n_samples,
+                                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pitch index work of the condition builder -- replaces the host arithmetic of add_pitch (modules/fastspeech/fs2.py:229-237):

@@ -592,6 +592,16 @@ def process_utterance_mel(wav, sr, n_fft, win_size, hop, n_mels, fmin, fmax, eps
     return torch.log10(torch.clamp(mel, min=eps)).transpose(1, 2)
 
 
+def process_utterance_linear(wav, n_fft, win_size, hop, min_level_db):
+    """The third return value of process_utterance(return_linear=True) (preprocessing/data_gen_utils.py:144-149): audio.normalize(audio.amp_to_db(
+    |X|), {'min_level_db': ...}) = (20 log10(max(1e-5, |X|)) - min_level_db) / -min_level_db (utils/audio.py:51-56) of the same centred, zero-padded
+    STFT; the wrappers transpose it to [T, n_bins] (network/vocoders/pwg.py:119-120).  wav [B,N] -> [B, 1 + N // hop, n_fft / 2 + 1]."""
+    spec = torch.stft(wav, n_fft, hop_length=hop, win_length=win_size, window=torch.hann_window(win_size), center=True,
+                      pad_mode="constant", normalized=False, onesided=True, return_complex=True).abs()
+    db = 20.0 * torch.log10(torch.clamp(spec, min=1e-5))
+    return ((db - min_level_db) / -min_level_db).transpose(1, 2)
+
+
 # ----------------------------------------------------------------------------------------------
 # Content encoder  (network/hubert/hubert_model.py)
 # ----------------------------------------------------------------------------------------------

@@ -201,6 +201,14 @@ def test_pwg_front_end_wav2spec_24k(tmp_path):
         err = np.abs(mel - ref).max()
         print("pwg wav2spec %d Hz, %d samples -> %d frames: max-abs err %.2e (mel range %.2f..%.2f)" % (sr, n, T, err, ref.min(), ref.max()))
         assert err < 2e-4, err
+        # return_linear=True (round 6): the normalised dB spectrogram beside the same wav / mel
+        set_hparams(dict(hp, min_level_db=-120), clear=False)
+        wav3, mel3, lin = HifiGANHip.wav2spec(path, return_linear=True)
+        assert np.array_equal(wav3, wav) and np.array_equal(mel3, mel) and lin.shape == (T, 257)
+        lref = O.process_utterance_linear(torch.from_numpy(src)[None], 512, 512, 128, -120.0)[0].numpy()
+        lerr = np.abs(lin - lref).max()
+        print("pwg wav2spec return_linear: max-abs err %.2e (range %.3f..%.3f)" % (lerr, lref.min(), lref.max()))
+        assert lerr < 2e-4 and 0.0 <= lref.min() and lin.min() >= 0.0, lerr
     with pytest.raises(NotImplementedError):
         set_hparams(dict(hp, loud_norm=True), clear=False)
         HifiGANHip.wav2spec(path)
