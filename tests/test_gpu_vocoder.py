@@ -207,8 +207,10 @@ def test_pwg_front_end_wav2spec_24k(tmp_path):
         assert np.array_equal(wav3, wav) and np.array_equal(mel3, mel) and lin.shape == (T, 257)
         lref = O.process_utterance_linear(torch.from_numpy(src)[None], 512, 512, 128, -120.0)[0].numpy()
         lerr = np.abs(lin - lref).max()
-        print("pwg wav2spec return_linear: max-abs err %.2e (range %.3f..%.3f)" % (lerr, lref.min(), lref.max()))
-        assert lerr < 2e-4 and 0.0 <= lref.min() and lin.min() >= 0.0, lerr
+        strong = lref >= 0.5                                   # bins above -60 dB: an fp32 FFT's rounding noise (~1e-6 absolute on this signal) is
+        serr = np.abs(lin - lref)[strong].max()                # invisible there; at -90 dB it is 0.3 % of |X| = 2e-4 of the normalised dB scale -- in
+        print("pwg wav2spec return_linear: max-abs err %.2e, %.2e on the bins above -60 dB (range %.3f..%.3f)" % (lerr, serr, lref.min(), lref.max()))
+        assert serr < 5e-5 and lerr < 1e-3 and 0.0 <= lref.min() and lin.min() >= 0.0, (lerr, serr)      # torch.stft's own fp32 arithmetic just the same
     with pytest.raises(NotImplementedError):
         set_hparams(dict(hp, loud_norm=True), clear=False)
         HifiGANHip.wav2spec(path)
