@@ -471,6 +471,32 @@ def test_mid_batch_auto_every_clip_with_a_golden(B):
     assert worst <= SHIP_BAR, errs
 
 
+def test_f16_w6_at_dilation_16_runs_the_fused_kernel_on_the_tiles_that_fit():
+    """with `dilation_cycle_length: 5` the largest dilation is 16, and the fused layer kernel's LDS plan on 128-frame tiles
+    (time tile + g block + the 6-bit g_lo code block: 172 032 B) exceeds the CU's 160 KB.  Round 5 then failed inside launch_fused_layer although
+    `auto` had picked f16_w6 for the call; `fused_nt()` now counts the code block when it chooses the tile width.  The 44.1 kHz architecture with
+    a 5-cycle, 20 clips x T = 861 (140 tiles: where the 128-frame tiling would be the choice), 20 DDPM steps at the precision `auto` picks: runs,
+    on 64- or 32-frame tiles, two clips within the coarse-chain bar of the oracle."""
+    from diffsvc_amd.denoiser import DiffNetHip
+    hp = dict(synth.HPARAMS_44K, dilation_cycle_length=5, K_step=20)
+    B, T, n_units, seed = 20, 861, 500, 43
+    precision = DiffNetHip(128, hparams=hp).precision_for("ddpm", 1, frames=B * T, clips=B)
+    assert precision == "f16_w6"
+    sd, den, smp = make_handles(hp, 0, precision)
+    clips = list(range(B))
+    hub, m2p, f0 = clip_batch(hp, clips, T, n_units)
+    cond, _, _ = O.build_cond(sd, hub, m2p, f0.clone(), hp)
+    mel = smp.sample(cond.transpose(1, 2).contiguous().cuda(), 20, mel2ph=m2p.cuda(), seed=seed, first_clip=0, use_graph=False).cpu()
+    nt = smp.profile_gate_kernel(B, T, 1)[2]
+    errs = []
+    for c in (3, 17):
+        r = oracle_sample(hp, sd, [c], T, n_units, 1, seed, 20)
+        errs.append((mel[c] - r["mel_out"][0]).abs().max().item())
+    print("f16_w6 at dilation 16 (cycle 5), 20 clips: fused kernel on %d-frame tiles, 20-step mel max-abs err %s" % (32 * nt, ["%.2e" % e for e in errs]))
+    assert nt in (1, 2), nt
+    assert torch.isfinite(mel).all() and max(errs) < 2e-3, errs
+
+
 @pytest.mark.parametrize("tag", ["w1", "w2", "w3"])
 def test_batched_precision_across_weight_statistics(tag):
     """the shipped batched precision (f16_w6) measures 4.0e-4 ... 6.1e-4 on the random-init checkpoint (1.65x of margin) and
