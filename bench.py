@@ -707,6 +707,12 @@ def main():
             torch.cuda.synchronize(); ts = time.perf_counter()
             pipe.infer(hub, m2p, f0, speedup=args.speedup, seed=151, clip_ids=clip_ids, use_graph=not args.no_graph, full_length=True)
             torch.cuda.synchronize(); solo_value = B * CLIP_SECONDS / (time.perf_counter() - ts)
+    whole_job = None
+    if world > 1 and rank == 0 and not os.environ.get("DSVC_BENCH_NO_STRONG"):
+        # north_star's own ratio -- "speed-up at N GPUs vs 1 GPU on the batched config" -- needs the WHOLE N x B-clip job on one device as its
+        # denominator (strong scaling), not one rank's share: rank 0 runs it here, alone, as N batches of B through its pipeline
+        # (SvcPipeline.infer_job; the bucket and the captured chain of this batch size exist already), the other ranks wait at the barrier
+        whole_job = time_job(pipe, n_clips, B, dev, args.ddpm_steps, overlap=True, warm=False)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -748,6 +754,12 @@ def main():
                                    "the other ranks waiting at a barrier" % (B, args.ddpm_steps, "DDPM" if args.speedup <= 1 else "PLMS/%d" % args.speedup)),
             "roofline": roof,
         }
+        if whole_job is not None:
+            result["strong_scaling"] = {"job_clips": n_clips, "one_gpu_s_per_job": whole_job["s_per_job"], "one_gpu_value": whole_job["value"],
+                                        "n_gpu_s_per_job": elapsed / args.steps, "speedup_vs_1gpu_whole_job": whole_job["s_per_job"] / (elapsed / args.steps),
+                                        "what": "the same %d-clip job on ONE device (rank 0 alone, %d batches of %d through one pipeline, no gather) against the "
+                                                "%d-rank job of this line, gather included: north_star's '>= 6x at 8 GPUs vs 1 GPU on the batched config'"
+                                                % (n_clips, whole_job["batches"], B, world)}
         if world == 1 and B == 1 and args.speedup <= 1 and roof["bound"] == "mfma":
             # the single clip is frozen, with the evidence on the line
             roof["frozen_since"] = "r4"

@@ -241,6 +241,12 @@ def test_bench_multi_gpu_line_carries_its_own_one_gpu_denominator():
     assert d["config"]["clips_per_gpu"] == 32 and one["config"]["clips_per_gpu"] == 32 and d["config"]["precision"] == one["config"]["precision"]
     assert abs(d["same_workload_1gpu"] / one["value"] - 1.0) < 0.05, (d["same_workload_1gpu"], one["value"])
     assert 0.8 < d["speedup_vs_1gpu_same_workload"] < 1.25 and abs(d["scaling_efficiency"] * 2 - d["speedup_vs_1gpu_same_workload"]) < 1e-9
+    # round 6: the STRONG-scaling ratio north_star asks for -- the whole 64-clip job on one device (rank 0 alone, two batches of 32) against the
+    # 2-rank job.  Two ranks time-slicing one device buy nothing: ~1 (on two real GPUs: ~2)
+    ss = d["strong_scaling"]
+    print("strong scaling: %d clips on one device %.2f s, on 2 ranks %.2f s, speed-up %.2f" % (ss["job_clips"], ss["one_gpu_s_per_job"], ss["n_gpu_s_per_job"], ss["speedup_vs_1gpu_whole_job"]))
+    assert ss["job_clips"] == 64 and 0.8 < ss["speedup_vs_1gpu_whole_job"] < 1.25, ss
+    assert abs(ss["one_gpu_value"] / one["value"] - 1.0) < 0.06, (ss["one_gpu_value"], one["value"])      # 2 x 32 back to back = the one-rank 32-clip rate
     t2 = _run_bench(2, 0, train=True)
     t1 = _run_bench(1, 0, train=True)
     print("bench --train --gpus 2 (shared device): value %.0f frames/s, same_workload_1gpu %.0f, one-rank job %.0f" % (t2["value"], t2["same_workload_1gpu"], t1["value"]))
