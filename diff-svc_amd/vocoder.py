@@ -218,8 +218,6 @@ class HifiGANHip(BaseVocoder):
         zero-padded to frames * hop.  Returns (wav [T*hop], mel [T, num_mels]) -- and, ``return_linear=True``, the normalised dB spectrogram
         [T, fft_size / 2 + 1] as third element (data_gen_utils.py:144-149: audio.normalize(audio.amp_to_db(|X|)) with hparams['min_level_db'])."""
         hp = get_hparams()
-        if hp.get("loud_norm"):
-            raise NotImplementedError("loud_norm (pyloudnorm BS.1770 normalisation) is not part of this path")
         sr, hop = hp["audio_sample_rate"], hp["hop_size"]
         fmin = 0 if hp["fmin"] == -1 else hp["fmin"]
         fmax = sr / 2 if hp["fmax"] == -1 else hp["fmax"]
@@ -228,6 +226,9 @@ class HifiGANHip(BaseVocoder):
         if key not in _melspec_cache:
             _melspec_cache[key] = MelspecHandle(sr, hp["fft_size"], hp["win_size"], hop, hp["audio_num_mel_bins"], fmin, fmax, clip_val=eps, mode=1)
         wav = read_wav(wav_fn, sr, mono="mean")                                  # librosa.core.load(wav_path, sr=...) averages channels
+        if hp.get("loud_norm"):                                                  # data_gen_utils.py:117-122: to -22 LUFS (BS.1770 as pyloudnorm 0.1.0
+            from .loudness import loud_norm                                      # implements it, restated in loudness.py: the package is absent here)
+            wav = loud_norm(wav, sr, -22.0).astype(np.float32)
         lin = None
         if return_linear:
             mel, lin = _melspec_cache[key].mel_and_linear(torch.from_numpy(wav)[None].cuda(), hp.get("min_level_db", -100))      # (process_utterance's default)

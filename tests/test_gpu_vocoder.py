@@ -211,6 +211,14 @@ def test_pwg_front_end_wav2spec_24k(tmp_path):
         serr = np.abs(lin - lref)[strong].max()                # invisible there; at -90 dB it is 0.3 % of |X| = 2e-4 of the normalised dB scale -- in
         print("pwg wav2spec return_linear: max-abs err %.2e, %.2e on the bins above -60 dB (range %.3f..%.3f)" % (lerr, serr, lref.min(), lref.max()))
         assert serr < 5e-5 and lerr < 1e-3 and 0.0 <= lref.min() and lin.min() >= 0.0, (lerr, serr)      # torch.stft's own fp32 arithmetic just the same
-    with pytest.raises(NotImplementedError):
-        set_hparams(dict(hp, loud_norm=True), clear=False)
-        HifiGANHip.wav2spec(path)
+    # loud_norm (round 6; data_gen_utils.py:117-122): the waveform is brought to -22 LUFS before the STFT -- the returned wav is the normalised one
+    # (BS.1770 as pyloudnorm implements it, restated on the host: diffsvc_amd/loudness.py), the mel is the mel OF that waveform
+    from diffsvc_amd.loudness import integrated_loudness
+    set_hparams(dict(hp, loud_norm=True), clear=False)
+    wav_n, mel_n = HifiGANHip.wav2spec(path)
+    src = read_wav(path, 24000)
+    assert abs(integrated_loudness(wav_n[:len(src)], 24000) - (-22.0)) < 0.02 and np.abs(wav_n).max() <= 1.0
+    gain = np.abs(wav_n).max() / np.abs(src).max()
+    ref_n = O.process_utterance_mel(torch.from_numpy((src * gain).astype(np.float32))[None], 24000, 512, 512, 128, 80, 30, 12000, eps=1e-6)[0].numpy()
+    assert np.abs(mel_n - ref_n).max() < 2e-4
+    set_hparams(dict(hp, loud_norm=False), clear=False)

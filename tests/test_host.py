@@ -468,3 +468,27 @@ def test_auto_precision_follows_the_workspace_buckets():
     assert net.precision_for("plms", 20, frames=7000, clips=1) == "f16_x3t" and net.precision_for("forward") == "f16_x3t"
     tiny = DiffNetHip(16, hparams=synth.tiny_hparams())
     assert tiny.precision_for("ddpm", 1, frames=100000, clips=100) == "f16_x3t"               # 64 channels: no fused layer kernel for this architecture
+
+
+def test_loud_norm_restatement_against_the_standards_conformance_point():
+    """``loud_norm`` (preprocessing/data_gen_utils.py:117-122) calls pyloudnorm==0.1.0 (requirements.txt:67), which is absent here: its BS.1770
+    integrated loudness is restated in diffsvc_amd/loudness.py -- parity unpinned at the dependency, pinned to the standard instead: a 997 Hz
+    full-scale sine measures -3.01 LKFS (ITU-R BS.1770-4, conformance tolerance +-0.1 LU; the audio-EQ-cookbook biquads pyloudnorm designs for
+    the signal's own rate give -3.05 ... -3.06), level changes map 1 : 1 to LU, silence below the absolute gate does not count, and normalising
+    lands on the target."""
+    from diffsvc_amd.loudness import integrated_loudness, loud_norm
+    for rate in (48000, 44100, 24000):
+        t = np.arange(rate * 5) / rate
+        x = np.sin(2 * np.pi * 997 * t)
+        L0 = integrated_loudness(x, rate)
+        assert abs(L0 - (-3.01)) < 0.1, (rate, L0)
+        assert abs(integrated_loudness(0.1 * x, rate) - (L0 - 20.0)) < 1e-6
+        gated = np.concatenate([x, np.zeros(rate * 5)])                     # trailing silence: gated out, not averaged in (ungated: L0 - 3.01);
+        assert L0 - 0.2 < integrated_loudness(gated, rate) <= L0            # the three blocks that straddle the edge pass the relative gate: -0.13 LU
+        assert abs(integrated_loudness(np.stack([x, x], axis=1), rate) - (L0 + 10 * np.log10(2.0))) < 1e-6      # two channels: powers add
+    y = loud_norm((0.05 * np.sin(2 * np.pi * 440 * np.arange(72000) / 24000)).astype(np.float32), 24000)
+    assert y.dtype == np.float32 and abs(integrated_loudness(y, 24000) + 22.0) < 1e-3
+    loud = loud_norm(np.sign(np.sin(2 * np.pi * 100 * np.arange(48000) / 24000)).astype(np.float32) * 0.001, 24000, target=-1.0)
+    assert np.abs(loud).max() <= 1.0 + 1e-6                                 # a target that would clip: rescaled to full scale (data_gen_utils.py:121-122)
+    with pytest.raises(ValueError):
+        integrated_loudness(np.zeros(100), 24000)
