@@ -331,8 +331,10 @@ def time_job(pipe, n_clips, cpb, dev, ddpm_steps, overlap=True, warm=True):
     hub, m2p, f0 = make_inputs(list(range(n_clips)), dev)
     if warm:                                                  # bucket + graph of this batch size on a short chain
         pipe.model.K_step = 130
-        pipe.infer_job(hub[:cpb], m2p[:cpb], f0[:cpb], clips_per_batch=cpb, seed=1, overlap=overlap)
-        pipe.model.K_step = ddpm_steps
+        try:
+            pipe.infer_job(hub[:cpb], m2p[:cpb], f0[:cpb], clips_per_batch=cpb, seed=1, overlap=overlap)
+        finally:
+            pipe.model.K_step = ddpm_steps
     torch.cuda.synchronize(); t0 = time.perf_counter()
     wav = pipe.infer_job(hub, m2p, f0, clips_per_batch=cpb, seed=2, overlap=overlap)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
