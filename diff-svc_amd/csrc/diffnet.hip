@@ -969,6 +969,9 @@ int dsvc_denoiser::launch_fused_layer(int l, const StepRef& step, hipStream_t st
                          l == 0 ? 1 : 0, rowmap(), 1};
 #ifdef DSVC_PROFILING
     static const int pf = getenv("DSVC_FUSED_PF") ? atoi(getenv("DSVC_FUSED_PF")) : 0;
+    // round 6 A/B (tools/gpu_r6_ablate.py): DSVC_TL_STREAM=0 = the fp32 residual / skip tiles with PLAIN loads and stores (cacheable in L2 / the
+    // 256 MB Infinity Cache: x32 + skip + both xh buffers of a 32-clip batch are 132 MB) instead of non-temporal ones; cproj stays non-temporal
+    if (getenv("DSVC_TL_STREAM")) oe.stream = atoi(getenv("DSVC_TL_STREAM"));
 #else
     constexpr int pf = 0;
 #endif

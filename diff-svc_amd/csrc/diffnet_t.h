@@ -114,6 +114,10 @@ struct TEpiResSkip {
         } else {
             const float* p = base + tiled_lane_base(row0 + 32 * nt, rt, tl_mt, lane);
             f32x4 v0, v1, v2, v3;
+#ifdef DSVC_PROFILING
+            // round 6 byte ablation (DSVC_TL_STREAM=3, WRONG results): 3 of the 4 dwordx4 per lane -- what 3-byte residual / skip elements could buy
+            if (e.stream & 2) { v0 = ld4_nt(p); v1 = ld4_nt(p + 256); v2 = ld4_nt(p + 512); v3 = v2; } else
+#endif
             if (e.stream) { v0 = ld4_nt(p); v1 = ld4_nt(p + 256); v2 = ld4_nt(p + 512); v3 = ld4_nt(p + 768); }
             else { v0 = ld4(p); v1 = ld4(p + 256); v2 = ld4(p + 512); v3 = ld4(p + 768); }
 #pragma unroll
@@ -168,6 +172,12 @@ struct TEpiResSkip {
             for (int i = 0; i < 16; ++i) v[i] = a[i] + c.b[i];
         }
         float* p = (res ? e.x32 : e.skip) + tiled_lane_base(row0 + 32 * nt, rt, res ? mt : mt - rt, lane);
+#ifdef DSVC_PROFILING
+        if (e.stream & 2) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) st4_nt(p + 256 * q, f32x4{v[4 * q] + v[12 + q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+        } else
+#endif
         if (e.stream) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) st4_nt(p + 256 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});

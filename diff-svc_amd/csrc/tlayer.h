@@ -59,6 +59,8 @@ struct TLayerArgs {
                                 // kernel (results unchanged): before its tile DMA a workgroup polls the flags of tiles i-1 / i+1 (set by the previous
                                 // launch) and takes one agent-scope acquire; after its last store it drains, releases at agent scope and sets its flag
     unsigned* flags;            // abl & 2: one word per frame tile
+    int dephase;                // env DSVC_TL_DEPHASE (second session of round 6): after "g complete" waves 4-7 (> 0) or 0-3 (< 0) sleep |dephase| x 1024 clocks,
+                                // so that the two waves of a SIMD enter the output phase out of step (one in its MFMA loop while the other stores / waits for its init loads)
 #endif
 };
 
@@ -481,6 +483,12 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
             if constexpr (G6) store_block6(NB - 1, gq6);
             __syncthreads();                               // g complete
             TL_STAMP(7);
+#ifdef DSVC_PROFILING
+            if (ga.dephase != 0 && ((ga.dephase > 0) == (wave >= 4))) {
+                const int n = ga.dephase > 0 ? ga.dephase : -ga.dephase;
+                for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+            }
+#endif
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = nxt[nt];
@@ -689,6 +697,7 @@ inline int tlayer_launch(const TGemmArgs& g, const float* cproj, const TGemmArgs
     a.step_ptr = g.step_ptr; a.step_off = g.step_off;
 #ifdef DSVC_PROFILING
     a.abl = getenv("DSVC_TL_ABL") ? atoi(getenv("DSVC_TL_ABL")) : 0;
+    a.dephase = getenv("DSVC_TL_DEPHASE") ? atoi(getenv("DSVC_TL_DEPHASE")) : 0;
     if (a.abl & 2) {
         static unsigned* flags = nullptr;
         if (!flags) { DSVC_HIP(hipMalloc(&flags, 4096 * 4)); DSVC_HIP(hipMemset(flags, 0xff, 4096 * 4)); }       // "every neighbour has arrived": the poll never waits
