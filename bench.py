@@ -841,8 +841,15 @@ def main():
                                                          "inside the real kernel: +3.1 % per step (+4 us per layer); it could hide at most the 1.75 us boundary "
                                                          "and the neighbour-independent part of the 9 us prologue: net < 1 %: not built",
                     "chip_filling_batch": "36 clips per batch (252 of 256 CUs hold a tile): +4 ... 5 % per clip (`job_256.chip_filling_batches` on this line)",
-                    "vocoder_under_next_batch": "second stream: +-0.1 % (`job_256` vs `job_256.no_overlap` on this line): the layer kernels leave no CU a co-resident workgroup fits on"},
-                "source": "profiles/r6c_layer_ablations.txt, profiles/r6b_bench.json (same-box A/B, profiling build for the ablations)"}
+                    "vocoder_under_next_batch": "second stream: +-0.1 % (`job_256` vs `job_256.no_overlap` on this line): the layer kernels leave no CU a co-resident workgroup fits on",
+                    "residual_skip_3_bytes_per_element": "byte ablation of the output phase (3 of the 4 dwordx4 per lane and tile of the fp32 residual / skip "
+                                                         "read-modify-write, -22 % of that phase's bytes; wrong results): -1.5 % per step (the in-kernel stamps: "
+                                                         "-1.8 us of the 41 us output phase) -- the phase is not HBM-byte-bound, a 3-byte residual / skip format is not built",
+                    "infinity_cache_residency": "plain instead of non-temporal accesses for the 132 MB a batch re-touches every layer: +-0.1 %",
+                    "output_phase_waves_out_of_step": "waves 4-7 (or 0-3) delayed by 1.7 ... 5 us after `g complete` so that a SIMD's two waves alternate MFMA loop / "
+                                                      "store + init-load wait: -0.8 ... +0.8 % (noise)"},
+                "source": "profiles/r6c_layer_ablations.txt, profiles/r6b_bench.json, profiles/r6m_stream_ablate.txt, profiles/r6m_dephase.txt, "
+                          "profiles/r6m_layer_stamps_w6.txt (same-box A/B, profiling build for the ablations)"}
             fit, why = load_error_fit(precb)
             if fit:
                 import math
