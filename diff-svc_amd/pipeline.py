@@ -155,6 +155,77 @@ class SvcPipeline:
                     t.record_stream(self._side)
         return out
 
+    # ---- an utterance's chunks as a few padded batches (round 6, second session) ----
+    # The reference's driver runs the chunks the slicer cut one after another at B = 1 (infer.py:44-67, infer_tool.py:155-159).  They are
+    # independent, and a padded batch equals the per-clip runs (``infer``: trailing ``mel2ph == 0`` frames are the convs' zero padding, the host
+    # glue is applied per clip), so a caller that has all the chunks in hand can trade the single clip's latency regime for the batched one.
+    # Cost model of one DDPM evaluation, in us (csrc/diffnet.hip: fused_nt's table of the fused layer kernel -- 45 / 65 / 125 us per layer on
+    # 32- / 64- / 128-frame tiles with one workgroup per CU -- and a straight line through bench.py's `ragged.ddpm` for the small tilings):
+    CHUNK_COST_FUSED = ((45.0, 32), (65.0, 64), (125.0, 128))
+    CHUNK_COST_SMALL = (237.0, 0.173)                     # a + b * rows
+    CHUNK_MAX_ROWS = 256 * 128                             # one round of 128-frame tiles
+
+    def _chunk_group_cost(self, B, T):
+        den = self.model.denoise_fn
+        rows = den.workspace_tiles(B, T) * 128
+        if rows // 128 >= den.BATCHED_TILES and den.precision_for("ddpm", 1, frames=B * T, clips=B) in ("f16_w6", "f16_w6n"):
+            per_layer = min(c * -(-(rows // w) // 256) for c, w in self.CHUNK_COST_FUSED)
+            return den.n_layers * per_layer + 40.0 + 0.0016 * rows
+        a, b = self.CHUNK_COST_SMALL
+        return a + b * rows
+
+    def plan_chunks(self, lengths):
+        """Groups of chunk indices (each group = one padded batch, longest chunk first) that minimise the modelled time of one DDPM evaluation
+        over the whole utterance: chunks sorted by length, contiguous groups, dynamic programme over the cut points."""
+        order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
+        n = len(order)
+        best = [0.0] + [float("inf")] * n
+        cut = [0] * (n + 1)
+        for i in range(1, n + 1):
+            for j in range(i):                               # group = order[j:i], padded to the length of order[j]
+                B, T = i - j, int(lengths[order[j]])
+                if B > 1 and self.model.denoise_fn.workspace_tiles(B, T) * 128 > self.CHUNK_MAX_ROWS:
+                    continue
+                c = best[j] + self._chunk_group_cost(B, T)
+                if c < best[i]:
+                    best[i], cut[i] = c, j
+        groups, i = [], n
+        while i > 0:
+            groups.append(order[cut[i]:i])
+            i = cut[i]
+        return groups[::-1]
+
+    @torch.no_grad()
+    def infer_chunks(self, chunks, speedup=1, seed=0, first_clip=0, use_graph=True, use_pe=False, batch=True):
+        """The chunks of ONE utterance -- a list of (hubert [n_i, H], mel2ph [T_i], f0 [T_i]) device tensors, every chunk with its own length --
+        to a list of PCM tensors [kept_frames_i * hop], in the order given.  Chunk i draws the noise streams of clip ``first_clip + i`` whatever
+        batch it lands in, so the result does not depend on the grouping beyond the operand precision `auto` picks by call size.
+        ``batch=False`` (and PLMS, which the reference defines for B = 1 only, diffusion.py:165-198,269-278) runs them one by one as the
+        reference's loop does."""
+        n = len(chunks)
+        lengths = [int(c[1].shape[-1]) for c in chunks]
+        groups = self.plan_chunks(lengths) if (batch and speedup <= 1 and n > 1) else [[i] for i in range(n)]
+        out = [None] * n
+        dev = chunks[0][1].device
+        for g in groups:
+            Tm = max(lengths[i] for i in g)
+            Nm = max(int(chunks[i][0].shape[-2]) for i in g)
+            H = int(chunks[g[0]][0].shape[-1])
+            hub = torch.zeros(len(g), Nm, H, device=dev, dtype=torch.float32)
+            m2p = torch.zeros(len(g), Tm, device=dev, dtype=torch.long)
+            f0 = torch.zeros(len(g), Tm, device=dev, dtype=torch.float32)
+            for b, i in enumerate(g):
+                h, m, f = chunks[i]
+                hub[b, :h.shape[-2]] = h.reshape(-1, H)
+                m2p[b, :lengths[i]] = m.reshape(-1)
+                f0[b, :lengths[i]] = f.reshape(-1)
+            ids = torch.tensor([first_clip + i for i in g], dtype=torch.int32, device=dev)
+            wav, lens = self.infer(hub, m2p, f0, speedup=speedup, seed=seed, clip_ids=ids, use_graph=use_graph, return_lens=True, use_pe=use_pe)
+            lens = lens.tolist()
+            for b, i in enumerate(g):
+                out[i] = wav[b, :lens[b]]
+        return out
+
     def check(self):
         """The deferred argument checks of the device path, at a point where the caller synchronises anyway (after the PCM has been read, at the
         end of a job): mel2ph entries outside [0, content frames] -- the reference's torch.gather raises an IndexError at once (fs2.py:100-102),
