@@ -516,3 +516,50 @@ def test_pipelined_job_equals_separate_batches_bit_for_bit(arch):
         torch.cuda.synchronize()
         assert torch.isfinite(job).all()
         assert torch.equal(job, ref), (arch, overlap, (job - ref).abs().max().item())
+
+
+def _utterance_chunks(hp, lens, first):
+    chunks = []
+    for i, T in enumerate(lens):
+        a, b, c, _ = synth.clip_inputs(first + i, T=T, n_units=max(2, T * 500 // 861), H=hp["hidden_size"])
+        chunks.append(tuple(torch.from_numpy(v).cuda() for v in (a, b, c)))
+    return chunks
+
+
+def test_infer_chunks_one_by_one_is_the_per_chunk_infer_loop_and_batched_stays_inside_the_bars():
+    """SvcPipeline.infer_chunks (round 6, second session): the chunks of one utterance (infer.py:44-67 hands them to the model one by one, each
+    with its own T) as a few padded batches.  ``batch=False`` IS the reference's loop -- bit-identical to ``infer`` per chunk.  Batched, chunk i
+    keeps the noise streams of clip ``first_clip + i``; a group whose rows fill the fused layer kernel runs at the batched precision (`auto`),
+    so its PCM differs from the one-by-one pass by what separates the two shipped operand schemes after 60 steps of the chain -- far inside
+    north_star's 1e-4 RMS -- and every chunk keeps its own length."""
+    from diffsvc_amd.pipeline import SvcPipeline
+    hp = dict(synth.HPARAMS_44K, K_step=60)
+    h = dict(synth.VOCODER_44K)
+    pipe = SvcPipeline(hp, synth.acoustic_state(hp, 0), synth.vocoder_state(h, 1), h, precision="auto", vocoder_precision="f16_x3")
+    lens = [430, 700, 861, 1200, 1600, 2100, 2600]
+    chunks = _utterance_chunks(hp, lens, 300)
+    hop = pipe.vocoder.hop
+    loop = [pipe.infer(c[0][None], c[1][None], c[2][None], seed=5, first_clip=300 + i, full_length=True)[0] for i, c in enumerate(chunks)]
+    one = pipe.infer_chunks(chunks, seed=5, first_clip=300, batch=False)
+    for i, (a, b) in enumerate(zip(one, loop)):
+        assert a.shape == (lens[i] * hop,) and torch.equal(a, b), (i, lens[i])
+    plan = pipe.plan_chunks(lens)
+    assert sorted(i for g in plan for i in g) == list(range(len(lens))) and len(plan) < len(lens), plan
+    assert any(pipe.model.denoise_fn.precision_for("ddpm", 1, frames=len(g) * lens[g[0]], clips=len(g)) == "f16_w6" for g in plan), plan
+    got = pipe.infer_chunks(chunks, seed=5, first_clip=300)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(got, loop)):
+        assert a.shape == b.shape and torch.isfinite(a).all(), (i, a.shape, b.shape)
+        rms = float((a.double() - b.double()).pow(2).mean().sqrt())
+        worst = max(worst, rms)
+        assert rms < 2e-5, (i, lens[i], rms)             # measured 1e-6 ... 4e-6 after 60 steps (two operand schemes, two tilings)
+    print("infer_chunks: plan %s, worst PCM rms against the one-by-one loop %.2e" % ([[lens[i] for i in g] for g in plan], worst))
+    # at a pinned precision the grouping changes the tiling only (fp32 summation order)
+    pipe2 = SvcPipeline(hp, synth.acoustic_state(hp, 0), synth.vocoder_state(h, 1), h, precision="f16_x3t", vocoder_precision="f16_x3")
+    sub = chunks[:3]
+    a2 = pipe2.infer_chunks(sub, seed=5, first_clip=300, batch=False)
+    pipe2.plan_chunks = lambda lengths: [[2, 1, 0]]
+    b2 = pipe2.infer_chunks(sub, seed=5, first_clip=300)
+    for i, (a, b) in enumerate(zip(a2, b2)):
+        assert float((a.double() - b.double()).pow(2).mean().sqrt()) < 2e-6, i
