@@ -14,7 +14,7 @@ PREC_F16_X3T = 4
 PREC_F16_W6 = 5
 PREC_F16_W6N = 6
 PRECISIONS = {"f16": PREC_F16, "f16_w2": PREC_F16_W2, "f16_x3": PREC_F16_X3, "f16_x3t": PREC_F16_X3T}
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def parse_precision(p):
@@ -52,7 +52,7 @@ class DenoiserCfg(ctypes.Structure):
 class SampleArgs(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("T", ctypes.c_int32), ("cond", ctypes.c_void_p), ("x_init", ctypes.c_void_p),
                 ("ref_mel", ctypes.c_void_p), ("mel2ph", ctypes.c_void_p), ("seed", ctypes.c_uint64),
-                ("first_clip", ctypes.c_int32), ("clip_ids", ctypes.c_void_p), ("clip_lens", ctypes.c_void_p),
+                ("first_clip", ctypes.c_int32), ("clip_ids", ctypes.c_void_p), ("clip_lens", ctypes.c_void_p), ("clip_lens_host", ctypes.c_void_p),
                 ("t_start", ctypes.c_int32), ("t_stop", ctypes.c_int32),
                 ("speedup", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("mel_out", ctypes.c_void_p),
                 ("x_out", ctypes.c_void_p)]

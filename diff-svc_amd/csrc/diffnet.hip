@@ -418,7 +418,19 @@ struct dsvc_denoiser : DenWs {
         const int m = dbg_fused_tail % 10;
         if (m == 2) return 1;
         if (m == 3) return 2;
-        return (rows_alloc / 64) * 2 <= device_cus() ? 2 : 1;
+        return (act_tiles[1] > 0 ? act_tiles[1] : rows_alloc / 64) * 2 <= device_cus() ? 2 : 1;
+    }
+    // ragged batches (dsvc_sample_args.clip_lens_host): 32- / 64- / 128-frame tiles that hold at least one frame of their clip.  The fused layer
+    // kernel's workgroups on the other tiles return at once (tlayer.h), so a launch costs its ACTIVE tiles' rounds; 0 = lengths unknown on the
+    // host (every tile counts).  Set per dsvc_sample call, cleared by whatever changes the bucket.
+    int act_tiles[3] = {0, 0, 0};
+    void set_active_tiles(const int32_t* lens_host, int B) {
+        act_tiles[0] = act_tiles[1] = act_tiles[2] = 0;
+        if (!lens_host) return;
+        for (int b = 0; b < B; ++b) {
+            int n = lens_host[b] < 1 ? 1 : (lens_host[b] > wsT ? wsT : lens_host[b]);
+            for (int i = 0; i < 3; ++i) act_tiles[i] += ceil_div(n, 32 << i);
+        }
     }
     int dbg_fused_nt = 0;        // "fused_nt": force the tile width of the fused kernel (A/B of the mid-size tilings); 0 = automatic
     bool defer_ok() const { return fused_layer_ok() && defer_skip && skipall_t.m_tiles > 0 && gall.p && tskip_supported(cfg.channels, rows_alloc); }
@@ -658,6 +670,7 @@ int dsvc_denoiser::ensure_x3t_codes() {
 
 int dsvc_denoiser::ensure_ws(int B, int T, hipStream_t st) {
     if (B < 1 || T < 1) return fail(DSVC_EINVAL, "bad batch/frames %d/%d", B, T);
+    act_tiles[0] = act_tiles[1] = act_tiles[2] = 0;       // (dsvc_sample sets them again when it is given the lengths)
     const int tp = bucket_rows(T);
     if ((long long)B * tp > 0x3fffff00) return fail(DSVC_EINVAL, "batch too large");
     ++ws_clock;
@@ -934,7 +947,8 @@ int dsvc_denoiser::fused_nt() const {
             // (the g_lo code block beside the time tile -- dilation 16 on 128-frame tiles needs 172 KB -- counts in the choice, so a
             //  checkpoint with dilation_cycle_length 5 runs f16_w6 on the 64- / 32-frame tiles instead of failing in launch_fused_layer)
             if (g6 && tlayer_smem(max_dil, Cp, true, width[i]) > 160 * 1024) continue;
-            const long c = (long)ceil_div(rows_alloc / (32 * width[i]), cus) * cost[i];
+            const int tiles = act_tiles[i] > 0 ? act_tiles[i] : rows_alloc / (32 * width[i]);          // (a ragged batch: the tiles that have work)
+            const long c = (long)ceil_div(tiles, cus) * cost[i];
             if (best < 0 || c < best) { best = c; nt = width[i]; }
         }
     }
@@ -1018,6 +1032,7 @@ struct SmpGraph {
     int prec = -1, unroll = 0;     // DDPM: steps per replay
     int interval = 0, first = -1, iters = 0;      // PLMS: its schedule
     int T = 0;                     // conv_gemm engine (f16_x3) only: its kernels take the call's T by value; 0 on the tgemm engine (any T of the bucket)
+    int nt = 0;                    // tile width of the fused layer kernel the chain was captured with (a ragged batch's lengths can move it within a bucket)
     unsigned long long last_use = 0;
 };
 
@@ -1144,7 +1159,7 @@ SmpGraph* dsvc_sampler::find_graph(const SmpGraph& w) {
     }
     for (SmpGraph& g : graphs)
         if (g.kind == w.kind && g.ws_id == w.ws_id && g.gen == w.gen && g.prec == w.prec && g.unroll == w.unroll && g.interval == w.interval &&
-            g.first == w.first && g.iters == w.iters && g.T == w.T) {
+            g.first == w.first && g.iters == w.iters && g.T == w.T && g.nt == w.nt) {
             g.last_use = ++clock;
             return &g;
         }
@@ -1197,6 +1212,7 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
         SmpGraph want{};
         want.kind = 0; want.ws_id = den->ws_id; want.gen = den->ws_gen; want.prec = den->cfg.precision; want.unroll = UNROLL;
         want.T = den->tpath ? 0 : a->T;
+        want.nt = den->fused_nt() | (den->fused_tail_mode() << 4);
         SmpGraph* gr = find_graph(want);
         if (!gr) {
             DSVC_TRY(eager_step());                       // one eager step first: sets every function attribute outside the capture
@@ -1294,7 +1310,7 @@ int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
         // eagerly (that also sets every function attribute outside a capture) and records the graph for the calls after it.
         SmpGraph want{};
         want.kind = 1; want.ws_id = den->ws_id; want.gen = den->ws_gen; want.prec = den->cfg.precision; want.interval = interval;
-        want.first = i_first; want.iters = iters; want.T = den->tpath ? 0 : a->T;
+        want.first = i_first; want.iters = iters; want.T = den->tpath ? 0 : a->T; want.nt = den->fused_nt() | (den->fused_tail_mode() << 4);
         if (SmpGraph* gr = find_graph(want)) {
             DSVC_HIP(hipGraphLaunch(gr->exec, st));
             ++stat_graph_launch;
@@ -1528,6 +1544,7 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
     DSVC_TRY(s->ensure_ws(B, T, st));
     d->tail_fused_last = false;                           // a new chain: nothing of a previous call's tail applies
     DSVC_TRY(d->set_clip_meta(a->clip_ids, a->first_clip, a->clip_lens, st));
+    d->set_active_tiles(a->clip_lens ? a->clip_lens_host : nullptr, B);       // (host copy of clip_lens, optional: the tile width is chosen by the tiles that have work)
     DSVC_TRY(d->prepare_cond(a->cond, B, T, st));
     stamp(1);
     float* xs = s->xstate.as<float>();

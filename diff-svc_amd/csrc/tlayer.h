@@ -260,6 +260,21 @@ tlayer_kernel(const TLayerArgs ga, const float* __restrict__ cproj, const TEpiRe
         __syncthreads();
     }
 #endif
+    // A tile that lies wholly beyond its clip's length -- the padding of a ragged batch (dsvc_sample_args.clip_lens: a clip occupies a bucket of
+    // Tp rows whatever its own length; tiles never straddle clips) -- has nothing to compute: its operand rows are the convs' zero padding and
+    // stay so, its residual / skip rows are read by nobody but its own later launches.  All it owes the rest of the launch is that the rows of the
+    // NEXT layer's operand it owns are zero (the last valid tile of the clip reads `dil` of them as its halo; in a re-used bucket they may
+    // still hold an earlier, longer clip), then it returns -- and its CU takes the next workgroup: a ragged batch costs its ACTIVE tiles
+    // (round 6, second session; the host picks the tile width by them when it is given the lengths, dsvc_sample_args.clip_lens_host).
+    if (oe.rm.rowclip[row0] < 0) {
+        if (oe.xh) {
+            const size_t n16 = (size_t)TN * (size_t)oe.ldh / 8;                  // 16-byte chunks of the tile's rows (row pitch ldh halfs, a multiple of 8)
+            half8* dst = reinterpret_cast<half8*>(oe.xh + (size_t)row0 * oe.ldh);
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t i = tid; i < n16; i += 512) dst[i] = z;
+        }
+        return;
+    }
     const int halo = ga.dil;                              // taps == 3
     const int rows_lds = TN + 2 * halo;
     const int chunks = ga.cin >> 3;

@@ -57,6 +57,15 @@ ttail_kernel(const TTailArgs a) {
 #else
 #define TT_STAMP() do { } while (0)
 #endif
+    // a tile beyond its clip's length (ragged batch): nothing to compute -- its rows of the next evaluation's layer-0 operand are zero padding
+    // (rewritten here: the bucket may hold an earlier, longer clip), everything else it would write is read by its own rows only (tlayer.h)
+    if (a.rm.rowclip[row0] < 0) {
+        const size_t n16 = (size_t)TT_TN * (size_t)a.ldh / 8;
+        half8* dst = reinterpret_cast<half8*>(a.xh + (size_t)row0 * a.ldh);
+        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t i = tid; i < n16; i += NTH) dst[i] = z;
+        return;
+    }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     constexpr int K1 = 2 * C, K3 = 2 * MP;                  // folded K of the skip / output projections and of the input projection
     constexpr unsigned rb1 = (unsigned)K1 * 2u, rb3 = (unsigned)K3 * 2u;  // LDS row bytes of the two tiles

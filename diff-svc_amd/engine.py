@@ -131,10 +131,11 @@ class SamplerHandle:
         return dict(zip(("prepare", "init", "chain", "finish"), [float(v) for v in out]))
 
     def sample(self, cond, t_start, speedup=1, x_init=None, mel2ph=None, seed=0, first_clip=0, t_stop=0,
-               use_graph=True, return_x=False, ref_mel=None, clip_ids=None, clip_lens=None):
+               use_graph=True, return_x=False, ref_mel=None, clip_ids=None, clip_lens=None, clip_lens_host=None):
         """cond [B,H,T] -> mel_out [B,T,M] (denormalised, masked).  See dsvc_sample_args.
         ref_mel [B,T,M]: use_gt_mel start (q_sample at t_start-1); clip_ids [B]: explicit Philox clip ids; clip_lens [B]: valid
-        frames per clip (frames beyond are the convs' zero padding, as if the clip ran alone)."""
+        frames per clip (frames beyond are the convs' zero padding, as if the clip ran alone); clip_lens_host: the same lengths as a host
+        sequence when the caller has them (scheduling only: the tile width of a ragged batch is then chosen by the tiles that have work)."""
         _need_cuda(cond, x_init, mel2ph, ref_mel, clip_ids, clip_lens)
         if cond.dim() != 3:
             raise RuntimeError("cond must be [B, hidden, T], got %s" % (tuple(cond.shape),))
@@ -163,10 +164,16 @@ class SamplerHandle:
             lens = clip_lens.to(torch.int32).contiguous()
             if lens.numel() != B:
                 raise RuntimeError("clip_lens must hold %d entries" % B)
+        lens_h = None
+        if clip_lens_host is not None and lens is not None:
+            if len(clip_lens_host) != B:
+                raise RuntimeError("clip_lens_host must hold %d entries" % B)
+            lens_h = (ctypes.c_int32 * B)(*[int(v) for v in clip_lens_host])
         a = _lib.SampleArgs(B, T, cond.data_ptr(), xi.data_ptr() if xi is not None else None,
                             rm.data_ptr() if rm is not None else None,
                             m2p.data_ptr() if m2p is not None else None, seed, first_clip,
                             ids.data_ptr() if ids is not None else None, lens.data_ptr() if lens is not None else None,
+                            ctypes.cast(lens_h, ctypes.c_void_p) if lens_h is not None else None,
                             t_start, t_stop,
                             int(speedup), 1 if use_graph else 0, mel.data_ptr(), xo.data_ptr() if xo is not None else None)
         self._ck(self._L.dsvc_sample(self._h, ctypes.byref(a), stream_ptr()))

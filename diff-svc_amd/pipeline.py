@@ -83,13 +83,14 @@ class SvcPipeline:
         B, T = mel2ph.shape
         valid = mel2ph > 0
         ragged = False if full_length else not bool(valid.all().item())       # (one tiny D2H before anything is launched)
-        clip_lens = None
+        clip_lens = lens_host = None
         if ragged:
             ar = torch.arange(1, T + 1, device=mel2ph.device)
             last = (valid * ar).amax(dim=1)                      # frames up to the last content frame (interior gaps stay inside)
             clip_lens = last.clamp(min=1).to(torch.int32)
+            lens_host = clip_lens.tolist()                       # (the ragged path has read the device once already; the sampler schedules by these)
         ret = self.model(hubert, mel2ph=mel2ph, f0=f0.clone(), infer=True, seed=seed, first_clip=first_clip, clip_ids=clip_ids,
-                         clip_lens=clip_lens, use_graph=use_graph)
+                         clip_lens=clip_lens, clip_lens_host=lens_host, use_graph=use_graph)
         mel = ret["mel_out"]
         mel_c = torch.clamp(mel, hp["mel_vmin"], hp["mel_vmax"])
         hop = self.vocoder.hop
@@ -163,14 +164,17 @@ class SvcPipeline:
     # 32- / 64- / 128-frame tiles with one workgroup per CU -- and a straight line through bench.py's `ragged.ddpm` for the small tilings):
     CHUNK_COST_FUSED = ((45.0, 32), (65.0, 64), (125.0, 128))
     CHUNK_COST_SMALL = (237.0, 0.173)                     # a + b * rows
-    CHUNK_MAX_ROWS = 256 * 128                             # one round of 128-frame tiles
+    CHUNK_MAX_ROWS = 2 * 256 * 128                         # the padded rectangle of a group (its workspace); what it costs is its active tiles
 
-    def _chunk_group_cost(self, B, T):
+    def _chunk_group_cost(self, lens):
+        """One DDPM evaluation of the padded batch of chunks of these lengths (longest first), us."""
         den = self.model.denoise_fn
+        B, T = len(lens), int(lens[0])
         rows = den.workspace_tiles(B, T) * 128
         if rows // 128 >= den.BATCHED_TILES and den.precision_for("ddpm", 1, frames=B * T, clips=B) in ("f16_w6", "f16_w6n"):
-            per_layer = min(c * -(-(rows // w) // 256) for c, w in self.CHUNK_COST_FUSED)
-            return den.n_layers * per_layer + 40.0 + 0.0016 * rows
+            # the fused kernel's workgroups on tiles beyond a clip's length return at once: a launch costs the rounds of its ACTIVE tiles (csrc/tlayer.h)
+            per_layer = min(c * -(-sum(-(-int(n) // w) for n in lens) // 256) for c, w in self.CHUNK_COST_FUSED)
+            return den.n_layers * per_layer + 40.0 + 0.0016 * float(sum(lens))
         a, b = self.CHUNK_COST_SMALL
         return a + b * rows
 
@@ -186,7 +190,7 @@ class SvcPipeline:
                 B, T = i - j, int(lengths[order[j]])
                 if B > 1 and self.model.denoise_fn.workspace_tiles(B, T) * 128 > self.CHUNK_MAX_ROWS:
                     continue
-                c = best[j] + self._chunk_group_cost(B, T)
+                c = best[j] + self._chunk_group_cost([int(lengths[k]) for k in order[j:i]])
                 if c < best[i]:
                     best[i], cut[i] = c, j
         groups, i = [], n

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DSVC_ABI_VERSION 8
+#define DSVC_ABI_VERSION 9
 
 /* The library is built with -fvisibility=hidden: the entry points below (and those of dsvc_debug.h) are its ONLY dynamic symbols -- no C++
  * internal, kernel stub or runtime template can interpose with (or be interposed by) another HIP library of the host process. */
@@ -143,6 +143,10 @@ typedef struct {
     const int32_t* clip_lens;  /* [B] device or NULL: valid frames per clip (1..T).  Frames >= clip_lens[b] are the convs'
                                 * ZERO PADDING, exactly as if clip b had been run alone at its own length (the reference is
                                 * B=1, infer_tool.py:277); their mel_out rows are 0.  NULL = every clip has T frames.       */
+    const int32_t* clip_lens_host; /* [B] HOST copy of clip_lens or NULL (ABI v9; read during the call only).  Scheduling only, never results: the
+                                * fused layer kernel's workgroups on tiles that lie wholly beyond their clip's length return at once, and
+                                * with the lengths known on the host the tile width is chosen by the tiles that have work (a ragged batch --
+                                * the chunks of one utterance, infer.py:44-67 -- then costs its own frames, not the padded rectangle)       */
     int32_t t_start;           /* K_step, or add_noise_step with ref_mel: runs t = t_start-1 ... 0           */
     int32_t t_stop;            /* normally 0; tests may stop the chain early (runs down to t_stop)           */
     int32_t speedup;           /* hparams['pndm_speedup']: <= 1 -> DDPM, > 1 -> PLMS with that interval      */

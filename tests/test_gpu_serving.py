@@ -137,3 +137,45 @@ def test_the_product_library_refuses_the_test_hooks():
     assert den_h._L is not den._L
     den_h.debug_set("two_launch_layer", 1)
     den_h.debug_set("two_launch_layer", 0)
+
+
+def _ragged_batch(hp, sd, lens, T, first=0):
+    conds, m2ps = [], []
+    for b, n in enumerate(lens):
+        c, m = _chunk(hp, sd, first + b, n)
+        conds.append(torch.nn.functional.pad(c, (0, T - n)))
+        m2ps.append(torch.nn.functional.pad(m, (0, T - n)))
+    return torch.cat(conds).contiguous(), torch.cat(m2ps).contiguous()
+
+
+def test_ragged_batch_skips_the_tiles_beyond_a_clips_length_without_changing_a_bit():
+    """Round 6, second session.  The fused layer kernel's workgroups on tiles that lie wholly beyond their clip's length return at once (they only
+    re-zero the operand rows they own), and with ``clip_lens_host`` the tile width is chosen by the tiles that have work.  Scheduling only:
+    (a) a ragged batch with and without the host lengths -- 32-frame tiles by active count against 64-frame tiles by the padded rectangle --
+    gives the same bits; (b) after a FULL batch has filled every row of the bucket, the ragged batch (skipped tiles sit on the full batch's
+    data) still equals a fresh handle's bit for bit.  (Parity of ragged batches against the oracle / the real reference: test_gpu_pipeline.py,
+    test_gpu_long.py -- unchanged by this.)"""
+    hp = dict(synth.HPARAMS_44K)
+    sd, den, smp = make_handles(hp, 0, "f16_w6")
+    T = 861
+    lens = [861, 700, 500, 300, 861, 100, 640, 33, 430, 250]                                  # 10 clips x 896 rows = 70 tiles of 128: the fused kernel
+    dev_lens = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    cond, m2p = _ragged_batch(hp, sd, lens, T)
+    kw = dict(mel2ph=m2p, seed=11, first_clip=40, t_stop=1000 - 150, use_graph=True, clip_lens=dev_lens)
+    plain = smp.sample(cond, 1000, **kw).clone()
+    hinted = smp.sample(cond, 1000, clip_lens_host=lens, **kw).clone()
+    assert torch.isfinite(hinted).all()
+    assert torch.equal(plain, hinted), (plain - hinted).abs().max().item()
+    for b, n in enumerate(lens):
+        assert float(hinted[b, n:].abs().max()) == 0.0 if n < T else True, b                 # mel_out rows beyond a clip's length are 0
+    # (b) fill the bucket with a full-length batch, then the ragged one again -- on this handle and on a fresh one
+    full_c, full_m = _ragged_batch(hp, sd, [T] * len(lens), T, first=20)
+    smp.sample(full_c, 1000, mel2ph=full_m, seed=3, first_clip=70, t_stop=1000 - 70, use_graph=True)
+    again = smp.sample(cond, 1000, clip_lens_host=lens, **kw).clone()
+    assert torch.equal(again, hinted), (again - hinted).abs().max().item()
+    st = smp.stats()
+    assert st["buckets_allocated"] == 1, st                                                     # one bucket served all four calls
+    del smp, den
+    _, den1, smp1 = make_handles(hp, 0, "f16_w6", sd=sd)
+    fresh = smp1.sample(cond, 1000, clip_lens_host=lens, **kw)
+    assert torch.equal(fresh, hinted), (fresh - hinted).abs().max().item()

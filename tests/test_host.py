@@ -505,7 +505,7 @@ def test_plan_chunks_groups_an_utterance_by_the_cost_model():
     den = DiffNetHip(hp["audio_num_mel_bins"], hparams=hp, precision="auto")
     stub = types.SimpleNamespace(model=types.SimpleNamespace(denoise_fn=den), CHUNK_COST_FUSED=SvcPipeline.CHUNK_COST_FUSED,
                                  CHUNK_COST_SMALL=SvcPipeline.CHUNK_COST_SMALL, CHUNK_MAX_ROWS=SvcPipeline.CHUNK_MAX_ROWS)
-    stub._chunk_group_cost = lambda B, T: SvcPipeline._chunk_group_cost(stub, B, T)
+    stub._chunk_group_cost = lambda lens: SvcPipeline._chunk_group_cost(stub, lens)
     rng = np.random.default_rng(5)
     cases = [[430, 700, 861, 1200, 1600, 2100, 2600], [861], [861, 861], [100, 7000], [2600] * 20] + [list(rng.integers(40, 3000, size=n)) for n in (3, 9, 17)]
     for lens in cases:
@@ -515,8 +515,9 @@ def test_plan_chunks_groups_an_utterance_by_the_cost_model():
         for g in plan:
             assert all(lens[g[k]] >= lens[g[k + 1]] for k in range(len(g) - 1)), (lens, g)
             assert len(g) == 1 or den.workspace_tiles(len(g), int(lens[g[0]])) * 128 <= SvcPipeline.CHUNK_MAX_ROWS, (lens, g)
-            cost += stub._chunk_group_cost(len(g), int(lens[g[0]]))
-        assert cost <= sum(stub._chunk_group_cost(1, int(t)) for t in lens) + 1e-6, (lens, plan)
+            cost += stub._chunk_group_cost([int(lens[i]) for i in g])
+        assert cost <= sum(stub._chunk_group_cost([int(t)]) for t in lens) + 1e-6, (lens, plan)
     plan = SvcPipeline.plan_chunks(stub, cases[0])
     assert len(plan) < 7 and max(len(g) for g in plan) >= 3, plan        # the seven chunks of bench.py's `ragged`: batching pays
-    assert [len(g) for g in SvcPipeline.plan_chunks(stub, [2600] * 20)].count(12) >= 1      # 12 x 2688 rows = one round of 128-frame tiles
+    big = SvcPipeline.plan_chunks(stub, [2600] * 20)                      # 21 active 128-frame tiles per chunk: no group beyond two rounds of workgroups
+    assert all(len(g) * 21 <= 512 for g in big) and len(big) <= 3, big

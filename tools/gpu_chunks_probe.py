@@ -35,7 +35,7 @@ for name, groups in (("planned", None), ("all in one batch", [[6, 5, 4, 3, 2, 1,
                      ("{2600,2100,1600} {1200,861} {700,430}", [[6, 5, 4], [3, 2], [1, 0]]), ("{2600,2100} {1600,1200,861,700,430}", [[6, 5], [4, 3, 2, 1, 0]])):
     pipe.plan_chunks = orig
     g = groups if groups is not None else plan
-    model = sum(pipe._chunk_group_cost(len(x), max(RAGGED_T[i] for i in x)) for x in g) * STEPS * 1e-6
+    model = sum(pipe._chunk_group_cost(sorted((RAGGED_T[i] for i in x), reverse=True)) for x in g) * STEPS * 1e-6
     t, o = run(True, groups)
     err = max(float((a - b).abs().max()) for a, b in zip(o, o_seq))
     print("%-48s %.3f s = %5.1fx RT (modelled sampler time %.3f s); max |PCM - one-by-one| %.2e" % (name, t, audio / t, model, err), flush=True)
