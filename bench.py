@@ -390,7 +390,9 @@ def time_ragged(pipe, dev, speedup, ddpm_steps):
                    "precisions": [pipe.model.denoise_fn.precision_for("ddpm", 1, frames=len(g) * RAGGED_T[g[0]], clips=len(g)) for g in plan],
                    "what": "SvcPipeline.infer_chunks: chunks sorted by length, contiguous groups chosen by a cost model of one evaluation "
                            "(fused layer kernel 45 / 65 / 125 us per layer by tile width, a line through the one-by-one numbers for the small tilings), "
-                           "each group one padded batch (trailing mel2ph == 0 frames are the convs' zero padding, after_infer's glue per clip)"}
+                           "each group one padded batch (trailing mel2ph == 0 frames are the convs' zero padding, after_infer's glue per clip); the fused "
+                           "kernels' workgroups on tiles wholly beyond a clip's length return at once and the tile width is chosen by the tiles that have "
+                           "work (dsvc_sample_args.clip_lens_host, ABI v9): a group is priced by its active tiles"}
     return {"workload": "%d chunks of one utterance, T = %s mel frames (%.0f s of audio), B = 1, %s + NSF-HiFiGAN, one pipeline"
                         % (len(chunks), list(RAGGED_T), audio, "%d-step DDPM" % ddpm_steps if speedup <= 1 else "PLMS (pndm_speedup %d)" % speedup),
             **({"batched_chunks": batched} if batched else {}),
