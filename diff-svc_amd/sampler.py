@@ -185,7 +185,8 @@ class GaussianDiffusionHip(nn.Module):
         self.denoise_fn.invalidate_cond()        # dsvc_sample recomputes the handle's hoisted conditioner projections for THIS cond
         mel = smp.sample(cond, t, speedup=speedup if speedup > 1 else 1, x_init=x_init, mel2ph=mel2ph, seed=seed,
                          first_clip=kwargs.get("first_clip", 0), use_graph=kwargs.get("use_graph", True), ref_mel=ref,
-                         clip_ids=kwargs.get("clip_ids"), clip_lens=kwargs.get("clip_lens"), clip_lens_host=kwargs.get("clip_lens_host"))
+                         clip_ids=kwargs.get("clip_ids"), clip_lens=kwargs.get("clip_lens"),
+                         **({"clip_lens_host": kwargs["clip_lens_host"]} if kwargs.get("clip_lens_host") is not None else {}))
         ret["mel_out"] = mel
         return ret
 

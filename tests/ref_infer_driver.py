@@ -66,7 +66,7 @@ class FakeSampler:
         self.sd.update({k: v.detach().float().cpu() for k, v in state.items()})
 
     def sample(self, cond, t_start, speedup=1, x_init=None, mel2ph=None, seed=0, first_clip=0, t_stop=0, use_graph=True,
-               return_x=False, ref_mel=None, clip_ids=None, clip_lens=None):
+               return_x=False, ref_mel=None, clip_ids=None, clip_lens=None, clip_lens_host=None):
         B, H, T = cond.shape
         M = self.den.mel_bins
         clips = [first_clip + b for b in range(B)]
