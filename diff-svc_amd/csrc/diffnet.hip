@@ -1208,7 +1208,11 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
                       && den->cfg.weight_variants > 1) ? den->cfg.weight_variants : 1;
     const int UNROLL = (nvar > 1 && nvar <= 64) ? nvar : 10;
     const bool aligned = UNROLL == nvar && nvar > 1;
-    if (a->use_graph && n >= 2 * UNROLL) {
+    // The fused layer kernel's regime needs no graph: a step is 21 launches of 45 ... 125 us each, the host enqueues them in < 0.1 ms, and eager
+    // launches pass every step by value just as the captured nodes do -- measured identical (32 clips 2.563 against 2.564 ms per step, 8 clips
+    // 0.986 / 0.986: profiles/r6s_eager_vs_graph.txt).  What a graph would cost there is its capture: 1 344 nodes per dither period for every new
+    // (batch, bucket, tile width) -- a serving loop over ragged batches meets a new one with almost every call.
+    if (a->use_graph && n >= 2 * UNROLL && !den->fused_layer_ok()) {
         SmpGraph want{};
         want.kind = 0; want.ws_id = den->ws_id; want.gen = den->ws_gen; want.prec = den->cfg.precision; want.unroll = UNROLL;
         want.T = den->tpath ? 0 : a->T;

@@ -150,7 +150,9 @@ typedef struct {
     int32_t t_start;           /* K_step, or add_noise_step with ref_mel: runs t = t_start-1 ... 0           */
     int32_t t_stop;            /* normally 0; tests may stop the chain early (runs down to t_stop)           */
     int32_t speedup;           /* hparams['pndm_speedup']: <= 1 -> DDPM, > 1 -> PLMS with that interval      */
-    int32_t use_graph;         /* replay the step through a captured hipGraph (1) or launch eagerly (0)      */
+    int32_t use_graph;         /* 1: replay the steps through captured hipGraphs where that pays (the latency-bound small tilings: ~10 us
+                                * kernels); large calls on the fused layer kernel are launched eagerly either way -- same speed, no capture.
+                                * 0: always launch eagerly                                                                              */
     float* mel_out;            /* [B,T,M] device: denorm_spec(x) * (mel2ph > 0)                              */
     float* x_out;              /* [B,1,M,T] device or NULL: final normalised state (for tests)              */
 } dsvc_sample_args;

@@ -23,8 +23,10 @@ print("plan:", [[RAGGED_T[i] for i in g] for g in plan], flush=True)
 def run(batch, groups=None):
     if groups is not None:
         pipe.plan_chunks = lambda lengths: groups
+    torch.cuda.synchronize(); t1 = time.perf_counter()
     out = pipe.infer_chunks(chunks, seed=3, first_clip=100, batch=batch)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    torch.cuda.synchronize(); print("   (first call %.3f s)" % (time.perf_counter() - t1), flush=True)
+    t0 = time.perf_counter()
     out = pipe.infer_chunks(chunks, seed=4, first_clip=100, batch=batch)
     torch.cuda.synchronize()
     return time.perf_counter() - t0, out
