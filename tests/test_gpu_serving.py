@@ -179,3 +179,36 @@ def test_ragged_batch_skips_the_tiles_beyond_a_clips_length_without_changing_a_b
     _, den1, smp1 = make_handles(hp, 0, "f16_w6", sd=sd)
     fresh = smp1.sample(cond, 1000, clip_lens_host=lens, **kw)
     assert torch.equal(fresh, hinted), (fresh - hinted).abs().max().item()
+
+
+@pytest.mark.parametrize("arch,seed", [("44k", 1), ("44k", 2), ("24k", 3)])
+def test_ragged_batches_with_random_lengths_do_not_depend_on_the_bucket_history_or_the_hint(arch, seed):
+    """Random ragged batches on the fused layer kernel (both channel-block counts: C = 384 and the 24 kHz architecture's C = 256), three calls on
+    ONE handle -- so each later batch meets the rows the earlier ones left behind the tiles it skips -- with the host lengths given or not:
+    every call equals the same call on a fresh handle bit for bit, and padded frames come out as zeros."""
+    hp = dict(synth.HPARAMS_44K) if arch == "44k" else dict(synth.HPARAMS_24K)
+    rng = np.random.default_rng(seed)
+    sd, den, smp = make_handles(hp, 0, "f16_w6")
+    calls = []
+    for k in range(3):
+        B = int(rng.integers(8, 14))
+        T = int(rng.choice([861, 700, 1100]))
+        lens = [int(v) for v in rng.integers(20, T + 1, size=B)]
+        lens[int(rng.integers(0, B))] = T                                                   # someone fills the bucket's length
+        cond, m2p = _ragged_batch(hp, sd, lens, T, first=10 * k)
+        kw = dict(mel2ph=m2p, seed=20 + k, first_clip=100 * k, t_stop=1000 - 70, use_graph=True,
+                  clip_lens=torch.tensor(lens, dtype=torch.int32, device="cuda"))
+        hint = lens if (k + seed) % 2 else None
+        out = smp.sample(cond, 1000, clip_lens_host=hint, **kw).clone()
+        assert torch.isfinite(out).all()
+        for b, n in enumerate(lens):
+            if n < T:
+                assert float(out[b, n:].abs().max()) == 0.0, (k, b, n)
+        calls.append((cond, kw, hint, out))
+    del smp, den
+    for k, (cond, kw, hint, out) in enumerate(calls):
+        _, den1, smp1 = make_handles(hp, 0, "f16_w6", sd=sd)
+        other = None if hint is not None else [int(v) for v in kw["clip_lens"].tolist()]     # ... and with the hint the other way round
+        fresh = smp1.sample(cond, 1000, clip_lens_host=other, **kw)
+        assert torch.equal(fresh, out), (arch, seed, k, (fresh - out).abs().max().item())
+        del smp1, den1
