@@ -161,9 +161,11 @@ class SvcPipeline:
     # independent, and a padded batch equals the per-clip runs (``infer``: trailing ``mel2ph == 0`` frames are the convs' zero padding, the host
     # glue is applied per clip), so a caller that has all the chunks in hand can trade the single clip's latency regime for the batched one.
     # Cost model of one DDPM evaluation, in us (csrc/diffnet.hip: fused_nt's table of the fused layer kernel -- 45 / 65 / 125 us per layer on
-    # 32- / 64- / 128-frame tiles with one workgroup per CU -- and a straight line through bench.py's `ragged.ddpm` for the small tilings):
+    # 32- / 64- / 128-frame tiles with one workgroup per CU -- and a straight line through measured small batches for the small tilings, whose
+    # kernels are latency-bound at one clip: three ten-second clips in one call run at 51.8x RT, six at 63.2x, against 25.8x one by one, at
+    # the SAME fp32-class operand scheme):
     CHUNK_COST_FUSED = ((45.0, 32), (65.0, 64), (125.0, 128))
-    CHUNK_COST_SMALL = (237.0, 0.173)                     # a + b * rows
+    CHUNK_COST_SMALL = (280.0, 0.12)                      # a + b * rows: one clip of 861 frames 0.386 ms per step, three 0.57, six 0.93 (profiles/r6u_chunks_small.txt)
     CHUNK_MAX_ROWS = 2 * 256 * 128                         # the padded rectangle of a group (its workspace); what it costs is its active tiles
 
     def _chunk_group_cost(self, lens):

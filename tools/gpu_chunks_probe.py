@@ -8,7 +8,7 @@ import diffsvc_amd
 from diffsvc_amd import synth
 from diffsvc_amd.pipeline import SvcPipeline
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-RAGGED_T = (430, 700, 861, 1200, 1600, 2100, 2600)
+RAGGED_T = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (430, 700, 861, 1200, 1600, 2100, 2600)
 dev = torch.device("cuda")
 hp = dict(synth.HPARAMS_44K, K_step=STEPS)
 h = dict(synth.VOCODER_44K)
@@ -33,8 +33,15 @@ def run(batch, groups=None):
 orig = pipe.plan_chunks
 t_seq, o_seq = run(False)
 print("one by one: %.3f s = %.1fx RT" % (t_seq, audio / t_seq), flush=True)
-for name, groups in (("planned", None), ("all in one batch", [[6, 5, 4, 3, 2, 1, 0]]), ("{2600,2100,1600} {1200,861,700,430}", [[6, 5, 4], [3, 2, 1, 0]]),
-                     ("{2600,2100,1600} {1200,861} {700,430}", [[6, 5, 4], [3, 2], [1, 0]]), ("{2600,2100} {1600,1200,861,700,430}", [[6, 5], [4, 3, 2, 1, 0]])):
+n = len(RAGGED_T)
+desc = sorted(range(n), key=lambda i: -RAGGED_T[i])
+alts = [("planned", None), ("all in one batch", [desc])]
+if n == 7:
+    alts += [("{2600,2100,1600} {1200,861,700,430}", [[6, 5, 4], [3, 2, 1, 0]]), ("{2600,2100,1600} {1200,861} {700,430}", [[6, 5, 4], [3, 2], [1, 0]]),
+             ("{2600,2100} {1600,1200,861,700,430}", [[6, 5], [4, 3, 2, 1, 0]])]
+elif n >= 4:
+    alts += [("two halves", [desc[:n // 2], desc[n // 2:]])]
+for name, groups in alts:
     pipe.plan_chunks = orig
     g = groups if groups is not None else plan
     model = sum(pipe._chunk_group_cost(sorted((RAGGED_T[i] for i in x), reverse=True)) for x in g) * STEPS * 1e-6
