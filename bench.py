@@ -376,18 +376,19 @@ def time_ragged(pipe, dev, speedup, ddpm_steps):
         run(ch, i)
         torch.cuda.synchronize(); fixed += time.perf_counter() - t0
     batched = None
-    if speedup <= 1:
+    if True:
         # the same chunks as a few padded batches (SvcPipeline.infer_chunks: the caller has the whole utterance in hand; chunk i keeps the noise
-        # streams of clip 100 + i, so only the operand precision `auto` picks by call size differs from the one-by-one pass)
+        # streams of clip 100 + i, so only the operand precision `auto` picks by call size differs from the one-by-one pass; PLMS: the same
+        # split-operand precision at any size)
         flat = [tuple(t[0] for t in ch) for ch in chunks]
-        plan = pipe.plan_chunks(list(RAGGED_T))
-        pipe.infer_chunks(flat, seed=60, first_clip=100)             # buckets built, chains captured
+        plan = pipe.plan_chunks(list(RAGGED_T), speedup)
+        pipe.infer_chunks(flat, seed=60, first_clip=100, speedup=speedup)             # buckets built, chains captured
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        pipe.infer_chunks(flat, seed=61, first_clip=100)
+        pipe.infer_chunks(flat, seed=61, first_clip=100, speedup=speedup)
         torch.cuda.synchronize(); tb = time.perf_counter() - t0
         batched = {"value": audio / tb, "unit": "audio-sec/wall-sec", "s_per_pass": tb, "vs_one_by_one": mixed / tb,
                    "plan": [[RAGGED_T[i] for i in g] for g in plan],
-                   "precisions": [pipe.model.denoise_fn.precision_for("ddpm", 1, frames=len(g) * RAGGED_T[g[0]], clips=len(g)) for g in plan],
+                   "precisions": [pipe.model.denoise_fn.precision_for("plms" if speedup > 1 else "ddpm", speedup, frames=len(g) * RAGGED_T[g[0]], clips=len(g)) for g in plan],
                    "what": "SvcPipeline.infer_chunks: chunks sorted by length, contiguous groups chosen by a cost model of one evaluation "
                            "(fused layer kernel 45 / 65 / 125 us per layer by tile width, a line through the one-by-one numbers for the small tilings), "
                            "each group one padded batch (trailing mel2ph == 0 frames are the convs' zero padding, after_infer's glue per clip); the fused "

@@ -168,20 +168,21 @@ class SvcPipeline:
     CHUNK_COST_SMALL = (280.0, 0.12)                      # a + b * rows: one clip of 861 frames 0.386 ms per step, three 0.57, six 0.93 (profiles/r6u_chunks_small.txt)
     CHUNK_MAX_ROWS = 2 * 256 * 128                         # the padded rectangle of a group (its workspace); what it costs is its active tiles
 
-    def _chunk_group_cost(self, lens):
-        """One DDPM evaluation of the padded batch of chunks of these lengths (longest first), us."""
+    def _chunk_group_cost(self, lens, speedup=1):
+        """One evaluation of the padded batch of chunks of these lengths (longest first), us.  PLMS (speedup > 1) stays on the split-operand
+        tilings at any size (DiffNetHip.AUTO): the line of the small tilings, whose slope also fits the batched f16_x3t rate (0.17 us per row)."""
         den = self.model.denoise_fn
         B, T = len(lens), int(lens[0])
         rows = den.workspace_tiles(B, T) * 128
-        if rows // 128 >= den.BATCHED_TILES and den.precision_for("ddpm", 1, frames=B * T, clips=B) in ("f16_w6", "f16_w6n"):
+        if speedup <= 1 and rows // 128 >= den.BATCHED_TILES and den.precision_for("ddpm", 1, frames=B * T, clips=B) in ("f16_w6", "f16_w6n"):
             # the fused kernel's workgroups on tiles beyond a clip's length return at once: a launch costs the rounds of its ACTIVE tiles (csrc/tlayer.h)
             per_layer = min(c * -(-sum(-(-int(n) // w) for n in lens) // 256) for c, w in self.CHUNK_COST_FUSED)
             return den.n_layers * per_layer + 40.0 + 0.0016 * float(sum(lens))
         a, b = self.CHUNK_COST_SMALL
         return a + b * rows
 
-    def plan_chunks(self, lengths):
-        """Groups of chunk indices (each group = one padded batch, longest chunk first) that minimise the modelled time of one DDPM evaluation
+    def plan_chunks(self, lengths, speedup=1):
+        """Groups of chunk indices (each group = one padded batch, longest chunk first) that minimise the modelled time of one evaluation
         over the whole utterance: chunks sorted by length, contiguous groups, dynamic programme over the cut points."""
         order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
         n = len(order)
@@ -192,7 +193,7 @@ class SvcPipeline:
                 B, T = i - j, int(lengths[order[j]])
                 if B > 1 and self.model.denoise_fn.workspace_tiles(B, T) * 128 > self.CHUNK_MAX_ROWS:
                     continue
-                c = best[j] + self._chunk_group_cost([int(lengths[k]) for k in order[j:i]])
+                c = best[j] + self._chunk_group_cost([int(lengths[k]) for k in order[j:i]], speedup)
                 if c < best[i]:
                     best[i], cut[i] = c, j
         groups, i = [], n
@@ -206,11 +207,12 @@ class SvcPipeline:
         """The chunks of ONE utterance -- a list of (hubert [n_i, H], mel2ph [T_i], f0 [T_i]) device tensors, every chunk with its own length --
         to a list of PCM tensors [kept_frames_i * hop], in the order given.  Chunk i draws the noise streams of clip ``first_clip + i`` whatever
         batch it lands in, so the result does not depend on the grouping beyond the operand precision `auto` picks by call size.
-        ``batch=False`` (and PLMS, which the reference defines for B = 1 only, diffusion.py:165-198,269-278) runs them one by one as the
-        reference's loop does."""
+        ``batch=False`` runs them one by one as the reference's loop does.  PLMS chunks are batched too: the reference's own PLMS loop only
+        works for B = 1 (``max(t - interval, 0)`` on the step tensor, diffusion.py:186), the sampler here runs it per clip of a batch exactly
+        as alone (tests/test_gpu_pipeline.py::test_ragged_batch_equals_per_clip_reference_runs), at the same split-operand precision."""
         n = len(chunks)
         lengths = [int(c[1].shape[-1]) for c in chunks]
-        groups = self.plan_chunks(lengths) if (batch and speedup <= 1 and n > 1) else [[i] for i in range(n)]
+        groups = self.plan_chunks(lengths, speedup) if (batch and n > 1) else [[i] for i in range(n)]
         out = [None] * n
         dev = chunks[0][1].device
         for g in groups:

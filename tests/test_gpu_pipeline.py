@@ -555,11 +555,20 @@ def test_infer_chunks_one_by_one_is_the_per_chunk_infer_loop_and_batched_stays_i
         worst = max(worst, rms)
         assert rms < 2e-5, (i, lens[i], rms)             # measured 1e-6 ... 4e-6 after 60 steps (two operand schemes, two tilings)
     print("infer_chunks: plan %s, worst PCM rms against the one-by-one loop %.2e" % ([[lens[i] for i in g] for g in plan], worst))
+    # PLMS chunks are batched too (the split-operand precision at any size: tilings only)
+    hp_p = dict(hp, K_step=1000)
+    pipe.hp = hp_p; pipe.model.K_step = 1000
+    plms_loop = pipe.infer_chunks(chunks[:4], seed=6, first_clip=300, speedup=20, batch=False)
+    plms_b = pipe.infer_chunks(chunks[:4], seed=6, first_clip=300, speedup=20)
+    assert len(pipe.plan_chunks(lens[:4], 20)) < 4
+    for i, (a, b) in enumerate(zip(plms_b, plms_loop)):
+        assert a.shape == b.shape and float((a.double() - b.double()).pow(2).mean().sqrt()) < 1e-5, (i, float((a.double() - b.double()).pow(2).mean().sqrt()))
+    pipe.hp = hp; pipe.model.K_step = 60
     # at a pinned precision the grouping changes the tiling only (fp32 summation order)
     pipe2 = SvcPipeline(hp, synth.acoustic_state(hp, 0), synth.vocoder_state(h, 1), h, precision="f16_x3t", vocoder_precision="f16_x3")
     sub = chunks[:3]
     a2 = pipe2.infer_chunks(sub, seed=5, first_clip=300, batch=False)
-    pipe2.plan_chunks = lambda lengths: [[2, 1, 0]]
+    pipe2.plan_chunks = lambda lengths, speedup=1: [[2, 1, 0]]
     b2 = pipe2.infer_chunks(sub, seed=5, first_clip=300)
     for i, (a, b) in enumerate(zip(a2, b2)):
         assert float((a.double() - b.double()).pow(2).mean().sqrt()) < 2e-6, i

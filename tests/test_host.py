@@ -505,7 +505,7 @@ def test_plan_chunks_groups_an_utterance_by_the_cost_model():
     den = DiffNetHip(hp["audio_num_mel_bins"], hparams=hp, precision="auto")
     stub = types.SimpleNamespace(model=types.SimpleNamespace(denoise_fn=den), CHUNK_COST_FUSED=SvcPipeline.CHUNK_COST_FUSED,
                                  CHUNK_COST_SMALL=SvcPipeline.CHUNK_COST_SMALL, CHUNK_MAX_ROWS=SvcPipeline.CHUNK_MAX_ROWS)
-    stub._chunk_group_cost = lambda lens: SvcPipeline._chunk_group_cost(stub, lens)
+    stub._chunk_group_cost = lambda lens, speedup=1: SvcPipeline._chunk_group_cost(stub, lens, speedup)
     rng = np.random.default_rng(5)
     cases = [[430, 700, 861, 1200, 1600, 2100, 2600], [861], [861, 861], [100, 7000], [2600] * 20] + [list(rng.integers(40, 3000, size=n)) for n in (3, 9, 17)]
     for lens in cases:
