@@ -189,7 +189,7 @@ class SvcPipeline:
         best = [0.0] + [float("inf")] * n
         cut = [0] * (n + 1)
         for i in range(1, n + 1):
-            for j in range(i):                               # group = order[j:i], padded to the length of order[j]
+            for j in range(max(0, i - 64), i):               # group = order[j:i], padded to the length of order[j]; at most 64 chunks per batch
                 B, T = i - j, int(lengths[order[j]])
                 if B > 1 and self.model.denoise_fn.workspace_tiles(B, T) * 128 > self.CHUNK_MAX_ROWS:
                     continue
