@@ -276,6 +276,22 @@ class SvcPipeline:
         return wav, torch.tensor([n * hop for n in kept], dtype=torch.int64, device=wav.device)
 
 
+def chunk_group_cost(den, lens, speedup=1, fused=SvcPipeline.CHUNK_COST_FUSED, small=SvcPipeline.CHUNK_COST_SMALL):
+    """SvcPipeline._chunk_group_cost for a bare DiffNetHip (the reference-side helper diffsvc_amd.svc_chunks has no SvcPipeline)."""
+    import types
+    stub = types.SimpleNamespace(model=types.SimpleNamespace(denoise_fn=den), CHUNK_COST_FUSED=fused, CHUNK_COST_SMALL=small)
+    return SvcPipeline._chunk_group_cost(stub, lens, speedup)
+
+
+def plan_chunk_groups(den, lengths, speedup=1):
+    """SvcPipeline.plan_chunks for a bare DiffNetHip."""
+    import types
+    stub = types.SimpleNamespace(model=types.SimpleNamespace(denoise_fn=den), CHUNK_COST_FUSED=SvcPipeline.CHUNK_COST_FUSED,
+                                 CHUNK_COST_SMALL=SvcPipeline.CHUNK_COST_SMALL, CHUNK_MAX_ROWS=SvcPipeline.CHUNK_MAX_ROWS)
+    stub._chunk_group_cost = lambda lens, sp=1: SvcPipeline._chunk_group_cost(stub, lens, sp)
+    return SvcPipeline.plan_chunks(stub, lengths, speedup)
+
+
 def pcm16(wav):
     """fp32 PCM in [-1, 1] -> int16 the way the reference's writer stores it (``soundfile.write(..., 'PCM_16')``, infer.py:70: libsndfile
     scales by 0x7FFF, rounds to nearest and clips)."""

@@ -69,9 +69,20 @@ class FakeSampler:
                return_x=False, ref_mel=None, clip_ids=None, clip_lens=None, clip_lens_host=None):
         B, H, T = cond.shape
         M = self.den.mel_bins
-        clips = [first_clip + b for b in range(B)]
+        clips = [int(v) for v in clip_ids.tolist()] if clip_ids is not None else [first_clip + b for b in range(B)]
         FakeSampler.calls.append(dict(t_start=t_start, speedup=speedup, seed=seed, T=T))
         assert ref_mel is None and x_init is None
+        if clip_lens is not None or B > 1:
+            # dsvc_sample_args.clip_lens: frames beyond a clip's length are the convs' zero padding, exactly as if the clip had run alone
+            lens = [int(v) for v in clip_lens.tolist()] if clip_lens is not None else [T] * B
+            assert clip_lens_host is None or list(clip_lens_host) == lens
+            out = torch.zeros(B, T, M)
+            for b in range(B):
+                n = lens[b]
+                out[b:b + 1, :n] = self.sample(cond[b:b + 1, :, :n].contiguous(), t_start, speedup, mel2ph=None if mel2ph is None else mel2ph[b:b + 1, :n],
+                                               seed=seed, first_clip=clips[b])
+                FakeSampler.calls.pop()
+            return out
         x = O.ddpm_noise_ref_layout(seed, clips, 0, T, M, O.PURPOSE_X_INIT)
         if speedup > 1:
             x = O.sample_plms(self.sd, cond, x, speedup, self.den.cyc, t_start=t_start)
@@ -186,4 +197,42 @@ out["wav_max_abs_diff"] = float(np.abs(np.asarray(wav_pred) - wav_ref).max())
 out["f0_pred_max_abs_diff"] = float(np.abs(np.asarray(f0_pred) - f0_c).max())
 out["f0_gt_is_shifted_input"] = bool(np.allclose(np.asarray(f0_gt)[f0_hz > 0], f0_hz[f0_hz > 0] * 2.0 ** (key / 12), rtol=1e-5))
 out["wav_rms"] = float(np.sqrt((wav_ref ** 2).mean()))
+
+# ---- the chunks of one utterance through diffsvc_amd.svc_chunks.infer_chunks (the reference's Svc object, its collate functions, ONE model call
+#      per planned group) against the reference's loop of Svc.infer calls: the glue must hand every chunk what the loop hands it ----
+from diffsvc_amd.svc_chunks import infer_chunks as svc_infer_chunks  # noqa: E402
+
+
+def wav_file_of(seconds, s_):
+    w_ = synth.speech_like_wav(s_, int(seconds * sr), sr)
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr)
+        w.writeframes(np.clip(np.rint(w_ * 32767.0), -32768, 32767).astype("<i2").tobytes())
+    buf.seek(0)
+    return buf
+
+
+secs = [0.31, 0.5, 0.22, 0.5]
+# (the reference's driver caches every f0 track it extracts in a JSON-able dict, infer_tool.py:205-217: a second pass over the same audio would read
+#  float64 lists back where the first pass had float32 arrays -- cleared between the passes so that all three see the same inputs)
+IT.f0_dict.clear()
+svc.vocoder.seed = 0
+loop = [svc.infer(wav_file_of(t, 7 + i), key=key, acc=acc, use_pe=False, use_crepe=True, seed=seed, first_clip=i) for i, t in enumerate(secs)]
+n_calls = len(FakeSampler.calls)
+IT.f0_dict.clear()
+svc.vocoder.seed = 0
+got = svc_infer_chunks(svc, [wav_file_of(t, 7 + i) for i, t in enumerate(secs)], key=key, acc=acc, use_pe=False, use_crepe=True, seed=seed)
+out["chunks_model_calls"] = len(FakeSampler.calls) - n_calls
+# (f0_pred and the waveform: exact.  f0_gt is 2 ** f0 evaluated by torch on the host over the padded batch: its vectorised loop and its scalar tail
+#  differ in the last bit, so a value's bits depend on where it sits in the tensor -- one ulp, 1.5e-5 Hz)
+out["chunks_equal_loop"] = bool(all(len(a) == 3 and np.array_equal(np.asarray(a[1]), np.asarray(b[1])) and np.array_equal(np.asarray(a[2]), np.asarray(b[2]))
+                                    and np.asarray(a[0]).shape == np.asarray(b[0]).shape and np.allclose(np.asarray(a[0]), np.asarray(b[0]), rtol=3e-7, atol=0)
+                                    for a, b in zip(got, loop)))
+out["chunks_lens"] = [int(len(a[2])) for a in got]
+out["chunks_diffs"] = [[float(np.abs(np.asarray(x, dtype=np.float64) - np.asarray(y, dtype=np.float64)).max()) if np.asarray(x).shape == np.asarray(y).shape else [list(np.asarray(x).shape), list(np.asarray(y).shape)] for x, y in zip(a, b)] for a, b in zip(got, loop)]
+IT.f0_dict.clear()
+svc.vocoder.seed = 0
+one = svc_infer_chunks(svc, [wav_file_of(t, 7 + i) for i, t in enumerate(secs)], key=key, acc=acc, use_pe=False, use_crepe=True, seed=seed, batch=False)
+out["chunks_unbatched_equal_loop"] = bool(all(all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b)) for a, b in zip(one, loop)))
 print("RESULT " + json.dumps(out))

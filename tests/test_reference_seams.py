@@ -42,7 +42,11 @@ def test_reference_svc_driver_runs_wav_to_wav_over_the_drop_ins():
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert line, r.stdout[-2000:]
     d = json.loads(line[-1][7:])
-    assert d["sampler_calls"] == [{"t_start": 40, "speedup": 10, "seed": 5, "T": d["frames"]}] and d["pndm_speedup_set_by_pre"]
+    assert d["sampler_calls"][0] == {"t_start": 40, "speedup": 10, "seed": 5, "T": d["frames"]} and d["pndm_speedup_set_by_pre"]
+    # diffsvc_amd.svc_chunks.infer_chunks: four chunks of the utterance through the reference's Svc object in fewer model calls than chunks,
+    # every chunk's (f0_gt, f0_pred, wav) equal to what the loop of Svc.infer calls returns
+    assert d["chunks_model_calls"] < 4 and d["chunks_equal_loop"] and d["chunks_unbatched_equal_loop"], d
+    assert len(set(d["chunks_lens"])) >= 3, d
     assert d["wav_len_ok"] and d["f0_gt_is_shifted_input"] and d["wav_rms"] > 0.05
     assert d["wav_max_abs_diff"] < 1e-6 and d["f0_pred_max_abs_diff"] == 0.0
 
