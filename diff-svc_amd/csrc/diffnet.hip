@@ -282,7 +282,8 @@ struct DenWs {
 };
 
 struct dsvc_denoiser : DenWs {
-    static constexpr int WS_CACHE = 8;          // buckets kept alive beside the active one (B = 1, T = 2600: 0.23 GB each at the 44.1 kHz architecture) ...
+    static constexpr int WS_CACHE = 24;         // buckets kept alive beside the active one (B = 1, T = 2600: 0.23 GB each at the 44.1 kHz architecture): the
+                                                // slicer's 5 ... 30 s chunks fall into 18 buckets of 128 rows -- the reference's chunk-by-chunk loop must not thrash ...
     static constexpr size_t WS_CACHE_BYTES = (size_t)32 << 30;      // ... as long as the parked ones hold no more than this (a 32-clip batch of 10 s clips is 2.5 GB)
     std::vector<DenWs> ws_cache;                // inactive buckets (their buffers are owned here until evicted)
     unsigned ws_next_id = 1;
@@ -1037,7 +1038,7 @@ struct SmpGraph {
 };
 
 struct dsvc_sampler : SmpWs {
-    static constexpr int GRAPH_CACHE = 12;      // captured chains kept per sampler (DDPM + PLMS over the buckets in use)
+    static constexpr int GRAPH_CACHE = 40;      // captured chains kept per sampler (DDPM + PLMS over the buckets in use: 18 buckets x 2 samplers for 5 ... 30 s chunks)
     dsvc_denoiser* den = nullptr;
     std::map<std::string, std::vector<float>> host;
     bool finalized = false;
