@@ -425,6 +425,8 @@ struct dsvc_denoiser : DenWs {
     // kernel's workgroups on the other tiles return at once (tlayer.h), so a launch costs its ACTIVE tiles' rounds; 0 = lengths unknown on the
     // host (every tile counts).  Set per dsvc_sample call, cleared by whatever changes the bucket.
     int act_tiles[3] = {0, 0, 0};
+    // ... and the same for the two-launch tilings (tgemm.h: TGemmArgs::skip_rowclip): the rowclip table while a ragged dsvc_sample call runs, else null
+    const int* skip_rc = nullptr;
     void set_active_tiles(const int32_t* lens_host, int B) {
         act_tiles[0] = act_tiles[1] = act_tiles[2] = 0;
         if (!lens_host) return;
@@ -672,6 +674,7 @@ int dsvc_denoiser::ensure_x3t_codes() {
 int dsvc_denoiser::ensure_ws(int B, int T, hipStream_t st) {
     if (B < 1 || T < 1) return fail(DSVC_EINVAL, "bad batch/frames %d/%d", B, T);
     act_tiles[0] = act_tiles[1] = act_tiles[2] = 0;       // (dsvc_sample sets them again when it is given the lengths)
+    skip_rc = nullptr;
     const int tp = bucket_rows(T);
     if ((long long)B * tp > 0x3fffff00) return fail(DSVC_EINVAL, "batch too large");
     ++ws_clock;
@@ -837,6 +840,7 @@ int dsvc_denoiser::eval_t(const float* x_fm, const StepRef& step, Tail tail, con
         a.x = x; a.cin = cin_pad; a.taps = taps; a.dil = dil; a.w = tp.w.as<_Float16>(); a.m_tiles = tp.m_tiles;
         a.w_planes = tp.planes; a.variant_halfs = (long long)tp.variant_halfs; a.n_variants = tp.n_variants;
         a.step_ptr = step.ptr; a.step_off = step.off; a.clip_rows = Tp;
+        a.set_skip_rowclip(skip_rc);                                              // (a ragged dsvc_sample call: tiles beyond a clip's length have no work)
         if (host_step >= 0 && tp.n_variants > 1 && step.per_clip == 0) {      // variant known at launch: pass it by value
             a.w += (size_t)(host_step % tp.n_variants) * tp.variant_halfs;
             a.n_variants = 1;
@@ -1033,7 +1037,7 @@ struct SmpGraph {
     int prec = -1, unroll = 0;     // DDPM: steps per replay
     int interval = 0, first = -1, iters = 0;      // PLMS: its schedule
     int T = 0;                     // conv_gemm engine (f16_x3) only: its kernels take the call's T by value; 0 on the tgemm engine (any T of the bucket)
-    int nt = 0;                    // tile width of the fused layer kernel the chain was captured with (a ragged batch's lengths can move it within a bucket)
+    int nt = 0;                    // tile width of the fused layer kernel the chain was captured with (a ragged batch's lengths can move it within a bucket), the fused tail's tiling << 4, 256 = captured with the padded-tile skip of the two-launch tilings on
     unsigned long long last_use = 0;
 };
 
@@ -1217,7 +1221,7 @@ int dsvc_sampler::run_ddpm(const dsvc_sample_args* a, hipStream_t st) {
         SmpGraph want{};
         want.kind = 0; want.ws_id = den->ws_id; want.gen = den->ws_gen; want.prec = den->cfg.precision; want.unroll = UNROLL;
         want.T = den->tpath ? 0 : a->T;
-        want.nt = den->fused_nt() | (den->fused_tail_mode() << 4);
+        want.nt = den->fused_nt() | (den->fused_tail_mode() << 4) | (den->skip_rc ? 256 : 0);
         SmpGraph* gr = find_graph(want);
         if (!gr) {
             DSVC_TRY(eager_step());                       // one eager step first: sets every function attribute outside the capture
@@ -1315,7 +1319,7 @@ int dsvc_sampler::run_plms(const dsvc_sample_args* a, hipStream_t st) {
         // eagerly (that also sets every function attribute outside a capture) and records the graph for the calls after it.
         SmpGraph want{};
         want.kind = 1; want.ws_id = den->ws_id; want.gen = den->ws_gen; want.prec = den->cfg.precision; want.interval = interval;
-        want.first = i_first; want.iters = iters; want.T = den->tpath ? 0 : a->T; want.nt = den->fused_nt() | (den->fused_tail_mode() << 4);
+        want.first = i_first; want.iters = iters; want.T = den->tpath ? 0 : a->T; want.nt = den->fused_nt() | (den->fused_tail_mode() << 4) | (den->skip_rc ? 256 : 0);
         if (SmpGraph* gr = find_graph(want)) {
             DSVC_HIP(hipGraphLaunch(gr->exec, st));
             ++stat_graph_launch;
@@ -1550,6 +1554,13 @@ int dsvc_sample(dsvc_sampler* s, const dsvc_sample_args* a, void* stream) {
     d->tail_fused_last = false;                           // a new chain: nothing of a previous call's tail applies
     DSVC_TRY(d->set_clip_meta(a->clip_ids, a->first_clip, a->clip_lens, st));
     d->set_active_tiles(a->clip_lens ? a->clip_lens_host : nullptr, B);       // (host copy of clip_lens, optional: the tile width is chosen by the tiles that have work)
+    if (a->clip_lens && d->tpath) {
+        // a ragged call on the two-launch tilings: tiles beyond a clip's length are skipped (TGemmArgs::skip_rowclip), so the operand rows there --
+        // the zero padding the last valid tile's halo reads -- are cleared here once: in a re-used bucket they may hold an earlier, longer clip
+        d->skip_rc = d->rowclip.as<int>();
+        DSVC_HIP(hipMemsetAsync(d->xh.p, 0, d->xh.bytes, st));
+        if (d->xh2.p) DSVC_HIP(hipMemsetAsync(d->xh2.p, 0, d->xh2.bytes, st));
+    }
     DSVC_TRY(d->prepare_cond(a->cond, B, T, st));
     stamp(1);
     float* xs = s->xstate.as<float>();

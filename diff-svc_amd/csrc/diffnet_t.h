@@ -35,6 +35,7 @@ __global__ void k_build_rowclip(int* __restrict__ rowclip, const int* __restrict
 
 // ---- K4+K5+K6: dilated conv + hoisted conditioner projection + gate -> g (fp16) ----
 struct TEpiGate {
+    static constexpr bool RAGGED_SKIP = true;     // (tgemm.h: epi_ragged_skip)
     struct Args {
         const float* cproj;     // accumulator-tiled (C/16 m_tiles per frame tile): registers 0..7 gate, 8..15 filter; both biases
                                 // folded in, pre-scaled like the weights (see gate_act_scaled)
@@ -86,6 +87,7 @@ struct TEpiGate {
 // ---- K7+K8 (+K3 of the NEXT layer): output 1x1; residual half updates x and emits the next layer's fp16 operand
 //      xh = fp16(x + film_next), skip half accumulates ----
 struct TEpiResSkip {
+    static constexpr bool RAGGED_SKIP = true;     // (tgemm.h: epi_ragged_skip)
     struct Args {
         float* x32;             // residual stream (in/out), accumulator-tiled with C/32 m_tiles
         _Float16* xh;           // [rows][ldh] next layer's MFMA operand, row 0 (guard rows precede); null on the last layer
@@ -248,6 +250,7 @@ struct TEpiResSkip {
 
 // ---- K1: input projection + ReLU -> x (fp32) and layer 0's operand xh = fp16(x + film_0) ----
 struct TEpiInProj {
+    static constexpr bool RAGGED_SKIP = true;     // (tgemm.h: epi_ragged_skip)
     struct Args {
         float* x32; _Float16* xh;
         const float* bias; const float* film; int film_step_stride; StepRef step;
@@ -304,6 +307,7 @@ struct TEpiInProj {
 
 // ---- K9a: skip projection + ReLU -> fp16 hi|lo operand planes of the final projection ----
 struct TEpiReluHalf {
+    static constexpr bool RAGGED_SKIP = true;     // (tgemm.h: epi_ragged_skip)
     struct Args { _Float16* out; int ld; const float* bias; int cout; };   // out [rows][2*ld]: hi plane, lo plane at +ld
     template <int NT_N>
     __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
@@ -332,6 +336,7 @@ struct TEpiReluHalf {
 
 // ---- K9b: final projection -> eps (fp32), for PLMS and DiffNet.forward ----
 struct TEpiEps {
+    static constexpr bool RAGGED_SKIP = true;     // (tgemm.h: epi_ragged_skip)
     struct Args { float* out; int M; const float* bias; };
     template <int NT_N>
     __device__ __forceinline__ void init(const Args&, int, int, int, f32x16 (&acc)[NT_N]) const {
@@ -360,6 +365,7 @@ struct TEpiEps {
 // ---- K9b+K10: final projection fused with the DDPM posterior step (diffusion.py:131-163); also refreshes the
 //      fp16 copy of the state that the next step's input projection reads ----
 struct TEpiDdpm {
+    static constexpr bool RAGGED_SKIP = true;     // (tgemm.h: epi_ragged_skip)
     struct Args {
         float* x;                   // [rows][M] sampler state (in/out)
         _Float16* xsh;              // [rows][2*ldh] fp16 hi|lo planes of the state (zero on gap rows)

@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -55,6 +56,7 @@ struct TGemmArgs {
     int w_planes;           // planes stored per fragment (>= NW)
     long long variant_halfs;// stride between dither variants
     int n_variants;         // >= 1
+    unsigned skip_lo;       // (ragged batches: low word of the rowclip pointer, see skip_hi)
     const int* step_ptr;    // device int: current diffusion step (variant = (step - step_off) % n_variants); may be null
     int step_off;           // (a launcher that knows the step passes w already offset to the variant and n_variants = 1: that takes the
                             //  dependent scalar load, ~0.4 us per kernel in the single-clip regime, out of the front of the weight stream)
@@ -69,6 +71,19 @@ struct TGemmArgs {
     // KP kernels (round 4; the trainer's data-gradient GEMMs, whose 2C-channel split rows do not fit LDS whole): input channels per plane that
     // one K phase brings into LDS (% 128 == 0, divides cin); the phases are double-buffered, see the KP path of the kernel
     int kp_cin;
+    // ragged batches (round 6; the sampler's plain tilings only -- KS == 1, no KP, FS == 1): rowclip table of the launch or null.  A workgroup
+    // whose frame tile lies wholly beyond its clip's length (rowclip[first row] < 0: tiles never straddle clips, a clip's valid rows are a
+    // prefix of its bucket) returns at once.  Everything such a tile would write is read by its own rows' later launches only -- every
+    // contraction is over channels -- except the operand rows a conv's halo reads, which the sampler clears once per ragged call.
+    // The pointer travels as two words in the struct's two alignment holes (skip_lo above, skip_hi here): the kernel arguments of every
+    // launch keep the size and the offsets they had (a ninth 8-byte field behind kp_cin moved the epilogue's arguments and measured +1.5 %
+    // on the single clip's split-K kernels, which never read it: profiles/r6ab_b1_lib_ab.txt).
+    unsigned skip_hi;
+    __host__ __device__ void set_skip_rowclip(const int* p) {
+        const unsigned long long v = (unsigned long long)p;
+        skip_lo = (unsigned)v; skip_hi = (unsigned)(v >> 32);
+    }
+    __device__ __forceinline__ const int* skip_rowclip() const { return (const int*)(((unsigned long long)skip_hi << 32) | skip_lo); }
 #ifdef DSVC_PROFILING       // profiling builds only (python -m diffsvc_amd.build --profiling): the product library has neither field nor branch
     unsigned long long* stamps;   // per-wave phase time stamps (s_memrealtime, 100 MHz), 16 per wave (env DSVC_TG_STAMPS)
     int dbg;                // ablation knobs (env DSVC_TG_DEBUG; results are WRONG when set): 1 = no acc-init loads, 2 = no epilogue,
@@ -77,6 +92,10 @@ struct TGemmArgs {
                             // end of the pass (both waves of a SIMD together) instead of staggered inside it, 1024 = no K-loop stagger
 #endif
 };
+
+#ifndef DSVC_PROFILING
+static_assert(sizeof(TGemmArgs) == 96, "TGemmArgs: the kernel-argument layout is part of the single clip's launch cost (see skip_hi)");
+#endif
 
 #ifdef DSVC_PROFILING
 #define TG_DBG(a, bit) ((a).dbg & (bit))
@@ -116,7 +135,7 @@ constexpr int TFRAG6_DWORDS = 384;        // one k_tpack6 fragment: [lane 64][16
 // is issued right behind the barrier that publishes phase p, so it runs under phase p's MFMAs; one barrier per phase.
 // FS = 2 (round 4; the vocoder's 128-channel stage: four 32-channel output tiles do not fill eight waves): the workgroup's time tile holds FS
 // frame sub-tiles of 32 NT_N frames, waves [0, WAVES/FS) work on the first, the rest on the second -- same LDS tile, same weight stream.
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0, int KP = 0, int FS = 1>
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0, int KP = 0, int FS = 1, int SKIP = 0>
 __global__ void __launch_bounds__(64 * WAVES * KS, MINW) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     static_assert(FS == 1 || (KS == 1 && !KP && WAVES % FS == 0), "frame sub-tiles: the resident-tile flow only");
@@ -134,6 +153,9 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     const int ks = KS > 1 ? wave_all / WAVES : 0;               // which slice of the K loop
     const int fb = FS > 1 ? (wave_all / WM) * TN : 0;         // this wave's frame sub-tile inside the workgroup's time tile
     const int row0 = blockIdx.x * TN * FS + fb;
+    if constexpr (SKIP) {                                 // (a ragged call's own instantiation: TGemmArgs::skip_hi)
+        if (a.skip_rowclip()[row0] < 0) return;
+    }
     constexpr bool STAMPS = NT_N == 1;                    // the phase stamps exist only in the small-batch kernels: in the 128-frame
                                                           // tiling their few SGPRs/VGPRs tip the register allocation into spills
     auto stamp = [&](int i) {
@@ -602,8 +624,16 @@ inline void tstamp_dump(const char* prefix) {
 }
 
 // n_rows must be a multiple of 32*NT_N; m_split = number of blockIdx.y slices the output-channel passes are dealt over
-template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0, int KP = 0, int FS = 1>
+// epilogues of the sampler's launches opt in to the padded-tile skip of ragged batches (`static constexpr bool RAGGED_SKIP = true`): only they get
+// the second instantiation
+template <class E, class = void> struct epi_ragged_skip { static constexpr bool value = false; };
+template <class E> struct epi_ragged_skip<E, std::void_t<decltype(E::RAGGED_SKIP)>> { static constexpr bool value = E::RAGGED_SKIP; };
+
+template <int NT_N, int WAVES, int MINW, int KG, int NW, class Epi, int SCHED = 1, int KS = 1, int NA = 1, int W6 = 0, int KP = 0, int FS = 1, int SKIP = 0>
 inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, int m_split, hipStream_t stream) {
+    if constexpr (!SKIP && KS == 1 && !KP && FS == 1 && epi_ragged_skip<Epi>::value) {
+        if ((a.skip_lo | a.skip_hi) != 0) return tgemm_launch<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS, NA, W6, KP, FS, 1>(a, ea, n_rows, m_split, stream);
+    }
     if (W6 && (!a.w6 || a.n_variants != 1 || a.cin % 64 != 0)) return fail(DSVC_EINVAL, "tgemm: the W6 kernels need the code plane of the variant to use");
     if (a.cin % (16 * KG) != 0) return fail(DSVC_EINVAL, "tgemm: cin %d not a multiple of %d", a.cin, 16 * KG);
     if (n_rows % (32 * NT_N * FS) != 0) return fail(DSVC_EINVAL, "tgemm: %d rows not a multiple of the %d-frame tile", n_rows, 32 * NT_N * FS);
@@ -616,7 +646,7 @@ inline int tgemm_launch(TGemmArgs a, const typename Epi::Args& ea, int n_rows, i
     const char* dbg_s = getenv("DSVC_TG_DEBUG");           // profiling ablations only; results are WRONG when set
     a.dbg = dbg_s ? atoi(dbg_s) : 0;
 #endif
-    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS, NA, W6, KP, FS>;
+    auto kern = tgemm_kernel<NT_N, WAVES, MINW, KG, NW, Epi, SCHED, KS, NA, W6, KP, FS, SKIP>;
     const size_t smem = KP ? 2 * tgemm_smem<NT_N>(a.taps, a.dil, a.kp_cin * NA)
                            : tgemm_smem<NT_N * FS>(a.taps, a.dil, a.cin * NA) + (size_t)(KS - 1) * WAVES * NT_N * 4096;
     if (smem > 160 * 1024) return fail(DSVC_EINVAL, "tgemm: %zu B of LDS requested", smem);

@@ -165,7 +165,8 @@ class SvcPipeline:
     # kernels are latency-bound at one clip: three ten-second clips in one call run at 51.8x RT, six at 63.2x, against 25.8x one by one, at
     # the SAME fp32-class operand scheme):
     CHUNK_COST_FUSED = ((45.0, 32), (65.0, 64), (125.0, 128))
-    CHUNK_COST_SMALL = (280.0, 0.12)                      # a + b * rows: one clip of 861 frames 0.386 ms per step, three 0.57, six 0.93 (profiles/r6u_chunks_small.txt)
+    CHUNK_COST_SMALL = (280.0, 0.12)                      # a + b * rows of the active tiles: one clip of 861 frames 0.386 ms per step, three 0.57, six 0.93 (profiles/r6u_chunks_small.txt);
+                                                          # ragged groups: profiles/r6ac_chunks.txt (the seven chunks as ONE PLMS batch 807x RT, as two 649x, one by one 495x)
     CHUNK_MAX_ROWS = 2 * 256 * 128                         # the padded rectangle of a group (its workspace); what it costs is its active tiles
 
     def _chunk_group_cost(self, lens, speedup=1):
@@ -178,8 +179,11 @@ class SvcPipeline:
             # the fused kernel's workgroups on tiles beyond a clip's length return at once: a launch costs the rounds of its ACTIVE tiles (csrc/tlayer.h)
             per_layer = min(c * -(-sum(-(-int(n) // w) for n in lens) // 256) for c, w in self.CHUNK_COST_FUSED)
             return den.n_layers * per_layer + 40.0 + 0.0016 * float(sum(lens))
+        # the two-launch tilings skip frame tiles beyond a clip's length too (csrc/tgemm.h: TGemmArgs::skip_hi; 64-frame tiles from 48 tiles of
+        # 128 rows, 32-frame tiles below): the line is walked with the rows of the ACTIVE tiles
+        w = 64 if rows // 128 >= den.BATCHED_TILES else 32
         a, b = self.CHUNK_COST_SMALL
-        return a + b * rows
+        return a + b * min(rows, sum(-(-int(n) // w) * w for n in lens))
 
     def plan_chunks(self, lengths, speedup=1):
         """Groups of chunk indices (each group = one padded batch, longest chunk first) that minimise the modelled time of one evaluation

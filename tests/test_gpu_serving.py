@@ -212,3 +212,49 @@ def test_ragged_batches_with_random_lengths_do_not_depend_on_the_bucket_history_
         fresh = smp1.sample(cond, 1000, clip_lens_host=other, **kw)
         assert torch.equal(fresh, out), (arch, seed, k, (fresh - out).abs().max().item())
         del smp1, den1
+
+
+@pytest.mark.parametrize("kind", ["ddpm", "plms"])
+def test_ragged_batch_on_the_two_launch_tilings_skips_padding_tiles_without_changing_a_bit(kind):
+    """The same for the split-operand tilings of small batches and PLMS (tgemm.h: TGemmArgs::skip_rowclip): workgroups on frame tiles wholly beyond
+    their clip's length return at once; the operand rows there are cleared once per ragged call.  On the conditioned checkpoint of the PLMS
+    goldens (random-init weights let PLMS amplify the last bits of two tilings beyond any bar): a ragged batch after a FULL batch has filled the
+    bucket equals the same batch on a fresh handle bit for bit; its full-length clip -- the golden's (clip, noise) pair -- stays within 1e-4 of the
+    REAL reference's mel as it does alone; every clip equals its own solo run at its own length up to the two tilings' summation order."""
+    from test_gpu_headline import load_golden, golden_state
+    g = load_golden("plmsc_44k_T861_s20")
+    hp = dict(synth.HPARAMS_44K)
+    sd = golden_state(g, hp)
+    _, den, smp = make_handles(hp, 0, "f16_x3t", sd=sd)
+    T, seed = 861, int(g["seed"])
+    clips, lens = [int(g["clips"][0]), 11, 12, 13], [861, 300, 100, 640]
+    ids = torch.tensor(clips, dtype=torch.int32, device="cuda")
+    parts = [_chunk(hp, sd, c, n) for c, n in zip(clips, lens)]
+    cond = torch.cat([torch.nn.functional.pad(c, (0, T - n)) for (c, _), n in zip(parts, lens)]).contiguous()
+    m2p = torch.cat([torch.nn.functional.pad(m, (0, T - n)) for (_, m), n in zip(parts, lens)]).contiguous()
+    dev_lens = torch.tensor(lens, dtype=torch.int32, device="cuda")
+
+    def run(s, c, m, **kw):
+        if kind == "plms":
+            return s.sample(c, 1000, speedup=20, mel2ph=m, seed=seed, use_graph=True, **kw)
+        return s.sample(c, 1000, mel2ph=m, seed=seed, t_stop=1000 - 150, use_graph=True, **kw)
+    full_c, full_m = _ragged_batch(hp, sd, [T] * len(lens), T, first=20)
+    run(smp, full_c, full_m, first_clip=70)                                                  # every row of the bucket now holds a full-length clip's data
+    got = run(smp, cond, m2p, clip_ids=ids, clip_lens=dev_lens, clip_lens_host=lens).clone()
+    again = run(smp, cond, m2p, clip_ids=ids, clip_lens=dev_lens, clip_lens_host=lens)
+    assert torch.isfinite(got).all() and torch.equal(got, again)
+    for b, n in enumerate(lens):
+        if n < T:
+            assert float(got[b, n:].abs().max()) == 0.0, b
+    if kind == "plms":
+        err = float((got[0].cpu() - torch.from_numpy(g["mel_out"])[0]).abs().max())
+        print("PLMS-50, the golden's clip inside a ragged batch of four: mel max-abs err vs the real reference %.2e" % err)
+        assert err < 1e-4, err
+    del smp, den
+    _, den1, smp1 = make_handles(hp, 0, "f16_x3t", sd=sd)
+    fresh = run(smp1, cond, m2p, clip_ids=ids, clip_lens=dev_lens, clip_lens_host=lens)
+    assert torch.equal(fresh, got), (fresh - got).abs().max().item()
+    for b, n in enumerate(lens):                                                             # a clip alone at its own length
+        solo = run(smp1, parts[b][0], parts[b][1], first_clip=clips[b])
+        err = float((solo[0] - got[b, :n]).abs().max())
+        assert err < 1e-4, (kind, b, n, err)
