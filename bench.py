@@ -393,7 +393,8 @@ def time_ragged(pipe, dev, speedup, ddpm_steps):
                            "(fused layer kernel 45 / 65 / 125 us per layer by tile width, a line through the one-by-one numbers for the small tilings), "
                            "each group one padded batch (trailing mel2ph == 0 frames are the convs' zero padding, after_infer's glue per clip); the fused "
                            "kernels' workgroups on tiles wholly beyond a clip's length return at once and the tile width is chosen by the tiles that have "
-                           "work (dsvc_sample_args.clip_lens_host, ABI v9): a group is priced by its active tiles"}
+                           "work (dsvc_sample_args.clip_lens_host, ABI v9), and so do the two-launch tilings' workgroups (csrc/tgemm.h SKIP: PLMS chunks, DDPM "
+                           "groups under 48 tiles): a group is priced by its active tiles"}
     return {"workload": "%d chunks of one utterance, T = %s mel frames (%.0f s of audio), B = 1, %s + NSF-HiFiGAN, one pipeline"
                         % (len(chunks), list(RAGGED_T), audio, "%d-step DDPM" % ddpm_steps if speedup <= 1 else "PLMS (pndm_speedup %d)" % speedup),
             **({"batched_chunks": batched} if batched else {}),

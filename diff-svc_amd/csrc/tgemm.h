@@ -76,8 +76,9 @@ struct TGemmArgs {
     // prefix of its bucket) returns at once.  Everything such a tile would write is read by its own rows' later launches only -- every
     // contraction is over channels -- except the operand rows a conv's halo reads, which the sampler clears once per ragged call.
     // The pointer travels as two words in the struct's two alignment holes (skip_lo above, skip_hi here): the kernel arguments of every
-    // launch keep the size and the offsets they had (a ninth 8-byte field behind kp_cin moved the epilogue's arguments and measured +1.5 %
-    // on the single clip's split-K kernels, which never read it: profiles/r6ab_b1_lib_ab.txt).
+    // launch keep the size and the offsets they had (a ninth 8-byte field behind kp_cin moved the epilogue's arguments by 8 bytes: the single clip's
+    // gate kernel then fetches them with an s_load_dwordx4 at kernarg + 0x78, which straddles into a third 64-byte line -- a serialized scalar-cache
+    // miss in front of the weight stream, measured +1.5 % on the headline, profiles/r6ab_skip_field_lib_ab.txt; the ISA differs in nothing else).
     unsigned skip_hi;
     __host__ __device__ void set_skip_rowclip(const int* p) {
         const unsigned long long v = (unsigned long long)p;
@@ -168,6 +169,18 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     };
     stamp(0);
     const int halo = (a.taps >> 1) * a.dil;
+    if constexpr (KS > 1 && sizeof(TGemmArgs) + sizeof(typename Epi::Args) > 128) {
+        // the single clip's kernels (round 6, third session): the scalar cache fetches a 64-byte line of the kernel arguments when it is first
+        // read, and the compiler reads a by-value struct lazily -- the first read of line 2 or 3 (the epilogue's later fields) sits in the middle
+        // of the front path, a serialized miss of ~0.14 us in front of the weight stream.  One word of each further line is read here, in the
+        // same batch as the first argument loads: -0.8 % on the headline (same-box A/B, profiles/r6ag_kernarg_touch_lib_ab.txt).  Reading ALL
+        // arguments in one batch at entry (values laundered through an empty asm) was measured too: no gain over not touching at all.
+        typedef const int __attribute__((address_space(4))) kint;
+        kint* ka = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
+        int touch = ka[32];
+        if constexpr (sizeof(TGemmArgs) + sizeof(typename Epi::Args) > 192) touch |= ka[48];
+        asm volatile("; kernel-argument lines 2+ are in the scalar cache (%0)" :: "s"(touch));
+    }
     const int rows_lds = TN * FS + 2 * halo;
     const int row_halfs = a.cin * NA;                    // NA = 2: [hi plane | lo plane]
     const int chunks = row_halfs >> 3;                   // 16-B chunks per row
