@@ -169,11 +169,11 @@ tgemm_kernel(const TGemmArgs a, const typename Epi::Args ea) {
     };
     stamp(0);
     const int halo = (a.taps >> 1) * a.dil;
-    if constexpr (KS > 1 && sizeof(TGemmArgs) + sizeof(typename Epi::Args) > 128) {
-        // the single clip's kernels (round 6, third session): the scalar cache fetches a 64-byte line of the kernel arguments when it is first
+    if constexpr (NT_N == 1 && sizeof(TGemmArgs) + sizeof(typename Epi::Args) > 128) {
+        // the 32-frame tilings (the single clip and small batches; round 6, third session): the scalar cache fetches a 64-byte line of the kernel arguments when it is first
         // read, and the compiler reads a by-value struct lazily -- the first read of line 2 or 3 (the epilogue's later fields) sits in the middle
         // of the front path, a serialized miss of ~0.14 us in front of the weight stream.  One word of each further line is read here, in the
-        // same batch as the first argument loads: -0.8 % on the headline (same-box A/B, profiles/r6ag_kernarg_touch_lib_ab.txt).  Reading ALL
+        // same batch as the first argument loads: -0.8 % on the headline, on three and on six clips (same-box A/Bs, profiles/r6ag_kernarg_touch_lib_ab.txt).  Reading ALL
         // arguments in one batch at entry (values laundered through an empty asm) was measured too: no gain over not touching at all.
         typedef const int __attribute__((address_space(4))) kint;
         kint* ka = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
