@@ -7,6 +7,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <type_traits>
 
 #include "../../include/dsvc.h"
 #include "../../include/dsvc_debug.h"
@@ -207,6 +208,15 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
         const int tiles = rows_alloc / 32, passes = ceil_div(a.m_tiles, 4);
         int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
         // (a.w6: the w_lo * x_hi term of these small tilings on the 6-bit MFMA -- the caller packed the code plane and knows the dither variant)
+        if constexpr (std::is_same<Epi, TEpiGate>::value) {
+            // the dilated conv (3 taps: 18 weight groups per output tile at C = 384) over FOUR K slices -- 12 waves per workgroup, slices of 4 / 5 / 4 / 5
+            // groups, the finishing wave on a short one -- instead of three slices of 6 (round 6, third session; same-box A/B, profiles/r6ap_ks4_lib_ab.txt):
+            // 0.3847 -> 0.3777 ms per DDPM step (-1.8 %), the PLMS-50 chain 20.82 -> 20.63 ms (-0.9 %).  Five slices (15 waves, 4 / 3 / 4 / 3 / 4) lose it
+            // again (0.386).  The 1x1 projections have 6 groups (two per slice either way) and stay on three.
+            if (tiles * ceil_div(a.m_tiles, 3) <= 256 && a.taps == 3 && (a.cin >> 4) / KG * a.taps >= 12)
+                return a.w6 ? tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 4, 2, 1>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st)
+                            : tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 4, 2>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st);
+        }
         if (tiles * ceil_div(a.m_tiles, 3) <= 256)
             return a.w6 ? tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 3, 2, 1>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st)
                         : tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 3, 2>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st);
