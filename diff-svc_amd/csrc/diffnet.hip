@@ -220,6 +220,22 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
         if (tiles * ceil_div(a.m_tiles, 3) <= 256)
             return a.w6 ? tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 3, 2, 1>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st)
                         : tgemm_launch<1, 3, 3, KG, NW, Epi, 1, 3, 2>(a, e, rows_alloc, ceil_div(a.m_tiles, 3), st);
+        if constexpr (std::is_same<Epi, TEpiGate>::value || std::is_same<Epi, TEpiResSkip>::value) {
+            // 33 ... 64 frame tiles (a single clip of 12 ... 23 s, two ten-second clips; round 6, third session): still fewer workgroups than CUs if a
+            // workgroup takes 4 / 6 output tiles, and split-K then keeps 12 waves on the CU where the plain tiling below has 4 per workgroup.  Same box
+            // (profiles/r6at_tiers.txt), ms per DDPM step: T = 1100 0.424 -> 0.401, T = 1300 0.500 -> 0.460, T = 1600 0.507 -> 0.481, two clips of 861
+            // 0.507 -> 0.478, the PLMS-50 chain at T = 1600 29.4 -> 27.1 ms.  8 output tiles x 2 slices (16 waves, up to 85 tiles) is SLOWER than the
+            // plain tiling (T = 2100 0.541 -> 0.581, T = 2600 0.587 -> 0.625, three clips 0.590 -> 0.615): not built.  Ragged calls stay on the plain
+            // tiling, whose workgroups on padded tiles return at once (TGemmArgs::skip_hi).
+            if ((a.skip_lo | a.skip_hi) == 0) {
+                if (tiles * ceil_div(a.m_tiles, 4) <= 256)
+                    return a.w6 ? tgemm_launch<1, 4, 3, KG, NW, Epi, 1, 3, 2, 1>(a, e, rows_alloc, ceil_div(a.m_tiles, 4), st)
+                                : tgemm_launch<1, 4, 3, KG, NW, Epi, 1, 3, 2>(a, e, rows_alloc, ceil_div(a.m_tiles, 4), st);
+                if (tiles * ceil_div(a.m_tiles, 6) <= 256)
+                    return a.w6 ? tgemm_launch<1, 6, 3, KG, NW, Epi, 1, 2, 2, 1>(a, e, rows_alloc, ceil_div(a.m_tiles, 6), st)
+                                : tgemm_launch<1, 6, 3, KG, NW, Epi, 1, 2, 2>(a, e, rows_alloc, ceil_div(a.m_tiles, 6), st);
+            }
+        }
         return a.w6 ? tgemm_launch<1, 4, 2, KG, NW, Epi, 1, 1, 2, 1>(a, e, rows_alloc, ms, st) : tgemm_launch<1, 4, 2, KG, NW, Epi, 1, 1, 2>(a, e, rows_alloc, ms, st);
     }
     if (rows_alloc / 128 >= 48) {

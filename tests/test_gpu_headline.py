@@ -240,13 +240,16 @@ def _tap_errors(den, sd, spec, t, cond, rows_of):
 
 @pytest.mark.parametrize("precision,B,T,fused", [("f16_w2", 1, 45, True), ("f16_d64", 1, 45, True), ("f16_d64", 2, 861, True),
                                                  ("f16_w2", 8, 861, True), ("f16_d64", 8, 861, True), ("f16_d64", 8, 861, False),
-                                                 ("f16_m64", 1, 45, True), ("f16_m64", 8, 861, True)])
+                                                 ("f16_m64", 1, 45, True), ("f16_m64", 8, 861, True),
+                                                 ("f16_x3t", 1, 861, True), ("f16_x3t", 1, 1100, True), ("f16_x3t", 1, 1600, True), ("f16_x3t", 2, 861, True),
+                                                 ("f16_x3t", 1, 2100, True)])
 def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused, hooks):
     """Per-layer localisation on the PRODUCT engine (tgemm): after every residual block the residual stream x_l, the gate
     output g_l and the running skip sum are compared with the oracle -- for the split-K single-clip tiling (T=45 and T=861), the
     small-batch tiling (B=2) and the 128-frame throughput tiling (B=8 x 861).  The throughput tiling runs a layer as ONE fused
     kernel whose gate output never leaves the CU (tlayer.h), so g is tapped on its two-launch form (fused=False); x and the skip
-    sum are tapped on both."""
+    sum are tapped on both.  The shipped single-clip precision f16_x3t (split operands, fp32-class) on each of its split-K tilings: 3 output tiles x 4 / 3
+    K slices (T = 861: up to 32 frame tiles), 4 x 3 (T = 1100: up to 42), 6 x 2 (T = 1600 and two clips of 861: up to 64), and the plain tiling beyond."""
     hp = dict(synth.HPARAMS_44K)
     sd, den, _ = make_handles(hp, 0, precision)
     g = np.random.Generator(np.random.PCG64(5 + B))
@@ -261,8 +264,11 @@ def test_tgemm_engine_layer_taps_vs_oracle(precision, B, T, fused, hooks):
     # fp16 activations: one rounding of an O(1..4) value is 2^-11 relative; 20 layers of it stay well under these bars, a
     # mis-indexed tile or a wrong dilation does not
     tol = 1.5e-2 if precision != "f16_w2" else 1e-2
+    if precision == "f16_x3t":
+        tol = 2e-4                                           # (hi + lo weights, hi | lo activations: fp32-class; measured ~2e-5 after 20 layers)
     g_live = not (fused and B * Tp >= 6144)                  # the fused kernel keeps g in LDS: the debug buffer is not written
-    assert worst["x"][0] < tol and (worst["g"][0] < tol or not g_live) and worst["s"][0] < 4 * tol, worst
+    g_tol = 1e-3 if precision == "f16_x3t" else tol          # (the tap reads the hi plane of g: one fp16 rounding of an O(1) value)
+    assert worst["x"][0] < tol and (worst["g"][0] < g_tol or not g_live) and worst["s"][0] < 4 * tol, worst
 
 
 @pytest.mark.parametrize("precision", ["f16_m64", "f16_d64", "f16_w2", "f16_x3", "f16_x3t"])

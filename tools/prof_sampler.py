@@ -1,4 +1,4 @@
-"""Sampler-only workload for rocprofv3: python tools/prof_sampler.py <B> <steps> <precision> [graph]"""
+"""Sampler-only workload for rocprofv3: python tools/prof_sampler.py <B> <steps> <precision> [graph] [T]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,9 +18,10 @@ smp = SamplerHandle(den, sd)
 for kv in os.environ.get("DSVC_PROF_KNOBS", "").split(","):          # e.g. DSVC_PROF_KNOBS=fused_tail=1 (dsvc_denoiser_debug_set keys)
     if "=" in kv:
         den.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
-cond = torch.randn(B, 256, 861, device="cuda") * 0.5
+T = int(sys.argv[5]) if len(sys.argv) > 5 else 861
+cond = torch.randn(B, 256, T, device="cuda") * 0.5
 smp.sample(cond, 130 if graph else 25, seed=1, use_graph=graph)      # (graph: two dither periods, so that the capture happens here)
 torch.cuda.synchronize(); t0 = time.time()
 smp.sample(cond, steps, seed=2, use_graph=graph)
 torch.cuda.synchronize(); dt = time.time() - t0
-print("B=%d %s steps=%d graph=%d: %.3f ms/step" % (B, prec, steps, graph, dt / steps * 1e3))
+print("B=%d %s steps=%d graph=%d%s: %.3f ms/step" % (B, prec, steps, graph, "" if T == 861 else " T=%d" % T, dt / steps * 1e3))
