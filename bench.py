@@ -784,13 +784,14 @@ def main():
                                                 "%d-rank job of this line, gather included: north_star's '>= 6x at 8 GPUs vs 1 GPU on the batched config'"
                                                 % (n_clips, whole_job["batches"], B, world)}
         if world == 1 and B == 1 and args.speedup <= 1 and roof["bound"] == "mfma":
-            # the single clip is frozen, with the evidence on the line
-            roof["frozen_since"] = "r4"
+            # the single clip's state with the evidence on the line.  (Round 6's third session moved it for the first time since r4: -2.6 % per
+            # step by same-box A/B -- a scalar-cache miss off the kernels' front path, the gate conv over four K slices: DESIGN 4.1 (viii), (ix).)
+            roof["frozen_since"] = "r4 (r6, third session: -2.6 % per step, gate kernel 10.5 -> 10.2 us on the same class of box; the floor model is unchanged)"
             roof["target_feasibility"] = {
                 "target_x_rt": 200.0, "ceiling_x_rt": 55.0,
                 "why": "20 000 serially dependent layer evaluations per clip, two launches each: at the stated latency floors (gate 4.9 us + res/skip 3.5 us per "
                        "layer + 43 graph-node boundaries per step) a 1000-step clip cannot go below ~0.18 s = 55x RT; both kernels have sat at 44-48 % of those "
-                       "floors for two rounds (r4: 10.3 / 7.7 us, r5: 10.3 / 7.7 us, r6: unchanged) with everything in design/tgemm.md tried (XCD-major placement "
+                       "floors for two rounds (r4: 10.3 / 7.7 us, r5: 10.3 / 7.7 us, r6: 10.0 / 7.6 us on a fast box) with everything in design/tgemm.md tried (XCD-major placement "
                        "-12 %, split-K variants, 6-bit lo plane +7.5 %); one frame tile's eight slices already share two XCDs, so the all-to-all hand-off of a "
                        "persistent layer costs 26-28 us (tools/micro/handoff.hip) against 18 us for the two launches",
                 "what_serves_the_target_instead": "batching: 32 clips per GPU run at 123-125x RT per GPU (`batched`), 36 at 129-131x (`job_256.chip_filling_batches`)"}

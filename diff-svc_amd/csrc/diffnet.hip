@@ -208,6 +208,18 @@ int tlaunch(const TGemmArgs& a, const typename Epi::Args& e, int rows_alloc, hip
         const int tiles = rows_alloc / 32, passes = ceil_div(a.m_tiles, 4);
         int ms = 512 / tiles; ms = ms < 1 ? 1 : (ms > passes ? passes : ms);
         // (a.w6: the w_lo * x_hi term of these small tilings on the 6-bit MFMA -- the caller packed the code plane and knows the dither variant)
+        if constexpr (std::is_same<Epi, TEpiGate>::value || std::is_same<Epi, TEpiResSkip>::value) {
+            // up to 21 frame tiles (a clip of <= 7.3 s; round 6, third session): 2 output tiles per workgroup -- 12 output slices, up to 252 workgroups where 3
+            // per workgroup leave a third of the CUs idle -- with the same K slices (4 for the dilated conv, 3 for the 1x1).  Same box, ms per DDPM step:
+            // T = 200 0.335 -> 0.305, T = 430 0.338 -> 0.315 (profiles/r6at_tiers.txt).
+            if (tiles * ceil_div(a.m_tiles, 2) <= 256 && (a.m_tiles % 2) == 0 && (a.skip_lo | a.skip_hi) == 0) {
+                if (a.taps == 3)
+                    return a.w6 ? tgemm_launch<1, 2, 2, KG, NW, Epi, 1, 4, 2, 1>(a, e, rows_alloc, ceil_div(a.m_tiles, 2), st)
+                                : tgemm_launch<1, 2, 2, KG, NW, Epi, 1, 4, 2>(a, e, rows_alloc, ceil_div(a.m_tiles, 2), st);
+                return a.w6 ? tgemm_launch<1, 2, 2, KG, NW, Epi, 1, 3, 2, 1>(a, e, rows_alloc, ceil_div(a.m_tiles, 2), st)
+                            : tgemm_launch<1, 2, 2, KG, NW, Epi, 1, 3, 2>(a, e, rows_alloc, ceil_div(a.m_tiles, 2), st);
+            }
+        }
         if constexpr (std::is_same<Epi, TEpiGate>::value) {
             // the dilated conv (3 taps: 18 weight groups per output tile at C = 384) over FOUR K slices -- 12 waves per workgroup, slices of 4 / 5 / 4 / 5
             // groups, the finishing wave on a short one -- instead of three slices of 6 (round 6, third session; same-box A/B, profiles/r6ap_ks4_lib_ab.txt):
